@@ -1,0 +1,197 @@
+"""Seeded synthetic river networks and runoff forcing.
+
+The reference ships no test data (route/input/ holds only a README), so every parity case and
+the benchmark run on networks grown here.  The generator is a level-synchronous random
+binary-merge (Shreve) tree grown upstream from the outlets, P(2 upstreams) ~ 0.48, P(1) = 0.04,
+P(0) ~ 0.48, with a mild width controller so the network reaches N reaches with roughly
+`depth` hops along the longest path instead of dying out like a critical branching process.
+
+Reach attributes follow the reference's river-network file variables
+(docs/source/users_guide/Input_files.rst:58-118) and the defaults of
+route/ancillary_data/param.nml.default:1-12; derived attributes follow
+process_ntopo.f90:176-197 (width = wscale*sqrt(totalArea), storage = area(depth)*length).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+HIGH_DEPTH = 100000.0  # globalData.f90:189
+
+
+@dataclass
+class RiverNetwork:
+    """Arrays use the reference's conventions: reach / HRU indices are 1-based, downIndex <= 0
+    marks an outlet, immediate upstreams are stored CSR-style in UREACHI order."""
+
+    N: int
+    H: int
+    downIndex: np.ndarray      # int32 [N]
+    reachId: np.ndarray        # int32 [N]
+    upOffset: np.ndarray       # int32 [N+1]
+    upIndex: np.ndarray        # int32 [nUp]
+    upGood: np.ndarray         # int32 [nUp]   goodBas flag per upstream slot
+    hruOffset: np.ndarray      # int32 [N+1]
+    hruIndex: np.ndarray       # int32 [nHru]
+    hruWeight: np.ndarray      # float64 [nHru]
+    params: dict = field(default_factory=dict)   # name -> float64 [N]
+
+    PARAM_ORDER = ("R_SLOPE", "R_MAN_N", "R_WIDTH", "R_DEPTH", "RLENGTH", "R_STORAGE",
+                   "SIDE_SLOPE", "FLDP_SLOPE", "BASAREA", "TOTAREA", "MINFLOW")
+
+    def param_matrix(self) -> np.ndarray:
+        """[11, N] row-major in PARAM_ORDER."""
+        return np.ascontiguousarray(np.stack([self.params[k] for k in self.PARAM_ORDER]).astype(np.float64))
+
+    def topo_order(self) -> np.ndarray:
+        """A processing order (0-based reach indices), upstream before downstream."""
+        down = self.downIndex.astype(np.int64) - 1
+        dist = hops_to_outlet(down)
+        return np.argsort(-dist, kind="stable").astype(np.int32)
+
+    def n_levels(self) -> int:
+        return int(hops_to_outlet(self.downIndex.astype(np.int64) - 1).max()) + 1
+
+
+def hops_to_outlet(down0: np.ndarray) -> np.ndarray:
+    """Number of hops from each reach to its outlet (outlet = 0). down0: 0-based, <0 = outlet."""
+    n = down0.shape[0]
+    dist = np.zeros(n, dtype=np.int64)
+    ptr = down0.copy()
+    active = np.nonzero(ptr >= 0)[0]
+    # pointer-jumping would be O(log depth); a plain frontier walk from the outlets is simpler:
+    # build children lists and BFS.
+    order = np.argsort(down0, kind="stable")
+    sorted_down = down0[order]
+    starts = np.searchsorted(sorted_down, np.arange(n), side="left")
+    ends = np.searchsorted(sorted_down, np.arange(n), side="right")
+    frontier = np.nonzero(down0 < 0)[0]
+    d = 0
+    while frontier.size:
+        dist[frontier] = d
+        cnt = ends[frontier] - starts[frontier]
+        tot = int(cnt.sum())
+        if tot == 0:
+            break
+        base = np.repeat(starts[frontier], cnt)
+        off = np.arange(tot) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+        frontier = order[base + off]
+        d += 1
+    del active, ptr
+    return dist
+
+
+def build_upstream_csr(downIndex: np.ndarray):
+    """UREACHI lists from downstream indices (1-based in, 1-based out), ordered by reach index."""
+    n = downIndex.shape[0]
+    down0 = downIndex.astype(np.int64) - 1
+    has = down0 >= 0
+    src = np.nonzero(has)[0]
+    dst = down0[has]
+    order = np.argsort(dst, kind="stable")
+    counts = np.bincount(dst, minlength=n)
+    upOffset = np.zeros(n + 1, dtype=np.int32)
+    upOffset[1:] = np.cumsum(counts)
+    upIndex = (src[order] + 1).astype(np.int32)
+    return upOffset, upIndex
+
+
+def make_network(N: int, seed: int = 20240529, depth: int | None = None, n_outlets: int | None = None,
+                 floodplain: bool = False, zero_area_frac: float = 0.0, p3: float = 0.0) -> RiverNetwork:
+    rng = np.random.default_rng(seed)
+    if depth is None:
+        depth = max(4, int(round(2.6 * np.sqrt(N))))          # ~800 at 100k, ~4.5k at 3M
+    if n_outlets is None:
+        n_outlets = max(1, N // 50000)
+    n_outlets = min(n_outlets, N)
+    w_target = max(2.0, N / depth)
+    down = np.full(N, 0, dtype=np.int64)                       # 1-based downstream index, 0 = outlet
+    frontier = np.arange(n_outlets, dtype=np.int64)
+    n_made = n_outlets
+    while n_made < N:
+        w = frontier.size
+        if w == 0:                                             # everything died out: new coastal outlet
+            frontier = np.array([n_made], dtype=np.int64)
+            n_made += 1
+            continue
+        p2 = float(np.clip(0.48 + 0.15 * (1.0 - w / w_target), 0.30, 0.66))
+        p1 = 0.04
+        u = rng.random(w)
+        nchild = np.where(u < p2, 2, np.where(u < p2 + p1, 1, 0))
+        if p3 > 0:                                             # occasional triple confluence
+            nchild = np.where(rng.random(w) < p3, 3, nchild)
+        if w < 4:
+            nchild = np.maximum(nchild, 1)
+        tot = int(nchild.sum())
+        if tot == 0:
+            nchild[rng.integers(w)] = 1
+            tot = 1
+        if n_made + tot > N:                                   # trim the last level
+            keep = N - n_made
+            cs = np.cumsum(nchild)
+            nchild = np.where(cs <= keep, nchild, np.maximum(0, nchild - (cs - keep)))
+            tot = int(nchild.sum())
+        parents = np.repeat(frontier, nchild)
+        children = np.arange(n_made, n_made + tot, dtype=np.int64)
+        down[children] = parents + 1
+        n_made += tot
+        frontier = children
+    # shuffle reach numbering so that array order carries no topological information
+    perm = rng.permutation(N)                                   # new index of old reach i is perm[i]
+    down_new = np.zeros(N, dtype=np.int64)
+    has = down > 0
+    down_new[perm[has]] = perm[down[has] - 1] + 1
+    downIndex = down_new.astype(np.int32)
+    upOffset, upIndex = build_upstream_csr(downIndex)
+
+    length = np.clip(np.exp(rng.normal(np.log(3000.0), 0.6, N)), 200.0, 30000.0)
+    slope = np.maximum(np.exp(rng.uniform(np.log(1e-4), np.log(5e-2), N)), 1e-6)   # min_slope, public_var.f90:30
+    basarea = np.exp(rng.normal(np.log(2.5e7), 0.5, N))
+    if zero_area_frac > 0:
+        # a few headwater reaches without any contributing area (exercises goodBas = .false.)
+        head = np.nonzero(np.diff(upOffset) == 0)[0]
+        z = head[rng.random(head.size) < zero_area_frac]
+        basarea[z] = 0.0
+    # accumulate total area upstream -> downstream
+    totarea = basarea.copy()
+    down0 = downIndex.astype(np.int64) - 1
+    dist = hops_to_outlet(down0)
+    for d in range(int(dist.max()), 0, -1):
+        idx = np.nonzero(dist == d)[0]
+        np.add.at(totarea, down0[idx], totarea[idx])
+    wscale, dscale = 0.001, 0.0006
+    width = wscale * np.sqrt(np.maximum(totarea, 1.0))
+    if floodplain:
+        rdepth = dscale * np.sqrt(np.maximum(totarea, 1.0))
+    else:
+        rdepth = np.full(N, HIGH_DEPTH)
+    side = np.zeros(N)
+    storage = rdepth * (width + side * rdepth) * length        # hydraulic.f90:207-238 storage()
+    params = dict(R_SLOPE=slope, R_MAN_N=np.full(N, 0.01), R_WIDTH=width, R_DEPTH=rdepth,
+                  RLENGTH=length, R_STORAGE=storage, SIDE_SLOPE=side, FLDP_SLOPE=np.full(N, 1000.0),
+                  BASAREA=basarea, TOTAREA=totarea, MINFLOW=np.zeros(N))
+    # goodBas: all upstream slots of a reach share the flag "own total area > verySmall"
+    # (network_topo.f90:769-775)
+    good_reach = (totarea > np.finfo(np.float64).tiny).astype(np.int32)
+    upGood = np.repeat(good_reach, np.diff(upOffset)).astype(np.int32)
+    hruOffset = np.arange(N + 1, dtype=np.int32)               # one HRU per reach, weight 1
+    hruIndex = np.arange(1, N + 1, dtype=np.int32)
+    hruWeight = np.ones(N)
+    return RiverNetwork(N=N, H=N, downIndex=downIndex, reachId=np.arange(1001, 1001 + N, dtype=np.int32),
+                        upOffset=upOffset, upIndex=upIndex, upGood=upGood, hruOffset=hruOffset,
+                        hruIndex=hruIndex, hruWeight=hruWeight, params=params)
+
+
+def make_runoff(H: int, n_steps: int, seed: int = 7, t0: int = 0, base: float = 1e-8,
+                storm_prob: float = 0.01, storm_amp: float = 1e-6) -> np.ndarray:
+    """runoff[t, h] in m/s: low seasonal base flow plus sparse storm pulses."""
+    rng = np.random.default_rng(seed)
+    phi = rng.uniform(0, 2 * np.pi, H)
+    t = np.arange(t0, t0 + n_steps, dtype=np.float64)[:, None]
+    ro = base * (1.0 + np.sin(2 * np.pi * t / 168.0 + phi[None, :]))
+    rng2 = np.random.default_rng(seed + 1000003 * (t0 + 1))
+    pulses = rng2.random((n_steps, H))
+    amp = rng2.random((n_steps, H))
+    ro += np.where(pulses < storm_prob, storm_amp * amp * amp, 0.0)
+    return np.ascontiguousarray(ro)

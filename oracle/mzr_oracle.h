@@ -1,0 +1,82 @@
+/*
+ * mzr_oracle.h -- CPU restatement of mizuRoute's per-timestep reach-routing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle: a plain-C, scalar, one-reach-at-a-time
+ * restatement of the reference algorithm.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  The product (mizuroute_amd/csrc, libmzr_hip.so) never links,
+ * includes or calls anything in this directory.
+ *
+ * Parity pin: every routine is checked against the UNMODIFIED reference Fortran solvers run in
+ * oracle/_ref (see oracle/README.md) through tests/test_oracle_vs_ref.py and the committed
+ * fixtures in tests/golden/.
+ *
+ * Reference files restated (all under /root/reference/route/build/src/):
+ *   main_route.f90:29-409      orc_step (prologue + ordered sweep)
+ *   process_remap.f90:319-422  basin2reach
+ *   basinUH.f90:19-178         hillslope unit-hydrograph delay
+ *   accum_runoff.f90:32-93     SUM
+ *   irf_route.f90:40-264       IRF
+ *   kwt_route.f90:36-1622      KWT (kwt_rch, getusq_rch, qexmul_rch, remove_rch, kinwav_rch, interp_rch,
+ *                              extract_from_rch)
+ *   mc_route.f90:46-416        Muskingum-Cunge
+ *   dfw_route.f90:49-370, kwe_route.f90:46-363, advection_diffusion.f90:19-258   DW / KW
+ *   hydraulic.f90:46-535       channel geometry, Newton normal depth, celerity, diffusivity
+ *   water_balance.f90:22-112   per-reach water balance
+ */
+#ifndef MZR_ORACLE_H
+#define MZR_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* routing method ids, public_var.f90:73-80 */
+enum { ORC_SUM = 0, ORC_IRF = 1, ORC_KWT = 2, ORC_KW = 3, ORC_MC = 4, ORC_DW = 5 };
+
+/* per-reach parameter rows of the `par` array (row-major [ORC_NPAR][N]) */
+enum { ORC_P_SLOPE = 0, ORC_P_MAN_N, ORC_P_WIDTH, ORC_P_DEPTH, ORC_P_LENGTH, ORC_P_STORAGE,
+       ORC_P_SIDE_SLOPE, ORC_P_FLDP_SLOPE, ORC_P_BASAREA, ORC_P_TOTAREA, ORC_P_MINFLOW, ORC_NPAR };
+
+/* flux selectors for orc_get_flux */
+enum { ORC_F_Q = 0, ORC_F_VOL0, ORC_F_VOL1, ORC_F_INFLOW, ORC_F_ELE, ORC_F_FLOODVOL, ORC_F_WB,
+       ORC_F_BASIN_QR1, ORC_F_BASIN_QR0, ORC_F_BASIN_QI };
+
+#define ORC_MAXQPAR 20   /* public_var.f90:36 */
+#define ORC_WCAP    32   /* padded wave capacity of state get/set */
+
+typedef struct orc orc_t;
+
+/* indices are 1-based like the reference; downIndex <= 0 marks an outlet */
+orc_t *orc_create(int N, int H, const int *downIndex, const int *upOff, const int *upIdx,
+                  const int *upGood, const int *hruOff, const int *hruIdx, const double *hruW,
+                  const double *par /* [ORC_NPAR][N] */);
+void orc_destroy(orc_t *o);
+
+int orc_config(orc_t *o, double dt, int nRoutes, const int *methods, int doesBasinRoute,
+               int hw_drain_point, double min_length_route, double runoffMin, int is_flux_wm);
+int orc_set_uh(orc_t *o, int ntdhBas, const double *fracFuture, const int *uhOff, const double *uh);
+
+/* one time step == one call of main_route; returns the reference's ierr (0 ok) */
+int orc_step(orc_t *o, double T0, double T1, const double *runoff /* [H] */,
+             const double *wmflux /* [N] or NULL */);
+/* nSteps steps; Qout/volOut [nSteps][nRoutes][N] (may be NULL); returns first ierr */
+int orc_run(orc_t *o, int nSteps, double t_start, const double *runoff /* [nSteps][H] */,
+            double *Qout, double *volOut);
+const char *orc_last_error(const orc_t *o);
+
+int orc_get_flux(const orc_t *o, int route, int which, double *out /* [N] */);
+/* KWT state, padded [N][ORC_WCAP] */
+int orc_get_kwt_state(const orc_t *o, int *nw, double *qf, double *ti, double *tr, int *rf);
+int orc_set_kwt_state(orc_t *o, const int *nw, const double *qf, const double *ti, const double *tr,
+                      const int *rf);
+int orc_get_irf_state(const orc_t *o, double *qfuture /* concatenated per uhOff */);
+int orc_get_mol_state(const orc_t *o, int method, double *q /* [N][nMol] */);
+int orc_get_basin_state(const orc_t *o, double *qfuture /* [N][ntdhBas] */);
+/* statistics for the roofline model: particles read/written by KWT in the last step */
+int orc_get_kwt_traffic(const orc_t *o, long long *w_in, long long *w_up, long long *w_out,
+                        long long *n_head, long long *n_route, long long *n_edges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,404 @@
+/* CPU oracle: driver, basin2reach, hillslope UH, SUM, IRF (test infrastructure; see mzr_oracle.h). */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "orc_internal.h"
+
+static void *xcalloc(size_t n, size_t sz) {
+  void *p = calloc(n ? n : 1, sz);
+  if (!p) { fprintf(stderr, "orc: out of memory\n"); abort(); }
+  return p;
+}
+
+orc_t *orc_create(int N, int H, const int *downIndex, const int *upOff, const int *upIdx,
+                  const int *upGood, const int *hruOff, const int *hruIdx, const double *hruW,
+                  const double *par) {
+  orc_t *o = (orc_t *)xcalloc(1, sizeof(orc_t));
+  o->N = N; o->H = H;
+  o->down = (int *)xcalloc(N, sizeof(int));
+  o->upOff = (int *)xcalloc(N + 1, sizeof(int));
+  o->nGood = (int *)xcalloc(N, sizeof(int));
+  o->hruOff = (int *)xcalloc(N + 1, sizeof(int));
+  memcpy(o->upOff, upOff, (N + 1) * sizeof(int));
+  memcpy(o->hruOff, hruOff, (N + 1) * sizeof(int));
+  int nUp = upOff[N], nHru = hruOff[N];
+  o->upIdx = (int *)xcalloc(nUp, sizeof(int));
+  o->upGood = (int *)xcalloc(nUp, sizeof(int));
+  o->hruIdx = (int *)xcalloc(nHru, sizeof(int));
+  o->hruW = (double *)xcalloc(nHru, sizeof(double));
+  for (int i = 0; i < N; i++) o->down[i] = downIndex[i] > 0 ? downIndex[i] - 1 : -1;
+  for (int e = 0; e < nUp; e++) { o->upIdx[e] = upIdx[e] - 1; o->upGood[e] = upGood[e] != 0; }
+  for (int e = 0; e < nHru; e++) { o->hruIdx[e] = hruIdx[e] - 1; o->hruW[e] = hruW[e]; }
+  for (int i = 0; i < N; i++) {
+    int c = 0;
+    for (int e = upOff[i]; e < upOff[i + 1]; e++) c += o->upGood[e];
+    o->nGood[i] = c;   /* count(NETOPO_in(i)%goodBas) */
+  }
+  for (int p = 0; p < ORC_NPAR; p++) {
+    o->par[p] = (double *)xcalloc(N, sizeof(double));
+    memcpy(o->par[p], par + (size_t)p * N, N * sizeof(double));
+  }
+  /* processing order: any upstream->downstream order gives identical results because a reach
+     reads only its immediate upstreams' current-step outputs (main_route.f90:356-405). */
+  o->order = (int *)xcalloc(N, sizeof(int));
+  int *indeg = (int *)xcalloc(N, sizeof(int));
+  for (int i = 0; i < N; i++) indeg[i] = upOff[i + 1] - upOff[i];
+  int head = 0, tail = 0;
+  for (int i = 0; i < N; i++) if (indeg[i] == 0) o->order[tail++] = i;
+  while (head < tail) {
+    int r = o->order[head++];
+    int d = o->down[r];
+    if (d >= 0 && --indeg[d] == 0) o->order[tail++] = d;
+  }
+  free(indeg);
+  if (tail != N) { snprintf(o->msg, sizeof o->msg, "orc_create/network has a cycle or dangling upstream"); }
+  o->BASIN_QI = (double *)xcalloc(N, sizeof(double));
+  o->BASIN_QR0 = (double *)xcalloc(N, sizeof(double));
+  o->BASIN_QR1 = (double *)xcalloc(N, sizeof(double));
+  o->REACH_WM_FLUX = (double *)xcalloc(N, sizeof(double));
+  for (int m = 0; m < 6; m++) o->idx[m] = -1;
+  o->hw_drain_point = 2; o->doesBasinRoute = 1;
+  return o;
+}
+
+void orc_destroy(orc_t *o) {
+  if (!o) return;
+  free(o->down); free(o->upOff); free(o->upIdx); free(o->upGood); free(o->nGood);
+  free(o->hruOff); free(o->hruIdx); free(o->hruW); free(o->order);
+  for (int p = 0; p < ORC_NPAR; p++) free(o->par[p]);
+  free(o->fracFuture); free(o->uhOff); free(o->uh);
+  free(o->BASIN_QI); free(o->BASIN_QR0); free(o->BASIN_QR1); free(o->REACH_WM_FLUX);
+  free(o->QFUTURE); free(o->route); free(o->QFUTURE_IRF); free(o->kw); free(o->nkw);
+  free(o->molKW); free(o->molMC); free(o->molDW);
+  free(o);
+}
+
+const char *orc_last_error(const orc_t *o) { return o->msg; }
+
+/* cold-start state, init_model_data.f90:399-505 */
+int orc_config(orc_t *o, double dt, int nRoutes, const int *methods, int doesBasinRoute,
+               int hw_drain_point, double min_length_route, double runoffMin, int is_flux_wm) {
+  int N = o->N;
+  o->dt = dt; o->nRoutes = nRoutes; o->doesBasinRoute = doesBasinRoute;
+  o->hw_drain_point = hw_drain_point; o->min_length_route = min_length_route;
+  o->runoffMin = runoffMin; o->is_flux_wm = is_flux_wm;
+  for (int m = 0; m < 6; m++) o->idx[m] = -1;
+  for (int i = 0; i < nRoutes; i++) {
+    if (methods[i] < 0 || methods[i] > 5) { snprintf(o->msg, sizeof o->msg, "route_network/routing method id expect digits 0-5"); return 81; }
+    o->methods[i] = methods[i]; o->idx[methods[i]] = i;
+  }
+  free(o->route); o->route = (orc_hyd *)xcalloc((size_t)nRoutes * N, sizeof(orc_hyd));
+  free(o->kw); free(o->nkw); o->kw = NULL; o->nkw = NULL;
+  free(o->molKW); free(o->molMC); free(o->molDW); o->molKW = o->molMC = o->molDW = NULL;
+  if (o->idx[ORC_KWT] >= 0) {
+    o->kw = (orc_fpoint *)xcalloc((size_t)N * ORC_KWSTORE, sizeof(orc_fpoint));
+    o->nkw = (int *)xcalloc(N, sizeof(int));
+    for (int i = 0; i < N; i++) o->nkw[i] = -1;   /* KWAVE unallocated */
+  }
+  if (o->idx[ORC_KW] >= 0) o->molKW = (double *)xcalloc((size_t)N * ORC_NMOL_KW, sizeof(double));
+  if (o->idx[ORC_MC] >= 0) o->molMC = (double *)xcalloc((size_t)N * ORC_NMOL_MC, sizeof(double));
+  if (o->idx[ORC_DW] >= 0) o->molDW = (double *)xcalloc((size_t)N * ORC_NMOL_DW, sizeof(double));
+  return 0;
+}
+
+int orc_set_uh(orc_t *o, int ntdhBas, const double *fracFuture, const int *uhOff, const double *uh) {
+  int N = o->N;
+  o->ntdhBas = ntdhBas;
+  free(o->fracFuture); o->fracFuture = (double *)xcalloc(ntdhBas, sizeof(double));
+  memcpy(o->fracFuture, fracFuture, ntdhBas * sizeof(double));
+  free(o->QFUTURE); o->QFUTURE = (double *)xcalloc((size_t)N * ntdhBas, sizeof(double));
+  free(o->uhOff); free(o->uh); free(o->QFUTURE_IRF);
+  o->uhOff = (int *)xcalloc(N + 1, sizeof(int));
+  if (uhOff) {
+    memcpy(o->uhOff, uhOff, (N + 1) * sizeof(int));
+    o->uh = (double *)xcalloc(uhOff[N], sizeof(double));
+    memcpy(o->uh, uh, uhOff[N] * sizeof(double));
+    o->QFUTURE_IRF = (double *)xcalloc(uhOff[N], sizeof(double));
+  } else {
+    o->uh = NULL; o->QFUTURE_IRF = NULL;
+  }
+  return 0;
+}
+
+/* process_remap.f90:319-422 (time_conv = length_conv = 1 are applied by the caller's units) */
+static int basin2reach(orc_t *o, const double *basinRunoff, double *reachRunoff) {
+  const double negRunoffTol = -1.e-3;   /* public_var.f90:31 */
+  for (int r = 0; r < o->N; r++) {
+    int n = o->hruOff[r + 1] - o->hruOff[r];
+    if (n > 0) {
+      double acc = 0.0;
+      for (int e = o->hruOff[r]; e < o->hruOff[r + 1]; e++) {
+        double ro = basinRunoff[o->hruIdx[e]];
+        if (ro < negRunoffTol) {
+          snprintf(o->msg, sizeof o->msg, "basin2reach/exceeded negative runoff tolerance for HRU %d", o->hruIdx[e] + 1);
+          return 20;
+        }
+        acc = acc + o->hruW[e] * ro * 1.0 * 1.0;   /* *time_conv*length_conv */
+      }
+      if (acc < o->runoffMin) acc = o->runoffMin;
+      reachRunoff[r] = acc * o->par[ORC_P_BASAREA][r];
+    } else {
+      reachRunoff[r] = o->runoffMin;
+    }
+  }
+  return 0;
+}
+
+/* basinUH.f90:70-178 (hru_irf + irf_conv), non-lake reaches */
+static void hru_irf(orc_t *o, int r) {
+  int n = o->ntdhBas;
+  double *qf = o->QFUTURE + (size_t)r * n;
+  o->BASIN_QR0[r] = o->BASIN_QR1[r];
+  for (int j = 0; j < n; j++) qf[j] = qf[j] + o->fracFuture[j] * o->BASIN_QI[r];
+  o->BASIN_QR1[r] = qf[0];
+  for (int j = 1; j < n; j++) qf[j - 1] = qf[j];
+  qf[n - 1] = 0.0;
+}
+
+/* accum_runoff.f90:32-93 */
+int orc_sum_rch(orc_t *o, int r) {
+  orc_hyd *h = &HYD(o, ORC_SUM, r);
+  h->REACH_Q = o->BASIN_QR1[r];
+  double q_upstream = 0.0;
+  if (o->upOff[r + 1] > o->upOff[r]) {
+    for (int e = o->upOff[r]; e < o->upOff[r + 1]; e++) q_upstream = q_upstream + HYD(o, ORC_SUM, o->upIdx[e]).REACH_Q;
+    h->REACH_Q = h->REACH_Q + q_upstream;
+  }
+  return 0;
+}
+
+/* Shared preamble of irf_rch / mc_rch / dfw_rch / kw_rch: irf_route.f90:81-142, mc_route.f90:83-146,
+   dfw_route.f90:87-149, kwe_route.f90:83-145 */
+void orc_preamble(orc_t *o, int r, int method, double *q_upstream_out, double *q_upstream_mod_out,
+                  double *Qlat_out, int *isHW_out) {
+  orc_hyd *h = &HYD(o, method, r);
+  int nUps = o->nGood[r];
+  int isHW = 1;
+  double q_upstream = 0.0, q_upstream_mod = 0.0, Qlat = 0.0;
+  double Qabs = o->REACH_WM_FLUX[r];
+  h->REACH_WM_FLUX_actual = o->REACH_WM_FLUX[r];
+  h->REACH_VOL[0] = h->REACH_VOL[1];
+  if (nUps > 0) {
+    isHW = 0;
+    for (int i = 0; i < nUps; i++) {        /* do iUps = 1,nUps ; cycle if .not.goodBas(iUps) */
+      int e = o->upOff[r] + i;
+      if (!o->upGood[e]) continue;
+      q_upstream = q_upstream + HYD(o, method, o->upIdx[e]).REACH_Q;
+    }
+    q_upstream_mod = q_upstream;
+    Qlat = o->BASIN_QR1[r];
+  } else {
+    if (o->hw_drain_point == 1) {
+      q_upstream = q_upstream + o->BASIN_QR1[r];
+      q_upstream_mod = q_upstream;
+      Qlat = 0.0;
+    } else if (o->hw_drain_point == 2) {
+      q_upstream_mod = q_upstream;
+      Qlat = o->BASIN_QR1[r];
+    }
+  }
+  h->REACH_INFLOW = q_upstream;
+  if (o->REACH_WM_FLUX[r] != ORC_REALMISSING && o->is_flux_wm) {
+    double dt = o->dt;
+    if (Qabs > 0) {
+      if (h->REACH_VOL[1] / dt > Qabs) {
+        h->REACH_VOL[1] = h->REACH_VOL[1] - Qabs * dt;
+      } else {
+        Qabs = Qabs - h->REACH_VOL[1] / dt;
+        h->REACH_VOL[1] = 0.0;
+        if (q_upstream > Qabs) {
+          q_upstream_mod = q_upstream - Qabs;
+        } else {
+          Qabs = Qabs - q_upstream;
+          q_upstream_mod = 0.0;
+          if (Qlat > Qabs) {
+            Qlat = Qlat - Qabs;
+          } else {
+            Qabs = Qabs - Qlat;
+            Qlat = 0.0;
+            h->REACH_WM_FLUX_actual = o->REACH_WM_FLUX[r] - Qabs;
+          }
+        }
+      }
+    } else {
+      Qlat = Qlat - Qabs;
+    }
+  }
+  *q_upstream_out = q_upstream; *q_upstream_mod_out = q_upstream_mod; *Qlat_out = Qlat; *isHW_out = isHW;
+}
+
+/* water_balance.f90:22-112 (non-lake) */
+void orc_comp_reach_wb(orc_t *o, int r, int method, double Qupstream, double Qlat) {
+  orc_hyd *h = &HYD(o, method, r);
+  double dt = o->dt;
+  double dVol = h->REACH_VOL[1] - h->REACH_VOL[0];
+  double Qin = Qupstream * dt;
+  double Qlateral = Qlat * dt;
+  double precip = 0.0;
+  double Qout = -1.0 * h->REACH_Q * dt;
+  double Qtake_actual = -1.0 * h->REACH_WM_FLUX_actual * dt;
+  double evapo = 0.0;
+  h->WB = dVol - (Qin + Qlateral + precip + Qtake_actual + Qout + evapo);
+}
+
+/* irf_route.f90:40-264 */
+int orc_irf_rch(orc_t *o, int r) {
+  orc_hyd *h = &HYD(o, ORC_IRF, r);
+  double q_upstream, q_upstream_mod, Qlat; int isHW;
+  orc_preamble(o, r, ORC_IRF, &q_upstream, &q_upstream_mod, &Qlat, &isHW);
+  /* conv_upsbas_qr, irf_route.f90:210-264; called with q_upstream_mod */
+  double qu = q_upstream_mod;
+  int nTDH = o->uhOff[r + 1] - o->uhOff[r];
+  double *qf = o->QFUTURE_IRF + o->uhOff[r];
+  const double *uh = o->uh + o->uhOff[r];
+  if (o->par[ORC_P_LENGTH][r] > o->min_length_route) {
+    for (int j = 0; j < nTDH; j++) qf[j] = qf[j] + uh[j] * qu;
+    /* `*0.999` is a default-real literal in the reference (irf_route.f90:245) */
+    double lim = (fmax(0.0, h->REACH_VOL[1]) / o->dt + qu) * (double)0.999f;
+    qf[0] = fmin(lim, qf[0]);
+    h->REACH_VOL[1] = h->REACH_VOL[1] - (qf[0] - qu) * o->dt;
+    h->REACH_Q = qf[0] + Qlat;
+    for (int j = 1; j < nTDH; j++) qf[j - 1] = qf[j];   /* eoshift(shift=1) */
+    qf[nTDH - 1] = 0.0;
+  } else {
+    for (int j = 0; j < nTDH; j++) qf[j] = 0.0;
+    qf[0] = qu;
+    h->REACH_Q = qf[0] + Qlat;
+    h->REACH_VOL[0] = 0.0;
+    h->REACH_VOL[1] = 0.0;
+  }
+  orc_comp_reach_wb(o, r, ORC_IRF, q_upstream, Qlat);
+  return 0;
+}
+
+/* main_route.f90:29-268 + route_network 273-409 */
+int orc_step(orc_t *o, double T0, double T1, const double *runoff, const double *wmflux) {
+  int N = o->N, ierr = 0;
+  o->msg[0] = 0;
+  if (o->is_flux_wm && wmflux) { for (int r = 0; r < N; r++) o->REACH_WM_FLUX[r] = wmflux[r]; }
+  else { for (int r = 0; r < N; r++) o->REACH_WM_FLUX[r] = 0.0; }
+  double *reachRunoff = (double *)xcalloc(N, sizeof(double));
+  ierr = basin2reach(o, runoff, reachRunoff);
+  if (ierr) { free(reachRunoff); return ierr; }
+  if (o->doesBasinRoute == 1) {
+    for (int r = 0; r < N; r++) o->BASIN_QI[r] = reachRunoff[r];
+    for (int r = 0; r < N; r++) hru_irf(o, r);
+  } else {
+    for (int r = 0; r < N; r++) { o->BASIN_QR0[r] = o->BASIN_QR1[r]; o->BASIN_QR1[r] = reachRunoff[r]; }
+  }
+  free(reachRunoff);
+  o->w_in = o->w_up = o->w_out = o->n_head = o->n_route = o->n_edges = 0;
+  for (int ix = 0; ix < o->nRoutes; ix++) {
+    int m = o->methods[ix];
+    for (int k = 0; k < N; k++) {
+      int r = o->order[k];
+      switch (m) {
+        case ORC_SUM: ierr = orc_sum_rch(o, r); break;
+        case ORC_IRF: ierr = orc_irf_rch(o, r); break;
+        case ORC_KWT: ierr = orc_kwt_rch(o, r, T0, T1); break;
+        case ORC_KW:  ierr = orc_dw_rch(o, r, ORC_KW); break;
+        case ORC_MC:  ierr = orc_mc_rch(o, r, T0, T1); break;
+        case ORC_DW:  ierr = orc_dw_rch(o, r, ORC_DW); break;
+      }
+      if (ierr) return ierr;
+    }
+  }
+  return 0;
+}
+
+int orc_run(orc_t *o, int nSteps, double t_start, const double *runoff, double *Qout, double *volOut) {
+  int N = o->N;
+  for (int it = 0; it < nSteps; it++) {
+    double T0 = t_start + (double)it * o->dt;
+    double T1 = T0 + o->dt;
+    int ierr = orc_step(o, T0, T1, runoff + (size_t)it * o->H, NULL);
+    if (ierr) return ierr;
+    for (int ix = 0; ix < o->nRoutes; ix++) {
+      size_t base = ((size_t)it * o->nRoutes + ix) * N;
+      if (Qout)   for (int r = 0; r < N; r++) Qout[base + r] = o->route[(size_t)ix * N + r].REACH_Q;
+      if (volOut) for (int r = 0; r < N; r++) volOut[base + r] = o->route[(size_t)ix * N + r].REACH_VOL[1];
+    }
+  }
+  return 0;
+}
+
+int orc_get_flux(const orc_t *o, int route, int which, double *out) {
+  int N = o->N;
+  if (which >= ORC_F_BASIN_QR1) {
+    const double *src = which == ORC_F_BASIN_QR1 ? o->BASIN_QR1 : which == ORC_F_BASIN_QR0 ? o->BASIN_QR0 : o->BASIN_QI;
+    memcpy(out, src, N * sizeof(double));
+    return 0;
+  }
+  if (route < 0 || route >= o->nRoutes) return 1;
+  const orc_hyd *h = o->route + (size_t)route * N;
+  for (int r = 0; r < N; r++) {
+    switch (which) {
+      case ORC_F_Q: out[r] = h[r].REACH_Q; break;
+      case ORC_F_VOL0: out[r] = h[r].REACH_VOL[0]; break;
+      case ORC_F_VOL1: out[r] = h[r].REACH_VOL[1]; break;
+      case ORC_F_INFLOW: out[r] = h[r].REACH_INFLOW; break;
+      case ORC_F_ELE: out[r] = h[r].REACH_ELE; break;
+      case ORC_F_FLOODVOL: out[r] = h[r].FLOOD_VOL[1]; break;
+      case ORC_F_WB: out[r] = h[r].WB; break;
+      default: return 1;
+    }
+  }
+  return 0;
+}
+
+int orc_get_kwt_state(const orc_t *o, int *nw, double *qf, double *ti, double *tr, int *rf) {
+  if (!o->kw) return 1;
+  for (int r = 0; r < o->N; r++) {
+    int n = o->nkw[r] < 0 ? 0 : o->nkw[r];
+    nw[r] = n;
+    for (int k = 0; k < ORC_WCAP; k++) {
+      size_t d = (size_t)r * ORC_WCAP + k;
+      if (k < n) {
+        const orc_fpoint *p = &o->kw[(size_t)r * ORC_KWSTORE + k];
+        qf[d] = p->QF; ti[d] = p->TI; tr[d] = p->TR; rf[d] = p->RF;
+      } else { qf[d] = ti[d] = tr[d] = ORC_REALMISSING; rf[d] = 0; }
+    }
+  }
+  return 0;
+}
+
+int orc_set_kwt_state(orc_t *o, const int *nw, const double *qf, const double *ti, const double *tr, const int *rf) {
+  if (!o->kw) return 1;
+  for (int r = 0; r < o->N; r++) {
+    o->nkw[r] = nw[r] > 0 ? nw[r] : -1;
+    for (int k = 0; k < nw[r]; k++) {
+      size_t s = (size_t)r * ORC_WCAP + k;
+      orc_fpoint *p = &o->kw[(size_t)r * ORC_KWSTORE + k];
+      p->QF = qf[s]; p->TI = ti[s]; p->TR = tr[s]; p->RF = rf[s];
+    }
+  }
+  return 0;
+}
+
+int orc_get_irf_state(const orc_t *o, double *qfuture) {
+  if (!o->QFUTURE_IRF) return 1;
+  memcpy(qfuture, o->QFUTURE_IRF, o->uhOff[o->N] * sizeof(double));
+  return 0;
+}
+
+int orc_get_mol_state(const orc_t *o, int method, double *q) {
+  const double *src = method == ORC_KW ? o->molKW : method == ORC_MC ? o->molMC : method == ORC_DW ? o->molDW : NULL;
+  int n = method == ORC_MC ? ORC_NMOL_MC : ORC_NMOL_KW;
+  if (!src) return 1;
+  memcpy(q, src, (size_t)o->N * n * sizeof(double));
+  return 0;
+}
+
+int orc_get_basin_state(const orc_t *o, double *qfuture) {
+  if (!o->QFUTURE) return 1;
+  memcpy(qfuture, o->QFUTURE, (size_t)o->N * o->ntdhBas * sizeof(double));
+  return 0;
+}
+
+int orc_get_kwt_traffic(const orc_t *o, long long *w_in, long long *w_up, long long *w_out,
+                        long long *n_head, long long *n_route, long long *n_edges) {
+  *w_in = o->w_in; *w_up = o->w_up; *w_out = o->w_out;
+  *n_head = o->n_head; *n_route = o->n_route; *n_edges = o->n_edges;
+  return 0;
+}

@@ -1,0 +1,71 @@
+/* Internal definitions of the CPU oracle (test infrastructure; see mzr_oracle.h). */
+#ifndef ORC_INTERNAL_H
+#define ORC_INTERNAL_H
+#include "mzr_oracle.h"
+
+#define ORC_REALMISSING (-9999.0)   /* public_var.f90:45 */
+#define ORC_NMOL_KW 20              /* init_model_data.f90:386-394 */
+#define ORC_NMOL_MC 2
+#define ORC_NMOL_DW 20
+#define ORC_KWSTORE 40              /* storage per reach for KWAVE (size <= MAXQPAR+1) */
+
+/* dataTypes.f90:291-302 (QM is always -9999 on this path and is not stored) */
+typedef struct { double QF, TI, TR; int RF; } orc_fpoint;
+
+/* dataTypes.f90:346-358, one per (reach, active method) */
+typedef struct {
+  double REACH_ELE, REACH_INFLOW, FLOOD_VOL[2], REACH_Q, REACH_VOL[2], REACH_WM_FLUX_actual, WB;
+} orc_hyd;
+
+struct orc {
+  int N, H;
+  /* topology (0-based internally) */
+  int *down;            /* [N] downstream index or -1 */
+  int *upOff, *upIdx;   /* CSR of immediate upstreams (UREACHI order) */
+  int *upGood;          /* per edge goodBas flag */
+  int *nGood;           /* [N] count(goodBas) */
+  int *hruOff, *hruIdx; double *hruW;
+  int *order;           /* [N] processing order, upstream -> downstream */
+  double *par[ORC_NPAR];
+  /* config */
+  double dt, min_length_route, runoffMin;
+  int nRoutes, methods[6], idx[6];   /* idx[method] = slot or -1 */
+  int doesBasinRoute, hw_drain_point, is_flux_wm;
+  /* unit hydrographs */
+  int ntdhBas; double *fracFuture; int *uhOff; double *uh;
+  /* fluxes / state */
+  double *BASIN_QI, *BASIN_QR0, *BASIN_QR1, *REACH_WM_FLUX;
+  double *QFUTURE;      /* [N][ntdhBas] hillslope */
+  orc_hyd *route;       /* [nRoutes][N] */
+  double *QFUTURE_IRF;  /* concatenated per uhOff */
+  orc_fpoint *kw; int *nkw;   /* [N][ORC_KWSTORE]; nkw = -1 unallocated */
+  double *molKW, *molMC, *molDW;
+  /* KWT traffic statistics of the last step */
+  long long w_in, w_up, w_out, n_head, n_route, n_edges;
+  char msg[512];
+};
+
+#define HYD(o, m, r) ((o)->route[(size_t)(o)->idx[m] * (o)->N + (r)])
+
+/* hydraulic.f90 */
+double orc_Btop(double yin, double b, double zc, double zf, double bankDepth);
+double orc_Pwet(double yin, double b, double zc, double zf, double bankDepth);
+double orc_flow_area(double yin, double b, double zc, double zf, double bankDepth);
+double orc_water_height(double flowArea, double b, double zc, double zf, double bankDepth);
+double orc_flow_depth(double Qin, double b, double zc, double S, double n, double zf, double bankDepth);
+double orc_celerity(double Qin, double y, double b, double zc, double S, double n, double zf, double bankDepth);
+double orc_diffusivity(double Qin, double y, double b, double zc, double S, double n, double zf, double bankDepth);
+/* advection_diffusion.f90 */
+void orc_solve_ade(double L, int nMol, double dt_local, double FluxUpstream, double ck, double dk,
+                   const double *FluxPrev, double *FluxSolved);
+
+int orc_sum_rch(orc_t *o, int r);
+int orc_irf_rch(orc_t *o, int r);
+int orc_mc_rch(orc_t *o, int r, double T0, double T1);
+int orc_dw_rch(orc_t *o, int r, int method);   /* ORC_DW or ORC_KW */
+int orc_kwt_rch(orc_t *o, int r, double T0, double T1);
+/* shared preamble of irf/mc/dw/kw (irf_route.f90:81-142) */
+void orc_preamble(orc_t *o, int r, int method, double *q_upstream, double *q_upstream_mod,
+                  double *Qlat, int *isHW);
+void orc_comp_reach_wb(orc_t *o, int r, int method, double Qupstream, double Qlat);
+#endif

@@ -1,0 +1,135 @@
+"""ctypes wrapper of oracle/libmzr_oracle.so (the plain-C restatement; see mzr_oracle.h).
+
+TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libmzr_oracle.so")
+
+SUM, IRF, KWT, KW, MC, DW = 0, 1, 2, 3, 4, 5
+F_Q, F_VOL0, F_VOL1, F_INFLOW, F_ELE, F_FLOODVOL, F_WB, F_BASIN_QR1, F_BASIN_QR0, F_BASIN_QI = range(10)
+WCAP = 32
+NMOL = {KW: 20, MC: 2, DW: 20}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "libmzr_oracle.so"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+        dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, dp, dp]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_config.argtypes = [C.c_void_p, C.c_double, C.c_int, ip, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+        L.orc_set_uh.argtypes = [C.c_void_p, C.c_int, dp, C.c_void_p, C.c_void_p]
+        L.orc_step.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, C.c_void_p]
+        L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_get_flux.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+        L.orc_get_kwt_state.argtypes = [C.c_void_p, ip, dp, dp, dp, ip]
+        L.orc_set_kwt_state.argtypes = [C.c_void_p, ip, dp, dp, dp, ip]
+        L.orc_get_irf_state.argtypes = [C.c_void_p, dp]
+        L.orc_get_mol_state.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_get_basin_state.argtypes = [C.c_void_p, dp]
+        LL = C.POINTER(C.c_longlong)
+        L.orc_get_kwt_traffic.argtypes = [C.c_void_p, LL, LL, LL, LL, LL, LL]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """One routing domain on the CPU oracle."""
+
+    def __init__(self, net, dt, methods, frac_future, uh_offset=None, uh=None, does_basin_route=1,
+                 hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, is_flux_wm=0):
+        L = lib()
+        self.net, self.N, self.H = net, net.N, net.H
+        self.methods = list(methods)
+        self.h = L.orc_create(net.N, net.H, net.downIndex, net.upOffset, net.upIndex, net.upGood,
+                              net.hruOffset, net.hruIndex, net.hruWeight, net.param_matrix())
+        m = np.asarray(self.methods, dtype=np.int32)
+        rc = L.orc_config(self.h, float(dt), len(m), m, does_basin_route, hw_drain_point,
+                          float(min_length_route), float(runoff_min), int(is_flux_wm))
+        if rc:
+            raise RuntimeError(self.error())
+        self.ntdh = len(frac_future)
+        ff = np.ascontiguousarray(frac_future, dtype=np.float64)
+        if uh_offset is not None:
+            self.uh_offset = np.ascontiguousarray(uh_offset, dtype=np.int32)
+            self.uh = np.ascontiguousarray(uh, dtype=np.float64)
+            L.orc_set_uh(self.h, self.ntdh, ff, self.uh_offset.ctypes.data, self.uh.ctypes.data)
+        else:
+            self.uh_offset = None
+            L.orc_set_uh(self.h, self.ntdh, ff, None, None)
+        self.dt = float(dt)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_destroy(self.h)
+            self.h = None
+
+    def error(self):
+        return lib().orc_last_error(self.h).decode()
+
+    def step(self, T0, T1, runoff):
+        return lib().orc_step(self.h, float(T0), float(T1), np.ascontiguousarray(runoff, dtype=np.float64), None)
+
+    def run(self, runoff, t_start=0.0, want_vol=False):
+        runoff = np.ascontiguousarray(runoff, dtype=np.float64)
+        n = runoff.shape[0]
+        Q = np.zeros((n, len(self.methods), self.N))
+        V = np.zeros((n, len(self.methods), self.N)) if want_vol else None
+        rc = lib().orc_run(self.h, n, float(t_start), runoff, Q.ctypes.data, V.ctypes.data if want_vol else None)
+        if rc:
+            raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
+        return (Q, V) if want_vol else Q
+
+    def flux(self, route, which):
+        out = np.zeros(self.N)
+        lib().orc_get_flux(self.h, route, which, out)
+        return out
+
+    def kwt_state(self):
+        nw = np.zeros(self.N, np.int32)
+        qf = np.zeros((self.N, WCAP)); ti = np.zeros((self.N, WCAP)); tr = np.zeros((self.N, WCAP))
+        rf = np.zeros((self.N, WCAP), np.int32)
+        lib().orc_get_kwt_state(self.h, nw, qf, ti, tr, rf)
+        return nw, qf, ti, tr, rf
+
+    def irf_state(self):
+        out = np.zeros(int(self.uh_offset[-1]))
+        lib().orc_get_irf_state(self.h, out)
+        return out
+
+    def mol_state(self, method):
+        out = np.zeros((self.N, NMOL[method]))
+        lib().orc_get_mol_state(self.h, method, out)
+        return out
+
+    def basin_state(self):
+        out = np.zeros((self.N, self.ntdh))
+        lib().orc_get_basin_state(self.h, out)
+        return out
+
+    def kwt_traffic(self):
+        v = [C.c_longlong(0) for _ in range(6)]
+        lib().orc_get_kwt_traffic(self.h, *[C.byref(x) for x in v])
+        return dict(zip(("w_in", "w_up", "w_out", "n_head", "n_route", "n_edges"), [x.value for x in v]))

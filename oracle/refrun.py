@@ -1,0 +1,158 @@
+"""Run the reference-solver harness oracle/_ref/ref_route (unmodified reference Fortran solvers +
+shim modules, see oracle/README.md) on a case and parse its binary dump.
+
+TEST INFRASTRUCTURE ONLY.  Used (a) in this container to pin the C restatement and to generate
+the committed fixtures in tests/golden/, (b) by bench.py's cpu_baseline leg ("kind": "reference").
+Nothing here reads /root/reference at run time; only oracle/build_ref.sh does, at build time.
+"""
+from __future__ import annotations
+
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXE = os.path.join(HERE, "_ref", "ref_route")
+MAGIC_IN = 0x4D5A5243 - 0  # placeholder, real values below
+MAGIC_IN = 1297765955
+MAGIC_OUT = 1297765967
+WCAP = 32
+NMOL = {3: 20, 4: 2, 5: 20}
+
+
+def available() -> bool:
+    return os.path.exists(EXE) and os.access(EXE, os.X_OK)
+
+
+def build():
+    subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
+
+
+def serial_schedule(net):
+    """One order, one branch, all reaches upstream->downstream (a valid serial schedule)."""
+    order = net.topo_order() + 1
+    return np.array([0, 1], np.int32), np.array([0, net.N], np.int32), order.astype(np.int32)
+
+
+def level_schedule(net):
+    """orders = hop-distance levels, every reach its own branch: exposes all parallelism the
+    reference's OpenMP loop (main_route.f90:356-405) can use on this network."""
+    from mizuroute_amd.synthetic import hops_to_outlet
+    dist = hops_to_outlet(net.downIndex.astype(np.int64) - 1)
+    order = np.argsort(-dist, kind="stable")
+    levels = dist[order]
+    nlev = int(dist.max()) + 1
+    counts = np.bincount(int(dist.max()) - levels, minlength=nlev)
+    orderOffset = np.zeros(nlev + 1, np.int32)
+    orderOffset[1:] = np.cumsum(counts)
+    branchOffset = np.arange(net.N + 1, dtype=np.int32)
+    return orderOffset, branchOffset, (order + 1).astype(np.int32)
+
+
+def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_point=2,
+               min_length_route=0.0, runoff_min=0.0, fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0,
+               t_start=0.0, uh=None, schedule=None, dump_every=1):
+    """uh: None -> the harness calls the reference's basinUH/make_uh; else (frac, uhOffset, uh)."""
+    runoff = np.ascontiguousarray(runoff, dtype=np.float64)
+    n_steps = runoff.shape[0]
+    orderOffset, branchOffset, seg = schedule if schedule is not None else serial_schedule(net)
+    m = list(methods) + [-1] * (6 - len(methods))
+    with open(path, "wb") as f:
+        f.write(struct.pack("<2i", MAGIC_IN, 1))
+        ints = [net.N, net.H, n_steps, len(methods)] + m + [does_basin_route, hw_drain_point,
+                int(net.upOffset[-1]), int(net.hruOffset[-1]), len(orderOffset) - 1, len(branchOffset) - 1,
+                1 if uh is not None else 0, len(uh[0]) if uh is not None else 0,
+                int(uh[1][-1]) if uh is not None else 0, int(dump_every)]
+        f.write(struct.pack(f"<{len(ints)}i", *ints))
+        f.write(struct.pack("<8d", dt, min_length_route, runoff_min, fshape, tscale, velo, diff, t_start))
+        for a in (net.downIndex, net.reachId, net.upOffset, net.upIndex, net.upGood, net.hruOffset, net.hruIndex):
+            f.write(np.ascontiguousarray(a, dtype="<i4").tobytes())
+        f.write(np.ascontiguousarray(net.hruWeight, dtype="<f8").tobytes())
+        # par(N,11) column-major == [11][N] row-major
+        f.write(np.ascontiguousarray(net.param_matrix(), dtype="<f8").tobytes())
+        for a in (orderOffset, branchOffset, seg):
+            f.write(np.ascontiguousarray(a, dtype="<i4").tobytes())
+        if uh is not None:
+            f.write(np.ascontiguousarray(uh[0], dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(uh[1], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(uh[2], dtype="<f8").tobytes())
+        # runoff(H, nSteps) column-major == [nSteps][H] row-major
+        f.write(runoff.astype("<f8").tobytes())
+
+
+class _Reader:
+    def __init__(self, buf):
+        self.b, self.p = buf, 0
+
+    def i(self, n=1):
+        v = np.frombuffer(self.b, "<i4", n, self.p); self.p += 4 * n
+        return v if n > 1 else int(v[0])
+
+    def d(self, n=1):
+        v = np.frombuffer(self.b, "<f8", n, self.p); self.p += 8 * n
+        return v.copy() if n > 1 else float(v[0])
+
+
+def read_output(path, methods):
+    r = _Reader(open(path, "rb").read())
+    magic, N, n_steps, n_routes, ntdh_bas, dump_every = r.i(6)
+    assert magic == MAGIC_OUT
+    out = dict(N=N, n_steps=n_steps, steps=[], Q=[], VOL=[], QR1=[])
+    while True:
+        it = r.i()
+        if it == -1:
+            break
+        q = r.d(N * n_routes).reshape(n_routes, N)
+        v = r.d(N * n_routes).reshape(n_routes, N)
+        qr1 = r.d(N)
+        out["steps"].append(it); out["Q"].append(q); out["VOL"].append(v); out["QR1"].append(qr1)
+    out["ierr"], out["ierr_step"] = r.i(), r.i()
+    out["wall"] = r.d()
+    out["Q"] = np.array(out["Q"]); out["VOL"] = np.array(out["VOL"]); out["QR1"] = np.array(out["QR1"])
+    out["frac_future"] = r.d(ntdh_bas) if ntdh_bas > 1 else np.array([r.d()])
+    out["uh_offset"] = r.i(N + 1).astype(np.int32)
+    out["uh"] = r.d(int(out["uh_offset"][-1]))
+    out["basin_qfuture"] = r.d(N * ntdh_bas).reshape(N, ntdh_bas)
+    out["state"] = {}
+    for ix in range(n_routes):
+        m = r.i()
+        st = {}
+        flux = r.d(N * 7).reshape(N, 7)
+        for k, name in enumerate(("Q", "VOL0", "VOL1", "INFLOW", "ELE", "FLOODVOL", "WB")):
+            st[name] = flux[:, k].copy()
+        if m == 1:
+            st["irf_qfuture"] = r.d(int(out["uh_offset"][-1]))
+        elif m == 2:
+            nw = np.zeros(N, np.int32); w = np.zeros((N, 4, WCAP))
+            for i in range(N):
+                nw[i] = r.i()
+                w[i] = r.d(4 * WCAP).reshape(4, WCAP)
+            st["nw"] = nw; st["qf"] = w[:, 0]; st["ti"] = w[:, 1]; st["tr"] = w[:, 2]; st["rf"] = w[:, 3].astype(np.int32)
+        elif m in NMOL:
+            st["mol"] = r.d(N * NMOL[m]).reshape(N, NMOL[m])
+        out["state"][m] = st
+    return out
+
+
+def run_case(net, runoff, dt, methods, nthreads=1, keep=None, **kw):
+    """Write a case, run the reference harness, return the parsed dump (+ 'stdout')."""
+    if not available():
+        raise FileNotFoundError(EXE)
+    tmpdir = keep or tempfile.mkdtemp(prefix="mzrref_")
+    case, outp = os.path.join(tmpdir, "case.bin"), os.path.join(tmpdir, "out.bin")
+    write_case(case, net, runoff, dt, methods, **kw)
+    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    res = subprocess.run([EXE, case, outp, str(nthreads)], capture_output=True, text=True, env=env)
+    if res.returncode != 0:
+        raise RuntimeError(f"ref_route failed rc={res.returncode}: {res.stdout}\n{res.stderr}")
+    out = read_output(outp, methods)
+    out["stdout"] = res.stdout
+    mt = re.search(r"reach_steps_per_s=\s*([0-9.E+\-]+)", res.stdout)
+    out["reach_steps_per_s"] = float(mt.group(1)) if mt else None
+    if keep is None:
+        os.remove(case); os.remove(outp); os.rmdir(tmpdir)
+    return out
