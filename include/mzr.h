@@ -1,0 +1,118 @@
+/*
+ * mzr.h -- C-ABI of the MI355X-native river-routing hot path (libmzr_hip.so).
+ *
+ * Drop-in boundary for mizuRoute's per-timestep sweep.  The reference's plugin point is the
+ * per-reach `base_route_rch%route` (route/build/src/base_route.f90:29-61) called from
+ * `route_network` (main_route.f90:273-409); that granularity is useless for a GPU, so the cut is
+ * one level up: one call per (domain, time window), replacing `main_route`
+ * (main_route.f90:29-268) as called from `mpi_route` (mpi_process.f90:1217,1294).
+ *
+ * Conventions shared with the reference:
+ *   - every real is FP64 (nrtype.f90:8), every index int32, reach/HRU indices are 1-based,
+ *     a downstream index <= 0 marks an outlet (NETOPO%DREACHI);
+ *   - per-reach arrays are in the CALLER's reach order (the order of NETOPO_in / RCHFLX_out);
+ *     the library keeps its own level-sorted device layout and permutes at the boundary;
+ *   - every entry point returns the reference's integer `ierr` (0 = ok; 20/30/40/60/81 keep the
+ *     meaning they have in the Fortran sources) and mzr_last_error() returns the message chain.
+ *
+ * All pointers are plain host pointers unless the name ends in `_dev`; nothing crosses the
+ * boundary but pointers, sizes and scalars (bindable with ISO_C_BINDING, see
+ * mizuroute_amd/fortran/mzr_c.f90 and INTEGRATION.md).  A handle is bound to one HIP device and is
+ * not thread-safe (like the reference: one host thread per rank enters main_route).
+ */
+#ifndef MZR_H
+#define MZR_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mzr_domain *mzr_handle;
+
+/* routing method ids == digits of <route_opt>, public_var.f90:73-80 */
+enum { MZR_SUM = 0, MZR_IRF = 1, MZR_KWT = 2, MZR_KW = 3, MZR_MC = 4, MZR_DW = 5 };
+
+/* flux selectors (fields of dataTypes.f90:346-377 STRFLX / hydraulic) */
+enum { MZR_F_Q = 0, MZR_F_VOL0 = 1, MZR_F_VOL1 = 2, MZR_F_INFLOW = 3, MZR_F_ELE = 4,
+       MZR_F_FLOODVOL = 5, MZR_F_WB = 6, MZR_F_BASIN_QR1 = 7, MZR_F_BASIN_QR0 = 8, MZR_F_BASIN_QI = 9 };
+
+#define MZR_MAXQPAR 20     /* public_var.f90:36 */
+#define MZR_WCAP    32     /* padded wave capacity of mzr_get/set_kwt_state rows */
+#define MZR_MAX_UPSTREAM 8 /* immediate upstream reaches per reach supported by the KWT merge */
+
+/* Mirrors the public_var / globalData knobs the hot path reads (read_control.f90:118-600). */
+typedef struct mzr_config {
+  double dt;                  /* <dt_qsim> simulation time step [s]                        */
+  int    nRoutes;             /* number of active methods                                  */
+  int    routeMethods[6];     /* their ids, in <route_opt> order (flux slot = position)    */
+  int    doesBasinRoute;      /* 1: hillslope UH delay (basinUH.f90), 0: runoff is routed  */
+  int    hw_drain_point;      /* 1 top_reach, 2 bottom_reach (default)                     */
+  double min_length_route;    /* pass-through below this reach length [m]                  */
+  double runoffMin;           /* public_var.f90:145                                        */
+  double negRunoffTol;        /* public_var.f90:31 (-1e-3)                                 */
+  double time_conv, length_conv;  /* <units_qsim> conversion to m/s (read_control.f90:458-469) */
+  int    maxWindow;           /* largest number of time steps per mzr_run call             */
+  int    device;              /* HIP device ordinal                                        */
+} mzr_config;
+
+void mzr_default_config(mzr_config *cfg);
+
+/* replaces init_route_method (init_model_data.f90:753-805) */
+int mzr_create(const mzr_config *cfg, mzr_handle *out);
+int mzr_destroy(mzr_handle h);
+int mzr_last_error(mzr_handle h, char *buf, int len);
+
+/* replaces put_data_struct's topology part (process_ntopo.f90:354-504): NETOPO%DREACHI, UREACHI,
+   goodBas, HRUIX, HRUWGT, REACHID.  upGood may be NULL (all .true.). */
+int mzr_set_network(mzr_handle h, int nRch, int nHru, const int *downIndex, const int *upOffset,
+                    const int *upIndex, const int *upGood, const int *hruOffset, const int *hruIndex,
+                    const double *hruWeight, const int *reachId);
+/* RPARAM fields by name: R_SLOPE R_MAN_N R_WIDTH R_DEPTH RLENGTH R_STORAGE SIDE_SLOPE FLDP_SLOPE
+   BASAREA TOTAREA MINFLOW (dataTypes.f90:183-195) */
+int mzr_set_param(mzr_handle h, const char *name, const double *values);
+/* NETOPO%UH per reach (process_param.f90:99-262 make_uh), CSR by reach */
+int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh);
+/* FRAC_FUTURE (process_param.f90:13-92 basinUH) */
+int mzr_set_frac_future(mzr_handle h, int n, const double *frac);
+/* cold start (init_model_data.f90:399-505); must follow the setters above */
+int mzr_init_state(mzr_handle h);
+
+/* One time step == one main_route call (main_route.f90:29): T0,T1 = TSEC(1:2). runoff[nHru]. */
+int mzr_step(mzr_handle h, double T0, double T1, const double *runoff);
+/* nSteps <= maxWindow steps in one call, time-skewed over the level schedule.
+   runoff[nSteps][nHru]; step k covers [t_start + k*dt, t_start + (k+1)*dt]. */
+int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff);
+/* same, runoff already resident in device memory (zero copy); launches are asynchronous on the
+   handle's stream, errors surface at the next mzr_sync / mzr_get_* call */
+int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev);
+int mzr_sync(mzr_handle h);
+
+/* latest value of a flux field, caller's reach order, out[nRch] */
+int mzr_get_flux(mzr_handle h, int method, int which, double *out);
+/* discharge of every step of the last window: out[nSteps][nRch] */
+int mzr_get_window_q(mzr_handle h, int method, double *out);
+/* device-side history accumulation (histVars_data.f90:154-246): mean REACH_Q since the last reset */
+int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset);
+
+/* state in the restart-file layout (write_restart_pio.f90:1039-1290) */
+int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry, double *texit, int *routed);
+int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, const double *tentry,
+                      const double *texit, const int *routed);
+int mzr_get_irf_state(mzr_handle h, double *qfuture /* CSR by uhOffset */);
+int mzr_get_mol_state(mzr_handle h, int method, double *q /* [nRch][nMolecule] */);
+int mzr_get_basin_state(mzr_handle h, double *qfuture /* [nRch][n] */);
+
+/* schedule / measurement introspection */
+int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
+/* kernel-time accounting of the routing sweep since the last reset:
+   launches and summed device time [ms] (HIP events on the handle's stream) per method */
+int mzr_set_profiling(mzr_handle h, int on);
+int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset);
+/* particle traffic counters of the KWT sweep since the last reset (for the roofline model) */
+int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long long *w_out,
+                        long long *n_head, long long *n_route, long long *n_edges, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

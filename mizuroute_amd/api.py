@@ -1,0 +1,247 @@
+"""Python host side above the C-ABI of libmzr_hip.so (include/mzr.h).
+
+Mirrors the call sequence of the reference's driver around its hot path:
+  init_route_method / put_data_struct / init_state_data -> RoutingDomain(...)
+  main_route(basinRunoff, ..., RCHFLX, RCHSTA)           -> RoutingDomain.step(T0, T1, runoff)
+  (new) a whole window of steps, time-skewed on device   -> RoutingDomain.run(runoff[nSteps, H])
+Error behaviour follows the reference: an integer ierr plus a message chain
+(main_route.f90:93,159); here a non-zero ierr raises MzrError(ierr, message).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+SUM, IRF, KWT, KW, MC, DW = 0, 1, 2, 3, 4, 5
+F_Q, F_VOL0, F_VOL1, F_INFLOW, F_ELE, F_FLOODVOL, F_WB, F_BASIN_QR1, F_BASIN_QR0, F_BASIN_QI = range(10)
+WCAP = 32
+NMOL = {KW: 20, MC: 2, DW: 20}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libmzr_hip.so")
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile the HIP kernels + C-ABI for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    subprocess.run(cmd, check=True, stdout=None if verbose else subprocess.DEVNULL)
+    return lib_path()
+
+
+class MzrConfig(C.Structure):
+    _fields_ = [("dt", C.c_double), ("nRoutes", C.c_int), ("routeMethods", C.c_int * 6),
+                ("doesBasinRoute", C.c_int), ("hw_drain_point", C.c_int),
+                ("min_length_route", C.c_double), ("runoffMin", C.c_double), ("negRunoffTol", C.c_double),
+                ("time_conv", C.c_double), ("length_conv", C.c_double), ("maxWindow", C.c_int), ("device", C.c_int)]
+
+
+_lib = None
+
+EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", "mzr_set_network",
+           "mzr_set_param", "mzr_set_uh", "mzr_set_frac_future", "mzr_init_state", "mzr_step", "mzr_run",
+           "mzr_run_dev", "mzr_sync", "mzr_get_flux", "mzr_get_window_q", "mzr_get_mean_q",
+           "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
+           "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
+           "mzr_get_kwt_traffic"]
+
+
+def load_library():
+    """dlopen libmzr_hip.so; fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(mizuroute_amd has no CPU fallback)")
+    L = C.CDLL(path)
+    ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+    vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+    L.mzr_default_config.argtypes = [C.POINTER(MzrConfig)]
+    L.mzr_default_config.restype = None
+    L.mzr_create.argtypes = [C.POINTER(MzrConfig), C.POINTER(vp)]
+    L.mzr_destroy.argtypes = [vp]
+    L.mzr_last_error.argtypes = [vp, C.c_char_p, ci]
+    L.mzr_set_network.argtypes = [vp, ci, ci, ip, ip, ip, vp, ip, ip, dp, vp]
+    L.mzr_set_param.argtypes = [vp, C.c_char_p, dp]
+    L.mzr_set_uh.argtypes = [vp, ip, dp]
+    L.mzr_set_frac_future.argtypes = [vp, ci, dp]
+    L.mzr_init_state.argtypes = [vp]
+    L.mzr_step.argtypes = [vp, cd, cd, dp]
+    L.mzr_run.argtypes = [vp, ci, cd, dp]
+    L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
+    L.mzr_sync.argtypes = [vp]
+    L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
+    L.mzr_get_window_q.argtypes = [vp, ci, dp]
+    L.mzr_get_mean_q.argtypes = [vp, ci, dp, ci]
+    L.mzr_get_kwt_state.argtypes = [vp, ip, dp, dp, dp, ip]
+    L.mzr_set_kwt_state.argtypes = [vp, ip, dp, dp, dp, ip]
+    L.mzr_get_irf_state.argtypes = [vp, dp]
+    L.mzr_get_mol_state.argtypes = [vp, ci, dp]
+    L.mzr_get_basin_state.argtypes = [vp, dp]
+    L.mzr_get_schedule.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.mzr_set_profiling.argtypes = [vp, ci]
+    LL = C.POINTER(C.c_longlong)
+    L.mzr_get_timing.argtypes = [vp, ci, LL, C.POINTER(cd), LL, ci]
+    L.mzr_get_kwt_traffic.argtypes = [vp, LL, LL, LL, LL, LL, LL, ci]
+    _lib = L
+    return L
+
+
+class MzrError(RuntimeError):
+    def __init__(self, ierr, message):
+        super().__init__(f"ierr={ierr}: {message}")
+        self.ierr, self.message = ierr, message
+
+
+class RoutingDomain:
+    """One routing domain (a whole network, or one sub-basin partition) resident on one GPU."""
+
+    def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
+                 hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0):
+        L = load_library()
+        self.L, self.net, self.N, self.H = L, net, net.N, net.H
+        self.methods = list(methods)
+        self.dt = float(dt)
+        cfg = MzrConfig()
+        L.mzr_default_config(C.byref(cfg))
+        cfg.dt = float(dt); cfg.nRoutes = len(self.methods)
+        for i, m in enumerate(self.methods):
+            cfg.routeMethods[i] = int(m)
+        cfg.doesBasinRoute = int(does_basin_route); cfg.hw_drain_point = int(hw_drain_point)
+        cfg.min_length_route = float(min_length_route); cfg.runoffMin = float(runoff_min)
+        cfg.maxWindow = int(max_window); cfg.device = int(device)
+        self.max_window = int(max_window)
+        self.h = C.c_void_p()
+        self._check(L.mzr_create(C.byref(cfg), C.byref(self.h)))
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self._keep = [i32(net.upGood), i32(net.reachId)]
+        self._check(L.mzr_set_network(self.h, net.N, net.H, i32(net.downIndex), i32(net.upOffset), i32(net.upIndex),
+                                      self._keep[0].ctypes.data, i32(net.hruOffset), i32(net.hruIndex),
+                                      f64(net.hruWeight), self._keep[1].ctypes.data))
+        for name in net.PARAM_ORDER:
+            self._check(L.mzr_set_param(self.h, name.encode(), f64(net.params[name])))
+        if frac_future is not None:
+            ff = f64(frac_future)
+            self.ntdh_bas = len(ff)
+            self._check(L.mzr_set_frac_future(self.h, len(ff), ff))
+        if uh_offset is not None:
+            self.uh_offset = i32(uh_offset)
+            self._check(L.mzr_set_uh(self.h, self.uh_offset, f64(uh)))
+        self._check(L.mzr_init_state(self.h))
+
+    # ---- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            buf = C.create_string_buffer(1024)
+            self.L.mzr_last_error(self.h, buf, 1024)
+            raise MzrError(rc, buf.value.decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.mzr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the hot path
+    def step(self, T0, T1, runoff):
+        """One main_route call: TSEC(1:2) = (T0, T1), runoff[nHru] in m/s."""
+        self._check(self.L.mzr_step(self.h, float(T0), float(T1), np.ascontiguousarray(runoff, dtype=np.float64)))
+
+    def run(self, runoff, t_start=0.0):
+        """runoff[nSteps, nHru]; returns REACH_Q[nSteps, nRoutes, nRch] (caller's reach order)."""
+        runoff = np.ascontiguousarray(runoff, dtype=np.float64)
+        n = runoff.shape[0]
+        out = np.zeros((n, len(self.methods), self.N))
+        done = 0
+        while done < n:
+            w = min(self.max_window, n - done)
+            self._check(self.L.mzr_run(self.h, w, float(t_start) + done * self.dt, runoff[done:done + w]))
+            for ix, m in enumerate(self.methods):
+                buf = np.zeros((w, self.N))
+                self._check(self.L.mzr_get_window_q(self.h, m, buf))
+                out[done:done + w, ix, :] = buf
+            done += w
+        return out
+
+    def run_device(self, n_steps, t_start, runoff_dev_ptr):
+        """Asynchronous window on device-resident runoff [n_steps, nHru] (e.g. a torch tensor's data_ptr())."""
+        self._check(self.L.mzr_run_dev(self.h, int(n_steps), float(t_start), C.c_void_p(int(runoff_dev_ptr))))
+
+    def sync(self):
+        self._check(self.L.mzr_sync(self.h))
+
+    # ---- results / state
+    def flux(self, method, which=F_Q):
+        out = np.zeros(self.N)
+        self._check(self.L.mzr_get_flux(self.h, method, which, out))
+        return out
+
+    def window_q(self, method, n_steps):
+        out = np.zeros((n_steps, self.N))
+        self._check(self.L.mzr_get_window_q(self.h, method, out))
+        return out
+
+    def mean_q(self, method, reset=False):
+        out = np.zeros(self.N)
+        self._check(self.L.mzr_get_mean_q(self.h, method, out, int(reset)))
+        return out
+
+    def kwt_state(self):
+        nw = np.zeros(self.N, np.int32)
+        qf = np.zeros((self.N, WCAP)); ti = np.zeros((self.N, WCAP)); tr = np.zeros((self.N, WCAP))
+        rf = np.zeros((self.N, WCAP), np.int32)
+        self._check(self.L.mzr_get_kwt_state(self.h, nw, qf, ti, tr, rf))
+        return nw, qf, ti, tr, rf
+
+    def set_kwt_state(self, nw, qf, ti, tr, rf):
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        self._check(self.L.mzr_set_kwt_state(self.h, c(nw, np.int32), c(qf, np.float64), c(ti, np.float64),
+                                             c(tr, np.float64), c(rf, np.int32)))
+
+    def irf_state(self):
+        out = np.zeros(int(self.uh_offset[-1]))
+        self._check(self.L.mzr_get_irf_state(self.h, out))
+        return out
+
+    def mol_state(self, method):
+        out = np.zeros((self.N, NMOL[method]))
+        self._check(self.L.mzr_get_mol_state(self.h, method, out))
+        return out
+
+    def basin_state(self):
+        out = np.zeros((self.N, self.ntdh_bas))
+        self._check(self.L.mzr_get_basin_state(self.h, out))
+        return out
+
+    # ---- schedule / measurement
+    def schedule(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._check(self.L.mzr_get_schedule(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_profiling(self, on):
+        self._check(self.L.mzr_set_profiling(self.h, int(bool(on))))
+
+    def timing(self, method, reset=False):
+        n, ms, rs = C.c_longlong(0), C.c_double(0), C.c_longlong(0)
+        self._check(self.L.mzr_get_timing(self.h, method, C.byref(n), C.byref(ms), C.byref(rs), int(reset)))
+        return dict(launches=n.value, kernel_ms=ms.value, reach_steps=rs.value)
+
+    def kwt_traffic(self, reset=False):
+        v = [C.c_longlong(0) for _ in range(6)]
+        self._check(self.L.mzr_get_kwt_traffic(self.h, *[C.byref(x) for x in v], int(reset)))
+        return dict(zip(("w_in", "w_up", "w_out", "n_head", "n_route", "n_edges"), [x.value for x in v]))

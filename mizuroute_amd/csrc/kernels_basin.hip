@@ -1,0 +1,75 @@
+// HRU -> reach mapping and hillslope unit-hydrograph delay for a whole time window (gfx950).
+//
+// Replaces, for W time steps at once:
+//   basin2reach                      route/build/src/process_remap.f90:319-422
+//   IRF_route_basin/hru_irf/irf_conv route/build/src/basinUH.f90:19-178
+//
+// The reference keeps a per-reach shift register QFUTURE(1:n) and, every step, adds
+// FRAC_FUTURE(j)*BASIN_QI to slot j, emits slot 1 and shifts.  Neither step depends on the river
+// network, so the whole window is computed before the routing sweep, fully parallel over
+// (reach, step).  The value emitted at step t entered the register at slot t-tau+1 at step tau, so
+//   BASIN_QR(1)(t) = (((S0(t) + F(t)*QI(0)) + F(t-1)*QI(1)) + ... ) + F(0)*QI(t)     t <  n
+//                  = (((F(n-1)*QI(t-n+1)) + F(n-2)*QI(t-n+2)) + ... ) + F(0)*QI(t)   t >= n
+// with the additions in exactly the order the shift register performs them (oldest first), hence
+// bit-identical to the reference; the register contents after the window follow from the same
+// fold for the virtual output times W..W+n-2.
+#include "mzr_device.h"
+
+// grid: x over reaches, y over steps of the window
+__global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (r >= d.N) return;
+  const double *ro = d.runoff + (size_t)t * d.H;
+  const int e0 = d.hruOff[r], e1 = d.hruOff[r + 1];
+  double rr;
+  if (e1 > e0) {
+    double acc = 0.0;
+    for (int e = e0; e < e1; ++e) {
+      const double v = ro[d.hruIdx[e]];
+      if (v < d.negRunoffTol) mzr_raise(d, 20, r, t, 1);   // process_remap.f90:397-402
+      acc = acc + d.hruW[e] * v * d.time_conv * d.length_conv;
+    }
+    if (acc < d.runoffMin) acc = d.runoffMin;
+    rr = acc * d.basarea[r];
+  } else {
+    rr = d.runoffMin;
+  }
+  if (d.doesBasinRoute == 1) d.qi[(size_t)t * d.N + r] = rr;
+  else d.qlat[(size_t)(t + 1) * d.N + r] = rr;            // main_route.f90:223-226
+}
+
+// grid: x over reaches, y over steps: BASIN_QR(1) of step t
+__global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (r >= d.N) return;
+  const int n = d.ntdhBas, N = d.N;
+  double acc = (t < n) ? d.basS0[(size_t)t * N + r] : 0.0;
+  const int tau0 = t - n + 1 > 0 ? t - n + 1 : 0;
+  for (int tau = tau0; tau <= t; ++tau) acc = acc + d.fracFuture[t - tau] * d.qi[(size_t)tau * N + r];
+  d.qlat[(size_t)(t + 1) * N + r] = acc;
+}
+
+// grid: x over reaches, y over register slots j: QFUTURE(j+1) after the window
+__global__ void __launch_bounds__(256) k_hillslope_state(MzrDev d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (r >= d.N) return;
+  const int n = d.ntdhBas, N = d.N, W = d.W;
+  const int tv = W + j;                       // step at which this slot would be emitted
+  double acc = (tv < n) ? d.basS0[(size_t)tv * N + r] : 0.0;
+  const int tau0 = tv - n + 1 > 0 ? tv - n + 1 : 0;
+  for (int tau = tau0; tau < W; ++tau) acc = acc + d.fracFuture[tv - tau] * d.qi[(size_t)tau * N + r];
+  d.basS1[(size_t)j * N + r] = acc;
+}
+
+void mzr_launch_basin(const MzrDev &d, hipStream_t stream) {
+  dim3 block(256), grid((d.N + 255) / 256, d.W);
+  hipLaunchKernelGGL(k_basin2reach, grid, block, 0, stream, d);
+  if (d.doesBasinRoute == 1) {
+    hipLaunchKernelGGL(k_hillslope_out, grid, block, 0, stream, d);
+    dim3 gridS((d.N + 255) / 256, d.ntdhBas);
+    hipLaunchKernelGGL(k_hillslope_state, gridS, block, 0, stream, d);
+  }
+}

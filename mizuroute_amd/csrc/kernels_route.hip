@@ -1,0 +1,357 @@
+// Stage kernels for the Eulerian reach solvers (gfx950): one lane per reach, one launch per stage.
+//
+//   SUM  accum_inst_runoff   route/build/src/accum_runoff.f90:32-93
+//   IRF  irf_rch             route/build/src/irf_route.f90:40-264
+//   MC   mc_rch              route/build/src/mc_route.f90:46-416
+//   DW   dfw_rch             route/build/src/dfw_route.f90:49-370
+//   KW   kw_rch              route/build/src/kwe_route.f90:46-363
+//   channel hydraulics       route/build/src/hydraulic.f90:46-535
+//   implicit ADE + Thomas    route/build/src/advection_diffusion.f90:19-258
+//   water balance            route/build/src/water_balance.f90:22-112
+//
+// Schedule: in launch `s` lane r advances reach r through window step t = s - sigma[r].  A reach
+// is exactly one stage behind each of its immediate upstreams, so the upstream discharge of step
+// t (written one launch earlier) is final, and reaches at different depths of the network work
+// on different time steps of the window in the same launch (time-skewed level sweep).
+// These solvers are FP64 transcendental-bound (Newton iterations with pow), not HBM-bound.
+#include "mzr_device.h"
+
+namespace {
+
+constexpr double c13 = 1.0 / 3.0, c23 = 2.0 / 3.0, c53 = 5.0 / 3.0, c103 = 10.0 / 3.0;
+
+struct Chan { double b, zc, S, n, zf, D; };   // width, side slope, slope, Manning n, floodplain slope, bank depth
+
+__device__ __forceinline__ double d_Btop(double y, const Chan &c) {
+  if (y <= c.D) return c.b + 2 * y * c.zc;
+  const double bt = c.b + 2 * c.D * c.zc;
+  return bt + c.zf * (y - c.D) * 2;
+}
+__device__ __forceinline__ double d_Pwet(double y, const Chan &c) {
+  if (y <= c.D) return c.b + 2 * y * sqrt(1 + c.zc * c.zc);
+  const double p = c.b + 2 * c.D * sqrt(1 + c.zc * c.zc);
+  return p + 2 * (y - c.D) * sqrt(1 + c.zf * c.zf);
+}
+__device__ __forceinline__ double d_area(double y, const Chan &c) {
+  if (y <= c.D) return y * (c.b + c.zc * y);
+  const double a = c.D * (c.b + c.zc * c.D);
+  return a + (y - c.D) * (d_Btop(y, c) + d_Btop(c.D, c)) / 2.0;
+}
+__device__ double d_water_height(double flowArea, const Chan &c) {
+  const double A_bank = d_area(c.D, c);
+  if (flowArea > A_bank) {
+    const double Bb = d_Btop(c.D, c);
+    const double disc = Bb * Bb - 4.0 * c.zf * (A_bank - flowArea);
+    return c.D + (-Bb + sqrt(disc)) / (2.0 * c.zf);
+  }
+  if (c.zc == 0) return flowArea / c.b;
+  return (-c.b + sqrt(c.b * c.b + 4.0 * flowArea * c.zc)) / (2.0 * c.zc);
+}
+// Newton-Raphson normal depth, hydraulic.f90:306-433 (integer powers as left-to-right products)
+__device__ double d_flow_depth(double Qin, const Chan &c) {
+  if (!(Qin > 1.e-50)) return 0.0;
+  const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c), Bbf = d_Btop(c.D, c);
+  const double sqS = sqrt(c.S);
+  const double Qbf = Abf * pow(Abf / Pbf, c23) * sqS / c.n;
+  double err = 100.0, fd = 0.0;
+  if (Qin < Qbf) {
+    const double t = sqS / c.n / Qin;
+    const double Coef1 = t * t * t;
+    const double Coef2 = 2 * sqrt(c.zc * c.zc + 1.0);
+    double y0 = pow(1.0 / Coef1 / (c.b * c.b * c.b), 1.0 / 5.0);
+    int guard = 0;
+    while (err > 0.005 && guard++ < 200) {
+      const double A = d_area(y0, c), Bt = d_Btop(y0, c), P = d_Pwet(y0, c);
+      const double A4 = A * A * A * A, A5 = A4 * A;
+      const double h = Coef1 * A5 / (P * P) - 1.0;
+      const double dhdy = Coef1 * (5 * A4 * Bt * P - 2 * Coef2 * A5) / (P * P * P);
+      fd = y0 - h / dhdy;
+      err = fabs((fd - y0) / fd);
+      y0 = fd;
+    }
+  } else {
+    double y0 = c.D + 2.0;
+    const double Coef1 = sqS / c.n / pow(Pbf, c23);
+    const double Coef2 = 2 * pow(c.zf / 2, c53) * sqS / c.n / pow(c.zf * c.zf + 1.0, c13);
+    int guard = 0;
+    while (err > 0.005 && guard++ < 200) {
+      const double ye = y0 - c.D;
+      const double h = Coef1 * pow(Abf + Bbf * ye, c53) + Coef2 * pow(ye, c103) / pow(ye, c23) - Qin;
+      const double dhdy = Coef1 * c53 * Bbf * pow(Abf + Bbf * ye, c23) + Coef2 * (c103 - c23) * pow(ye, c53);
+      fd = y0 - h / dhdy;
+      err = fabs((fd - y0) / fd);
+      y0 = fd;
+    }
+  }
+  return fd;
+}
+__device__ double d_friction_slope(double Qin, double y, const Chan &c) {
+  const double A = d_area(y, c), P = d_Pwet(y, c);
+  const double v = Qin * c.n / A / pow(A / P, c23);
+  return v * v;
+}
+__device__ double d_celerity(double Qin, double y, const Chan &c) {
+  if (!(y > 0.0)) return 0.0;
+  const double Bt = d_Btop(y, c);
+  const double Sf = d_friction_slope(Qin, y, c);
+  return c53 * pow(Sf, 0.3) * pow(Qin, 0.4) / pow(Bt, 0.4) / pow(c.n, 0.6);
+}
+__device__ double d_diffusivity(double Qin, double y, const Chan &c) {
+  if (!(y > 0.0)) return 0.0;
+  const double Bt = d_Btop(y, c);
+  const double Sf = d_friction_slope(Qin, y, c);
+  return fabs(Qin) / Sf / Bt / 2.0;
+}
+
+// Implicit central-difference ADE with Neumann outflow (advec_scheme=2, downBC=2, wck=wdk=1;
+// dfw_route.f90:36-37) solved with the reference's Thomas recurrence.  With these weights the
+// matrix rows are constant, so the forward sweep needs no arrays besides D and b1.
+template <int NM>
+__device__ void d_solve_ade(double L, double dtl, double Fup, double ck, double dk, const double *prev, double *sol) {
+  const double wck = 1.0, wdk = 1.0;
+  const int Nx = NM - 1;
+  const double dx = L / (Nx - 1);
+  const double Cd = dk * dtl / (dx * dx);
+  const double Ca = ck * dtl / dx;
+  const double midv = 2.0 + 4 * wdk * Cd;
+  const double upv = wck * Ca - 2.0 * wdk * Cd;        // diagonal(3:NM,1)
+  const double lowv = -wck * Ca - 2.0 * wdk * Cd;      // diagonal(1:NM-2,3)
+  const double e1 = (1.0 - wck) * Ca + 2.0 * (1.0 - wdk) * Cd;
+  const double e2 = 2.0 - 4.0 * (1.0 - wdk) * Cd;
+  const double e3 = (1.0 - wck) * Ca - 2.0 * (1.0 - wdk) * Cd;
+  double D[NM + 1], b1[NM + 1];
+  // row values, 1-based like advection_diffusion.f90
+  auto mid = [&](int i) { return (i == 1 || i == NM) ? 1.0 : midv; };
+  auto up = [&](int i) { return i >= 3 ? upv : 0.0; };
+  auto low = [&](int i) { return i <= NM - 2 ? lowv : (i == NM - 1 ? -1.0 : 0.0); };
+  auto rhs = [&](int i) {
+    if (i == 1) return Fup;
+    if (i == NM) return prev[NM - 1] - prev[NM - 2];
+    return e1 * prev[i - 2] + e2 * prev[i - 1] - e3 * prev[i];
+  };
+  D[1] = mid(1); b1[1] = rhs(1);
+#pragma unroll
+  for (int i = 2; i <= NM; ++i) {
+    const double coef = low(i - 1) / D[i - 1];
+    D[i] = mid(i) - coef * up(i);
+    b1[i] = rhs(i) - coef * b1[i - 1];
+  }
+  sol[NM - 1] = b1[NM] / D[NM];
+#pragma unroll
+  for (int i = NM - 1; i >= 1; --i) sol[i - 1] = (b1[i] - up(i + 1) * sol[i]) / D[i];
+}
+
+// shared preamble of irf/mc/dw/kw (irf_route.f90:81-100; water management is not active here)
+struct Pre { double q_up, q_up_mod, Qlat; bool isHW; };
+__device__ __forceinline__ Pre d_preamble(const MzrDev &d, int r, const double *Qrow, double qlat) {
+  Pre p; p.q_up = 0.0; p.isHW = true;
+  const int ng = d.nGood[r];
+  if (ng > 0) {
+    p.isHW = false;
+    const int u0 = d.upStart[r];
+    const uint32_t gm = d.goodMask[r];
+    for (int i = 0; i < ng; ++i) {                 // do iUps=1,nUps ; cycle if .not.goodBas(iUps)
+      if (!((gm >> i) & 1u)) continue;
+      p.q_up = p.q_up + Qrow[u0 + i];
+    }
+    p.q_up_mod = p.q_up; p.Qlat = qlat;
+  } else if (d.hw_drain_point == 1) {
+    p.q_up = p.q_up + qlat; p.q_up_mod = p.q_up; p.Qlat = 0.0;
+  } else {
+    p.q_up_mod = p.q_up; p.Qlat = qlat;
+  }
+  return p;
+}
+
+// water_balance.f90:22-112 (non-lake, no abstraction)
+__device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, double Qlat, double Qout, double dt) {
+  const double dVol = vol1 - vol0;
+  const double Qin = Qup * dt, Qlateral = Qlat * dt, precip = 0.0;
+  const double Qo = -1.0 * Qout * dt, Qtake = -1.0 * 0.0 * dt, evapo = 0.0;
+  return dVol - (Qin + Qlateral + precip + Qtake + Qo + evapo);
+}
+
+__device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
+  Chan c; c.b = d.width[r]; c.zc = d.side[r]; c.S = d.slope[r]; c.n = d.mann[r]; c.zf = d.fldp[r]; c.D = d.depth[r];
+  return c;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
+  const int r = rBegin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rEnd) return;
+  const int t = s - d.sigma[r];
+  if (t < 0 || t >= d.W) return;
+  const int N = d.N;
+  double *Qrow = d.Q + (size_t)t * N;
+  const double qlat = d.qlat[(size_t)(t + 1) * N + r];
+  const double dt = d.dt;
+
+  if (METHOD == 0) {   // SUM: all upstreams, regardless of goodBas (accum_runoff.f90:60-75)
+    double q = qlat;
+    const int nu = d.nUp[r];
+    if (nu > 0) {
+      const int u0 = d.upStart[r];
+      double qu = 0.0;
+      for (int i = 0; i < nu; ++i) qu = qu + Qrow[u0 + i];
+      q = q + qu;
+    }
+    Qrow[r] = q;
+    d.qsum[r] += q;
+    return;
+  }
+
+  const Pre p = d_preamble(d, r, Qrow, qlat);
+  d.inflow[r] = p.q_up;
+  double vol = d.vol[r];
+  const double vol_prev = vol;        // REACH_VOL(0) = REACH_VOL(1)
+  double vol0 = vol_prev;
+  const double L = d.length[r];
+  double Qout;
+
+  if (METHOD == 1) {   // IRF: conv_upsbas_qr, irf_route.f90:210-264
+    const int nt = d.ntdh[r];
+    const double qu = p.q_up_mod;
+    if (L > d.min_length_route) {
+      double q0 = d.irfQ[r] + d.uh[r] * qu;
+      const double lim = (fmax(0.0, vol) / dt + qu) * (double)0.999f;   // default-real literal, :245
+      q0 = fmin(lim, q0);
+      vol = vol - (q0 - qu) * dt;
+      Qout = q0 + p.Qlat;
+      for (int j = 1; j < nt; ++j) {
+        const double v = d.irfQ[(size_t)j * N + r] + d.uh[(size_t)j * N + r] * qu;
+        d.irfQ[(size_t)(j - 1) * N + r] = v;                             // eoshift(shift=1)
+      }
+      d.irfQ[(size_t)(nt - 1) * N + r] = 0.0;
+    } else {
+      for (int j = 0; j < nt; ++j) d.irfQ[(size_t)j * N + r] = 0.0;
+      d.irfQ[r] = qu;
+      Qout = qu + p.Qlat;
+      vol0 = 0.0; vol = 0.0;
+    }
+  } else if (METHOD == 4) {   // Muskingum-Cunge, mc_route.f90:204-416
+    const Chan c = d_chan(d, r);
+    const double Q00 = d.mol[r], Q01 = d.mol[(size_t)N + r];
+    double Q10, Q11, flood = 0.0, ele = 0.0;
+    if (!p.isHW || d.hw_drain_point == 1) {
+      if (L > d.min_length_route) {
+        const double theta = dt / L;
+        Q10 = p.q_up_mod;
+        double Qbar = (Q00 + Q10 + Q01) / 3.0;
+        if (Qbar > 1.e-50) {
+          double depth = d_flow_depth(fabs(Qbar), c);
+          double ck = d_celerity(fabs(Qbar), depth, c);
+          double Cn = ck * theta;
+          int ntSub = 1; double dTsub = dt;
+          if (Cn > 1.0) { ntSub = (int)ceil(dt / L * ck); dTsub = dt / ntSub; }
+          const double Y = 0.5;
+          double qin_prev = Q00, qout_prev = Q01, ssum = 0.0;
+          for (int ix = 1; ix <= ntSub; ++ix) {
+            const double qin = Q10;
+            double qo;
+            Qbar = (qin + qin_prev + qout_prev) / 3.0;
+            if (Qbar > 1.e-50) {
+              depth = d_flow_depth(fabs(Qbar), c);
+              const double topWidth = d_Btop(depth, c);
+              ck = d_celerity(fabs(Qbar), depth, c);
+              const double X = 0.5 * (1.0 - Qbar / (topWidth * c.S * ck * L));
+              Cn = ck * dTsub / L;
+              const double den = 1 - X + Cn * (1 - Y);
+              const double C0 = (-X + Cn * (1 - Y)) / den;
+              const double C1 = (X + Cn * Y) / den;
+              const double C2 = (1 - X - Cn * Y) / den;
+              qo = C0 * qin + C1 * qin_prev + C2 * qout_prev;
+              qo = fmax(0.0, qo);
+            } else {
+              qo = 0.0;
+            }
+            ssum = ssum + qo;
+            qin_prev = qin; qout_prev = qo;
+          }
+          Q11 = ssum / (double)ntSub;
+          if (fabs(Q11) > 0.0) {
+            const double pr = fmin((vol / dt + Q10) * (double)0.999f / Q11, 1.0);   // default-real literal, :352
+            Q11 = Q11 * pr;
+          }
+        } else {
+          Q11 = 0.0;
+        }
+        vol = vol + (Q10 - Q11) * dt;
+        const double stor = d.storage[r];
+        flood = vol > stor ? vol - stor : 0.0;
+        ele = d_water_height(vol / L, c);
+        Qout = Q11 + p.Qlat;
+      } else {
+        Q10 = p.q_up_mod; Q11 = p.q_up_mod;
+        Qout = p.q_up_mod + p.Qlat;
+        vol0 = 0.0; vol = 0.0;
+      }
+    } else {
+      Q10 = 0.0; Q11 = 0.0; Qout = p.Qlat; vol0 = 0.0; vol = 0.0;
+    }
+    d.mol[r] = Q10; d.mol[(size_t)N + r] = Q11;
+    d.floodvol[r] = flood; d.ele[r] = ele;
+  } else {   // DW (5) and KW (3): dfw_route.f90:209-370, kwe_route.f90:205-363
+    constexpr int NM = 20;
+    const Chan c = d_chan(d, r);
+    const double Qu = p.q_up_mod;
+    double flood = 0.0, ele = 0.0;
+    if (!p.isHW || d.hw_drain_point == 1) {
+      if (L > d.min_length_route) {
+        double prev[NM], sol[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) prev[i] = d.mol[(size_t)i * N + r];
+        const double Qbar = (Qu + prev[0] + prev[NM - 2]) / 3.0;
+        const double depth = d_flow_depth(fabs(Qbar), c);
+        const double ck = d_celerity(fabs(Qbar), depth, c);
+        const double dk = (METHOD == 5) ? d_diffusivity(fabs(Qbar), depth, c) : 0.0;
+        d_solve_ade<NM>(L, dt / 1, Qu, ck, dk, prev, sol);
+        if (fabs(sol[NM - 2]) > 0.0) {
+          const double volTmp = fmax(0.0, vol);
+          const double qoutTmp = sol[NM - 2] * dt;
+          const double pr = fmin((volTmp + dt * Qu) * 0.999 / qoutTmp, 1.0);
+#pragma unroll
+          for (int i = 1; i < NM; ++i) sol[i] = sol[i] * pr;
+        }
+        vol = vol + (Qu - sol[NM - 2]) * dt;
+        const double stor = d.storage[r];
+        flood = vol > stor ? vol - stor : 0.0;
+        ele = d_water_height(vol / L, c);
+        Qout = sol[NM - 2] + p.Qlat;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) d.mol[(size_t)i * N + r] = sol[i];
+      } else {
+        Qout = Qu + p.Qlat;
+        for (int i = 0; i < NM - 1; ++i) d.mol[(size_t)i * N + r] = 0.0;
+        d.mol[(size_t)(NM - 1) * N + r] = Qout;
+        vol0 = 0.0; vol = 0.0;
+      }
+    } else {
+      Qout = p.Qlat; vol0 = 0.0; vol = 0.0;
+      for (int i = 0; i < NM - 1; ++i) d.mol[(size_t)i * N + r] = 0.0;
+      d.mol[(size_t)(NM - 1) * N + r] = Qout;
+    }
+    d.floodvol[r] = flood; d.ele[r] = ele;
+  }
+  Qrow[r] = Qout;
+  d.vol[r] = vol; d.vol0[r] = vol0;
+  d.wb[r] = d_wb(vol, vol0, p.q_up, p.Qlat, Qout, dt);
+  d.qsum[r] += Qout;
+}
+
+void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {
+  const int n = rEnd - rBegin;
+  if (n <= 0) return;
+  dim3 block(256), grid((n + 255) / 256);
+  switch (method) {
+    case 0: hipLaunchKernelGGL(k_stage<0>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 1: hipLaunchKernelGGL(k_stage<1>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 3: hipLaunchKernelGGL(k_stage<3>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 4: hipLaunchKernelGGL(k_stage<4>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 5: hipLaunchKernelGGL(k_stage<5>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    default: break;
+  }
+}

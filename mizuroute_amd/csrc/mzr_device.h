@@ -1,0 +1,82 @@
+// Device-side view of one routing domain (gfx950).  Everything a kernel needs is in this POD,
+// passed by value as kernel argument.  All per-reach arrays are in the library's INTERNAL reach
+// order: reaches sorted by stage (= longest-path position counted from the outlet), and inside a
+// stage in breadth-first order from the outlets, so that
+//   * every stage is one contiguous index range  -> one coalesced launch per stage,
+//   * the immediate upstreams of reach r are the contiguous range [upStart[r], upStart[r]+nUp[r])
+//     in UREACHI order                             -> no index list, neighbouring lanes read
+//                                                     neighbouring upstream rows.
+// Ragged per-reach state (KWT particles, IRF convolution windows, sub-reach molecules) is stored
+// "row-major by slot": element k of reach r lives at [k*N + r], so lanes of a wavefront that walk
+// their rows in step touch consecutive addresses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MZR_MAXQPAR_DEV 20 // MAXQPAR, public_var.f90:36
+#define MZR_KW_CAP   20   // at-rest particles per reach (MAXQPAR, public_var.f90:36)
+#define MZR_OB_CAP   21   // outbox entries per reach: KWAVE(0:NR+1) + first non-routed
+#define MZR_MAXUP    8    // immediate upstreams handled by the KWT merge
+#define MZR_NMOL_KW  20   // init_model_data.f90:386-394
+#define MZR_NMOL_MC  2
+#define MZR_NMOL_DW  20
+
+// error record written by the first failing lane (atomicCAS on code)
+struct MzrErr { int code; int reach; int step; int where; };
+
+// kwt traffic counters (particles), accumulated with wave-level reductions
+struct MzrKwtStat { unsigned long long w_in, w_up, w_out, n_head, n_route, n_edges; };
+
+struct MzrDev {
+  int N, H;
+  int W;                  // steps in the current window
+  int nStages;            // longest path (reaches) in the domain
+  // ---- topology (internal order)
+  const int      *sigma;      // [N] stage of each reach (0 = farthest from the outlet)
+  const int      *upStart;    // [N]
+  const uint8_t  *nUp;        // [N] size(UREACHI)
+  const uint8_t  *nGood;      // [N] count(goodBas)
+  const uint32_t *goodMask;   // [N] bit i = goodBas(i+1)
+  const uint8_t  *isOutlet;   // [N] DREACHK <= 0
+  const int      *hruOff;     // [N+1]
+  const int      *hruIdx;     // [nHru] 0-based index into a runoff row (caller HRU order)
+  const double   *hruW;       // [nHru]
+  // ---- parameters (RPARAM, dataTypes.f90:183-195)
+  const double *slope, *mann, *width, *depth, *length, *storage, *side, *fldp, *basarea, *minflow;
+  // ---- configuration
+  double dt, min_length_route, runoffMin, negRunoffTol, time_conv, length_conv, t_start;
+  double T1_single;       // end of step for single-step windows (mzr_step passes TSEC(2) explicitly)
+  int hw_drain_point, doesBasinRoute;
+  // ---- hillslope
+  int ntdhBas;
+  const double *fracFuture;   // [ntdhBas]
+  const double *runoff;       // [W][H]
+  double *qi;                 // [W][N] BASIN_QI per step
+  double *qlat;               // [W+1][N] BASIN_QR(1); row 0 = value before the window
+  const double *basS0;        // [ntdhBas][N] hillslope QFUTURE before the window
+  double *basS1;              // [ntdhBas][N] ... after the window
+  // ---- per-method flux rows
+  double *Q;                  // [W][N] REACH_Q of the method being launched
+  double *vol, *vol0, *inflow, *ele, *floodvol, *wb;   // [N] latest
+  double *qsum;               // [N] running sum of REACH_Q (history mean)
+  // ---- IRF
+  int maxtdh;
+  const uint16_t *ntdh;       // [N]
+  const double *uh;           // [maxtdh][N]
+  double *irfQ;               // [maxtdh][N]
+  // ---- KW / MC / DW molecules
+  double *mol;                // [nMol][N]
+  // ---- KWT
+  int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
+  double *kwQ, *kwTI, *kwTR;  // [MZR_KW_CAP][N]
+  int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
+  double *obQ, *obT;          // [2][MZR_OB_CAP][N]
+  MzrKwtStat *kwtStat;
+  MzrErr *err;
+};
+
+__device__ __forceinline__ void mzr_raise(const MzrDev &d, int code, int reach, int step, int where) {
+  if (atomicCAS(&d.err->code, 0, code) == 0) {
+    d.err->reach = reach; d.err->step = step; d.err->where = where;
+  }
+}

@@ -1,0 +1,640 @@
+// Host side of libmzr_hip.so: the C-ABI of include/mzr.h.
+//
+// Replaces, for one routing domain on one MI355X:
+//   main_route / route_network          route/build/src/main_route.f90:29-409
+//   put_data_struct (AoS -> device SoA) route/build/src/process_ntopo.f90:354-504
+//   init_state_data (cold start)        route/build/src/init_model_data.f90:399-505
+//   omp_domain_decomposition            route/build/src/domain_decomposition.f90:168-445
+//       -> replaced by a stage schedule: stage(r) = Dmax - hops(r -> outlet).  Every edge of the
+//          river tree then spans exactly one stage, which is what lets the sweep be skewed in
+//          time: launch s advances reach r through step s - stage(r) of the window.
+// There is no CPU fallback: every compute entry point launches HIP kernels.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mzr.h"
+#include "mzr_device.h"
+
+void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
+void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
+void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, hipStream_t stream);
+
+namespace {
+
+template <typename T> struct DBuf {
+  T *p = nullptr; size_t n = 0;
+  void alloc(size_t cnt) {
+    free();
+    n = cnt;
+    if (cnt) { if (hipMalloc((void **)&p, cnt * sizeof(T)) != hipSuccess) { p = nullptr; n = 0; throw std::string("hipMalloc failed"); } }
+  }
+  void zero(hipStream_t s = 0) { if (p) (void)hipMemsetAsync(p, 0, n * sizeof(T), s); }
+  void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); }
+  void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DBuf() { free(); }
+};
+
+struct RouteBufs {
+  int method = -1;
+  DBuf<double> Q;                                   // [maxWindow][N]
+  DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum;   // [N]
+  DBuf<double> mol;                                 // [nMol][N]
+  long long nLaunches = 0, reachSteps = 0; double kernel_ms = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
+};
+
+__global__ void k_gather_rows(const double *src, double *dst, const int *ext2int, int N, int rows) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (e < N && t < rows) dst[(size_t)t * N + e] = src[(size_t)t * N + ext2int[e]];
+}
+
+}  // namespace
+
+struct mzr_domain {
+  mzr_config cfg;
+  hipStream_t stream = nullptr;
+  std::string msg;
+  int N = 0, H = 0, nStages = 0, maxStageWidth = 0, wk = 64;
+  bool haveNet = false, haveState = false;
+  std::vector<int> int2ext, ext2int, stageStart, reachId;
+  std::vector<uint8_t> h_nGood, h_nUp;
+  // device topology / params
+  DBuf<int> sigma, upStart, hruOff, hruIdx, d_ext2int;
+  DBuf<uint8_t> nUp, nGood, isOutlet;
+  DBuf<uint32_t> goodMask;
+  DBuf<double> hruW;
+  DBuf<double> par[11];
+  static const char *parName(int i) {
+    static const char *n[11] = {"R_SLOPE", "R_MAN_N", "R_WIDTH", "R_DEPTH", "RLENGTH", "R_STORAGE", "SIDE_SLOPE",
+                                "FLDP_SLOPE", "BASAREA", "TOTAREA", "MINFLOW"};
+    return n[i];
+  }
+  // unit hydrographs
+  int ntdhBas = 0, maxtdh = 0;
+  DBuf<double> fracFuture, uh, irfQ;
+  DBuf<uint16_t> ntdh;
+  std::vector<int> uhOff;
+  // window buffers
+  DBuf<double> runoffW, qi, qlat, basS[2], scratchOut;
+  int basCur = 0;
+  int lastW = 0;
+  bool havePrevQlat = false;
+  // kwt
+  DBuf<int> kwN, obN;
+  DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
+  DBuf<MzrKwtStat> kwtStat;
+  DBuf<MzrErr> err;
+  RouteBufs route[6];
+  bool profiling = false;
+  long long stepsDone = 0;
+};
+
+namespace {
+
+int fail(mzr_handle h, int code, const std::string &m) { h->msg = m; return code; }
+
+int idxOf(mzr_handle h, int method) {
+  for (int i = 0; i < h->cfg.nRoutes; ++i) if (h->cfg.routeMethods[i] == method) return i;
+  return -1;
+}
+
+void fillDev(mzr_handle h, MzrDev &d) {
+  memset(&d, 0, sizeof d);
+  d.N = h->N; d.H = h->H; d.nStages = h->nStages;
+  d.sigma = h->sigma.p; d.upStart = h->upStart.p; d.nUp = h->nUp.p; d.nGood = h->nGood.p;
+  d.goodMask = h->goodMask.p; d.isOutlet = h->isOutlet.p;
+  d.hruOff = h->hruOff.p; d.hruIdx = h->hruIdx.p; d.hruW = h->hruW.p;
+  d.slope = h->par[0].p; d.mann = h->par[1].p; d.width = h->par[2].p; d.depth = h->par[3].p;
+  d.length = h->par[4].p; d.storage = h->par[5].p; d.side = h->par[6].p; d.fldp = h->par[7].p;
+  d.basarea = h->par[8].p; d.minflow = h->par[10].p;
+  d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
+  d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
+  d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
+  d.ntdhBas = h->ntdhBas; d.fracFuture = h->fracFuture.p;
+  d.qi = h->qi.p; d.qlat = h->qlat.p;
+  d.basS0 = h->basS[h->basCur].p; d.basS1 = h->basS[h->basCur ^ 1].p;
+  d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
+  d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
+  d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
+  d.kwtStat = h->kwtStat.p; d.err = h->err.p;
+}
+
+void setRoute(mzr_handle h, MzrDev &d, int ix) {
+  RouteBufs &rb = h->route[ix];
+  d.Q = rb.Q.p; d.vol = rb.vol.p; d.vol0 = rb.vol0.p; d.inflow = rb.inflow.p; d.ele = rb.ele.p;
+  d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p;
+}
+
+int checkDeviceError(mzr_handle h) {
+  MzrErr e;
+  if (hipMemcpy(&e, h->err.p, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, 99, "mzr/hipMemcpy(err) failed");
+  if (e.code == 0) return 0;
+  (void)hipMemset(h->err.p, 0, sizeof(MzrErr));
+  const int ext = (e.reach >= 0 && e.reach < h->N) ? h->int2ext[e.reach] : -1;
+  const int id = (ext >= 0 && !h->reachId.empty()) ? h->reachId[ext] : ext + 1;
+  const char *what = "routing error";
+  switch (e.where) {
+    case 1: what = "basin2reach/exceeded negative runoff tolerance"; break;
+    case 10: what = "kwt_rch/qexmul_rch/work array bounds exceeded"; break;
+    case 11: what = e.code == 20 ? "kwt_rch/getusq_rch/qexmul_rch/stuck in the continuous do-loop"
+                  : e.code == 30 ? "kwt_rch/getusq_rch/qexmul_rch/expect process in order of time"
+                  : e.code == 40 ? "kwt_rch/getusq_rch/qexmul_rch/the times are not ordered as we assume"
+                                 : "kwt_rch/getusq_rch/qexmul_rch/QD_TEMP bounds exceeded"; break;
+    case 12: what = "kwt_rch/negative flow extracted from upstream reach"; break;
+    case 13: what = e.code == 20 ? "kwt_rch/kinwav_rch/zero flow" : e.code == 30 ? "kwt_rch/kinwav_rch/TEXIT equals TEXIT2 in kinwav"
+                                                                                  : "kwt_rch/kinwav_rch/RUPDATE/array bounds exceeded"; break;
+    case 14: what = "kwt_rch/no waiting particle left in reach"; break;
+    case 15: what = "kwt_rch/interp_rch/bad bounds"; break;
+  }
+  char buf[512];
+  snprintf(buf, sizeof buf, "main_routing/route_network/%s [reach index %d id %d, window step %d]", what, ext + 1, id, e.step);
+  return fail(h, e.code, buf);
+}
+
+}  // namespace
+
+extern "C" {
+
+void mzr_default_config(mzr_config *c) {
+  memset(c, 0, sizeof *c);
+  c->dt = 3600.0; c->nRoutes = 1; c->routeMethods[0] = MZR_KWT;
+  c->doesBasinRoute = 1; c->hw_drain_point = 2; c->min_length_route = 0.0; c->runoffMin = 0.0;
+  c->negRunoffTol = -1.e-3; c->time_conv = 1.0; c->length_conv = 1.0; c->maxWindow = 64; c->device = 0;
+}
+
+int mzr_create(const mzr_config *cfg, mzr_handle *out) {
+  if (!cfg || !out) return 1;
+  mzr_domain *h = new mzr_domain();
+  h->cfg = *cfg;
+  *out = h;
+  if (cfg->nRoutes < 1 || cfg->nRoutes > 6) return fail(h, 81, "mzr_create/nRoutes must be 1..6");
+  for (int i = 0; i < cfg->nRoutes; ++i) {
+    const int m = cfg->routeMethods[i];
+    if (m < 0 || m > 5) return fail(h, 81, "route_network/routing method id expect digits 0-5. Check <route_opt> in control file");
+    h->route[i].method = m;
+  }
+  if (cfg->maxWindow < 1) return fail(h, 1, "mzr_create/maxWindow must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(h, 90, "mzr_create/no HIP device available: this library has no CPU path");
+  if (hipSetDevice(cfg->device) != hipSuccess) return fail(h, 90, "mzr_create/hipSetDevice failed");
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(h, 90, "mzr_create/hipStreamCreate failed");
+  return 0;
+}
+
+int mzr_destroy(mzr_handle h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  for (auto &rb : h->route) for (auto &e : rb.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int mzr_last_error(mzr_handle h, char *buf, int len) {
+  if (!h || !buf || len <= 0) return 1;
+  snprintf(buf, len, "%s", h->msg.c_str());
+  return 0;
+}
+
+int mzr_set_network(mzr_handle h, int N, int H, const int *downIndex, const int *upOffset, const int *upIndex,
+                    const int *upGood, const int *hruOffset, const int *hruIndex, const double *hruWeight,
+                    const int *reachId) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->cfg.device);
+  try {
+    h->N = N; h->H = H;
+    // ---- breadth-first levels from the outlets; upstreams appended in UREACHI order
+    std::vector<int> level; level.reserve(N);
+    std::vector<int> levelStart{0};
+    for (int i = 0; i < N; ++i) if (downIndex[i] <= 0) level.push_back(i);
+    size_t lo = 0;
+    while (lo < level.size()) {
+      const size_t hi = level.size();
+      levelStart.push_back((int)hi);
+      for (size_t k = lo; k < hi; ++k) {
+        const int r = level[k];
+        for (int e = upOffset[r]; e < upOffset[r + 1]; ++e) {
+          const int u = upIndex[e] - 1;
+          if (u < 0 || u >= N || downIndex[u] - 1 != r) return fail(h, 20, "mzr_set_network/upstream list inconsistent with downIndex");
+          level.push_back(u);
+        }
+      }
+      lo = hi;
+    }
+    if ((int)level.size() != N) return fail(h, 20, "mzr_set_network/network has a cycle or a reach not connected to an outlet");
+    const int nLev = (int)levelStart.size() - 1;
+    h->nStages = nLev;
+    // internal order: stage 0 = deepest level
+    h->int2ext.assign(N, 0); h->ext2int.assign(N, 0); h->stageStart.assign(nLev + 1, 0);
+    std::vector<int> sigma(N);
+    int pos = 0; h->maxStageWidth = 0;
+    for (int s = 0; s < nLev; ++s) {
+      const int lev = nLev - 1 - s;
+      h->stageStart[s] = pos;
+      const int w = levelStart[lev + 1] - levelStart[lev];
+      h->maxStageWidth = std::max(h->maxStageWidth, w);
+      for (int k = levelStart[lev]; k < levelStart[lev + 1]; ++k) { h->int2ext[pos] = level[k]; h->ext2int[level[k]] = pos; sigma[pos] = s; ++pos; }
+    }
+    h->stageStart[nLev] = N;
+    std::vector<int> upStart(N, 0);
+    std::vector<uint8_t> nUp(N), nGood(N), isOut(N);
+    std::vector<uint32_t> gmask(N, 0);
+    const bool kwt = idxOf(h, MZR_KWT) >= 0;
+    int wkNeed = 21;
+    for (int i = 0; i < N; ++i) {
+      const int e = h->int2ext[i];
+      const int nu = upOffset[e + 1] - upOffset[e];
+      if (nu > 32) return fail(h, 20, "mzr_set_network/more than 32 immediate upstream reaches are not supported");
+      nUp[i] = (uint8_t)nu;
+      isOut[i] = downIndex[e] <= 0;
+      int ng = 0;
+      for (int k = 0; k < nu; ++k) {
+        const int good = upGood ? (upGood[upOffset[e] + k] != 0) : 1;
+        if (good) { gmask[i] |= 1u << k; ++ng; }
+        const int ui = h->ext2int[upIndex[upOffset[e] + k] - 1];
+        if (k == 0) upStart[i] = ui;
+        else if (ui != upStart[i] + k) return fail(h, 20, "mzr_set_network/internal ordering error");
+      }
+      nGood[i] = (uint8_t)ng;
+    }
+    if (kwt) {
+      for (int i = 0; i < N; ++i) {
+        if (nGood[i] == 0) continue;
+        if (nUp[i] > MZR_MAX_UPSTREAM) return fail(h, 20, "mzr_set_network/KWT supports at most 8 immediate upstream reaches per reach");
+        int nr = 0;
+        for (int k = 0; k < nUp[i]; ++k) nr += nGood[upStart[i] + k] > 0;
+        wkNeed = std::max(wkNeed, 20 + nUp[i] + 19 * nr);
+      }
+    }
+    h->wk = wkNeed <= 64 ? 64 : wkNeed <= 128 ? 128 : 192;
+    h->h_nGood = nGood; h->h_nUp = nUp;
+    std::vector<int> hOff(N + 1, 0), hIdx; std::vector<double> hW;
+    for (int i = 0; i < N; ++i) {
+      const int e = h->int2ext[i];
+      for (int k = hruOffset[e]; k < hruOffset[e + 1]; ++k) {
+        if (hruIndex[k] < 1 || hruIndex[k] > H) return fail(h, 20, "mzr_set_network/HRU index out of range");
+        hIdx.push_back(hruIndex[k] - 1); hW.push_back(hruWeight[k]);
+      }
+      hOff[i + 1] = (int)hIdx.size();
+    }
+    h->reachId.assign(N, 0);
+    for (int i = 0; i < N; ++i) h->reachId[i] = reachId ? reachId[i] : i + 1;
+    h->sigma.upload(sigma); h->upStart.upload(upStart); h->nUp.upload(nUp); h->nGood.upload(nGood);
+    h->goodMask.upload(gmask); h->isOutlet.upload(isOut);
+    h->hruOff.upload(hOff); h->hruIdx.upload(hIdx); h->hruW.upload(hW);
+    h->d_ext2int.upload(h->ext2int);
+    for (int p = 0; p < 11; ++p) { h->par[p].alloc(N); h->par[p].zero(); }
+    h->haveNet = true; h->haveState = false;
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_network/" + e); }
+  return 0;
+}
+
+int mzr_set_param(mzr_handle h, const char *name, const double *values) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_param/network not set") : 1;
+  (void)hipSetDevice(h->cfg.device);
+  for (int p = 0; p < 11; ++p) {
+    if (strcmp(name, mzr_domain::parName(p)) == 0) {
+      std::vector<double> v(h->N);
+      for (int i = 0; i < h->N; ++i) v[i] = values[h->int2ext[i]];
+      (void)hipMemcpy(h->par[p].p, v.data(), h->N * sizeof(double), hipMemcpyHostToDevice);
+      return 0;
+    }
+  }
+  return fail(h, 20, std::string("mzr_set_param/unknown parameter ") + name);
+}
+
+int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_uh/network not set") : 1;
+  (void)hipSetDevice(h->cfg.device);
+  const int N = h->N;
+  h->uhOff.assign(uhOffset, uhOffset + N + 1);
+  int mx = 1;
+  for (int e = 0; e < N; ++e) mx = std::max(mx, uhOffset[e + 1] - uhOffset[e]);
+  h->maxtdh = mx;
+  std::vector<double> pad((size_t)mx * N, 0.0);
+  std::vector<uint16_t> nt(N);
+  for (int i = 0; i < N; ++i) {
+    const int e = h->int2ext[i];
+    const int n = uhOffset[e + 1] - uhOffset[e];
+    if (n < 1) return fail(h, 20, "mzr_set_uh/empty unit hydrograph");
+    nt[i] = (uint16_t)n;
+    for (int j = 0; j < n; ++j) pad[(size_t)j * N + i] = uh[uhOffset[e] + j];
+  }
+  try { h->uh.upload(pad); h->ntdh.upload(nt); } catch (const std::string &e) { return fail(h, 91, "mzr_set_uh/" + e); }
+  return 0;
+}
+
+int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
+  if (!h || n < 1) return 1;
+  (void)hipSetDevice(h->cfg.device);
+  h->ntdhBas = n;
+  try { h->fracFuture.upload(std::vector<double>(frac, frac + n)); } catch (const std::string &e) { return fail(h, 91, "mzr_set_frac_future/" + e); }
+  return 0;
+}
+
+int mzr_init_state(mzr_handle h) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_init_state/network not set") : 1;
+  (void)hipSetDevice(h->cfg.device);
+  const size_t N = h->N, W = h->cfg.maxWindow;
+  if (h->cfg.doesBasinRoute == 1 && h->ntdhBas < 1) return fail(h, 20, "mzr_init_state/FRAC_FUTURE not set");
+  try {
+    h->runoffW.alloc(W * h->H);
+    if (h->cfg.doesBasinRoute == 1) {
+      h->qi.alloc(W * N);
+      h->basS[0].alloc((size_t)h->ntdhBas * N); h->basS[1].alloc((size_t)h->ntdhBas * N);
+      h->basS[0].zero(); h->basS[1].zero();
+    }
+    h->basCur = 0;
+    h->qlat.alloc((W + 1) * N); h->qlat.zero();
+    h->scratchOut.alloc(W * N);
+    h->err.alloc(1); h->err.zero();
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      const int m = rb.method;
+      rb.Q.alloc(W * N); rb.Q.zero();
+      for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum}) { b->alloc(N); b->zero(); }
+      if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
+      if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); }
+      if (m == MZR_IRF) {
+        if (h->maxtdh < 1) return fail(h, 20, "mzr_init_state/reach unit hydrographs not set (IRF)");
+        h->irfQ.alloc((size_t)h->maxtdh * N); h->irfQ.zero();
+      }
+      if (m == MZR_KWT) {
+        h->kwN.alloc(N); h->kwN.zero();
+        h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
+        h->kwQ.zero(); h->kwTI.zero(); h->kwTR.zero();
+        h->obN.alloc(2 * N); h->obN.zero();
+        h->obQ.alloc((size_t)2 * MZR_OB_CAP * N); h->obT.alloc((size_t)2 * MZR_OB_CAP * N);
+        h->obQ.zero(); h->obT.zero();
+        h->kwtStat.alloc(1); h->kwtStat.zero();
+      }
+      rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0;
+    }
+  } catch (const std::string &e) { return fail(h, 91, "mzr_init_state/" + e); }
+  if (hipDeviceSynchronize() != hipSuccess) return fail(h, 92, "mzr_init_state/device error");
+  h->haveState = true; h->stepsDone = 0; h->lastW = 0;
+  return 0;
+}
+
+static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
+  if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
+  if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  const int N = h->N;
+  hipStream_t st = h->stream;
+  // carry BASIN_QR(1) of the last step of the previous window into row 0
+  if (h->lastW > 0)
+    (void)hipMemcpyAsync(h->qlat.p, h->qlat.p + (size_t)h->lastW * N, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st);
+  MzrDev d; fillDev(h, d);
+  d.W = W; d.t_start = t_start; d.T1_single = T1_single; d.runoff = runoff_dev;
+  mzr_launch_basin(d, st);
+  if (h->cfg.doesBasinRoute == 1) h->basCur ^= 1;
+  const int nS = h->nStages;
+  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+    RouteBufs &rb = h->route[ix];
+    setRoute(h, d, ix);
+    const bool prof = h->profiling;
+    if (prof) rb.evUsed = 0;
+    for (int s = 0; s < nS + W - 1; ++s) {
+      const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
+      const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
+      if (rE <= rB) continue;
+      if (prof) {
+        if (rb.evUsed == rb.events.size()) {
+          hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b);
+        }
+        (void)hipEventRecord(rb.events[rb.evUsed].first, st);
+      }
+      if (rb.method == MZR_KWT) mzr_launch_stage_kwt(d, h->wk, s, rB, rE, st);
+      else mzr_launch_stage(rb.method, d, s, rB, rE, st);
+      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, st); ++rb.evUsed; }
+      ++rb.nLaunches;
+    }
+    rb.reachSteps += (long long)N * W;
+  }
+  h->lastW = W; h->stepsDone += W;
+  if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
+  return 0;
+}
+
+int mzr_sync(mzr_handle h) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->cfg.device);
+  const hipError_t e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess) return fail(h, 92, std::string("mzr_sync/") + hipGetErrorString(e));
+  if (h->profiling) {
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      for (size_t k = 0; k < rb.evUsed; ++k) { float ms = 0; (void)hipEventElapsedTime(&ms, rb.events[k].first, rb.events[k].second); rb.kernel_ms += ms; }
+      rb.evUsed = 0;
+    }
+  }
+  return checkDeviceError(h);
+}
+
+int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev) {
+  if (!h) return 1;
+  return run_window(h, nSteps, t_start, t_start + h->cfg.dt, runoff_dev);
+}
+
+int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
+  if (!h) return 1;
+  if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipMemcpyAsync(h->runoffW.p, runoff, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
+  if (rc) return rc;
+  return mzr_sync(h);
+}
+
+int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
+  if (!h) return 1;
+  if (!h->haveState) return fail(h, 20, "mzr_step/state not initialised (call mzr_init_state)");
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipMemcpyAsync(h->runoffW.p, runoff, (size_t)h->H * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  const int rc = run_window(h, 1, T0, T1, h->runoffW.p);
+  if (rc) return rc;
+  return mzr_sync(h);
+}
+
+// ---- getters: device (internal order) -> host (caller order)
+static int pullRow(mzr_handle h, const double *src, double *out) {
+  std::vector<double> tmp(h->N);
+  if (hipMemcpy(tmp.data(), src, h->N * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(h, 92, "mzr_get/hipMemcpy failed");
+  for (int e = 0; e < h->N; ++e) out[e] = tmp[h->ext2int[e]];
+  return 0;
+}
+
+int mzr_get_flux(mzr_handle h, int method, int which, double *out) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_flux/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const size_t N = h->N;
+  if (which >= MZR_F_BASIN_QR1) {
+    if (which == MZR_F_BASIN_QR1) return pullRow(h, h->qlat.p + (size_t)h->lastW * N, out);
+    if (which == MZR_F_BASIN_QR0) return pullRow(h, h->qlat.p + (size_t)std::max(0, h->lastW - 1) * N, out);
+    if (which == MZR_F_BASIN_QI && h->cfg.doesBasinRoute == 1 && h->lastW > 0) return pullRow(h, h->qi.p + (size_t)(h->lastW - 1) * N, out);
+    return fail(h, 20, "mzr_get_flux/field not available");
+  }
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_flux/method not active");
+  RouteBufs &rb = h->route[ix];
+  switch (which) {
+    case MZR_F_Q: return pullRow(h, rb.Q.p + (size_t)std::max(0, h->lastW - 1) * N, out);
+    case MZR_F_VOL0: return pullRow(h, rb.vol0.p, out);
+    case MZR_F_VOL1: return pullRow(h, rb.vol.p, out);
+    case MZR_F_INFLOW: return pullRow(h, rb.inflow.p, out);
+    case MZR_F_ELE: return pullRow(h, rb.ele.p, out);
+    case MZR_F_FLOODVOL: return pullRow(h, rb.floodvol.p, out);
+    case MZR_F_WB: return pullRow(h, rb.wb.p, out);
+  }
+  return fail(h, 20, "mzr_get_flux/unknown field");
+}
+
+int mzr_get_window_q(mzr_handle h, int method, double *out) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_window_q/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_window_q/method not active");
+  const int N = h->N, W = h->lastW;
+  if (W < 1) return fail(h, 20, "mzr_get_window_q/no window has been run");
+  dim3 block(256), grid((N + 255) / 256, W);
+  hipLaunchKernelGGL(k_gather_rows, grid, block, 0, h->stream, h->route[ix].Q.p, h->scratchOut.p, h->d_ext2int.p, N, W);
+  if (hipMemcpyAsync(out, h->scratchOut.p, (size_t)W * N * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+    return fail(h, 92, "mzr_get_window_q/hipMemcpy failed");
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, 92, "mzr_get_window_q/sync failed");
+  return 0;
+}
+
+int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_mean_q/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_mean_q/method not active");
+  rc = pullRow(h, h->route[ix].qsum.p, out); if (rc) return rc;
+  const double n = (double)std::max<long long>(1, h->stepsDone);
+  for (int e = 0; e < h->N; ++e) out[e] /= n;
+  if (reset) { h->route[ix].qsum.zero(h->stream); h->stepsDone = 0; (void)hipStreamSynchronize(h->stream); }
+  return 0;
+}
+
+int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry, double *texit, int *routed) {
+  if (!h || !h->haveState || !h->kwN.p) return h ? fail(h, 20, "mzr_get_kwt_state/KWT not active") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N;
+  std::vector<int> n(N);
+  std::vector<double> q((size_t)MZR_KW_CAP * N), ti(q.size()), tr(q.size());
+  (void)hipMemcpy(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(q.data(), h->kwQ.p, q.size() * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(ti.data(), h->kwTI.p, q.size() * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(tr.data(), h->kwTR.p, q.size() * sizeof(double), hipMemcpyDeviceToHost);
+  for (int e = 0; e < N; ++e) {
+    const int i = h->ext2int[e];
+    numWaves[e] = n[i];
+    for (int k = 0; k < MZR_WCAP; ++k) {
+      const size_t o = (size_t)e * MZR_WCAP + k;
+      if (k < n[i]) {
+        qwave[o] = q[(size_t)k * N + i]; tentry[o] = ti[(size_t)k * N + i]; texit[o] = tr[(size_t)k * N + i];
+        routed[o] = (k == 0 && h->h_nGood[i] > 0) ? 1 : 0;   // element 0 = last routed particle
+      } else { qwave[o] = tentry[o] = texit[o] = -9999.0; routed[o] = 0; }
+    }
+  }
+  return 0;
+}
+
+int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, const double *tentry, const double *texit, const int *routed) {
+  if (!h || !h->haveState || !h->kwN.p) return h ? fail(h, 20, "mzr_set_kwt_state/KWT not active") : 1;
+  (void)routed;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N;
+  std::vector<int> n(N);
+  std::vector<double> q((size_t)MZR_KW_CAP * N, 0.0), ti(q.size(), 0.0), tr(q.size(), 0.0);
+  for (int e = 0; e < N; ++e) {
+    const int i = h->ext2int[e];
+    if (numWaves[e] > MZR_KW_CAP) return fail(h, 20, "mzr_set_kwt_state/more than MAXQPAR waves in a reach");
+    n[i] = numWaves[e];
+    for (int k = 0; k < numWaves[e]; ++k) {
+      const size_t o = (size_t)e * MZR_WCAP + k;
+      q[(size_t)k * N + i] = qwave[o]; ti[(size_t)k * N + i] = tentry[o]; tr[(size_t)k * N + i] = texit[o];
+    }
+  }
+  (void)hipMemcpy(h->kwN.p, n.data(), N * sizeof(int), hipMemcpyHostToDevice);
+  (void)hipMemcpy(h->kwQ.p, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice);
+  (void)hipMemcpy(h->kwTI.p, ti.data(), q.size() * sizeof(double), hipMemcpyHostToDevice);
+  (void)hipMemcpy(h->kwTR.p, tr.data(), q.size() * sizeof(double), hipMemcpyHostToDevice);
+  return 0;
+}
+
+int mzr_get_irf_state(mzr_handle h, double *qfuture) {
+  if (!h || !h->haveState || !h->irfQ.p) return h ? fail(h, 20, "mzr_get_irf_state/IRF not active") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N;
+  std::vector<double> v((size_t)h->maxtdh * N);
+  (void)hipMemcpy(v.data(), h->irfQ.p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
+  for (int e = 0; e < N; ++e) {
+    const int i = h->ext2int[e];
+    for (int j = 0; j < h->uhOff[e + 1] - h->uhOff[e]; ++j) qfuture[h->uhOff[e] + j] = v[(size_t)j * N + i];
+  }
+  return 0;
+}
+
+int mzr_get_mol_state(mzr_handle h, int method, double *qout) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_mol_state/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0 || !h->route[ix].mol.p) return fail(h, 81, "mzr_get_mol_state/method not active");
+  const int N = h->N, nm = method == MZR_MC ? MZR_NMOL_MC : MZR_NMOL_KW;
+  std::vector<double> v((size_t)nm * N);
+  (void)hipMemcpy(v.data(), h->route[ix].mol.p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
+  for (int e = 0; e < N; ++e) for (int j = 0; j < nm; ++j) qout[(size_t)e * nm + j] = v[(size_t)j * N + h->ext2int[e]];
+  return 0;
+}
+
+int mzr_get_basin_state(mzr_handle h, double *qfuture) {
+  if (!h || !h->haveState || h->cfg.doesBasinRoute != 1) return h ? fail(h, 20, "mzr_get_basin_state/hillslope routing not active") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N, n = h->ntdhBas;
+  std::vector<double> v((size_t)n * N);
+  (void)hipMemcpy(v.data(), h->basS[h->basCur].p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
+  for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) qfuture[(size_t)e * n + j] = v[(size_t)j * N + h->ext2int[e]];
+  return 0;
+}
+
+int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {
+  if (!h || !h->haveNet) return 1;
+  *nStages = h->nStages; *maxStageWidth = h->maxStageWidth;
+  return 0;
+}
+
+int mzr_set_profiling(mzr_handle h, int on) { if (!h) return 1; h->profiling = on != 0; return 0; }
+
+int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset) {
+  if (!h) return 1;
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_timing/method not active");
+  RouteBufs &rb = h->route[ix];
+  *nLaunches = rb.nLaunches; *kernel_ms = rb.kernel_ms; *reachSteps = rb.reachSteps;
+  if (reset) { rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0; }
+  return 0;
+}
+
+int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long long *w_out, long long *n_head,
+                        long long *n_route, long long *n_edges, int reset) {
+  if (!h || !h->kwtStat.p) return h ? fail(h, 20, "mzr_get_kwt_traffic/KWT not active") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  MzrKwtStat s;
+  (void)hipMemcpy(&s, h->kwtStat.p, sizeof s, hipMemcpyDeviceToHost);
+  *w_in = (long long)s.w_in; *w_up = (long long)s.w_up; *w_out = (long long)s.w_out;
+  *n_head = (long long)s.n_head; *n_route = (long long)s.n_route; *n_edges = (long long)s.n_edges;
+  if (reset) (void)hipMemset(h->kwtStat.p, 0, sizeof s);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+"""Generate the committed golden fixtures from the REFERENCE itself.
+
+Run in the build container only (needs oracle/_ref/ref_route, i.e. /root/reference + flang):
+    python tests/golden/make_golden.py
+Each fixture holds the inputs (network, parameters, runoff), the reference's setup products
+(FRAC_FUTURE from basinUH, per-reach UH from make_uh; process_param.f90) and the reference's outputs
+(REACH_Q and REACH_VOL of every step and method, final solver state) as produced by the unmodified
+reference solvers driven by oracle/ref_harness/ref_driver.f90.  Fixtures are data only.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from mizuroute_amd.synthetic import make_network, make_runoff  # noqa: E402
+from oracle import refrun  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    # BASELINE config 0: Cameo-like ~50 reaches, IRF, daily step as in route/settings/SAMPLE.control
+    "cameo50_irf": dict(N=50, seed=101, methods=[1], dt=86400.0, steps=30, net_kw={}, ro_kw=dict(storm_prob=0.2, storm_amp=3e-7)),
+    # every method on one small tree (one triple confluence allowed), hourly step
+    "tree150_all": dict(N=150, seed=202, methods=[0, 1, 2, 3, 4, 5], dt=3600.0, steps=72, net_kw=dict(p3=0.04),
+                        ro_kw=dict(storm_prob=0.05, storm_amp=2e-6)),
+    # KWT under stormy forcing, with zero-area headwaters (goodBas = F) and particle thinning
+    "tree400_kwt": dict(N=400, seed=303, methods=[2], dt=3600.0, steps=120, net_kw=dict(p3=0.03, zero_area_frac=0.05),
+                        ro_kw=dict(storm_prob=0.08, storm_amp=4e-6)),
+    # KWT with a daily step: every particle leaves within the step, long merged trains
+    "tree200_kwt_daily": dict(N=200, seed=404, methods=[2], dt=86400.0, steps=40, net_kw={},
+                              ro_kw=dict(storm_prob=0.3, storm_amp=5e-7)),
+}
+
+
+def save_case(name, spec):
+    net = make_network(spec["N"], seed=spec["seed"], **spec["net_kw"])
+    ro = make_runoff(net.H, spec["steps"], seed=spec["seed"] + 1, **spec["ro_kw"])
+    out = refrun.run_case(net, ro, spec["dt"], spec["methods"])
+    assert out["ierr"] == 0, out["stdout"]
+    d = dict(N=net.N, H=net.H, dt=spec["dt"], methods=np.array(spec["methods"], np.int32),
+             downIndex=net.downIndex, reachId=net.reachId, upOffset=net.upOffset, upIndex=net.upIndex,
+             upGood=net.upGood, hruOffset=net.hruOffset, hruIndex=net.hruIndex, hruWeight=net.hruWeight,
+             params=net.param_matrix(), runoff=ro,
+             frac_future=out["frac_future"], uh_offset=out["uh_offset"], uh=out["uh"],
+             ref_Q=out["Q"], ref_VOL=out["VOL"], ref_QR1=out["QR1"], ref_basin_qfuture=out["basin_qfuture"])
+    for m, st in out["state"].items():
+        for k, v in st.items():
+            d[f"ref_state_{m}_{k}"] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(name, "N", net.N, "levels", net.n_levels(), "->", os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    if not refrun.available():
+        refrun.build()
+    for name, spec in CASES.items():
+        save_case(name, spec)

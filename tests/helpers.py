@@ -1,0 +1,39 @@
+"""Shared test helpers: fixtures -> RiverNetwork, error metrics."""
+import os
+
+import numpy as np
+
+from mizuroute_amd.synthetic import RiverNetwork
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_CASES = ["cameo50_irf", "tree150_all", "tree400_kwt", "tree200_kwt_daily"]
+REL_TOL = 1e-6          # BASELINE.json north_star: discharge within 1e-6 relative of the reference
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    par = z["params"]
+    net = RiverNetwork(N=int(z["N"]), H=int(z["H"]), downIndex=z["downIndex"], reachId=z["reachId"],
+                       upOffset=z["upOffset"], upIndex=z["upIndex"], upGood=z["upGood"],
+                       hruOffset=z["hruOffset"], hruIndex=z["hruIndex"], hruWeight=z["hruWeight"],
+                       params={k: par[i].copy() for i, k in enumerate(RiverNetwork.PARAM_ORDER)})
+    return net, z
+
+
+def rel_err(a, b, floor=1e-9):
+    """max relative error over entries where |reference| > floor (SURVEY.md 8d parity report)."""
+    a, b = np.asarray(a), np.asarray(b)
+    m = np.abs(a) > floor
+    if not m.any():
+        return 0.0
+    return float((np.abs(a - b)[m] / np.abs(a)[m]).max())
+
+
+def parity_report(ref, got, floor=1e-9):
+    ref, got = np.asarray(ref), np.asarray(got)
+    m = np.abs(ref) > floor
+    r = np.abs(ref - got)[m] / np.abs(ref)[m]
+    return dict(max_rel=float(r.max()) if r.size else 0.0,
+                p999=float(np.quantile(r, 0.999)) if r.size else 0.0,
+                frac_within=float((r <= REL_TOL).mean()) if r.size else 1.0,
+                bit_identical=float((ref == got).mean()))
