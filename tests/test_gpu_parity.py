@@ -44,10 +44,10 @@ def test_matches_reference_golden(name, window, hip_lib):
     if 2 in methods:
         nw, qf, ti, tr, rf = dom.kwt_state()
         assert np.array_equal(nw, z["ref_state_2_nw"]), "particle counts differ"
-        assert np.array_equal(rf, z["ref_state_2_rf"]), "routed flags differ"
+        mask = np.arange(rf.shape[1])[None, :] < nw[:, None]
+        assert np.array_equal(rf[mask], z["ref_state_2_rf"][mask]), "routed flags differ"
         for got, key in ((qf, "qf"), (ti, "ti"), (tr, "tr")):
             ref = z[f"ref_state_2_{key}"]
-            mask = np.arange(ref.shape[1])[None, :] < nw[:, None]
             assert np.allclose(got[mask], ref[mask], rtol=REL_TOL, atol=0), key
     for meth in (3, 4, 5):
         if meth in methods:
