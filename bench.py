@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Benchmark of the routing hot path on MI355X: reaches*timesteps/s on the BASELINE.json workload.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N=1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic HDMA-CONUS-like sub-basin, ~100k reaches per GPU,
+KWT routing (route_opt 2), dt = 3600 s, hillslope unit-hydrograph delay on (fshape 2.5,
+tscale 86400 s), cold start + W spin-up steps (untimed), then K timed steps.  A "step" is one
+simulation time step of the whole domain (one main_route call in the reference); the device
+executes them in time-skewed windows.  Forcing is generated on the device before the
+timed region, so `value` is the HBM-resident rate.
+
+One JSON line on rank 0 with the contract fields plus
+  "roofline":     HBM roofline of the dominant kernel (KWT stage sweep): algorithmic bytes from the
+                  device particle counters x SURVEY.md 8(d) byte model, / summed kernel time from HIP
+                  events recorded around every stage launch on the library's stream;
+  "cpu_baseline": the reference's own Fortran solvers (oracle/_ref, unmodified sources) timed on the
+                  host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_REACH = 100_000          # reaches per GPU (BASELINE.json configs[1])
+DT = 3600.0
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def kwt_bytes(tr):
+    """Algorithmic bytes of the KWT sweep from particle counters:
+    routed reach: 25*(W_in + W_up + W_out) + 68 + 44*U ; headwater reach: 53."""
+    return 25 * (tr["w_in"] + tr["w_up"] + tr["w_out"]) + 68 * tr["n_route"] + 44 * tr["n_edges"] + 53 * tr["n_head"]
+
+
+def device_runoff(torch, H, n_steps, t0, seed, device):
+    """runoff[t, h] [m/s] on the device: low seasonal base flow + sparse storm pulses."""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    phi = torch.rand(H, generator=g, device=device, dtype=torch.float64) * (2 * np.pi)
+    g2 = torch.Generator(device=device); g2.manual_seed(seed * 1000003 + t0 + 17)
+    t = torch.arange(t0, t0 + n_steps, device=device, dtype=torch.float64)[:, None]
+    ro = 1e-8 * (1.0 + torch.sin(2 * np.pi * t / 168.0 + phi[None, :]))
+    pulse = torch.rand((n_steps, H), generator=g2, device=device, dtype=torch.float64)
+    amp = torch.rand((n_steps, H), generator=g2, device=device, dtype=torch.float64)
+    ro += torch.where(pulse < 0.01, 1e-6 * amp * amp, torch.zeros_like(amp))
+    return ro.contiguous()
+
+
+def cpu_baseline(net, frac, sample_steps, budget_s=30.0):
+    """Reference Fortran solvers (oracle/_ref/ref_route) on the host cores, bounded sample."""
+    from oracle import refrun
+    import mizuroute_amd as m
+    if not refrun.available():
+        return None
+    cores = os.cpu_count() or 1
+    ro = m.make_runoff(net.H, sample_steps, seed=7, storm_prob=0.01, storm_amp=1e-6)
+    uh_off = np.arange(net.N + 1, dtype=np.int32)
+    uh = np.ones(net.N)
+    common = dict(uh=(frac, uh_off, uh), dump_every=0)
+    t0 = time.time()
+    one = refrun.run_case(net, ro, DT, [2], nthreads=1, **common)
+    best, used, note = one["reach_steps_per_s"], 1, f"1 thread {one['reach_steps_per_s']:.3e}"
+    if cores > 1 and time.time() - t0 < budget_s:
+        allc = refrun.run_case(net, ro, DT, [2], nthreads=cores, schedule=refrun.level_schedule(net), **common)
+        note += f"; {cores} OpenMP threads (level schedule) {allc['reach_steps_per_s']:.3e}"
+        if allc["reach_steps_per_s"] > best:
+            best, used = allc["reach_steps_per_s"], cores
+    return {"value": best, "unit": "reaches*timesteps/s", "cores": used, "kind": "reference",
+            "sample": f"same {net.N}-reach network, KWT, cold start, first {sample_steps} steps; "
+                      f"unmodified reference kwt_route.f90/main_route.f90 built with flang -O2; {note}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=768)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--window", type=int, default=256)
+    ap.add_argument("--reaches", type=int, default=N_REACH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mizuroute_amd as m
+    from mizuroute_amd import uh as uhmod
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- workload: one ~100k-reach sub-basin per GPU (weak scaling; sub-basins drain to separate
+    # outlets, so no mainstem exchange is needed between ranks in this configuration)
+    net = m.make_network(args.reaches, seed=20240529 + rank)
+    frac = uhmod.basin_uh(DT, 2.5, 86400.0)
+    W = max(1, min(args.window, max(args.steps, 1)))
+    dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W, device=local_rank)
+    n_stages, max_width = dom.schedule()
+
+    def run_steps(ro, t_first):
+        done = 0
+        while done < ro.shape[0]:
+            w = min(W, ro.shape[0] - done)
+            dom.run_device(w, (t_first + done) * DT, ro[done:done + w].data_ptr())
+            done += w
+
+    ro_warm = device_runoff(torch, net.H, args.warmup, 0, 7 + rank, dev) if args.warmup > 0 else None
+    ro_time = device_runoff(torch, net.H, args.steps, args.warmup, 7 + rank, dev)
+    torch.cuda.synchronize()
+    if ro_warm is not None:
+        run_steps(ro_warm, 0)
+    dom.sync()
+    dom.timing(m.KWT, reset=True)
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(ro_time, args.warmup)
+    dom.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tm = dom.timing(m.KWT, reset=True)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    total_reach_steps = float(net.N) * args.steps * world
+    value = total_reach_steps / elapsed
+
+    # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
+    # every stage launch on the library's stream, on the window that follows the timed region
+    roof = None
+    if rank == 0:
+        dom.kwt_traffic(reset=True)
+        dom.set_profiling(True)
+        ro_prof = device_runoff(torch, net.H, W, args.warmup + args.steps, 7 + rank, dev)
+        torch.cuda.synchronize()
+        run_steps(ro_prof, args.warmup + args.steps)
+        dom.sync()
+        dom.set_profiling(False)
+        pt = dom.timing(m.KWT, reset=True)
+        tr = dom.kwt_traffic(reset=True)
+        bytes_total = kwt_bytes(tr)
+        launches = max(1, pt["launches"])
+        avg_ms = pt["kernel_ms"] / launches
+        achieved = bytes_total / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "kwt_hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("reaches") == net.N and tj.get("window") == W:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "k_stage_kwt", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_total / launches,
+                "bytes_per_reach_step": bytes_total / max(1, tr["n_route"] + tr["n_head"]),
+                "avg_launch_us": avg_ms * 1e3, "launches": launches,
+                "particles_per_routed_reach": (tr["w_in"] + tr["w_up"] + tr["w_out"]) / max(1, tr["n_route"])}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(net, frac, sample_steps=24)
+        except Exception as e:   # the baseline is reported, never required
+            cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        out = {
+            "metric": "reaches*timesteps/s", "value": value, "unit": "reaches*timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on",
+                       "reaches_per_gpu": net.N, "reaches_total": net.N * world, "stages": n_stages,
+                       "max_stage_width": max_width, "window_steps": W,
+                       "simulated_years_per_wallclock_day": (args.steps * DT / 31536000.0) / (elapsed / 86400.0),
+                       "kernel_time_fraction": tm["kernel_ms"] * 1e-3 / elapsed if tm["kernel_ms"] else None,
+                       "parallelism": f"{world} sub-basin(s), one per GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,8 @@
 //    step t in the same launch.
 //  * Expected exit times of a reach's own waiting particles are recomputed by kinwav every step,
 //    so only TR of element 0 is read back; the others are written for restart files only.
-//  * Work arrays (own particles + merged upstream particles, up to WK) live in private memory.
+//  * Work arrays (own particles + merged upstream particles) live in LDS: each wavefront carves a
+//    1024-particle pool among its 64 reaches by need (prefix sum), no private-memory arrays.
 //
 // Bound by HBM traffic of the particle rows: see DESIGN.md for the bytes-per-reach-step model.
 #include <float.h>
@@ -68,6 +69,47 @@ __device__ int d_interp_rch(const double *TOLD, const double *QOLD, int NOLD, do
   return 0;
 }
 
+
+// ---- x**0.4 and x**0.6 for x >= 0 -------------------------------------------------------------
+// The celerity law wc = (5/3) K**0.6 q**0.4 (kwt_route.f90:1290) and the stage inversion
+// A = (q/K)**0.6 of the shock speed (:1331-1332) are the only transcendental work of this kernel,
+// and a generic FP64 pow() costs more instructions than everything else a reach does.
+//   x**(2/5) = z*v * 2**(2k),  v = (z**3)**(-1/5)      x = z * 2**(5k), z in [1,32)
+//   x**(3/5) = z*w * 2**(3k),  w = (z**2)**(-1/5)
+// Inverse fifth root: single-precision hardware seed (v_log_f32 / v_exp_f32), two division-free
+// Newton steps v <- v*(1.2 - 0.2*a*v**5), the last with fused residual.  The reference raises to
+// the DOUBLES nearest 0.4 / 0.6 (exponents (ALFA-1)/ALFA and 1/ALFA evaluated in FP64), which
+// differ from 2/5 and 3/5 by -+2.22e-17; the factor (1 + delta*ln x) restores that.  Measured
+// against the correctly rounded power: max 2.3 ulp, mean 0.44 ulp (same class as libm's pow).
+__device__ __forceinline__ double pow_fifths(double x, bool three) {
+  if (!(x > 0.0)) return x == 0.0 ? 0.0 : NAN;
+  if (isinf(x)) return x;
+  int e;
+  const double m = frexp(x, &e);            // x = m * 2**e, m in [0.5,1)
+  const int e1 = e - 1;                     // x = (2m) * 2**e1 ; e1 = 5k + j, j in 0..4
+  const int k = (e1 >= 0) ? e1 / 5 : -((4 - e1) / 5);
+  const int j = e1 - 5 * k;
+  const double z = ldexp(m, j + 1);
+  const float lz = __builtin_amdgcn_logf((float)z);                        // log2(z)
+  const double a = three ? z * z : z * z * z;
+  double v = (double)__builtin_amdgcn_exp2f((three ? -0.4f : -0.6f) * lz);
+  {
+    const double v2 = v * v, v4 = v2 * v2;
+    v = v * (1.2 - 0.2 * (a * (v4 * v)));
+  }
+  {
+    const double v2 = v * v, v4 = v2 * v2, v5 = v4 * v;
+    v = fma(v, 0.2 * fma(-a, v5, 1.0), v);
+  }
+  const double lnx = ((double)lz + 5.0 * (double)k) * 0.6931471805599453;
+  const double dl = three ? -2.2204460492503132e-17 : 2.2204460492503132e-17;
+  double y = z * v;
+  y = fma(y, dl * lnx, y);
+  return ldexp(y, three ? 3 * k : 2 * k);
+}
+__device__ __forceinline__ double pow_0p4(double x) { return pow_fifths(x, false); }   // x**((ALFA-1)/ALFA)
+__device__ __forceinline__ double pow_0p6(double x) { return pow_fifths(x, true); }    // x**(1/ALFA)
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -76,301 +118,466 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 }  // namespace
 
-template <int WK>
-__global__ void __launch_bounds__(256) k_stage_kwt(MzrDev d, int s, int rBegin, int rEnd) {
-  const int r = rBegin + blockIdx.x * blockDim.x + threadIdx.x;
+// ------------------------------------------------------------------------------------------------
+// k-way merge of the upstream series (qexmul_rch :860-976) with the two particles that bracket
+// each series' cursor held in registers: a series is touched in memory only when its cursor
+// advances.  MAXS = 4 covers the binary confluence (2 basin + 2 reach series) fully unrolled.
+// Returns ND >= 0, or -(ierr) on a reference consistency error.
+template <int MAXS>
+__device__ __forceinline__ int kwt_merge(int nup, int u0, int NUPS, double RW, double T0, double T1,
+                                         const uint8_t *nGood, const double *width,
+                                         const double *qlat_prev, const double *qlat_cur, const int *obN,
+                                         const double *obQ, const double *obT, int N, double *QD, double *TD, int IMAX) {
+  constexpr int MU = MAXS / 2;
+  int su[MAXS], slen[MAXS], snr[MAXS], itim[MAXS];
+  double sc[MAXS], ct[MAXS], qb[MAXS], tb[MAXS], qe[MAXS], te[MAXS];
+  // upstream slot of the k-th reach-type series
+  int rmap[MU];
+  {
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < MU; ++i) {
+      rmap[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < MU; ++i) {
+      if (i < nup && nGood[u0 + i] > 0) {
+#pragma unroll
+        for (int j = 0; j < MU; ++j) if (j == cnt) rmap[j] = i;
+        ++cnt;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    su[i] = 0; slen[i] = 0; snr[i] = 0; itim[i] = 1; sc[i] = 0.0; ct[i] = DBL_MAX; qb[i] = tb[i] = qe[i] = te[i] = 0.0;
+    if (i < NUPS) {
+      if (i < nup) {                                   // basin series {BASIN_QR(0)@T0, BASIN_QR(1)@T1} :771-787
+        const int u = u0 + i;
+        su[i] = u; slen[i] = 2; snr[i] = 2; sc[i] = 1.0 / RW;
+        qb[i] = qlat_prev[u]; tb[i] = T0; qe[i] = qlat_cur[u]; te[i] = T1; ct[i] = T1;
+      } else {                                         // routed particles of a non-headwater upstream :792-858
+        int slot = 0;
+#pragma unroll
+        for (int j = 0; j < MU; ++j) if (j == i - nup) slot = rmap[j];
+        const int u = u0 + slot;
+        const int nr = obN[u];                         // count(RF) = NR_u + 2
+        su[i] = u; snr[i] = nr; slen[i] = nr + 1; sc[i] = width[u] / RW;
+        qb[i] = obQ[u]; tb[i] = obT[u]; qe[i] = obQ[(size_t)N + u]; te[i] = obT[(size_t)N + u]; ct[i] = te[i];
+      }
+    }
+  }
+  unsigned done = 0;
+  const unsigned all = (1u << NUPS) - 1u;
+  int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff;
+  double TIME_LAST = -DBL_MAX;
+  for (;;) {
+    int JUPS = 0; double cmin = ct[0];                 // MINLOC(CTIME): first minimum
+#pragma unroll
+    for (int i = 1; i < MAXS; ++i) if (i < NUPS && ct[i] < cmin) { cmin = ct[i]; JUPS = i; }
+    int kj = 0, nrj = 0, lenj = 0;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) if (i == JUPS) { kj = itim[i]; nrj = snr[i]; lenj = slen[i]; }
+    if (JUPS == JUPS_OLD && kj == ITIM_OLD) return -20;   // stuck in the continuous do-loop :901-903
+    JUPS_OLD = JUPS; ITIM_OLD = kj;
+    if (!((done >> JUPS) & 1u)) {
+      if (kj >= nrj) {                                 // cursor on a non-routed particle: series finished
+        done |= 1u << JUPS;
+#pragma unroll
+        for (int i = 0; i < MAXS; ++i) if (i == JUPS) ct[i] = DBL_MAX;
+      } else {
+        const double CT = cmin;
+        const double TIME_OLD = IPRT >= 1 ? TIME_LAST : -DBL_MAX;
+        if (CT < TIME_OLD) return -30;
+        if (CT != TIME_OLD) {
+          double Q_AGG = 0.0;
+          bool bad = false;
+#pragma unroll
+          for (int i = 0; i < MAXS; ++i) {
+            if (i < NUPS) {
+              double SFLOW;
+              if (i == JUPS) {
+                SFLOW = qe[i] * sc[i];
+              } else {
+                // IBEG = IWAV-1, IEND = IWAV whenever TR(IWAV) >= CT, which holds for every
+                // consistent series (the cursor time is never below the merge time)
+                if (te[i] < CT || tb[i] > CT || itim[i] < 1) bad = true;
+                const double SLOPE = (qe[i] - qb[i]) / (te[i] - tb[i]);
+                const double PREDV = qb[i] + SLOPE * (CT - tb[i]);
+                SFLOW = PREDV * sc[i];
+              }
+              Q_AGG = Q_AGG + SFLOW;
+            }
+          }
+          if (bad) return -40;
+          if (IPRT >= IMAX) return -60;
+          QD[IPRT] = Q_AGG; TD[IPRT] = CT; TIME_LAST = CT; ++IPRT;
+        }
+        if (kj == lenj - 1) {
+          done |= 1u << JUPS;
+#pragma unroll
+          for (int i = 0; i < MAXS; ++i) if (i == JUPS) ct[i] = DBL_MAX;
+        } else {
+#pragma unroll
+          for (int i = 0; i < MAXS; ++i) {
+            if (i == JUPS) {
+              qb[i] = qe[i]; tb[i] = te[i];
+              if (i < nup) { qe[i] = 0.0; te[i] = DBL_MAX; }   // a basin series has two elements only
+              else { qe[i] = obQ[(size_t)(kj + 1) * N + su[i]]; te[i] = obT[(size_t)(kj + 1) * N + su[i]]; }
+              itim[i] = kj + 1; ct[i] = te[i];
+            }
+          }
+        }
+      }
+    }
+    if (done == all) break;
+  }
+  return IPRT;
+}
+
+// Confluences of more than two reaches are rare: their merge stays out of line with the series
+// cursors in private memory and every particle fetched from the outbox on demand, so that the
+// common (binary) path keeps a small register footprint.
+__device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double RW, double T0, double T1,
+                                              const uint8_t *nGood, const double *width, const double *qlat_prev,
+                                              const double *qlat_cur, const int *obN, const double *obQ,
+                                              const double *obT, int N, double *QD, double *TD, int IMAX) {
+  int su[2 * MZR_MAXUP], slen[2 * MZR_MAXUP], snr[2 * MZR_MAXUP], ITIM[2 * MZR_MAXUP];
+  double sc[2 * MZR_MAXUP], CTIME[2 * MZR_MAXUP];
+  int IUPR = 0;
+#pragma unroll 1
+  for (int i = 0; i < nup; ++i) { su[i] = u0 + i; slen[i] = 2; snr[i] = 2; sc[i] = 1.0 / RW; ITIM[i] = 1; CTIME[i] = T1; }
+#pragma unroll 1
+  for (int i = 0; i < nup; ++i) {
+    const int u = u0 + i;
+    if (nGood[u] > 0) {
+      const int si = nup + IUPR; ++IUPR;
+      const int nr = obN[u];
+      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = obT[(size_t)N + u];
+    }
+  }
+  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : obQ[(size_t)k * N + su[i]]; };
+  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : obT[(size_t)k * N + su[i]]; };
+  unsigned done = 0;
+  const unsigned all = (1u << NUPS) - 1u;
+  int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff;
+  double TIME_LAST = -DBL_MAX;
+#pragma unroll 1
+  for (;;) {
+    int JUPS = 0;
+#pragma unroll 1
+    for (int i = 1; i < NUPS; ++i) if (CTIME[i] < CTIME[JUPS]) JUPS = i;
+    if (JUPS == JUPS_OLD && ITIM[JUPS] == ITIM_OLD) return -20;
+    JUPS_OLD = JUPS; ITIM_OLD = ITIM[JUPS];
+    if (!((done >> JUPS) & 1u)) {
+      const int kj = ITIM[JUPS];
+      if (kj >= snr[JUPS]) { done |= 1u << JUPS; CTIME[JUPS] = DBL_MAX; }
+      else {
+        const double CT = CTIME[JUPS];
+        const double TIME_OLD = IPRT >= 1 ? TIME_LAST : -DBL_MAX;
+        if (CT < TIME_OLD) return -30;
+        if (CT != TIME_OLD) {
+          double Q_AGG = 0.0;
+#pragma unroll 1
+          for (int i = 0; i < NUPS; ++i) {
+            const int IWAV = ITIM[i];
+            double SFLOW;
+            if (i == JUPS) SFLOW = sQ(i, IWAV) * sc[i];
+            else {
+              int IBEG = IWAV;
+              if (sT(i, IBEG) >= CT) IBEG = IWAV - 1;
+              const int IEND = IBEG + 1;
+              if (IEND >= slen[i] || IBEG < 0) return -40;
+              const double tb = sT(i, IBEG), te = sT(i, IEND);
+              if (te < CT || tb > CT) return -40;
+              const double qb = sQ(i, IBEG), qe = sQ(i, IEND);
+              const double SLOPE = (qe - qb) / (te - tb);
+              SFLOW = (qb + SLOPE * (CT - tb)) * sc[i];
+            }
+            Q_AGG = Q_AGG + SFLOW;
+          }
+          if (IPRT >= IMAX) return -60;
+          QD[IPRT] = Q_AGG; TD[IPRT] = CT; TIME_LAST = CT; ++IPRT;
+        }
+        if (kj == slen[JUPS] - 1) { done |= 1u << JUPS; CTIME[JUPS] = DBL_MAX; }
+        else { ITIM[JUPS] = kj + 1; CTIME[JUPS] = sT(JUPS, kj + 1); }
+      }
+    }
+    if (done == all) break;
+  }
+  return IPRT;
+}
+
+#define KWT_POOL 1024   // particles of LDS work space per wavefront (3 x 8 B + 2 B each)
+
+// One wavefront per block.  Each lane first works out how many work-array entries its reach needs
+// (own particles + everything its upstreams routed), the wave carves the LDS pool with a prefix
+// sum, and lanes that do not fit wait for the next round of the same wave.
+__global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, int rEnd) {
+  __shared__ double sQ[KWT_POOL], sT[KWT_POOL], sX[KWT_POOL];
+  __shared__ unsigned short sL[KWT_POOL];
+  const int r = rBegin + blockIdx.x * 64 + threadIdx.x;
   const int N = d.N;
   unsigned long long st_in = 0, st_up = 0, st_out = 0, st_head = 0, st_route = 0, st_edges = 0;
   int t = -1;
   const bool live = (r < rEnd) && ((t = s - d.sigma[r]) >= 0) && (t < d.W);
+  const double T0 = d.t_start + (double)(t < 0 ? 0 : t) * d.dt;
+  const double T1 = (d.W == 1) ? d.T1_single : T0 + d.dt;   // mzr_step passes TSEC(2) explicitly
+  const double T_START = T0, T_END = T1;                    // RSTEP = 0
+  double *Qrow = d.Q + (size_t)(t < 0 ? 0 : t) * N;
+  const double *qlat_prev = d.qlat + (size_t)(t < 0 ? 0 : t) * N;       // BASIN_QR(0)
+  const double *qlat_cur = d.qlat + (size_t)((t < 0 ? 0 : t) + 1) * N;  // BASIN_QR(1)
+  const int par = t & 1;
+  const int *obN = d.obN + (size_t)par * N;
+  const double *obQ = d.obQ + (size_t)par * MZR_OB_CAP * N;
+  const double *obT = d.obT + (size_t)par * MZR_OB_CAP * N;
+
+  int need = 0, nup = 0, u0 = 0, ng = 0, n_own = 0, NUPS = 0, IMAX = 0;
+  double qlat_r = 0.0;
   if (live) {
-    const double T0 = d.t_start + (double)t * d.dt;
-    const double T1 = (d.W == 1) ? d.T1_single : T0 + d.dt;   // mzr_step passes TSEC(2) explicitly
-    const double T_START = T0, T_END = T1;                 // RSTEP = 0
-    double *Qrow = d.Q + (size_t)t * N;
-    const double *qlat_prev = d.qlat + (size_t)t * N;      // BASIN_QR(0)
-    const double *qlat_cur = d.qlat + (size_t)(t + 1) * N; // BASIN_QR(1)
-    const double qlat_r = qlat_cur[r];
-    const int ng = d.nGood[r];
-    do {
-      if (ng == 0) {   // headwater: kwt_route.f90:181-205
-        Qrow[r] = qlat_r;
-        d.qsum[r] += qlat_r;
-        d.inflow[r] = 0.0;
-        if (d.kwN[r] != 1) {   // single sentinel particle; static afterwards
-          d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0;
-        }
-        st_head = 1;
-        break;
-      }
+    qlat_r = qlat_cur[r];
+    ng = d.nGood[r];
+    if (ng == 0) {   // headwater: kwt_route.f90:181-205
+      Qrow[r] = qlat_r;
+      d.qsum[r] += qlat_r;
+      d.inflow[r] = 0.0;
+      if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0; }
+      st_head = 1;
+    } else {
       st_route = 1;
-      const int nup = d.nUp[r];
-      const int u0 = d.upStart[r];
-      const double RW = d.width[r];
-      const int par = t & 1;
-      const int *obN = d.obN + (size_t)par * N;
-      const double *obQ = d.obQ + (size_t)par * MZR_OB_CAP * N;
-      const double *obT = d.obT + (size_t)par * MZR_OB_CAP * N;
+      nup = d.nUp[r]; u0 = d.upStart[r];
       st_edges = nup;
+      n_own = d.kwN[r];
+      int NUPR = 0;
+      IMAX = nup;
+      for (int i = 0; i < nup; ++i) {
+        if (d.nGood[u0 + i] > 0) { ++NUPR; const int nr = obN[u0 + i]; IMAX += nr - 1; st_up += nr + 1; }
+      }
+      NUPS = nup + NUPR;
+      const int NJ0 = n_own == 0 ? 0 : n_own - 1;
+      need = NJ0 + 1 + (NUPS == 1 ? 1 : IMAX);
+      if (need > KWT_POOL) { mzr_raise(d, 60, r, t, 10); need = 0; }
+    }
+  }
 
-      double Qw[WK], Tw[WK], Xw[WK];   // Q_JRCH, TENTRY, T_EXIT (Xw doubles as ABSERR in remove)
+  bool pending = need > 0;
+  while (__any(pending)) {
+    // wave-wide inclusive prefix sum of the pending lanes' needs
+    int incl = pending ? need : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += v; }
+    const bool go = pending && incl <= KWT_POOL;
+    if (go) {
+      pending = false;
+      const int off = incl - need;
+      double *Qw = sQ + off, *Tw = sT + off, *Xw = sX + off;
+      unsigned short *Lw = sL + off;
+      do {
+        const double RW = d.width[r];
+        // ---- own particles (getusq_rch :598-608); element 0 = last routed particle
+        const bool cold = (n_own == 0);
+        const int NJ = cold ? 0 : n_own - 1;
+        for (int k = 0; k < n_own; ++k) { Qw[k] = d.kwQ[(size_t)k * N + r]; Tw[k] = d.kwTI[(size_t)k * N + r]; }
+        double X0 = cold ? 0.0 : d.kwTR[r];
+        st_in = n_own;
 
-      // ---- own particles (getusq_rch :598-608); element 0 = last routed particle
-      const int n_own = d.kwN[r];
-      const bool cold = (n_own == 0);
-      const int NJ = cold ? 0 : n_own - 1;
-      for (int k = 0; k < n_own; ++k) { Qw[k] = d.kwQ[(size_t)k * N + r]; Tw[k] = d.kwTI[(size_t)k * N + r]; }
-      if (!cold) Xw[0] = d.kwTR[r];
-      st_in = n_own;
-
-      // ---- qexmul_rch: merge upstream series into (QD,TD) = Qw/Tw[NJ+1 ...]
-      int ND = 0;
-      {
-        int NUPR = 0;
-        for (int i = 0; i < nup; ++i) NUPR += d.nGood[u0 + i] > 0 ? 1 : 0;
-        const int NUPS = nup + NUPR;
+        // ---- qexmul_rch
+        int ND;
         if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
-          Qw[NJ + 1] = qlat_cur[u0] / RW;
-          Tw[NJ + 1] = T1;
-          ND = 1;
+          Qw[NJ + 1] = qlat_cur[u0] / RW; Tw[NJ + 1] = T1; ND = 1;
+        } else if (nup <= 2) {   // binary confluence: <= 2 basin + 2 reach series, all in registers
+          ND = kwt_merge<4>(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1, IMAX);
         } else {
-          int su[2 * MZR_MAXUP], slen[2 * MZR_MAXUP], snr[2 * MZR_MAXUP], ITIM[2 * MZR_MAXUP];
-          double sc[2 * MZR_MAXUP], CTIME[2 * MZR_MAXUP];
-          int IMAX = nup, IUPR = 0;
-          for (int i = 0; i < nup; ++i) {            // basins :771-787
-            su[i] = u0 + i; slen[i] = 2; snr[i] = 2; sc[i] = 1.0 / RW; ITIM[i] = 1; CTIME[i] = T1;
-          }
-          for (int i = 0; i < nup; ++i) {            // reaches :792-858
-            const int u = u0 + i;
-            if (d.nGood[u] > 0) {
-              const int si = nup + IUPR; ++IUPR;
-              const int nr = obN[u];                 // count(RF) = NR_u + 2
-              su[si] = u; snr[si] = nr; slen[si] = nr + 1;   // NQ = min(NR+1, NS) = NR+1 (one waiting particle always exists)
-              sc[si] = d.width[u] / RW; ITIM[si] = 1; CTIME[si] = obT[(size_t)N + u];
-              IMAX += nr - 1;
-              st_up += nr + 1;
+          ND = kwt_merge_generic(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1, IMAX);
+        }
+        if (ND < 0) { mzr_raise(d, -ND, r, t, 11); break; }
+        if (cold) {   // getusq_rch :587-596
+          const double DT = T1 - T0;
+          Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; X0 = T0 - DT * 0;
+        }
+        int size = NJ + 1 + ND;
+
+        {   // kwt_rch :163-174
+          double mn = Qw[0];
+          for (int k = 1; k < size; ++k) { const double q = Qw[k]; mn = q < mn ? q : mn; }
+          if (mn < 0.0) { mzr_raise(d, 20, r, t, 12); break; }
+          double q_up = 0.0;
+          const uint32_t gm = d.goodMask[r];
+          for (int i = 0; i < ng; ++i) { if (!((gm >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
+          d.inflow[r] = q_up;
+        }
+
+        // ---- remove_rch :999-1123: drop the particle with the least interpolation error until < MAXQPAR
+        if (size > MZR_MAXQPAR_DEV) {
+          const int NPRT = size - 1;
+          for (int i = 0; i <= NPRT; ++i) Lw[i] = (unsigned short)(((i - 1) & 0xff) | ((i + 1) << 8));
+          Xw[NPRT] = DBL_MAX; Xw[0] = DBL_MAX;
+          {
+            double qa = Qw[0], ta = Tw[0], qb2 = Qw[1], tb2 = Tw[1];
+            for (int i = 1; i <= NPRT - 1; ++i) {
+              const double qc = Qw[i + 1], tc = Tw[i + 1];
+              Xw[i] = fabs(interp3(tb2, qa, qc, ta, tc) - qb2);
+              qa = qb2; ta = tb2; qb2 = qc; tb2 = tc;
             }
           }
-          if (NJ + 1 + IMAX > WK) { mzr_raise(d, 60, r, t, 10); break; }
-          // element k of series i: flow / exit time
-          auto sQ = [&](int i, int k) -> double {
-            return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : obQ[(size_t)k * N + su[i]];
+          int MPRT = NPRT;
+          while (MPRT >= MZR_MAXQPAR_DEV) {
+            int ISEL = 0; double emin = DBL_MAX;
+            for (int i = 1; i <= NPRT; ++i) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
+            if (ISEL == 0) break;                         // no finite interpolation error left (NaN/Inf input)
+            const unsigned short ls = Lw[ISEL];
+            const int pm = ls & 0xff, pn = ls >> 8;     // INDEX1(ISEL-1), INDEX1(ISEL+1)
+            const double qm = Qw[pm], tm = Tw[pm], qn = Qw[pn], tn = Tw[pn];
+            if (pm > 0) {
+              const int INEG = Lw[pm] & 0xff;
+              Xw[pm] = fabs(interp3(tm, Qw[INEG], qn, Tw[INEG], tn) - qm);
+            }
+            if (pn < NPRT) {
+              const int IPOS = Lw[pn] >> 8;
+              Xw[pn] = fabs(interp3(tn, qm, Qw[IPOS], tm, Tw[IPOS]) - qn);
+            }
+            Xw[ISEL] = INFINITY;                        // removed: never the minimum again
+            Lw[pm] = (unsigned short)((Lw[pm] & 0xff) | (pn << 8));
+            Lw[pn] = (unsigned short)((Lw[pn] & 0xff00) | pm);
+            --MPRT;
+          }
+          if (MPRT >= MZR_MAXQPAR_DEV) { mzr_raise(d, 62, r, t, 16); break; }
+          int k = 0;
+          for (int i = 0; i <= NPRT; i = Lw[i] >> 8) { Qw[k] = Qw[i]; Tw[k] = Tw[i]; ++k; }
+          size = MPRT + 1;
+        }
+        const int NQ1 = size - 1;
+
+        // ---- kinwav_rch :1130-1439 on particles 1..NQ1, in place:
+        //   Xw[i]   wave celerity of the group whose first particle is i   (WC)
+        //   alive   bit i set while particle i still heads a group
+        //   Xw[i+1] entry time of a merged group (T1 after :1335); flows of a merged group are the
+        //           min / max over its members (:1329-1330), recomputed when needed
+        int NQ2 = 0;
+        {
+          const double K = d.kwK[r];        // sqrt(R_SLOPE)/R_MAN_N           (host, once)
+          const double cw = d.kwCW[r];      // ALFA*K**(1/ALFA), ALFA = 5/3     (host, once)
+          const double XMX = d.length[r];
+          const int NI = NQ1;
+          for (int i = 1; i <= NI; ++i) Xw[i] = cw * pow_0p4(Qw[i]);
+          unsigned alive = NI >= 31 ? 0xfffffffeu : ((1u << (NI + 1)) - 2u);   // bits 1..NI
+          auto nextHead = [&](int h) -> int {           // next group head after h, or NI+1
+            const unsigned m = alive & ~((2u << h) - 1u);
+            return m ? __ffs(m) - 1 : NI + 1;
           };
-          auto sT = [&](int i, int k) -> double {
-            return i < nup ? (k == 0 ? T0 : T1) : obT[(size_t)k * N + su[i]];
-          };
-          unsigned done = 0;                         // MFLG bits
-          const unsigned all = (1u << NUPS) - 1u;
-          int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff, bad = 0;
-          double TIME_LAST = -DBL_MAX;
-          for (;;) {
-            int JUPS = 0;                            // MINLOC(CTIME): first minimum
-            for (int i = 1; i < NUPS; ++i) if (CTIME[i] < CTIME[JUPS]) JUPS = i;
-            if (JUPS == JUPS_OLD && ITIM[JUPS] == ITIM_OLD) { bad = 20; break; }   // :901-903
-            JUPS_OLD = JUPS; ITIM_OLD = ITIM[JUPS];
-            if (!((done >> JUPS) & 1u)) {
-              const int kj = ITIM[JUPS];
-              if (kj >= snr[JUPS]) {                 // particle not routed: series finished :910-912
-                done |= 1u << JUPS; CTIME[JUPS] = DBL_MAX;
-              } else {
-                const double CT = CTIME[JUPS];
-                const double TIME_OLD = IPRT >= 1 ? TIME_LAST : -DBL_MAX;
-                if (CT < TIME_OLD) { bad = 30; break; }
-                if (CT != TIME_OLD) {
-                  double Q_AGG = 0.0;
-                  for (int i = 0; i < NUPS; ++i) {
-                    const int IWAV = ITIM[i];
-                    double SFLOW;
-                    if (i == JUPS) {
-                      SFLOW = sQ(i, IWAV) * sc[i];
-                    } else {
-                      int IBEG = IWAV;
-                      if (sT(i, IBEG) >= CT) IBEG = IWAV - 1;
-                      const int IEND = IBEG + 1;
-                      const double tb = sT(i, IBEG), te = sT(i, IEND);
-                      if (IEND >= slen[i] || IBEG < 0 || te < CT || tb > CT) { bad = 40; break; }
-                      const double qb = sQ(i, IBEG), qe = sQ(i, IEND);
-                      const double SLOPE = (qe - qb) / (te - tb);
-                      const double PREDV = qb + SLOPE * (CT - tb);
-                      SFLOW = PREDV * sc[i];
-                    }
-                    Q_AGG = Q_AGG + SFLOW;
+          auto groupT = [&](int h, int hn) -> double { return hn - h > 1 ? Xw[h + 1] : Tw[h]; };
+          if (NI > 1) {
+            double X = 0.0;
+            for (;;) {
+              double XB = XMX; int IXB = 0, JXBsel = 0;
+              int jw = 1, iw = nextHead(1);
+              double wcj = Xw[jw], tj = groupT(jw, iw);
+              while (iw <= NI) {
+                const int inx = nextHead(iw);
+                const double wci = Xw[iw], ti = groupT(iw, inx);
+                if (!(wci == 0.0 || wcj == 0.0)) {
+                  const double WDIFF = 1.0 / wcj - 1.0 / wci;
+                  if (!(WDIFF == 0.0) && !(wci == wcj)) {
+                    const double XXB = (ti - tj) / WDIFF;
+                    if (!(XXB < X || XXB > XB)) { XB = XXB; IXB = iw; JXBsel = jw; }
                   }
-                  if (bad) break;
-                  if (IPRT >= IMAX) { bad = 60; break; }
-                  Qw[NJ + 1 + IPRT] = Q_AGG; Tw[NJ + 1 + IPRT] = CT; TIME_LAST = CT; ++IPRT;
                 }
-                if (kj == slen[JUPS] - 1) { done |= 1u << JUPS; CTIME[JUPS] = DBL_MAX; }
-                else { ITIM[JUPS] = kj + 1; CTIME[JUPS] = sT(JUPS, kj + 1); }
+                jw = iw; wcj = wci; tj = ti; iw = inx;
               }
+              if (XB == XMX) break;
+              // merge group IXB into group JXB (:1325-1346)
+              const int JXB = JXBsel;
+              const int endI = nextHead(IXB);
+              double q2 = Qw[JXB], q1 = Qw[JXB];
+              for (int j = JXB + 1; j < endI; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
+              const double A2 = pow_0p6(q2 / K);
+              const double A1 = pow_0p6(q1 / K);
+              const double CM = (q2 - q1) / (A2 - A1);
+              const double tJ = groupT(JXB, IXB);
+              const double wcJ = Xw[JXB];
+              alive &= ~(1u << IXB);
+              Xw[JXB + 1] = tJ + XB / wcJ - XB / CM;
+              Xw[JXB] = CM;
+              X = XB;
             }
-            if (done == all) break;
           }
-          if (bad) { mzr_raise(d, bad, r, t, 11); break; }
-          ND = IPRT;
-        }
-      }
-      if (cold) {   // getusq_rch :587-596
-        const double DT = T1 - T0;
-        Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; Xw[0] = T0 - DT * 0;
-      }
-      int size = NJ + 1 + ND;
-
-      {   // kwt_rch :163-174
-        double mn = Qw[0];
-        for (int k = 1; k < size; ++k) mn = Qw[k] < mn ? Qw[k] : mn;
-        if (mn < 0.0) { mzr_raise(d, 20, r, t, 12); break; }
-        double q_up = 0.0;
-        const uint32_t gm = d.goodMask[r];
-        for (int i = 0; i < ng; ++i) { if (!((gm >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
-        d.inflow[r] = q_up;
-      }
-
-      // ---- remove_rch :999-1123: drop the particle with the least interpolation error until < MAXQPAR
-      if (size > MZR_MAXQPAR_DEV) {
-        const int NPRT = size - 1;
-        uint8_t prv[WK], nxt[WK];
-        for (int i = 0; i <= NPRT; ++i) { prv[i] = (uint8_t)(i - 1); nxt[i] = (uint8_t)(i + 1); }
-        Xw[NPRT] = DBL_MAX;
-        const double X0keep = Xw[0];
-        Xw[0] = DBL_MAX;
-        for (int i = 1; i <= NPRT - 1; ++i)
-          Xw[i] = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
-        int MPRT = NPRT;
-        while (MPRT >= MZR_MAXQPAR_DEV) {
-          int ISEL = 0; double emin = Xw[0];
-          for (int i = 1; i <= NPRT; ++i) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
-          const int pm = prv[ISEL], pn = nxt[ISEL];       // INDEX1(ISEL-1), INDEX1(ISEL+1)
-          if (pm > 0) {
-            const int INEG = prv[pm];
-            Xw[pm] = fabs(interp3(Tw[pm], Qw[INEG], Qw[pn], Tw[INEG], Tw[pn]) - Qw[pm]);
-          }
-          if (pn < NPRT) {
-            const int IPOS = nxt[pn];
-            Xw[pn] = fabs(interp3(Tw[pn], Qw[pm], Qw[IPOS], Tw[pm], Tw[IPOS]) - Qw[pn]);
-          }
-          Xw[ISEL] = INFINITY;                           // removed: never the minimum again
-          nxt[pm] = (uint8_t)pn; prv[pn] = (uint8_t)pm;
-          --MPRT;
-        }
-        int k = 0;
-        for (int i = 0; i <= NPRT; i = nxt[i]) { Qw[k] = Qw[i]; Tw[k] = Tw[i]; ++k; }
-        size = MPRT + 1;
-        Xw[0] = X0keep;
-      }
-      const int NQ1 = size - 1;
-
-      // ---- kinwav_rch :1130-1439 on particles 1..NQ1 (Q0/T0 = Qw/Tw in place)
-      int NQ2 = 0;
-      {
-        const double ALFA = 5.0 / 3.0;
-        const double K = sqrt(d.slope[r]) / d.mann[r];
-        const double XMX = d.length[r];
-        constexpr int KC = MZR_MAXQPAR_DEV + 1;
-        double Q1[KC], Q2[KC], TT[KC], WC[KC];
-        uint8_t IX[KC], MF[KC];
-        int NN = NQ1;
-        const int NI = NQ1;
-        const double e1 = 1.0 / ALFA, e2 = (ALFA - 1.0) / ALFA;
-        const double cw = ALFA * pow(K, e1);
-        for (int i = 1; i <= NI; ++i) {
-          MF[i] = (uint8_t)i; IX[i] = (uint8_t)i;
-          Q1[i] = Q2[i] = Qw[i]; TT[i] = Tw[i];
-          WC[i] = cw * pow(Qw[i], e2);
-        }
-        if (NN > 1) {
-          double X = 0.0;
-          for (;;) {
-            double XB = XMX; int IXB = 0;
-            for (int IW = 2; IW <= NN; ++IW) {
-              const int JW = IW - 1;
-              if (WC[IW] == 0.0 || WC[JW] == 0.0) continue;
-              const double WDIFF = 1.0 / WC[JW] - 1.0 / WC[IW];
-              if (WDIFF == 0.0) continue;
-              if (WC[IW] == WC[JW]) continue;
-              const double XXB = (TT[IW] - TT[JW]) / WDIFF;
-              if (XXB < X || XXB > XB) continue;
-              XB = XXB; IXB = IW;
-            }
-            if (XB == XMX) break;
-            NN = NN - 1;
-            const int JXB = IXB - 1;
-            Q2[JXB] = fmax(Q2[JXB], Q2[IXB]);
-            Q1[JXB] = fmin(Q1[JXB], Q1[IXB]);
-            const double A2 = pow(Q2[JXB] / K, 1.0 / ALFA);
-            const double A1 = pow(Q1[JXB] / K, 1.0 / ALFA);
-            const double CM = (Q2[JXB] - Q1[JXB]) / (A2 - A1);
-            TT[JXB] = TT[JXB] + XB / WC[JXB] - XB / CM;
-            WC[JXB] = CM;
-            for (int i = IX[IXB]; i <= NI; ++i) MF[i] = (uint8_t)(MF[i] - 1);
-            for (int i = IXB; i <= NN; ++i) { IX[i] = IX[i + 1]; TT[i] = TT[i + 1]; WC[i] = WC[i + 1]; Q1[i] = Q1[i + 1]; Q2[i] = Q2[i + 1]; }
-            X = XB;
-          }
-        }
-        int ICOUNT = 0, bad = 0;
-        auto rUpdate = [&](double QNEW, double TOLD, double TNEW) {   // :1409-1437
-          ++ICOUNT;
-          if (ICOUNT > NI) { bad = 60; return; }
-          Qw[ICOUNT] = QNEW; Tw[ICOUNT] = TOLD;
-          double te = TNEW;
-          if (ICOUNT > 1) { if (te <= Xw[ICOUNT - 1]) te = Xw[ICOUNT - 1] + 1.0; }
-          if (ICOUNT == 1 && te <= T_START) te = T_START + 1.0;
-          Xw[ICOUNT] = te;
-        };
-        for (int IROUTE = 1; IROUTE <= NN && !bad; ++IROUTE) {
-          if (WC[IROUTE] < DBL_MIN) { bad = 20; break; }                       // zero flow :1365
-          const double TEXIT = fmin(XMX / WC[IROUTE] + TT[IROUTE], DBL_MAX);
-          double TNEXT = DBL_MAX;
-          if (IROUTE < NN) TNEXT = fmin(XMX / WC[IROUTE + 1] + TT[IROUTE + 1], DBL_MAX);
-          if (Q1[IROUTE] != Q2[IROUTE]) {
-            if (TEXIT < T_END) {
-              const double TEXIT2 = fmin(TEXIT + 1.0, TEXIT + 0.5 * (fmin(TNEXT, T_END) - TEXIT));
-              if (TEXIT2 == TEXIT) { bad = 30; break; }
-              rUpdate(Q1[IROUTE], TT[IROUTE], TEXIT);
-              if (bad) break;
-              rUpdate(Q2[IROUTE], TT[IROUTE], TEXIT2);
+          int ICOUNT = 0, bad = 0;
+          double xprev = 0.0;
+          auto rUpdate = [&](double QNEW, double TOLD, double TNEW) {   // :1409-1437
+            ++ICOUNT;
+            if (ICOUNT > NI) { bad = 60; return; }
+            double te = TNEW;
+            if (ICOUNT > 1) { if (te <= xprev) te = xprev + 1.0; }
+            if (ICOUNT == 1 && te <= T_START) te = T_START + 1.0;
+            Qw[ICOUNT] = QNEW; Tw[ICOUNT] = TOLD; Xw[ICOUNT] = te; xprev = te;
+          };
+          int h = 1;
+          int hn = NI >= 1 ? nextHead(1) : NI + 1;
+          double wc = NI >= 1 ? Xw[1] : 0.0, tg = NI >= 1 ? groupT(1, hn) : 0.0;
+          while (h <= NI && !bad) {
+            // look ahead to the next group before this group's slots are overwritten
+            const int hnn = hn <= NI ? nextHead(hn) : NI + 1;
+            const double wcn = hn <= NI ? Xw[hn] : 0.0;
+            const double tgn = hn <= NI ? groupT(hn, hnn) : 0.0;
+            if (wc < DBL_MIN) { bad = 20; break; }                       // zero flow :1365
+            const double TEXIT = fmin(XMX / wc + tg, DBL_MAX);
+            double TNEXT = DBL_MAX;
+            if (hn <= NI) TNEXT = fmin(XMX / wcn + tgn, DBL_MAX);
+            double q1 = Qw[h], q2 = q1;
+            for (int j = h + 1; j < hn; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
+            if (q1 != q2) {
+              if (TEXIT < T_END) {
+                const double TEXIT2 = fmin(TEXIT + 1.0, TEXIT + 0.5 * (fmin(TNEXT, T_END) - TEXIT));
+                if (TEXIT2 == TEXIT) { bad = 30; break; }
+                rUpdate(q1, tg, TEXIT);
+                if (bad) break;
+                rUpdate(q2, tg, TEXIT2);
+              } else {
+                for (int J = h; J < hn && !bad; ++J) rUpdate(Qw[J], Tw[J], TEXIT);
+              }
             } else {
-              for (int J = 1; J <= NI && !bad; ++J) if (MF[J] == IROUTE) rUpdate(Qw[J], Tw[J], TEXIT);
+              rUpdate(q1, tg, TEXIT);
             }
-          } else {
-            rUpdate(Q1[IROUTE], TT[IROUTE], TEXIT);
+            h = hn; hn = hnn; wc = wcn; tg = tgn;
           }
+          if (bad) { mzr_raise(d, bad, r, t, 13); break; }
+          NQ2 = ICOUNT;
         }
-        if (bad) { mzr_raise(d, bad, r, t, 13); break; }
-        NQ2 = ICOUNT;
-      }
 
-      // ---- time-step average and housekeeping, kwt_rch :257-311
-      int NR = 0;
-      for (int i = 1; i <= NQ2; ++i) NR += Xw[i] < T_END ? 1 : 0;   // count(FROUTE)-1
-      if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
-      double QNEW;
-      if (d_interp_rch(Xw, Qw, NR + 2, T_START, T_END, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
-      const double Qout = QNEW * RW + qlat_r;
-      Qrow[r] = Qout;
-      d.qsum[r] += Qout;
-      const double dTx = Xw[NR + 1] - Xw[NR];
-      const double Q_END = Qw[NR] + ((Qw[NR + 1] - Qw[NR]) / dTx) * (T_END - Xw[NR]);
-      const double TIMEI = Tw[NR] + ((Tw[NR + 1] - Tw[NR]) / dTx) * (T_END - Xw[NR]);
-      const int NN2 = NQ2 - NR;
-      // outbox for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
-      if (!d.isOutlet[r]) {
-        int *obNw = d.obN + (size_t)par * N;
-        double *obQw = d.obQ + (size_t)par * MZR_OB_CAP * N;
-        double *obTw = d.obT + (size_t)par * MZR_OB_CAP * N;
-        obNw[r] = NR + 2;
-        for (int k = 0; k <= NR; ++k) { obQw[(size_t)k * N + r] = Qw[k]; obTw[(size_t)k * N + r] = Xw[k]; }
-        obQw[(size_t)(NR + 1) * N + r] = Q_END;      obTw[(size_t)(NR + 1) * N + r] = T_END;
-        obQw[(size_t)(NR + 2) * N + r] = Qw[NR + 1]; obTw[(size_t)(NR + 2) * N + r] = Xw[NR + 1];
-      }
-      // at-rest state: KWAVE(NR+1:NQ2+1)
-      d.kwN[r] = NN2 + 1;
-      d.kwQ[r] = Q_END; d.kwTI[r] = TIMEI; d.kwTR[r] = T_END;
-      for (int j = 1; j <= NN2; ++j) {
-        d.kwQ[(size_t)j * N + r] = Qw[NR + j]; d.kwTI[(size_t)j * N + r] = Tw[NR + j]; d.kwTR[(size_t)j * N + r] = Xw[NR + j];
-      }
-      st_out = NQ2 + 2;
-    } while (0);
+        // ---- time-step average and housekeeping, kwt_rch :257-311
+        Xw[0] = X0;
+        int NR = 0;
+        for (int i = 1; i <= NQ2; ++i) NR += Xw[i] < T_END ? 1 : 0;   // count(FROUTE)-1
+        if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
+        double QNEW;
+        if (d_interp_rch(Xw, Qw, NR + 2, T_START, T_END, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
+        const double Qout = QNEW * RW + qlat_r;
+        Qrow[r] = Qout;
+        d.qsum[r] += Qout;
+        const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
+        const double dTx = xN1 - xN;
+        const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
+        const double TIMEI = tN + ((tN1 - tN) / dTx) * (T_END - xN);
+        const int NN2 = NQ2 - NR;
+        // outbox for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
+        if (!d.isOutlet[r]) {
+          int *obNw = d.obN + (size_t)par * N;
+          double *obQw = d.obQ + (size_t)par * MZR_OB_CAP * N;
+          double *obTw = d.obT + (size_t)par * MZR_OB_CAP * N;
+          obNw[r] = NR + 2;
+          for (int k = 0; k <= NR; ++k) { obQw[(size_t)k * N + r] = Qw[k]; obTw[(size_t)k * N + r] = Xw[k]; }
+          obQw[(size_t)(NR + 1) * N + r] = Q_END; obTw[(size_t)(NR + 1) * N + r] = T_END;
+          obQw[(size_t)(NR + 2) * N + r] = qN1;   obTw[(size_t)(NR + 2) * N + r] = xN1;
+        }
+        // at-rest state: KWAVE(NR+1:NQ2+1)
+        d.kwN[r] = NN2 + 1;
+        d.kwQ[r] = Q_END; d.kwTI[r] = TIMEI; d.kwTR[r] = T_END;
+        for (int j = 1; j <= NN2; ++j) {
+          d.kwQ[(size_t)j * N + r] = Qw[NR + j]; d.kwTI[(size_t)j * N + r] = Tw[NR + j]; d.kwTR[(size_t)j * N + r] = Xw[NR + j];
+        }
+        st_out = NQ2 + 2;
+      } while (0);
+    }
   }
   if (d.kwtStat) {
     const unsigned long long a = wave_sum(st_in), b = wave_sum(st_up), c = wave_sum(st_out);
@@ -383,10 +590,9 @@ __global__ void __launch_bounds__(256) k_stage_kwt(MzrDev d, int s, int rBegin, 
 }
 
 void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, hipStream_t stream) {
+  (void)wk;
   const int n = rEnd - rBegin;
   if (n <= 0) return;
-  dim3 block(256), grid((n + 255) / 256);
-  if (wk <= 64) hipLaunchKernelGGL(k_stage_kwt<64>, grid, block, 0, stream, d, s, rBegin, rEnd);
-  else if (wk <= 128) hipLaunchKernelGGL(k_stage_kwt<128>, grid, block, 0, stream, d, s, rBegin, rEnd);
-  else hipLaunchKernelGGL(k_stage_kwt<192>, grid, block, 0, stream, d, s, rBegin, rEnd);
+  dim3 block(64), grid((n + 63) / 64);
+  hipLaunchKernelGGL(k_stage_kwt, grid, block, 0, stream, d, s, rBegin, rEnd);
 }

@@ -43,6 +43,7 @@ struct MzrDev {
   const double   *hruW;       // [nHru]
   // ---- parameters (RPARAM, dataTypes.f90:183-195)
   const double *slope, *mann, *width, *depth, *length, *storage, *side, *fldp, *basarea, *minflow;
+  const double *kwK, *kwCW;   // KWT: K = sqrt(slope)/n and ALFA*K**(1/ALFA), precomputed on the host
   // ---- configuration
   double dt, min_length_route, runoffMin, negRunoffTol, time_conv, length_conv, t_start;
   double T1_single;       // end of step for single-step windows (mzr_step passes TSEC(2) explicitly)

@@ -70,6 +70,8 @@ struct mzr_domain {
   DBuf<uint32_t> goodMask;
   DBuf<double> hruW;
   DBuf<double> par[11];
+  std::vector<double> h_slope, h_mann;   // host copies (internal order) for derived KWT constants
+  DBuf<double> kwK, kwCW;
   static const char *parName(int i) {
     static const char *n[11] = {"R_SLOPE", "R_MAN_N", "R_WIDTH", "R_DEPTH", "RLENGTH", "R_STORAGE", "SIDE_SLOPE",
                                 "FLDP_SLOPE", "BASAREA", "TOTAREA", "MINFLOW"};
@@ -113,6 +115,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.slope = h->par[0].p; d.mann = h->par[1].p; d.width = h->par[2].p; d.depth = h->par[3].p;
   d.length = h->par[4].p; d.storage = h->par[5].p; d.side = h->par[6].p; d.fldp = h->par[7].p;
   d.basarea = h->par[8].p; d.minflow = h->par[10].p;
+  d.kwK = h->kwK.p; d.kwCW = h->kwCW.p;
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
@@ -304,6 +307,8 @@ int mzr_set_param(mzr_handle h, const char *name, const double *values) {
       std::vector<double> v(h->N);
       for (int i = 0; i < h->N; ++i) v[i] = values[h->int2ext[i]];
       (void)hipMemcpy(h->par[p].p, v.data(), h->N * sizeof(double), hipMemcpyHostToDevice);
+      if (p == 0) h->h_slope = v;
+      if (p == 1) h->h_mann = v;
       return 0;
     }
   }
@@ -367,6 +372,13 @@ int mzr_init_state(mzr_handle h) {
         h->irfQ.alloc((size_t)h->maxtdh * N); h->irfQ.zero();
       }
       if (m == MZR_KWT) {
+        if ((size_t)h->h_slope.size() != N || (size_t)h->h_mann.size() != N) return fail(h, 20, "mzr_init_state/R_SLOPE and R_MAN_N must be set before KWT state is initialised");
+        {   // kinwav_rch constants, kwt_route.f90:1273-1274,1290: evaluated once, with the host libm
+          const double ALFA = 5.0 / 3.0;
+          std::vector<double> K(N), CW(N);
+          for (size_t i = 0; i < N; ++i) { K[i] = std::sqrt(h->h_slope[i]) / h->h_mann[i]; CW[i] = ALFA * std::pow(K[i], 1.0 / ALFA); }
+          h->kwK.upload(K); h->kwCW.upload(CW);
+        }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
         h->kwQ.zero(); h->kwTI.zero(); h->kwTR.zero();
