@@ -1,0 +1,174 @@
+! ISO_C_BINDING interface to libmzr_hip.so (C-ABI: include/mzr.h).
+!
+! This is the module a mizuRoute maintainer adds to route/build/src/ to call the MI355X hot path
+! from the Fortran driver: `mpi_route` (mpi_process.f90:1217,1294) calls mzr_step (or mzr_run for a
+! window of steps) instead of `main_route` (main_route.f90:29).  See INTEGRATION.md.
+! All arrays are contiguous, caller-owned, in the caller's reach order; indices are 1-based.
+MODULE mzr_c
+  USE, INTRINSIC :: iso_c_binding
+  implicit none
+  private
+
+  integer(c_int), parameter, public :: MZR_SUM=0, MZR_IRF=1, MZR_KWT=2, MZR_KW=3, MZR_MC=4, MZR_DW=5
+  integer(c_int), parameter, public :: MZR_F_Q=0, MZR_F_VOL0=1, MZR_F_VOL1=2, MZR_F_INFLOW=3, MZR_F_ELE=4, &
+                                       MZR_F_FLOODVOL=5, MZR_F_WB=6, MZR_F_BASIN_QR1=7, MZR_F_BASIN_QR0=8, MZR_F_BASIN_QI=9
+  integer(c_int), parameter, public :: MZR_WCAP=32
+
+  ! struct mzr_config (include/mzr.h)
+  type, bind(C), public :: mzr_config
+    real(c_double)  :: dt
+    integer(c_int)  :: nRoutes
+    integer(c_int)  :: routeMethods(6)
+    integer(c_int)  :: doesBasinRoute
+    integer(c_int)  :: hw_drain_point
+    real(c_double)  :: min_length_route
+    real(c_double)  :: runoffMin
+    real(c_double)  :: negRunoffTol
+    real(c_double)  :: time_conv, length_conv
+    integer(c_int)  :: maxWindow
+    integer(c_int)  :: device
+  end type mzr_config
+
+  public :: mzr_default_config, mzr_create, mzr_destroy, mzr_last_error, mzr_set_network, mzr_set_param, &
+            mzr_set_uh, mzr_set_frac_future, mzr_init_state, mzr_step, mzr_run, mzr_sync, mzr_get_flux, &
+            mzr_get_window_q, mzr_get_mean_q, mzr_get_kwt_state, mzr_set_kwt_state, mzr_get_irf_state, &
+            mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule
+  public :: mzr_message
+
+  INTERFACE
+    subroutine mzr_default_config(cfg) bind(C, name='mzr_default_config')
+      import :: mzr_config
+      type(mzr_config), intent(out) :: cfg
+    end subroutine
+    integer(c_int) function mzr_create(cfg, h) bind(C, name='mzr_create')
+      import :: mzr_config, c_ptr, c_int
+      type(mzr_config), intent(in) :: cfg
+      type(c_ptr), intent(out) :: h
+    end function
+    integer(c_int) function mzr_destroy(h) bind(C, name='mzr_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function mzr_last_error(h, buf, len) bind(C, name='mzr_last_error')
+      import :: c_ptr, c_int, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(out) :: buf(*)
+      integer(c_int), value :: len
+    end function
+    integer(c_int) function mzr_set_network(h, nRch, nHru, downIndex, upOffset, upIndex, upGood, hruOffset, &
+                                            hruIndex, hruWeight, reachId) bind(C, name='mzr_set_network')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nRch, nHru
+      integer(c_int), intent(in) :: downIndex(*), upOffset(*), upIndex(*), upGood(*), hruOffset(*), hruIndex(*), reachId(*)
+      real(c_double), intent(in) :: hruWeight(*)
+    end function
+    integer(c_int) function mzr_set_param(h, name, values) bind(C, name='mzr_set_param')
+      import :: c_ptr, c_int, c_double, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: name(*)
+      real(c_double), intent(in) :: values(*)
+    end function
+    integer(c_int) function mzr_set_uh(h, uhOffset, uh) bind(C, name='mzr_set_uh')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), intent(in) :: uhOffset(*)
+      real(c_double), intent(in) :: uh(*)
+    end function
+    integer(c_int) function mzr_set_frac_future(h, n, frac) bind(C, name='mzr_set_frac_future')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: n
+      real(c_double), intent(in) :: frac(*)
+    end function
+    integer(c_int) function mzr_init_state(h) bind(C, name='mzr_init_state')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function mzr_step(h, T0, T1, runoff) bind(C, name='mzr_step')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), value :: T0, T1
+      real(c_double), intent(in) :: runoff(*)
+    end function
+    integer(c_int) function mzr_run(h, nSteps, t_start, runoff) bind(C, name='mzr_run')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), value :: t_start
+      real(c_double), intent(in) :: runoff(*)
+    end function
+    integer(c_int) function mzr_sync(h) bind(C, name='mzr_sync')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function mzr_get_flux(h, method, which, out) bind(C, name='mzr_get_flux')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method, which
+      real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_get_window_q(h, method, out) bind(C, name='mzr_get_window_q')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method
+      real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_get_mean_q(h, method, out, reset) bind(C, name='mzr_get_mean_q')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method, reset
+      real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_get_kwt_state(h, numWaves, qwave, tentry, texit, routed) bind(C, name='mzr_get_kwt_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), intent(out) :: numWaves(*), routed(*)
+      real(c_double), intent(out) :: qwave(*), tentry(*), texit(*)
+    end function
+    integer(c_int) function mzr_set_kwt_state(h, numWaves, qwave, tentry, texit, routed) bind(C, name='mzr_set_kwt_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), intent(in) :: numWaves(*), routed(*)
+      real(c_double), intent(in) :: qwave(*), tentry(*), texit(*)
+    end function
+    integer(c_int) function mzr_get_irf_state(h, qfuture) bind(C, name='mzr_get_irf_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: qfuture(*)
+    end function
+    integer(c_int) function mzr_get_mol_state(h, method, q) bind(C, name='mzr_get_mol_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method
+      real(c_double), intent(out) :: q(*)
+    end function
+    integer(c_int) function mzr_get_basin_state(h, qfuture) bind(C, name='mzr_get_basin_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(out) :: qfuture(*)
+    end function
+    integer(c_int) function mzr_get_schedule(h, nStages, maxStageWidth) bind(C, name='mzr_get_schedule')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), intent(out) :: nStages, maxStageWidth
+    end function
+  END INTERFACE
+
+CONTAINS
+
+  ! the reference's (ierr, message) convention: message chain of the last failing call
+  FUNCTION mzr_message(h) result(msg)
+    type(c_ptr), intent(in) :: h
+    character(len=512) :: msg
+    character(kind=c_char) :: buf(512)
+    integer :: i, rc
+    msg = ''
+    rc = mzr_last_error(h, buf, 512_c_int)
+    do i = 1, 512
+      if (buf(i) == c_null_char) exit
+      msg(i:i) = buf(i)
+    end do
+  END FUNCTION mzr_message
+
+END MODULE mzr_c

@@ -53,6 +53,47 @@ def level_schedule(net):
     return orderOffset, branchOffset, (order + 1).astype(np.int32)
 
 
+def streamorder_schedule(net):
+    """The reference's own intra-rank parallel schedule (domain_decomposition.f90:242-445,
+    `stream_order`): one "order" per Strahler stream order, one branch per connected run of reaches
+    of that order, processed upstream -> downstream inside a branch and in parallel across branches
+    (main_route.f90:356-405)."""
+    N = net.N
+    down0 = net.downIndex.astype(np.int64) - 1
+    order = net.topo_order()                      # upstream -> downstream
+    so = np.zeros(N, dtype=np.int64)
+    upOff, upIdx = net.upOffset, net.upIndex.astype(np.int64) - 1
+    for r in order:
+        ups = upIdx[upOff[r]:upOff[r + 1]]
+        if ups.size == 0:
+            so[r] = 1
+        else:
+            o = so[ups]
+            mx = o.max()
+            so[r] = mx + 1 if (o == mx).sum() >= 2 else mx
+    head = np.ones(N, dtype=bool)                  # a branch starts where no upstream has the same order
+    for r in range(N):
+        ups = upIdx[upOff[r]:upOff[r + 1]]
+        if ups.size and (so[ups] == so[r]).any():
+            head[r] = False
+    branches = {}
+    for r in order:
+        if head[r]:
+            chain = [r]
+            d = down0[r]
+            while d >= 0 and so[d] == so[r]:
+                chain.append(d)
+                d = down0[d]
+            branches.setdefault(int(so[r]), []).append(chain)
+    orderOffset, branchOffset, seg = [0], [0], []
+    for o in sorted(branches):
+        for ch in branches[o]:
+            seg.extend(ch)
+            branchOffset.append(len(seg))
+        orderOffset.append(len(branchOffset) - 1)
+    return (np.array(orderOffset, np.int32), np.array(branchOffset, np.int32), (np.array(seg, np.int64) + 1).astype(np.int32))
+
+
 def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_point=2,
                min_length_route=0.0, runoff_min=0.0, fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0,
                t_start=0.0, uh=None, schedule=None, dump_every=1):

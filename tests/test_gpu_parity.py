@@ -153,3 +153,32 @@ def test_window_split_invariance_at_benchmark_size(hip_lib):
     outlets = net.downIndex <= 0
     qr1 = a.flux(m.KWT, m.api.F_BASIN_QR1)
     assert np.isclose(Qa[-1, 1, outlets].sum(), qr1.sum(), rtol=1e-9)
+
+
+def test_fortran_host_drives_the_c_abi(hip_lib, oracle_lib, tmp_path):
+    """The ISO_C_BINDING module (mizuroute_amd/fortran/mzr_c.f90) and a Fortran time loop calling
+    mzr_step once per step -- the reference's own driver structure -- reproduce the oracle."""
+    import os
+    import subprocess
+    from oracle import refrun
+    exe = os.path.join(os.path.dirname(m.lib_path()), "..", "fortran", "mzr_demo")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    net = m.make_network(300, seed=77)
+    ro = m.make_runoff(net.H, 20, seed=78, storm_prob=0.05, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off = np.arange(0, 2 * net.N + 1, 2, dtype=np.int32)
+    uh = np.tile(np.array([0.6, 0.4]), net.N)
+    methods = [2, 1, 0]
+    case, out = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    refrun.write_case(case, net, ro, 3600.0, methods, uh=(ff, uh_off, uh))
+    res = subprocess.run([exe, case, out], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    n, steps, nr = np.frombuffer(raw[:12].tobytes(), dtype="<i4")
+    Q = np.frombuffer(raw[12:].tobytes(), dtype="<f8").reshape(steps, nr, n)
+    orc = oracle_lib.Oracle(net, 3600.0, methods, ff, uh_off, uh)
+    Qo = orc.run(ro)
+    for ix in range(nr):
+        rep = parity_report(Qo[:, ix], Q[:, ix])
+        assert rep["max_rel"] <= REL_TOL, (methods[ix], rep)

@@ -56,3 +56,5 @@ def test_openmp_schedule_gives_same_answer():
     a = refrun.run_case(net, ro, 3600.0, [2, 1])
     b = refrun.run_case(net, ro, 3600.0, [2, 1], nthreads=4, schedule=refrun.level_schedule(net))
     assert np.array_equal(a["Q"], b["Q"])
+    c = refrun.run_case(net, ro, 3600.0, [2, 1], nthreads=4, schedule=refrun.streamorder_schedule(net))
+    assert np.array_equal(a["Q"], c["Q"])
