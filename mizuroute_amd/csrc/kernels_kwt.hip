@@ -119,118 +119,109 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// k-way merge of the upstream series (qexmul_rch :860-976) with the two particles that bracket
-// each series' cursor held in registers: a series is touched in memory only when its cursor
-// advances.  MAXS = 4 covers the binary confluence (2 basin + 2 reach series) fully unrolled.
-// Returns ND >= 0, or -(ierr) on a reference consistency error.
-template <int MAXS>
-__device__ __forceinline__ int kwt_merge(int nup, int u0, int NUPS, double RW, double T0, double T1,
-                                         const uint8_t *nGood, const double *width,
-                                         const double *qlat_prev, const double *qlat_cur, const int *obN,
-                                         const double *obQ, const double *obT, int N, double *QD, double *TD, int IMAX) {
-  constexpr int MU = MAXS / 2;
-  int su[MAXS], slen[MAXS], snr[MAXS], itim[MAXS];
-  double sc[MAXS], ct[MAXS], qb[MAXS], tb[MAXS], qe[MAXS], te[MAXS];
-  // upstream slot of the k-th reach-type series
-  int rmap[MU];
+// qexmul_rch (:619-993) for the binary confluence (at most two upstream reaches), the shape of
+// almost every reach of a river network.  The reference's generic k-way merge then reduces to:
+//   * every upstream contributes its hillslope series {BASIN_QR(0)@T0, BASIN_QR(1)@T1}: a straight
+//     line, whose only own particle sits at T1 and is the LAST thing merged (MINLOC ties go to
+//     the lowest series index, and the basin series come first);
+//   * each non-headwater upstream contributes its routed particles (exit time < T1) and the
+//     interpolated end-of-step particle at exactly T1;
+//   so the output is the 2-way merge of the routed particles in time order (duplicated times
+//   emitted once), each with the other series interpolated at that time, followed by one particle
+//   at T1.  Arithmetic (scaling by width ratio, slope/prediction form, summation order over the
+//   series) is the reference's, statement by statement (:929-957).
+// The two particles bracketing each cursor live in registers and the next one is prefetched, so
+// the global-memory latency of the outbox overlaps the arithmetic of the current particle.
+__device__ __forceinline__ int kwt_merge_binary(int nup, int u0, double RW, double T0, double T1,
+                                                const uint8_t *nGood, const double *width,
+                                                const double *qlat_prev, const double *qlat_cur, const int *obN,
+                                                const double *obQ, const double *obT, int N, double *QD, double *TD) {
+  const double bsc = 1.0 / RW;               // UWIDTH(basin) = 1
+  const double dT10 = T1 - T0;
+  double b0q0, b0q1, b0sl, b1q0 = 0.0, b1sl = 0.0;
   {
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < MU; ++i) {
-      rmap[i] = 0;
-    }
-#pragma unroll
-    for (int i = 0; i < MU; ++i) {
-      if (i < nup && nGood[u0 + i] > 0) {
-#pragma unroll
-        for (int j = 0; j < MU; ++j) if (j == cnt) rmap[j] = i;
-        ++cnt;
-      }
-    }
+    b0q0 = qlat_prev[u0]; b0q1 = qlat_cur[u0]; b0sl = (b0q1 - b0q0) / dT10;
+    if (nup > 1) { b1q0 = qlat_prev[u0 + 1]; const double q1 = qlat_cur[u0 + 1]; b1sl = (q1 - b1q0) / dT10; }
   }
-#pragma unroll
-  for (int i = 0; i < MAXS; ++i) {
-    su[i] = 0; slen[i] = 0; snr[i] = 0; itim[i] = 1; sc[i] = 0.0; ct[i] = DBL_MAX; qb[i] = tb[i] = qe[i] = te[i] = 0.0;
-    if (i < NUPS) {
-      if (i < nup) {                                   // basin series {BASIN_QR(0)@T0, BASIN_QR(1)@T1} :771-787
-        const int u = u0 + i;
-        su[i] = u; slen[i] = 2; snr[i] = 2; sc[i] = 1.0 / RW;
-        qb[i] = qlat_prev[u]; tb[i] = T0; qe[i] = qlat_cur[u]; te[i] = T1; ct[i] = T1;
-      } else {                                         // routed particles of a non-headwater upstream :792-858
-        int slot = 0;
-#pragma unroll
-        for (int j = 0; j < MU; ++j) if (j == i - nup) slot = rmap[j];
-        const int u = u0 + slot;
-        const int nr = obN[u];                         // count(RF) = NR_u + 2
-        su[i] = u; snr[i] = nr; slen[i] = nr + 1; sc[i] = width[u] / RW;
-        qb[i] = obQ[u]; tb[i] = obT[u]; qe[i] = obQ[(size_t)N + u]; te[i] = obT[(size_t)N + u]; ct[i] = te[i];
-      }
-    }
+  // reach series A (first non-headwater upstream in UREACHI order) and B (second)
+  int ns = 0, uA = 0, uB = 0;
+  if (nGood[u0] > 0) { uA = u0; ns = 1; }
+  if (nup > 1 && nGood[u0 + 1] > 0) { if (ns == 0) uA = u0 + 1; else uB = u0 + 1; ++ns; }
+  int nrA = 0, nrB = 0, kA = 1, kB = 1;
+  double scA = 0.0, qbA = 0.0, tbA = 0.0, qeA = 0.0, teA = DBL_MAX, qnA = 0.0, tnA = 0.0;
+  double scB = 0.0, qbB = 0.0, tbB = 0.0, qeB = 0.0, teB = DBL_MAX, qnB = 0.0, tnB = 0.0;
+  if (ns > 0) {
+    nrA = obN[uA]; scA = width[uA] / RW;
+    qbA = obQ[uA]; tbA = obT[uA]; qeA = obQ[(size_t)N + uA]; teA = obT[(size_t)N + uA];
+    if (nrA > 2) { qnA = obQ[(size_t)2 * N + uA]; tnA = obT[(size_t)2 * N + uA]; }
   }
-  unsigned done = 0;
-  const unsigned all = (1u << NUPS) - 1u;
-  int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff;
+  if (ns > 1) {
+    nrB = obN[uB]; scB = width[uB] / RW;
+    qbB = obQ[uB]; tbB = obT[uB]; qeB = obQ[(size_t)N + uB]; teB = obT[(size_t)N + uB];
+    if (nrB > 2) { qnB = obQ[(size_t)2 * N + uB]; tnB = obT[(size_t)2 * N + uB]; }
+  }
+  if ((ns > 0 && nrA < 2) || (ns > 1 && nrB < 2)) return -40;   // upstream published nothing
+  int IPRT = 0;
   double TIME_LAST = -DBL_MAX;
   for (;;) {
-    int JUPS = 0; double cmin = ct[0];                 // MINLOC(CTIME): first minimum
-#pragma unroll
-    for (int i = 1; i < MAXS; ++i) if (i < NUPS && ct[i] < cmin) { cmin = ct[i]; JUPS = i; }
-    int kj = 0, nrj = 0, lenj = 0;
-#pragma unroll
-    for (int i = 0; i < MAXS; ++i) if (i == JUPS) { kj = itim[i]; nrj = snr[i]; lenj = slen[i]; }
-    if (JUPS == JUPS_OLD && kj == ITIM_OLD) return -20;   // stuck in the continuous do-loop :901-903
-    JUPS_OLD = JUPS; ITIM_OLD = kj;
-    if (!((done >> JUPS) & 1u)) {
-      if (kj >= nrj) {                                 // cursor on a non-routed particle: series finished
-        done |= 1u << JUPS;
-#pragma unroll
-        for (int i = 0; i < MAXS; ++i) if (i == JUPS) ct[i] = DBL_MAX;
-      } else {
-        const double CT = cmin;
-        const double TIME_OLD = IPRT >= 1 ? TIME_LAST : -DBL_MAX;
-        if (CT < TIME_OLD) return -30;
-        if (CT != TIME_OLD) {
-          double Q_AGG = 0.0;
-          bool bad = false;
-#pragma unroll
-          for (int i = 0; i < MAXS; ++i) {
-            if (i < NUPS) {
-              double SFLOW;
-              if (i == JUPS) {
-                SFLOW = qe[i] * sc[i];
-              } else {
-                // IBEG = IWAV-1, IEND = IWAV whenever TR(IWAV) >= CT, which holds for every
-                // consistent series (the cursor time is never below the merge time)
-                if (te[i] < CT || tb[i] > CT || itim[i] < 1) bad = true;
-                const double SLOPE = (qe[i] - qb[i]) / (te[i] - tb[i]);
-                const double PREDV = qb[i] + SLOPE * (CT - tb[i]);
-                SFLOW = PREDV * sc[i];
-              }
-              Q_AGG = Q_AGG + SFLOW;
-            }
-          }
-          if (bad) return -40;
-          if (IPRT >= IMAX) return -60;
-          QD[IPRT] = Q_AGG; TD[IPRT] = CT; TIME_LAST = CT; ++IPRT;
+    // next routed particle of each series: indices 1 .. nr-2 (index nr-1 is the end-of-step particle)
+    const double cA = (ns > 0 && kA <= nrA - 2) ? teA : DBL_MAX;
+    const double cB = (ns > 1 && kB <= nrB - 2) ? teB : DBL_MAX;
+    if (cA == DBL_MAX && cB == DBL_MAX) break;
+    const bool pickA = cA <= cB;               // MINLOC: ties -> lower series index
+    const double CT = pickA ? cA : cB;
+    if (!(CT < T1)) return -40;                // a routed particle leaves before the end of the step
+    if (CT < TIME_LAST) return -30;
+    if (CT != TIME_LAST) {
+      double Q_AGG = 0.0;
+      Q_AGG = Q_AGG + (b0q0 + b0sl * (CT - T0)) * bsc;
+      if (nup > 1) Q_AGG = Q_AGG + (b1q0 + b1sl * (CT - T0)) * bsc;
+      {
+        double SFLOW;
+        if (pickA) SFLOW = qeA * scA;
+        else {
+          if (teA < CT || tbA > CT) return -40;
+          const double SLOPE = (qeA - qbA) / (teA - tbA);
+          SFLOW = (qbA + SLOPE * (CT - tbA)) * scA;
         }
-        if (kj == lenj - 1) {
-          done |= 1u << JUPS;
-#pragma unroll
-          for (int i = 0; i < MAXS; ++i) if (i == JUPS) ct[i] = DBL_MAX;
-        } else {
-#pragma unroll
-          for (int i = 0; i < MAXS; ++i) {
-            if (i == JUPS) {
-              qb[i] = qe[i]; tb[i] = te[i];
-              if (i < nup) { qe[i] = 0.0; te[i] = DBL_MAX; }   // a basin series has two elements only
-              else { qe[i] = obQ[(size_t)(kj + 1) * N + su[i]]; te[i] = obT[(size_t)(kj + 1) * N + su[i]]; }
-              itim[i] = kj + 1; ct[i] = te[i];
-            }
-          }
-        }
+        Q_AGG = Q_AGG + SFLOW;
       }
+      if (ns > 1) {
+        double SFLOW;
+        if (!pickA) SFLOW = qeB * scB;
+        else {
+          if (teB < CT || tbB > CT) return -40;
+          const double SLOPE = (qeB - qbB) / (teB - tbB);
+          SFLOW = (qbB + SLOPE * (CT - tbB)) * scB;
+        }
+        Q_AGG = Q_AGG + SFLOW;
+      }
+      QD[IPRT] = Q_AGG; TD[IPRT] = CT; TIME_LAST = CT; ++IPRT;
     }
-    if (done == all) break;
+    if (pickA) {
+      qbA = qeA; tbA = teA; qeA = qnA; teA = tnA; ++kA;
+      if (kA + 1 <= nrA - 1) { qnA = obQ[(size_t)(kA + 1) * N + uA]; tnA = obT[(size_t)(kA + 1) * N + uA]; }
+    } else {
+      qbB = qeB; tbB = teB; qeB = qnB; teB = tnB; ++kB;
+      if (kB + 1 <= nrB - 1) { qnB = obQ[(size_t)(kB + 1) * N + uB]; tnB = obT[(size_t)(kB + 1) * N + uB]; }
+    }
+  }
+  {   // the particle at T1, led by the first basin series
+    const double CT = T1;
+    double Q_AGG = 0.0;
+    Q_AGG = Q_AGG + b0q1 * bsc;
+    if (nup > 1) Q_AGG = Q_AGG + (b1q0 + b1sl * (CT - T0)) * bsc;
+    if (ns > 0) {
+      if (teA < CT || tbA > CT) return -40;
+      const double SLOPE = (qeA - qbA) / (teA - tbA);
+      Q_AGG = Q_AGG + (qbA + SLOPE * (CT - tbA)) * scA;
+    }
+    if (ns > 1) {
+      if (teB < CT || tbB > CT) return -40;
+      const double SLOPE = (qeB - qbB) / (teB - tbB);
+      Q_AGG = Q_AGG + (qbB + SLOPE * (CT - tbB)) * scB;
+    }
+    QD[IPRT] = Q_AGG; TD[IPRT] = CT; ++IPRT;
   }
   return IPRT;
 }
@@ -308,6 +299,11 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
   return IPRT;
 }
 
+#ifdef MZR_KWT_TIMING
+#define TSTAMP(i) do { const long long _n = clock64(); if ((threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[i], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 #define KWT_POOL 1024   // particles of LDS work space per wavefront (3 x 8 B + 2 B each)
 
 // One wavefront per block.  Each lane first works out how many work-array entries its reach needs
@@ -332,6 +328,9 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
   const double *obQ = d.obQ + (size_t)par * MZR_OB_CAP * N;
   const double *obT = d.obT + (size_t)par * MZR_OB_CAP * N;
 
+#ifdef MZR_KWT_TIMING
+  long long _tprev = clock64();
+#endif
   int need = 0, nup = 0, u0 = 0, ng = 0, n_own = 0, NUPS = 0, IMAX = 0;
   double qlat_r = 0.0;
   if (live) {
@@ -360,6 +359,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
     }
   }
 
+  TSTAMP(0);
   bool pending = need > 0;
   while (__any(pending)) {
     // wave-wide inclusive prefix sum of the pending lanes' needs
@@ -377,19 +377,29 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
         // ---- own particles (getusq_rch :598-608); element 0 = last routed particle
         const bool cold = (n_own == 0);
         const int NJ = cold ? 0 : n_own - 1;
-        for (int k = 0; k < n_own; ++k) { Qw[k] = d.kwQ[(size_t)k * N + r]; Tw[k] = d.kwTI[(size_t)k * N + r]; }
         double X0 = cold ? 0.0 : d.kwTR[r];
+        for (int k = 0; k < n_own; k += 4) {   // four particles per trip: eight loads in flight before the LDS writes
+          double q[4], ti[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int kk = k + j < n_own ? k + j : n_own - 1;
+            q[j] = d.kwQ[(size_t)kk * N + r]; ti[j] = d.kwTI[(size_t)kk * N + r];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k + j < n_own) { Qw[k + j] = q[j]; Tw[k + j] = ti[j]; }
+        }
         st_in = n_own;
 
         // ---- qexmul_rch
         int ND;
         if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
           Qw[NJ + 1] = qlat_cur[u0] / RW; Tw[NJ + 1] = T1; ND = 1;
-        } else if (nup <= 2) {   // binary confluence: <= 2 basin + 2 reach series, all in registers
-          ND = kwt_merge<4>(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1, IMAX);
+        } else if (nup <= 2) {   // binary confluence
+          ND = kwt_merge_binary(nup, u0, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1);
         } else {
           ND = kwt_merge_generic(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1, IMAX);
         }
+        TSTAMP(1);
         if (ND < 0) { mzr_raise(d, -ND, r, t, 11); break; }
         if (cold) {   // getusq_rch :587-596
           const double DT = T1 - T0;
@@ -407,6 +417,15 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           d.inflow[r] = q_up;
         }
 
+        TSTAMP(2);
+#ifdef MZR_KWT_TIMING
+        {
+          const unsigned long long bm = __ballot(size > MZR_MAXQPAR_DEV);
+          if (size > MZR_MAXQPAR_DEV) { atomicAdd(&d.dbgCycles[8], 1ull); atomicAdd(&d.dbgCycles[9], (unsigned long long)(size - MZR_MAXQPAR_DEV)); atomicMax(&d.dbgCycles[10], (unsigned long long)size); atomicAdd(&d.dbgCycles[12], (unsigned long long)size); }
+          if (bm && (int)(threadIdx.x & 63) == __ffsll(bm) - 1) { atomicAdd(&d.dbgCycles[11], 1ull); atomicAdd(&d.dbgCycles[13], (unsigned long long)__popcll(bm)); }
+          atomicAdd(&d.dbgCycles[14], (unsigned long long)size); atomicAdd(&d.dbgCycles[15], 1ull);
+        }
+#endif
         // ---- remove_rch :999-1123: drop the particle with the least interpolation error until < MAXQPAR
         if (size > MZR_MAXQPAR_DEV) {
           const int NPRT = size - 1;
@@ -423,7 +442,17 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           int MPRT = NPRT;
           while (MPRT >= MZR_MAXQPAR_DEV) {
             int ISEL = 0; double emin = DBL_MAX;
-            for (int i = 1; i <= NPRT; ++i) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
+            {   // first minimum of ABSERR over 1..NPRT (removed entries hold +Inf); four LDS reads in flight
+              int i = 1;
+              for (; i + 3 <= NPRT; i += 4) {
+                const double e0 = Xw[i], e1 = Xw[i + 1], e2 = Xw[i + 2], e3 = Xw[i + 3];
+                if (e0 < emin) { emin = e0; ISEL = i; }
+                if (e1 < emin) { emin = e1; ISEL = i + 1; }
+                if (e2 < emin) { emin = e2; ISEL = i + 2; }
+                if (e3 < emin) { emin = e3; ISEL = i + 3; }
+              }
+              for (; i <= NPRT; ++i) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
+            }
             if (ISEL == 0) break;                         // no finite interpolation error left (NaN/Inf input)
             const unsigned short ls = Lw[ISEL];
             const int pm = ls & 0xff, pn = ls >> 8;     // INDEX1(ISEL-1), INDEX1(ISEL+1)
@@ -447,6 +476,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           size = MPRT + 1;
         }
         const int NQ1 = size - 1;
+        TSTAMP(3);
 
         // ---- kinwav_rch :1130-1439 on particles 1..NQ1, in place:
         //   Xw[i]   wave celerity of the group whose first particle is i   (WC)
@@ -460,6 +490,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           const double XMX = d.length[r];
           const int NI = NQ1;
           for (int i = 1; i <= NI; ++i) Xw[i] = cw * pow_0p4(Qw[i]);
+          TSTAMP(4);
           unsigned alive = NI >= 31 ? 0xfffffffeu : ((1u << (NI + 1)) - 2u);   // bits 1..NI
           auto nextHead = [&](int h) -> int {           // next group head after h, or NI+1
             const unsigned m = alive & ~((2u << h) - 1u);
@@ -475,7 +506,8 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
               while (iw <= NI) {
                 const int inx = nextHead(iw);
                 const double wci = Xw[iw], ti = groupT(iw, inx);
-                if (!(wci == 0.0 || wcj == 0.0)) {
+                // earlier wave faster and later entry: XXB < 0 <= X (or WDIFF == 0) -> no break, no division
+                if (!(wci == 0.0 || wcj == 0.0) && !(wcj > wci && ti > tj)) {
                   const double WDIFF = 1.0 / wcj - 1.0 / wci;
                   if (!(WDIFF == 0.0) && !(wci == wcj)) {
                     const double XXB = (ti - tj) / WDIFF;
@@ -501,6 +533,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
               X = XB;
             }
           }
+          TSTAMP(5);
           int ICOUNT = 0, bad = 0;
           double xprev = 0.0;
           auto rUpdate = [&](double QNEW, double TOLD, double TNEW) {   // :1409-1437
@@ -514,14 +547,14 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           int h = 1;
           int hn = NI >= 1 ? nextHead(1) : NI + 1;
           double wc = NI >= 1 ? Xw[1] : 0.0, tg = NI >= 1 ? groupT(1, hn) : 0.0;
+          double TEXIT = (NI >= 1 && !(wc < DBL_MIN)) ? fmin(XMX / wc + tg, DBL_MAX) : 0.0;
           while (h <= NI && !bad) {
             // look ahead to the next group before this group's slots are overwritten
             const int hnn = hn <= NI ? nextHead(hn) : NI + 1;
             const double wcn = hn <= NI ? Xw[hn] : 0.0;
             const double tgn = hn <= NI ? groupT(hn, hnn) : 0.0;
             if (wc < DBL_MIN) { bad = 20; break; }                       // zero flow :1365
-            const double TEXIT = fmin(XMX / wc + tg, DBL_MAX);
-            double TNEXT = DBL_MAX;
+            double TNEXT = DBL_MAX;                                      // = TEXIT of the next group (:1372)
             if (hn <= NI) TNEXT = fmin(XMX / wcn + tgn, DBL_MAX);
             double q1 = Qw[h], q2 = q1;
             for (int j = h + 1; j < hn; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
@@ -538,12 +571,13 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
             } else {
               rUpdate(q1, tg, TEXIT);
             }
-            h = hn; hn = hnn; wc = wcn; tg = tgn;
+            h = hn; hn = hnn; wc = wcn; tg = tgn; TEXIT = TNEXT;
           }
           if (bad) { mzr_raise(d, bad, r, t, 13); break; }
           NQ2 = ICOUNT;
         }
 
+        TSTAMP(6);
         // ---- time-step average and housekeeping, kwt_rch :257-311
         Xw[0] = X0;
         int NR = 0;
@@ -576,6 +610,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           d.kwQ[(size_t)j * N + r] = Qw[NR + j]; d.kwTI[(size_t)j * N + r] = Tw[NR + j]; d.kwTR[(size_t)j * N + r] = Xw[NR + j];
         }
         st_out = NQ2 + 2;
+        TSTAMP(7);
       } while (0);
     }
   }

@@ -73,6 +73,7 @@ struct MzrDev {
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
   double *obQ, *obT;          // [2][MZR_OB_CAP][N]
   MzrKwtStat *kwtStat;
+  unsigned long long *dbgCycles;   // [16] per-section wave cycles (only with -DMZR_KWT_TIMING)
   MzrErr *err;
 };
 

@@ -91,6 +91,7 @@ struct mzr_domain {
   DBuf<int> kwN, obN;
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
   DBuf<MzrKwtStat> kwtStat;
+  DBuf<unsigned long long> dbgCycles;
   DBuf<MzrErr> err;
   RouteBufs route[6];
   bool profiling = false;
@@ -125,7 +126,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
-  d.kwtStat = h->kwtStat.p; d.err = h->err.p;
+  d.kwtStat = h->kwtStat.p; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
 }
 
 void setRoute(mzr_handle h, MzrDev &d, int ix) {
@@ -386,6 +387,7 @@ int mzr_init_state(mzr_handle h) {
         h->obQ.alloc((size_t)2 * MZR_OB_CAP * N); h->obT.alloc((size_t)2 * MZR_OB_CAP * N);
         h->obQ.zero(); h->obT.zero();
         h->kwtStat.alloc(1); h->kwtStat.zero();
+        h->dbgCycles.alloc(16); h->dbgCycles.zero();
       }
       rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0;
     }
@@ -616,6 +618,15 @@ int mzr_get_basin_state(mzr_handle h, double *qfuture) {
   std::vector<double> v((size_t)n * N);
   (void)hipMemcpy(v.data(), h->basS[h->basCur].p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
   for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) qfuture[(size_t)e * n + j] = v[(size_t)j * N + h->ext2int[e]];
+  return 0;
+}
+
+// debug: per-section wave cycles of the KWT kernel (library built with -DMZR_KWT_TIMING)
+int mzr_debug_cycles(mzr_handle h, unsigned long long *out16, int reset) {
+  if (!h || !h->dbgCycles.p) return 1;
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipMemcpy(out16, h->dbgCycles.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (reset) (void)hipMemset(h->dbgCycles.p, 0, 16 * sizeof(unsigned long long));
   return 0;
 }
 

@@ -1,0 +1,29 @@
+"""Debug: per-section wave-cycle breakdown of the KWT stage kernel.
+Build the library with `make -C mizuroute_amd/csrc clean all EXTRA=-DMZR_KWT_TIMING` first."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import mizuroute_amd as m
+from mizuroute_amd import uh as uhmod
+sys.argv = sys.argv[:1]
+import bench
+net = m.make_network(100000, seed=20240529)
+frac = uhmod.basin_uh(3600.0, 2.5, 86400.0)
+W = 512
+dom = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=frac, max_window=W)
+dev = torch.device("cuda", 0)
+ro = bench.device_runoff(torch, net.H, W, 0, 7, dev); torch.cuda.synchronize()
+dom.run_device(W, 0.0, ro.data_ptr()); dom.sync()
+buf = (C.c_ulonglong * 16)()
+dom.L.mzr_debug_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+dom.L.mzr_debug_cycles(dom.h, buf, 1)
+ro = bench.device_runoff(torch, net.H, W, W, 7, dev); torch.cuda.synchronize()
+dom.run_device(W, W * 3600.0, ro.data_ptr()); dom.sync()
+dom.L.mzr_debug_cycles(dom.h, buf, 1)
+names = ["0 setup/need", "1 load own + merge", "2 min/inflow", "3 remove", "4 celerity pow", "5 shock search", "6 routing loop", "7 interp + stores"]
+tot = sum(buf[i] for i in range(8))
+for i, n in enumerate(names):
+    print(f"{n:22s} {buf[i]:16d}  {100.0*buf[i]/tot:5.1f}%")
+print("lanes needing remove", buf[8], "sum iterations", buf[9], "max size", buf[10], "waves with >=1 needing", buf[11],
+      "mean size of needing", buf[12] / max(1, buf[8]), "lanes needing per such wave", buf[13] / max(1, buf[11]),
+      "mean size all routed", buf[14] / max(1, buf[15]), "routed reach-steps", buf[15])
