@@ -15,10 +15,10 @@ import tempfile
 
 import numpy as np
 
+from mizuroute_amd.casefile import MAGIC_IN, serial_schedule, write_case  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 EXE = os.path.join(HERE, "_ref", "ref_route")
-MAGIC_IN = 0x4D5A5243 - 0  # placeholder, real values below
-MAGIC_IN = 1297765955
 MAGIC_OUT = 1297765967
 WCAP = 32
 NMOL = {3: 20, 4: 2, 5: 20}
@@ -30,12 +30,6 @@ def available() -> bool:
 
 def build():
     subprocess.check_call([os.path.join(HERE, "build_ref.sh")])
-
-
-def serial_schedule(net):
-    """One order, one branch, all reaches upstream->downstream (a valid serial schedule)."""
-    order = net.topo_order() + 1
-    return np.array([0, 1], np.int32), np.array([0, net.N], np.int32), order.astype(np.int32)
 
 
 def level_schedule(net):
@@ -92,37 +86,6 @@ def streamorder_schedule(net):
             branchOffset.append(len(seg))
         orderOffset.append(len(branchOffset) - 1)
     return (np.array(orderOffset, np.int32), np.array(branchOffset, np.int32), (np.array(seg, np.int64) + 1).astype(np.int32))
-
-
-def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_point=2,
-               min_length_route=0.0, runoff_min=0.0, fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0,
-               t_start=0.0, uh=None, schedule=None, dump_every=1):
-    """uh: None -> the harness calls the reference's basinUH/make_uh; else (frac, uhOffset, uh)."""
-    runoff = np.ascontiguousarray(runoff, dtype=np.float64)
-    n_steps = runoff.shape[0]
-    orderOffset, branchOffset, seg = schedule if schedule is not None else serial_schedule(net)
-    m = list(methods) + [-1] * (6 - len(methods))
-    with open(path, "wb") as f:
-        f.write(struct.pack("<2i", MAGIC_IN, 1))
-        ints = [net.N, net.H, n_steps, len(methods)] + m + [does_basin_route, hw_drain_point,
-                int(net.upOffset[-1]), int(net.hruOffset[-1]), len(orderOffset) - 1, len(branchOffset) - 1,
-                1 if uh is not None else 0, len(uh[0]) if uh is not None else 0,
-                int(uh[1][-1]) if uh is not None else 0, int(dump_every)]
-        f.write(struct.pack(f"<{len(ints)}i", *ints))
-        f.write(struct.pack("<8d", dt, min_length_route, runoff_min, fshape, tscale, velo, diff, t_start))
-        for a in (net.downIndex, net.reachId, net.upOffset, net.upIndex, net.upGood, net.hruOffset, net.hruIndex):
-            f.write(np.ascontiguousarray(a, dtype="<i4").tobytes())
-        f.write(np.ascontiguousarray(net.hruWeight, dtype="<f8").tobytes())
-        # par(N,11) column-major == [11][N] row-major
-        f.write(np.ascontiguousarray(net.param_matrix(), dtype="<f8").tobytes())
-        for a in (orderOffset, branchOffset, seg):
-            f.write(np.ascontiguousarray(a, dtype="<i4").tobytes())
-        if uh is not None:
-            f.write(np.ascontiguousarray(uh[0], dtype="<f8").tobytes())
-            f.write(np.ascontiguousarray(uh[1], dtype="<i4").tobytes())
-            f.write(np.ascontiguousarray(uh[2], dtype="<f8").tobytes())
-        # runoff(H, nSteps) column-major == [nSteps][H] row-major
-        f.write(runoff.astype("<f8").tobytes())
 
 
 class _Reader:
