@@ -74,6 +74,24 @@ int mzr_set_param(mzr_handle h, const char *name, const double *values);
 int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh);
 /* FRAC_FUTURE (process_param.f90:13-92 basinUH) */
 int mzr_set_frac_future(mzr_handle h, int n, const double *frac);
+/* Sub-basin partitioning (replaces the MPI domain decomposition, mpi_process.f90:473-606,1245-1329):
+   exportReach[] = reaches of THIS domain (tributary outlets) whose per-step boundary records are
+   shipped to the domain that owns their downstream reach; haloReach[] = reaches of this domain that
+   stand for tributary outlets computed elsewhere (no upstreams, no HRUs here; haloGood = their
+   count(goodBas) > 0 in the full network).  Indices are 1-based, caller's reach order.  Call
+   after mzr_set_network, before mzr_init_state. */
+int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach,
+                     const int *haloGood);
+/* number of doubles of a boundary record of nReach reaches over nSteps steps:
+   Q[nRoutes][nSteps][nReach] | BASIN_QR[nSteps+1][nReach] | obN[nSteps][nReach] |
+   obQ[nSteps][21][nReach] | obT[nSteps][21][nReach]  (the per-partition wire format) */
+long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach);
+/* pack the export reaches' records of the last window into rec_dev (device memory) */
+int mzr_export_boundary_dev(mzr_handle h, double *rec_dev);
+/* unpack a record of nSrc reaches (one source partition) into halo slots [haloBase, haloBase+nSrc)
+   for the next window of nSteps steps */
+int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase);
+
 /* cold start (init_model_data.f90:399-505); must follow the setters above */
 int mzr_init_state(mzr_handle h);
 

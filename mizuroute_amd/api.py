@@ -48,7 +48,8 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_run_dev", "mzr_sync", "mzr_get_flux", "mzr_get_window_q", "mzr_get_mean_q",
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
-           "mzr_get_kwt_traffic"]
+           "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
+           "mzr_import_boundary_dev"]
 
 
 def load_library():
@@ -60,6 +61,14 @@ def load_library():
     if not os.path.exists(path):
         raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(mizuroute_amd has no CPU fallback)")
+    # PyTorch bundles its own HIP runtime; when both live in one process torch must initialise its
+    # device context first or it no longer finds the GPU.  (Pure C/Fortran hosts are unaffected.)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     L = C.CDLL(path)
     ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
     dp = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -74,6 +83,11 @@ def load_library():
     L.mzr_set_uh.argtypes = [vp, ip, dp]
     L.mzr_set_frac_future.argtypes = [vp, ci, dp]
     L.mzr_init_state.argtypes = [vp]
+    L.mzr_set_boundary.argtypes = [vp, ci, ip, ci, ip, ip]
+    L.mzr_boundary_size.argtypes = [vp, ci, ci]
+    L.mzr_boundary_size.restype = C.c_longlong
+    L.mzr_export_boundary_dev.argtypes = [vp, vp]
+    L.mzr_import_boundary_dev.argtypes = [vp, ci, vp, ci, ci]
     L.mzr_step.argtypes = [vp, cd, cd, dp]
     L.mzr_run.argtypes = [vp, ci, cd, dp]
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
@@ -105,7 +119,8 @@ class RoutingDomain:
     """One routing domain (a whole network, or one sub-basin partition) resident on one GPU."""
 
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
-                 hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0):
+                 hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
+                 export_reaches=None, halo_reaches=None, halo_good=None):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -136,6 +151,13 @@ class RoutingDomain:
         if uh_offset is not None:
             self.uh_offset = i32(uh_offset)
             self._check(L.mzr_set_uh(self.h, self.uh_offset, f64(uh)))
+        self.n_export = 0 if export_reaches is None else len(export_reaches)
+        self.n_halo = 0 if halo_reaches is None else len(halo_reaches)
+        if self.n_export or self.n_halo:
+            ex = i32(export_reaches if export_reaches is not None else [])
+            ha = i32(halo_reaches if halo_reaches is not None else [])
+            hg = i32(halo_good if halo_good is not None else np.ones(len(ha)))
+            self._check(L.mzr_set_boundary(self.h, len(ex), ex, len(ha), ha, hg))
         self._check(L.mzr_init_state(self.h))
 
     # ---- plumbing
@@ -183,6 +205,16 @@ class RoutingDomain:
 
     def sync(self):
         self._check(self.L.mzr_sync(self.h))
+
+    # ---- partition boundary records (device pointers; see include/mzr.h for the wire format)
+    def boundary_size(self, n_steps, n_reach):
+        return int(self.L.mzr_boundary_size(self.h, int(n_steps), int(n_reach)))
+
+    def export_boundary(self, rec_dev_ptr):
+        self._check(self.L.mzr_export_boundary_dev(self.h, C.c_void_p(int(rec_dev_ptr))))
+
+    def import_boundary(self, n_steps, rec_dev_ptr, n_src, halo_base):
+        self._check(self.L.mzr_import_boundary_dev(self.h, int(n_steps), C.c_void_p(int(rec_dev_ptr)), int(n_src), int(halo_base)))
 
     # ---- results / state
     def flux(self, method, which=F_Q):

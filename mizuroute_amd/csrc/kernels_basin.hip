@@ -20,6 +20,7 @@ __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (r >= d.N) return;
+  if (d.haloSlot && d.haloSlot[r] >= 0) return;     // lateral inflow of a halo reach is imported
   const double *ro = d.runoff + (size_t)t * d.H;
   const int e0 = d.hruOff[r], e1 = d.hruOff[r + 1];
   double rr;
@@ -44,6 +45,7 @@ __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (r >= d.N) return;
+  if (d.haloSlot && d.haloSlot[r] >= 0) return;
   const int n = d.ntdhBas, N = d.N;
   double acc = (t < n) ? d.basS0[(size_t)t * N + r] : 0.0;
   const int tau0 = t - n + 1 > 0 ? t - n + 1 : 0;

@@ -333,7 +333,23 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
 #endif
   int need = 0, nup = 0, u0 = 0, ng = 0, n_own = 0, NUPS = 0, IMAX = 0;
   double qlat_r = 0.0;
-  if (live) {
+  bool halo = false;
+  if (live && d.haloSlot) {   // tributary outlet computed in another partition: replay its imported record
+    const int hs = d.haloSlot[r];
+    if (hs >= 0) {
+      halo = true;
+      const size_t nH = d.nHalo;
+      Qrow[r] = d.imQ[(size_t)t * nH + hs];
+      const int n = d.imN[(size_t)t * nH + hs];
+      d.obN[(size_t)par * N + r] = n;
+      double *oq = d.obQ + (size_t)par * MZR_OB_CAP * N, *ot = d.obT + (size_t)par * MZR_OB_CAP * N;
+      for (int k = 0; k <= n && n > 0; ++k) {
+        oq[(size_t)k * N + r] = d.imOQ[((size_t)t * MZR_OB_CAP + k) * nH + hs];
+        ot[(size_t)k * N + r] = d.imOT[((size_t)t * MZR_OB_CAP + k) * nH + hs];
+      }
+    }
+  }
+  if (live && !halo) {
     qlat_r = qlat_cur[r];
     ng = d.nGood[r];
     if (ng == 0) {   // headwater: kwt_route.f90:181-205
@@ -341,6 +357,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
       d.qsum[r] += qlat_r;
       d.inflow[r] = 0.0;
       if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0; }
+      if (d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
       st_head = 1;
     } else {
       st_route = 1;
@@ -593,6 +610,16 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
         const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
         const double TIMEI = tN + ((tN1 - tN) / dTx) * (T_END - xN);
         const int NN2 = NQ2 - NR;
+        // tributary outlet of a partition: the same record goes to the time-indexed export buffer
+        const int es = d.exportSlot ? d.exportSlot[r] : -1;
+        if (es >= 0) {
+          const size_t nE = d.nExp;
+          d.exN[(size_t)t * nE + es] = NR + 2;
+          double *eq = d.exOQ + (size_t)t * MZR_OB_CAP * nE, *et = d.exOT + (size_t)t * MZR_OB_CAP * nE;
+          for (int k = 0; k <= NR; ++k) { eq[(size_t)k * nE + es] = Qw[k]; et[(size_t)k * nE + es] = Xw[k]; }
+          eq[(size_t)(NR + 1) * nE + es] = Q_END; et[(size_t)(NR + 1) * nE + es] = T_END;
+          eq[(size_t)(NR + 2) * nE + es] = qN1;   et[(size_t)(NR + 2) * nE + es] = xN1;
+        }
         // outbox for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         if (!d.isOutlet[r]) {
           int *obNw = d.obN + (size_t)par * N;

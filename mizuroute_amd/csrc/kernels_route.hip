@@ -187,6 +187,10 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
   if (t < 0 || t >= d.W) return;
   const int N = d.N;
   double *Qrow = d.Q + (size_t)t * N;
+  if (d.haloSlot) {          // tributary outlet computed in another partition: discharge is imported
+    const int hs = d.haloSlot[r];
+    if (hs >= 0) { Qrow[r] = d.imQ[(size_t)t * d.nHalo + hs]; return; }
+  }
   const double qlat = d.qlat[(size_t)(t + 1) * N + r];
   const double dt = d.dt;
 

@@ -72,6 +72,15 @@ struct MzrDev {
   double *kwQ, *kwTI, *kwTR;  // [MZR_KW_CAP][N]
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
   double *obQ, *obT;          // [2][MZR_OB_CAP][N]
+  // ---- partition boundary (null / 0 in an unpartitioned domain)
+  const int *haloSlot;        // [N] slot of a halo reach, -1 otherwise
+  const int *exportSlot;      // [N] slot of an export reach, -1 otherwise
+  int nHalo, nExp, Wmax;
+  const double *imQ;          // [Wmax][nHalo] REACH_Q of the halo reaches (method being launched)
+  const int    *imN;          // [Wmax][nHalo]
+  const double *imOQ, *imOT;  // [Wmax][MZR_OB_CAP][nHalo]
+  int    *exN;                // [Wmax][nExp]
+  double *exOQ, *exOT;        // [Wmax][MZR_OB_CAP][nExp]
   MzrKwtStat *kwtStat;
   unsigned long long *dbgCycles;   // [16] per-section wave cycles (only with -DMZR_KWT_TIMING)
   MzrErr *err;

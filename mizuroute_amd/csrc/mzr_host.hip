@@ -44,6 +44,7 @@ struct RouteBufs {
   DBuf<double> Q;                                   // [maxWindow][N]
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum;   // [N]
   DBuf<double> mol;                                 // [nMol][N]
+  DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   long long nLaunches = 0, reachSteps = 0; double kernel_ms = 0.0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
@@ -52,6 +53,65 @@ __global__ void k_gather_rows(const double *src, double *dst, const int *ext2int
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (e < N && t < rows) dst[(size_t)t * N + e] = src[(size_t)t * N + ext2int[e]];
+}
+
+__global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  if (haloSlot && haloSlot[r] >= 0) return;
+  qlat[r] = qlat[(size_t)lastW * N + r];
+}
+
+// boundary record (include/mzr.h): Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB]
+struct RecView { double *Q, *ql, *n, *oq, *ot; };
+__host__ __device__ inline RecView recView(double *rec, int R, int W, int nB) {
+  RecView v;
+  v.Q = rec; v.ql = v.Q + (size_t)R * W * nB; v.n = v.ql + (size_t)(W + 1) * nB;
+  v.oq = v.n + (size_t)W * nB; v.ot = v.oq + (size_t)W * MZR_OB_CAP * nB;
+  return v;
+}
+struct QPtrs { const double *p[6]; };
+struct QPtrsW { double *p[6]; };
+
+// grid: x over export slots, y over steps 0..W (row W only carries the last BASIN_QR row)
+__global__ void k_pack_boundary(double *rec, int R, int W, int nB, int N, const int *expInt, QPtrs Q, const double *qlat,
+                                const int *exN, const double *exOQ, const double *exOT, int hasKwt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= nB) return;
+  const RecView v = recView(rec, R, W, nB);
+  const int r = expInt[b];
+  v.ql[(size_t)t * nB + b] = qlat[(size_t)t * N + r];
+  if (t >= W) return;
+  for (int m = 0; m < R; ++m) v.Q[((size_t)m * W + t) * nB + b] = Q.p[m][(size_t)t * N + r];
+  int n = 0;
+  if (hasKwt) n = exN[(size_t)t * nB + b];
+  v.n[(size_t)t * nB + b] = (double)n;
+  for (int k = 0; k < MZR_OB_CAP; ++k) {
+    const size_t o = ((size_t)t * MZR_OB_CAP + k) * nB + b;
+    const bool have = hasKwt && n > 0 && k <= n;
+    v.oq[o] = have ? exOQ[o] : 0.0; v.ot[o] = have ? exOT[o] : 0.0;
+  }
+}
+
+__global__ void k_unpack_boundary(const double *rec, int R, int W, int nB, int N, int nHalo, int haloBase, const int *haloInt,
+                                  QPtrsW imQ, double *qlat, int *imN, double *imOQ, double *imOT, int hasKwt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= nB) return;
+  const RecView v = recView(const_cast<double *>(rec), R, W, nB);
+  const int hs = haloBase + b;
+  const int r = haloInt[hs];
+  qlat[(size_t)t * N + r] = v.ql[(size_t)t * nB + b];
+  if (t >= W) return;
+  for (int m = 0; m < R; ++m) imQ.p[m][(size_t)t * nHalo + hs] = v.Q[((size_t)m * W + t) * nB + b];
+  if (hasKwt) {
+    imN[(size_t)t * nHalo + hs] = (int)v.n[(size_t)t * nB + b];
+    for (int k = 0; k < MZR_OB_CAP; ++k) {
+      const size_t o = ((size_t)t * MZR_OB_CAP + k) * nB + b, oh = ((size_t)t * MZR_OB_CAP + k) * nHalo + hs;
+      imOQ[oh] = v.oq[o]; imOT[oh] = v.ot[o];
+    }
+  }
 }
 
 }  // namespace
@@ -83,7 +143,7 @@ struct mzr_domain {
   DBuf<uint16_t> ntdh;
   std::vector<int> uhOff;
   // window buffers
-  DBuf<double> runoffW, qi, qlat, basS[2], scratchOut;
+  DBuf<double> runoffW, qi, qlat, qr0Last, basS[2], scratchOut;
   int basCur = 0;
   int lastW = 0;
   bool havePrevQlat = false;
@@ -92,6 +152,11 @@ struct mzr_domain {
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
   DBuf<MzrKwtStat> kwtStat;
   DBuf<unsigned long long> dbgCycles;
+  // partition boundary
+  int nExp = 0, nHalo = 0;
+  std::vector<int> h_expInt, h_haloInt, h_haloGood;
+  DBuf<int> haloSlot, exportSlot, expInt, haloInt, imN, exN;
+  DBuf<double> imOQ, imOT, exOQ, exOT;
   DBuf<MzrErr> err;
   RouteBufs route[6];
   bool profiling = false;
@@ -127,12 +192,16 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
   d.kwtStat = h->kwtStat.p; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
+  d.haloSlot = h->nHalo ? h->haloSlot.p : nullptr; d.exportSlot = h->nExp ? h->exportSlot.p : nullptr;
+  d.nHalo = h->nHalo; d.nExp = h->nExp; d.Wmax = h->cfg.maxWindow;
+  d.imN = h->imN.p; d.imOQ = h->imOQ.p; d.imOT = h->imOT.p;
+  d.exN = h->exN.p; d.exOQ = h->exOQ.p; d.exOT = h->exOT.p;
 }
 
 void setRoute(mzr_handle h, MzrDev &d, int ix) {
   RouteBufs &rb = h->route[ix];
   d.Q = rb.Q.p; d.vol = rb.vol.p; d.vol0 = rb.vol0.p; d.inflow = rb.inflow.p; d.ele = rb.ele.p;
-  d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p;
+  d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -345,6 +414,68 @@ int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
   return 0;
 }
 
+int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach, const int *haloGood) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_boundary/network not set") : 1;
+  (void)hipSetDevice(h->cfg.device);
+  const int N = h->N;
+  std::vector<int> hs(N, -1), es(N, -1);
+  h->h_expInt.assign(nExport, 0); h->h_haloInt.assign(nHalo, 0); h->h_haloGood.assign(nHalo, 0);
+  std::vector<uint8_t> ng = h->h_nGood;
+  for (int b = 0; b < nExport; ++b) {
+    const int e = exportReach[b] - 1;
+    if (e < 0 || e >= N) return fail(h, 20, "mzr_set_boundary/export reach index out of range");
+    const int i = h->ext2int[e];
+    es[i] = b; h->h_expInt[b] = i;
+  }
+  for (int b = 0; b < nHalo; ++b) {
+    const int e = haloReach[b] - 1;
+    if (e < 0 || e >= N) return fail(h, 20, "mzr_set_boundary/halo reach index out of range");
+    const int i = h->ext2int[e];
+    if (h->h_nUp[i] != 0) return fail(h, 20, "mzr_set_boundary/a halo reach must not have upstream reaches in this domain");
+    hs[i] = b; h->h_haloInt[b] = i; h->h_haloGood[b] = haloGood[b] != 0;
+    ng[i] = haloGood[b] ? 1 : 0;      // what its downstream reach sees: count(goodBas) of the full network
+  }
+  try {
+    h->nExp = nExport; h->nHalo = nHalo;
+    h->haloSlot.upload(hs); h->exportSlot.upload(es);
+    h->expInt.upload(h->h_expInt); h->haloInt.upload(h->h_haloInt);
+    h->h_nGood = ng; h->nGood.upload(ng);
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_boundary/" + e); }
+  h->haveState = false;
+  return 0;
+}
+
+long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach) {
+  if (!h) return -1;
+  const long long R = h->cfg.nRoutes, W = nSteps, B = nReach;
+  return R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B;
+}
+
+int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_export_boundary/state not initialised") : 1;
+  if (h->nExp == 0) return 0;
+  if (h->lastW < 1) return fail(h, 20, "mzr_export_boundary/no window has been run");
+  (void)hipSetDevice(h->cfg.device);
+  QPtrs q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].Q.p : nullptr;
+  dim3 block(64), grid((h->nExp + 63) / 64, h->lastW + 1);
+  hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, h->lastW, h->nExp, h->N,
+                     h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, h->kwN.p ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_export_boundary/launch failed");
+}
+
+int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_import_boundary/state not initialised") : 1;
+  if (nSrc == 0) return 0;
+  if (haloBase < 0 || haloBase + nSrc > h->nHalo) return fail(h, 20, "mzr_import_boundary/halo slot range out of bounds");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_import_boundary/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  QPtrsW q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].imQ.p : nullptr;
+  dim3 block(64), grid((nSrc + 63) / 64, nSteps + 1);
+  hipLaunchKernelGGL(k_unpack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, nSteps, nSrc, h->N, h->nHalo,
+                     haloBase, h->haloInt.p, q, h->qlat.p, h->imN.p, h->imOQ.p, h->imOT.p, h->kwN.p ? 1 : 0);
+  return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_import_boundary/launch failed");
+}
+
 int mzr_init_state(mzr_handle h) {
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_init_state/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
@@ -359,12 +490,22 @@ int mzr_init_state(mzr_handle h) {
     }
     h->basCur = 0;
     h->qlat.alloc((W + 1) * N); h->qlat.zero();
+    h->qr0Last.alloc(N); h->qr0Last.zero();
     h->scratchOut.alloc(W * N);
     h->err.alloc(1); h->err.zero();
+    if (h->nHalo) {
+      h->imN.alloc(W * h->nHalo); h->imN.zero();
+      h->imOQ.alloc(W * MZR_OB_CAP * h->nHalo); h->imOT.alloc(W * MZR_OB_CAP * h->nHalo); h->imOQ.zero(); h->imOT.zero();
+    }
+    if (h->nExp) {
+      h->exN.alloc(W * h->nExp); h->exN.zero();
+      h->exOQ.alloc(W * MZR_OB_CAP * h->nExp); h->exOT.alloc(W * MZR_OB_CAP * h->nExp); h->exOQ.zero(); h->exOT.zero();
+    }
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
       RouteBufs &rb = h->route[ix];
       const int m = rb.method;
       rb.Q.alloc(W * N); rb.Q.zero();
+      if (h->nHalo) { rb.imQ.alloc(W * h->nHalo); rb.imQ.zero(); }
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum}) { b->alloc(N); b->zero(); }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
       if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); }
@@ -403,11 +544,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
   hipStream_t st = h->stream;
-  // carry BASIN_QR(1) of the last step of the previous window into row 0
-  if (h->lastW > 0)
-    (void)hipMemcpyAsync(h->qlat.p, h->qlat.p + (size_t)h->lastW * N, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st);
   MzrDev d; fillDev(h, d);
   d.W = W; d.t_start = t_start; d.T1_single = T1_single; d.runoff = runoff_dev;
+  // carry BASIN_QR(1) of the last step of the previous window into row 0 (halo columns already
+  // hold the imported row 0 of this window)
+  if (h->lastW > 0)
+    hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot);
   mzr_launch_basin(d, st);
   if (h->cfg.doesBasinRoute == 1) h->basCur ^= 1;
   const int nS = h->nStages;

@@ -1,0 +1,213 @@
+"""Sub-basin partitioning of a river network across GPUs and the per-window boundary exchange.
+
+Replaces, on the reference side,
+  mpi_domain_decomposition / classify_river_basin / assign_node
+                                  route/build/src/domain_decomposition.f90:41-163,450-590,724-819
+  the per-step gather/scatter of  mpi_route  (route/build/src/mpi_process.f90:1245-1329)
+
+Same decomposition rule as the reference: a reach is MAINSTEM when it has more than N/nParts reaches
+upstream (domain_decomposition.f90:507-519); every sub-tree hanging on the mainstem (and every
+basin without mainstem) is a TRIBUTARY domain; tributaries are dealt to partitions largest-first
+onto the least-loaded partition, the mainstem counting towards partition 0, which also routes it.
+
+What differs from the reference is the exchange.  There, rank 0 gathers outlet discharge and KWT
+particles every step and scatters the stripped particles back.  Here every reach strips its own
+routed particles, so data only flows downstream: a tributary partition routes
+a whole window of steps, packs the boundary records of its outlet reaches once
+(`mzr_export_boundary_dev`) and sends them point-to-point to partition 0, whose mainstem domain
+replays them through halo reaches (`mzr_import_boundary_dev`).  One message per partition per
+window, no return message, and tributary partitions can run ahead of the mainstem.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .synthetic import RiverNetwork, hops_to_outlet
+
+
+@dataclass
+class Domain:
+    part: int                       # owning partition (rank)
+    kind: str                       # "trib" | "main"
+    net: RiverNetwork               # local network (1-based local indices)
+    reach_global: np.ndarray        # [n_local] global 0-based reach index of every local reach (halos included)
+    hru_global: np.ndarray          # [H_local] global 0-based HRU index of every local HRU
+    n_real: int                     # local reaches [0, n_real) are routed here; the rest are halo
+    export_local: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))   # 1-based
+    halo_local: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))     # 1-based
+    halo_good: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    halo_base: dict = field(default_factory=dict)   # source partition -> (first halo slot, count)
+
+
+@dataclass
+class Partition:
+    n_parts: int
+    trib: list                      # Domain per partition (may have zero reaches)
+    main: Domain | None             # mainstem domain (owned by partition 0) or None
+    part_of_reach: np.ndarray       # [N] partition that routes each reach
+    is_mainstem: np.ndarray         # [N] bool
+
+
+def subtree_sizes(net: RiverNetwork) -> np.ndarray:
+    """Number of reaches upstream of each reach, itself included."""
+    down0 = net.downIndex.astype(np.int64) - 1
+    dist = hops_to_outlet(down0)
+    cnt = np.ones(net.N, dtype=np.int64)
+    for d in range(int(dist.max()), 0, -1):
+        idx = np.nonzero(dist == d)[0]
+        np.add.at(cnt, down0[idx], cnt[idx])
+    return cnt
+
+
+def _local_network(net: RiverNetwork, real: np.ndarray, halos: np.ndarray) -> tuple:
+    """Local RiverNetwork over reaches `real` (routed here) followed by `halos` (tributary outlets
+    routed elsewhere).  UREACHI order is preserved; a reach whose downstream is not local becomes an
+    outlet; halo reaches keep their parameters but have no upstreams and no HRUs."""
+    loc = np.concatenate([real, halos]).astype(np.int64)
+    n_loc = loc.size
+    g2l = np.full(net.N, -1, dtype=np.int64)
+    g2l[loc] = np.arange(n_loc)
+    down0 = net.downIndex.astype(np.int64) - 1
+    dl = np.where(down0[loc] >= 0, g2l[np.maximum(down0[loc], 0)], -1)
+    downIndex = (dl + 1).astype(np.int32)
+    is_halo = np.zeros(n_loc, bool); is_halo[real.size:] = True
+    upOff = [0]; upIdx = []; upGood = []
+    hruOff = [0]; hruIdx = []; hruW = []
+    hru_g = []
+    for k, g in enumerate(loc):
+        if not is_halo[k]:
+            for e in range(net.upOffset[g], net.upOffset[g + 1]):
+                u = g2l[net.upIndex[e] - 1]
+                assert u >= 0, "upstream reach missing from the domain"
+                upIdx.append(u + 1); upGood.append(int(net.upGood[e]))
+            for e in range(net.hruOffset[g], net.hruOffset[g + 1]):
+                hru_g.append(int(net.hruIndex[e]) - 1); hruW.append(float(net.hruWeight[e]))
+                hruIdx.append(len(hru_g))
+        upOff.append(len(upIdx)); hruOff.append(len(hruIdx))
+    params = {k: np.ascontiguousarray(v[loc]) for k, v in net.params.items()}
+    sub = RiverNetwork(N=n_loc, H=max(1, len(hru_g)), downIndex=downIndex, reachId=net.reachId[loc].astype(np.int32),
+                       upOffset=np.array(upOff, np.int32), upIndex=np.array(upIdx, np.int32),
+                       upGood=np.array(upGood, np.int32), hruOffset=np.array(hruOff, np.int32),
+                       hruIndex=np.array(hruIdx, np.int32), hruWeight=np.array(hruW, np.float64), params=params)
+    return sub, loc, np.array(hru_g, np.int64)
+
+
+def partition_network(net: RiverNetwork, n_parts: int) -> Partition:
+    N = net.N
+    down0 = net.downIndex.astype(np.int64) - 1
+    cnt = subtree_sizes(net)
+    if n_parts <= 1:
+        is_main = np.zeros(N, bool)
+    else:
+        is_main = cnt > (N // n_parts)                 # domain_decomposition.f90:507-519
+    # tributary roots: non-mainstem reaches draining into the mainstem or straight to an outlet
+    root_mask = (~is_main) & ((down0 < 0) | is_main[np.maximum(down0, 0)])
+    roots = np.nonzero(root_mask)[0]
+    # label every non-mainstem reach with its root (walk down the levels from the roots)
+    root_of = np.full(N, -1, dtype=np.int64)
+    root_of[roots] = roots
+    dist = hops_to_outlet(down0)
+    order = np.argsort(dist, kind="stable")
+    for r in order:
+        if root_of[r] < 0 and not is_main[r]:
+            root_of[r] = root_of[down0[r]]
+    # largest-first onto the least-loaded partition; the mainstem is partition 0's initial load
+    load = np.zeros(n_parts, dtype=np.int64)
+    load[0] = int(is_main.sum())
+    part_of_root = {}
+    for r in roots[np.argsort(-cnt[roots], kind="stable")]:
+        p = int(np.argmin(load))
+        part_of_root[int(r)] = p
+        load[p] += cnt[r]
+    part_of_reach = np.zeros(N, dtype=np.int64)
+    nm = ~is_main
+    part_of_reach[nm] = np.array([part_of_root[int(x)] for x in root_of[nm]], dtype=np.int64) if nm.any() else 0
+    part_of_reach[is_main] = 0
+    trib = []
+    exports = []                                       # per partition: global indices of export reaches
+    for p in range(n_parts):
+        real = np.nonzero(nm & (part_of_reach == p))[0]
+        sub, loc, hru_g = _local_network(net, real, np.zeros(0, np.int64))
+        ex_g = np.array([r for r in roots if part_of_root[int(r)] == p and down0[r] >= 0], dtype=np.int64)
+        g2l = {int(g): k for k, g in enumerate(loc)}
+        ex_l = np.array([g2l[int(g)] + 1 for g in ex_g], dtype=np.int32)
+        trib.append(Domain(part=p, kind="trib", net=sub, reach_global=loc, hru_global=hru_g, n_real=real.size,
+                           export_local=ex_l))
+        exports.append(ex_g)
+    main = None
+    if is_main.any():
+        real = np.nonzero(is_main)[0]
+        halos = np.concatenate(exports) if exports else np.zeros(0, np.int64)
+        sub, loc, hru_g = _local_network(net, real, halos)
+        halo_local = (np.arange(real.size, real.size + halos.size) + 1).astype(np.int32)
+        up_cnt_good = np.array([int(net.upGood[net.upOffset[g]:net.upOffset[g + 1]].sum()) for g in halos], dtype=np.int32)
+        base, hb = 0, {}
+        for p in range(n_parts):
+            hb[p] = (base, int(exports[p].size)); base += int(exports[p].size)
+        main = Domain(part=0, kind="main", net=sub, reach_global=loc, hru_global=hru_g, n_real=real.size,
+                      halo_local=halo_local, halo_good=(up_cnt_good > 0).astype(np.int32), halo_base=hb)
+    return Partition(n_parts=n_parts, trib=trib, main=main, part_of_reach=part_of_reach, is_mainstem=is_main)
+
+
+class PartitionedRouter:
+    """Drives the domains of ONE partition (rank) window by window.
+
+    transport: object with send(tensor, dst) / recv(tensor, src) (torch.distributed P2P over RCCL
+    in production; an in-process loopback in the single-GPU test).  make_domain(domain, **kw) builds
+    the compute object for a Domain (RoutingDomain in production).
+    """
+
+    def __init__(self, part: Partition, rank: int, make_domain, transport, alloc, max_window: int):
+        self.part, self.rank, self.transport, self.alloc, self.W = part, rank, transport, alloc, max_window
+        td = part.trib[rank]
+        self.trib_spec = td
+        self.trib = make_domain(td, export_reaches=td.export_local) if td.n_real > 0 else None
+        self.main_spec = part.main if (rank == 0 and part.main is not None) else None
+        self.main = None
+        if self.main_spec is not None:
+            ms = self.main_spec
+            self.main = make_domain(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good)
+        self.n_routes = None
+
+    def _rec_size(self, dom, w, n):
+        return dom.boundary_size(w, n)
+
+    def run_window(self, w, t_start, runoff_trib_ptr, runoff_main_ptr):
+        """One window of w steps.  Pointers are device pointers to [w, H_local] runoff of the
+        tributary domain and (rank 0) the mainstem domain."""
+        part = self.part
+        rec = None
+        n_exp = self.trib_spec.export_local.size
+        if self.trib is not None:
+            self.trib.run_device(w, t_start, runoff_trib_ptr)
+            if n_exp and part.main is not None:
+                rec = self.alloc(self.trib.boundary_size(w, n_exp))
+                self.trib.export_boundary(rec.data_ptr())
+                self.trib.sync()
+        if part.main is None:
+            return
+        if self.rank != 0:
+            if rec is not None:
+                self.transport.send(rec, 0)
+            return
+        # rank 0: collect every partition's record into the mainstem halos, then route the mainstem
+        for p in range(part.n_parts):
+            base, n = self.main_spec.halo_base[p]
+            if n == 0:
+                continue
+            if p == 0:
+                buf = rec
+            else:
+                buf = self.alloc(self.main.boundary_size(w, n))
+                self.transport.recv(buf, p)
+            self.main.import_boundary(w, buf.data_ptr(), n, base)
+            self.main.sync()
+        self.main.run_device(w, t_start, runoff_main_ptr)
+
+    def sync(self):
+        if self.trib is not None:
+            self.trib.sync()
+        if self.main is not None:
+            self.main.sync()

@@ -182,3 +182,57 @@ def test_fortran_host_drives_the_c_abi(hip_lib, oracle_lib, tmp_path):
     for ix in range(nr):
         rep = parity_report(Qo[:, ix], Q[:, ix])
         assert rep["max_rel"] <= REL_TOL, (methods[ix], rep)
+
+
+def test_partitioned_network_equals_whole(hip_lib):
+    """Sub-basin partitioning with one-way boundary records (mainstem on partition 0) reproduces the
+    unpartitioned run bit for bit: every reach sees exactly the upstream records it would have seen.
+    All partitions run on this one GPU; the transport is an in-process loopback (the RCCL path is
+    the same code with torch.distributed send/recv, tests/test_partition.py covers it over gloo)."""
+    import torch
+    from mizuroute_amd.partition import PartitionedRouter, partition_network
+    net = m.make_network(6000, seed=8, p3=0.02)
+    nparts, W, steps = 3, 16, 32
+    P = partition_network(net, nparts)
+    assert P.main is not None and sum(d.export_local.size for d in P.trib) > 0
+    ro = m.make_runoff(net.H, steps, seed=9, storm_prob=0.05, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off = np.arange(0, 2 * net.N + 1, 2, dtype=np.int32)
+    uh = np.tile(np.array([0.6, 0.4]), net.N)
+    methods = [m.KWT, m.IRF, m.SUM]
+    whole = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=W)
+    Qw = whole.run(ro)
+
+    box = {}
+
+    def make(spec, **kw):
+        g = spec.reach_global
+        off = np.zeros(g.size + 1, np.int32); off[1:] = np.cumsum(np.diff(uh_off)[g])
+        u = np.concatenate([uh[uh_off[x]:uh_off[x + 1]] for x in g])
+        return m.RoutingDomain(spec.net, 3600.0, methods, frac_future=ff, uh_offset=off, uh=u, max_window=W, **kw)
+
+    routers = []
+    for rank in range(nparts):
+        class T:
+            def __init__(self, me): self.me = me
+            def send(self, t, dst): box[(self.me, dst)] = t.clone()
+            def recv(self, t, src): t.copy_(box[(src, 0)]); torch.cuda.synchronize()
+        routers.append(PartitionedRouter(P, rank, make, T(rank), lambda n: torch.zeros(n, dtype=torch.float64, device="cuda"), W))
+    Q = np.full((steps, len(methods), net.N), np.nan)
+    dev = torch.device("cuda")
+    for w0 in range(0, steps, W):
+        for rank in list(range(1, nparts)) + [0]:          # tributary partitions first, mainstem owner last
+            r = routers[rank]
+            rt = torch.from_numpy(np.ascontiguousarray(ro[w0:w0 + W][:, r.trib_spec.hru_global])).to(dev) if r.trib is not None else None
+            rm = torch.from_numpy(np.ascontiguousarray(ro[w0:w0 + W][:, r.main_spec.hru_global])).to(dev) if r.main is not None else None
+            r.run_window(W, w0 * 3600.0, rt.data_ptr() if rt is not None else 0, rm.data_ptr() if rm is not None else 0)
+            r.sync()
+            for dom, spec in ((r.trib, r.trib_spec), (r.main, r.main_spec)):
+                if dom is None:
+                    continue
+                for ix, meth in enumerate(methods):
+                    q = dom.window_q(meth, W)
+                    Q[w0:w0 + W, ix, spec.reach_global[:spec.n_real]] = q[:, :spec.n_real]
+    assert not np.isnan(Q).any()
+    for ix, meth in enumerate(methods):
+        assert np.array_equal(Q[:, ix], Qw[:, ix]), f"method {meth} differs between partitioned and whole-network runs"
