@@ -98,35 +98,85 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MZR_BENCH_SINGLE_DEVICE"):      # debugging aid: several ranks share cuda:0 (gloo transport)
+        local_rank = 0
     dist = None
+    backend = "nccl"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MZR_BENCH_BACKEND", "nccl")   # "gloo" only for single-GPU debugging
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    # ---- workload: one ~100k-reach sub-basin per GPU (weak scaling; sub-basins drain to separate
-    # outlets, so no mainstem exchange is needed between ranks in this configuration)
-    net = m.make_network(args.reaches, seed=20240529 + rank)
+    # ---- workload.  N = 1: BASELINE.json configs[1], one ~100k-reach sub-basin.  N > 1 (weak
+    # scaling): ONE network of N x 100k reaches partitioned by the reference's rule (mainstem =
+    # reaches with more than total/N reaches upstream, tributary sub-basins dealt largest-first;
+    # mizuroute_amd/partition.py); tributary partitions ship their outlet reaches' boundary records to
+    # the mainstem owner (rank 0) once per window over RCCL point-to-point.
     frac = uhmod.basin_uh(DT, 2.5, 86400.0)
     W = max(1, min(args.window, max(args.steps, 1)))
-    dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W, device=local_rank)
+    net = m.make_network(args.reaches * world, seed=20240529)
+    router = None
+    if world == 1:
+        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W, device=local_rank)
+        doms = [(dom, net.H)]
+    else:
+        from mizuroute_amd.partition import PartitionedRouter, partition_network
+        P = partition_network(net, world, build_for=[rank])
+
+        class Transport:
+            def send(self, t, dst):
+                dist.send(t if backend == "nccl" else t.cpu(), dst)
+
+            def recv(self, t, src):
+                if backend == "nccl":
+                    dist.recv(t, src)
+                else:                                   # gloo moves host tensors
+                    h = torch.empty(t.shape, dtype=t.dtype)
+                    dist.recv(h, src)
+                    t.copy_(h)
+                torch.cuda.current_stream().synchronize()
+
+        def make(spec, **kw):
+            return m.RoutingDomain(spec.net, DT, [m.KWT], frac_future=frac, max_window=W, device=local_rank, **kw)
+
+        router = PartitionedRouter(P, rank, make, Transport(),
+                                   lambda n: torch.empty(n, dtype=torch.float64, device=dev), W)
+        dom = router.trib if router.trib is not None else router.main
+        doms = [(d, sp.net.H) for d, sp in ((router.trib, router.trib_spec), (router.main, router.main_spec)) if d is not None]
     n_stages, max_width = dom.schedule()
 
-    def run_steps(ro, t_first):
-        done = 0
-        while done < ro.shape[0]:
-            w = min(W, ro.shape[0] - done)
-            dom.run_device(w, (t_first + done) * DT, ro[done:done + w].data_ptr())
+    def gen(n_steps, t0):
+        return [device_runoff(torch, H, n_steps, t0, 7 + rank + 101 * i, dev) for i, (_, H) in enumerate(doms)]
+
+    def run_steps(ros, t_first):
+        n, done = ros[0].shape[0], 0
+        while done < n:
+            w = min(W, n - done)
+            if router is None:
+                dom.run_device(w, (t_first + done) * DT, ros[0][done:done + w].data_ptr())
+            else:
+                ptrs = [r[done:done + w].data_ptr() for r in ros]
+                pt = ptrs[0] if router.trib is not None else 0
+                pm = ptrs[-1] if router.main is not None else 0
+                router.run_window(w, (t_first + done) * DT, pt, pm)
             done += w
 
-    ro_warm = device_runoff(torch, net.H, args.warmup, 0, 7 + rank, dev) if args.warmup > 0 else None
-    ro_time = device_runoff(torch, net.H, args.steps, args.warmup, 7 + rank, dev)
+    def sync_all():
+        for d, _ in doms:
+            d.sync()
+
+    ro_warm = gen(args.warmup, 0) if args.warmup > 0 else None
+    ro_time = gen(args.steps, args.warmup)
     torch.cuda.synchronize()
     if ro_warm is not None:
         run_steps(ro_warm, 0)
-    dom.sync()
+    sync_all()
     dom.timing(m.KWT, reset=True)
 
     if dist is not None:
@@ -134,29 +184,38 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(ro_time, args.warmup)
-    dom.sync()
+    sync_all()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tm = dom.timing(m.KWT, reset=True)
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    total_reach_steps = float(net.N) * args.steps * world
+    total_reach_steps = float(net.N) * args.steps
     value = total_reach_steps / elapsed
 
     # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
     # every stage launch on the library's stream, on the window that follows the timed region
     roof = None
+    if world > 1:      # every rank takes part in the profiled window (the exchange is collective)
+        if rank != 0:
+            ro_prof = gen(W, args.warmup + args.steps)
+            torch.cuda.synchronize()
+            dist.barrier()
+            run_steps(ro_prof, args.warmup + args.steps)
+            sync_all()
     if rank == 0:
         dom.kwt_traffic(reset=True)
         dom.set_profiling(True)
-        ro_prof = device_runoff(torch, net.H, W, args.warmup + args.steps, 7 + rank, dev)
+        ro_prof = gen(W, args.warmup + args.steps)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         run_steps(ro_prof, args.warmup + args.steps)
-        dom.sync()
+        sync_all()
         dom.set_profiling(False)
         pt = dom.timing(m.KWT, reset=True)
         tr = dom.kwt_traffic(reset=True)
@@ -169,7 +228,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("reaches") == net.N and tj.get("window") == W:
+                if world == 1 and tj.get("reaches") == net.N and tj.get("window") == W:
                     traffic = tj["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -181,9 +240,9 @@ def main():
                 "particles_per_routed_reach": (tr["w_in"] + tr["w_up"] + tr["w_out"]) / max(1, tr["n_route"])}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         try:
-            cpu = cpu_baseline(net, frac, sample_steps=24)
+            cpu = cpu_baseline(net if world == 1 else m.make_network(args.reaches, seed=20240529), frac, sample_steps=24)
         except Exception as e:   # the baseline is reported, never required
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
 
@@ -194,11 +253,13 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on",
-                       "reaches_per_gpu": net.N, "reaches_total": net.N * world, "stages": n_stages,
+                       "reaches_per_gpu": net.N // world, "reaches_total": net.N, "stages": n_stages,
                        "max_stage_width": max_width, "window_steps": W,
                        "simulated_years_per_wallclock_day": (args.steps * DT / 31536000.0) / (elapsed / 86400.0),
                        "kernel_time_fraction": tm["kernel_ms"] * 1e-3 / elapsed if tm["kernel_ms"] else None,
-                       "parallelism": f"{world} sub-basin(s), one per GPU"},
+                       "parallelism": ("1 domain" if world == 1 else
+                                       f"{world} sub-basin partitions (reference mainstem rule), mainstem on rank 0, "
+                                       "one boundary-record message per partition per window over RCCL p2p")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

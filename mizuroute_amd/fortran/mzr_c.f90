@@ -32,7 +32,8 @@ MODULE mzr_c
   public :: mzr_default_config, mzr_create, mzr_destroy, mzr_last_error, mzr_set_network, mzr_set_param, &
             mzr_set_uh, mzr_set_frac_future, mzr_init_state, mzr_step, mzr_run, mzr_sync, mzr_get_flux, &
             mzr_get_window_q, mzr_get_mean_q, mzr_get_kwt_state, mzr_set_kwt_state, mzr_get_irf_state, &
-            mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule
+            mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule, mzr_set_boundary, mzr_boundary_size, &
+            mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev
   public :: mzr_message
 
   INTERFACE
@@ -152,6 +153,32 @@ MODULE mzr_c
       import :: c_ptr, c_int
       type(c_ptr), value :: h
       integer(c_int), intent(out) :: nStages, maxStageWidth
+    end function
+    integer(c_int) function mzr_set_boundary(h, nExport, exportReach, nHalo, haloReach, haloGood) bind(C, name='mzr_set_boundary')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: nExport, nHalo
+      integer(c_int), intent(in) :: exportReach(*), haloReach(*), haloGood(*)
+    end function
+    integer(c_long_long) function mzr_boundary_size(h, nSteps, nReach) bind(C, name='mzr_boundary_size')
+      import :: c_ptr, c_int, c_long_long
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps, nReach
+    end function
+    integer(c_int) function mzr_export_boundary_dev(h, rec_dev) bind(C, name='mzr_export_boundary_dev')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, rec_dev
+    end function
+    integer(c_int) function mzr_import_boundary_dev(h, nSteps, rec_dev, nSrc, haloBase) bind(C, name='mzr_import_boundary_dev')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, rec_dev
+      integer(c_int), value :: nSteps, nSrc, haloBase
+    end function
+    integer(c_int) function mzr_run_dev(h, nSteps, t_start, runoff_dev) bind(C, name='mzr_run_dev')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h, runoff_dev
+      integer(c_int), value :: nSteps
+      real(c_double), value :: t_start
     end function
   END INTERFACE
 

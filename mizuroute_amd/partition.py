@@ -94,7 +94,9 @@ def _local_network(net: RiverNetwork, real: np.ndarray, halos: np.ndarray) -> tu
     return sub, loc, np.array(hru_g, np.int64)
 
 
-def partition_network(net: RiverNetwork, n_parts: int) -> Partition:
+def partition_network(net: RiverNetwork, n_parts: int, build_for=None) -> Partition:
+    """build_for: partitions whose Domain objects (local networks) are materialised; None = all.
+    A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full."""
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
     cnt = subtree_sizes(net)
@@ -127,17 +129,30 @@ def partition_network(net: RiverNetwork, n_parts: int) -> Partition:
     part_of_reach[is_main] = 0
     trib = []
     exports = []                                       # per partition: global indices of export reaches
+    want = set(range(n_parts)) if build_for is None else set(build_for)
+    root_part = np.array([part_of_root[int(r)] for r in roots], dtype=np.int64) if roots.size else np.zeros(0, np.int64)
     for p in range(n_parts):
+        ex_g = roots[(root_part == p) & (down0[roots] >= 0)].astype(np.int64)
+        exports.append(ex_g)
+        if p not in want:
+            trib.append(Domain(part=p, kind="trib", net=None, reach_global=np.zeros(0, np.int64),
+                               hru_global=np.zeros(0, np.int64), n_real=int((nm & (part_of_reach == p)).sum()),
+                               export_local=np.zeros(ex_g.size, np.int32)))
+            continue
         real = np.nonzero(nm & (part_of_reach == p))[0]
         sub, loc, hru_g = _local_network(net, real, np.zeros(0, np.int64))
-        ex_g = np.array([r for r in roots if part_of_root[int(r)] == p and down0[r] >= 0], dtype=np.int64)
-        g2l = {int(g): k for k, g in enumerate(loc)}
-        ex_l = np.array([g2l[int(g)] + 1 for g in ex_g], dtype=np.int32)
+        g2l = np.full(N, -1, dtype=np.int64); g2l[loc] = np.arange(loc.size)
+        ex_l = (g2l[ex_g] + 1).astype(np.int32)
         trib.append(Domain(part=p, kind="trib", net=sub, reach_global=loc, hru_global=hru_g, n_real=real.size,
                            export_local=ex_l))
-        exports.append(ex_g)
     main = None
-    if is_main.any():
+    if is_main.any() and 0 not in want:
+        hb, base = {}, 0
+        for p in range(n_parts):
+            hb[p] = (base, int(exports[p].size)); base += int(exports[p].size)
+        main = Domain(part=0, kind="main", net=None, reach_global=np.zeros(0, np.int64), hru_global=np.zeros(0, np.int64),
+                      n_real=int(is_main.sum()), halo_base=hb)
+    if is_main.any() and 0 in want:
         real = np.nonzero(is_main)[0]
         halos = np.concatenate(exports) if exports else np.zeros(0, np.int64)
         sub, loc, hru_g = _local_network(net, real, halos)
