@@ -53,6 +53,7 @@ typedef struct mzr_config {
   double time_conv, length_conv;  /* <units_qsim> conversion to m/s (read_control.f90:458-469) */
   int    maxWindow;           /* largest number of time steps per mzr_run call             */
   int    device;              /* HIP device ordinal                                        */
+  int    is_flux_wm;          /* 1: water-management abstraction/injection fluxes are applied */
 } mzr_config;
 
 void mzr_default_config(mzr_config *cfg);
@@ -104,6 +105,11 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff);
    handle's stream, errors surface at the next mzr_sync / mzr_get_* call */
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev);
 int mzr_sync(mzr_handle h);
+/* water-management flux REACH_WM_FLUX for the NEXT window: flux[nSteps][nRch] in m3/s, caller's
+   reach order; > 0 abstraction, < 0 injection for IRF/KW/MC/DW (irf_route.f90:118-142), Qtake for
+   KWT (kwt_route.f90:351-455); -9999 = missing.  Only read when cfg.is_flux_wm = 1
+   (main_route.f90:110-116). */
+int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux);
 
 /* latest value of a flux field, caller's reach order, out[nRch] */
 int mzr_get_flux(mzr_handle h, int method, int which, double *out);

@@ -38,7 +38,8 @@ class MzrConfig(C.Structure):
     _fields_ = [("dt", C.c_double), ("nRoutes", C.c_int), ("routeMethods", C.c_int * 6),
                 ("doesBasinRoute", C.c_int), ("hw_drain_point", C.c_int),
                 ("min_length_route", C.c_double), ("runoffMin", C.c_double), ("negRunoffTol", C.c_double),
-                ("time_conv", C.c_double), ("length_conv", C.c_double), ("maxWindow", C.c_int), ("device", C.c_int)]
+                ("time_conv", C.c_double), ("length_conv", C.c_double), ("maxWindow", C.c_int), ("device", C.c_int),
+                ("is_flux_wm", C.c_int)]
 
 
 _lib = None
@@ -49,7 +50,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev"]
+           "mzr_import_boundary_dev", "mzr_set_wm_flux"]
 
 
 def load_library():
@@ -92,6 +93,7 @@ def load_library():
     L.mzr_run.argtypes = [vp, ci, cd, dp]
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_sync.argtypes = [vp]
+    L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
     L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
     L.mzr_get_window_q.argtypes = [vp, ci, dp]
     L.mzr_get_mean_q.argtypes = [vp, ci, dp, ci]
@@ -120,7 +122,7 @@ class RoutingDomain:
 
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
                  hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
-                 export_reaches=None, halo_reaches=None, halo_good=None):
+                 export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -132,7 +134,8 @@ class RoutingDomain:
             cfg.routeMethods[i] = int(m)
         cfg.doesBasinRoute = int(does_basin_route); cfg.hw_drain_point = int(hw_drain_point)
         cfg.min_length_route = float(min_length_route); cfg.runoffMin = float(runoff_min)
-        cfg.maxWindow = int(max_window); cfg.device = int(device)
+        cfg.maxWindow = int(max_window); cfg.device = int(device); cfg.is_flux_wm = int(is_flux_wm)
+        self.is_flux_wm = int(is_flux_wm)
         self.max_window = int(max_window)
         self.h = C.c_void_p()
         self._check(L.mzr_create(C.byref(cfg), C.byref(self.h)))
@@ -183,14 +186,17 @@ class RoutingDomain:
         """One main_route call: TSEC(1:2) = (T0, T1), runoff[nHru] in m/s."""
         self._check(self.L.mzr_step(self.h, float(T0), float(T1), np.ascontiguousarray(runoff, dtype=np.float64)))
 
-    def run(self, runoff, t_start=0.0):
-        """runoff[nSteps, nHru]; returns REACH_Q[nSteps, nRoutes, nRch] (caller's reach order)."""
+    def run(self, runoff, t_start=0.0, wm_flux=None):
+        """runoff[nSteps, nHru] (and wm_flux[nSteps, nRch] if is_flux_wm); returns
+        REACH_Q[nSteps, nRoutes, nRch] (caller's reach order)."""
         runoff = np.ascontiguousarray(runoff, dtype=np.float64)
         n = runoff.shape[0]
         out = np.zeros((n, len(self.methods), self.N))
         done = 0
         while done < n:
             w = min(self.max_window, n - done)
+            if self.is_flux_wm:
+                self._check(self.L.mzr_set_wm_flux(self.h, w, np.ascontiguousarray(wm_flux[done:done + w], dtype=np.float64)))
             self._check(self.L.mzr_run(self.h, w, float(t_start) + done * self.dt, runoff[done:done + w]))
             for ix, m in enumerate(self.methods):
                 buf = np.zeros((w, self.N))

@@ -5,13 +5,14 @@ Read by mizuroute_amd/fortran/mzr_demo.f90 (the Fortran host demo of the C-ABI) 
 harness that drives the reference solvers.  Layout (all int32 / float64):
   magic 'MZRC', version
   N, H, nSteps, nRoutes, routeMethods[6], doesBasinRoute, hw_drain_point, nUp, nHru, nOrder, nBranch,
-  uhSource, ntdhBas, nUh, dumpEvery
+  uhSource, ntdhBas, nUh, dumpEvery, isFluxWm
   dt, min_length_route, runoffMin, fshape, tscale, velo, diff, t_start
   downIndex[N] reachId[N] upOffset[N+1] upIndex[nUp] upGood[nUp] hruOffset[N+1] hruIndex[nHru] hruWeight[nHru]
   par[11][N]   (RiverNetwork.PARAM_ORDER)
   orderOffset[nOrder+1] branchOffset[nBranch+1] seg[N]       (a processing schedule for CPU drivers)
   if uhSource == 1: fracFuture[ntdhBas] uhOffset[N+1] uh[nUh]
   runoff[nSteps][H]
+  if isFluxWm == 1: wmflux[nSteps][N]   (REACH_WM_FLUX, + abstraction / - injection, m3/s)
 """
 from __future__ import annotations
 
@@ -31,18 +32,18 @@ def serial_schedule(net):
 
 def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_point=2,
                min_length_route=0.0, runoff_min=0.0, fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0,
-               t_start=0.0, uh=None, schedule=None, dump_every=1):
+               t_start=0.0, uh=None, schedule=None, dump_every=1, wm_flux=None):
     """uh: None -> the harness calls the reference's basinUH/make_uh; else (frac, uhOffset, uh)."""
     runoff = np.ascontiguousarray(runoff, dtype=np.float64)
     n_steps = runoff.shape[0]
     orderOffset, branchOffset, seg = schedule if schedule is not None else serial_schedule(net)
     m = list(methods) + [-1] * (6 - len(methods))
     with open(path, "wb") as f:
-        f.write(struct.pack("<2i", MAGIC_IN, 1))
+        f.write(struct.pack("<2i", MAGIC_IN, 2))
         ints = [net.N, net.H, n_steps, len(methods)] + m + [does_basin_route, hw_drain_point,
                 int(net.upOffset[-1]), int(net.hruOffset[-1]), len(orderOffset) - 1, len(branchOffset) - 1,
                 1 if uh is not None else 0, len(uh[0]) if uh is not None else 0,
-                int(uh[1][-1]) if uh is not None else 0, int(dump_every)]
+                int(uh[1][-1]) if uh is not None else 0, int(dump_every), 1 if wm_flux is not None else 0]
         f.write(struct.pack(f"<{len(ints)}i", *ints))
         f.write(struct.pack("<8d", dt, min_length_route, runoff_min, fshape, tscale, velo, diff, t_start))
         for a in (net.downIndex, net.reachId, net.upOffset, net.upIndex, net.upGood, net.hruOffset, net.hruIndex):
@@ -58,5 +59,7 @@ def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_poin
             f.write(np.ascontiguousarray(uh[2], dtype="<f8").tobytes())
         # runoff(H, nSteps) column-major == [nSteps][H] row-major
         f.write(runoff.astype("<f8").tobytes())
+        if wm_flux is not None:
+            f.write(np.ascontiguousarray(wm_flux, dtype="<f8").tobytes())
 
 

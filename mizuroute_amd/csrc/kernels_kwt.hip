@@ -492,6 +492,26 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           for (int i = 0; i <= NPRT; i = Lw[i] >> 8) { Qw[k] = Qw[i]; Tw[k] = Tw[i]; ++k; }
           size = MPRT + 1;
         }
+        // ---- extract_from_rch :351-455 (water abstraction / injection on the particles).  Its
+        // recomputed exit times are overwritten by kinwav below, so only the flows change.
+        if (d.is_flux_wm && d.wm) {
+          const double Qtake = d.wm[(size_t)t * N + r];
+          if (Qtake != -9999.0) {
+            double Qavg;
+            if (d_interp_rch(Tw, Qw, size, T_START, T_END, &Qavg)) { mzr_raise(d, 1, r, t, 17); break; }
+            const double totQ = Qavg * RW;
+            if (Qtake > 0.0) {
+              const double Qfrac = Qtake / totQ;
+              for (int i = 1; i < size; ++i) Qw[i] = Qw[i] * (1.0 + Qfrac);
+            } else if (Qtake < 0.0 && fabs(Qtake) < totQ) {
+              const double Qfrac = fabs(Qtake) / totQ;
+              for (int i = 1; i < size; ++i) Qw[i] = Qw[i] * (1.0 - Qfrac);
+            } else {
+              const double mf = d.minflow[r];
+              for (int i = 0; i < size; ++i) Qw[i] = mf;
+            }
+          }
+        }
         const int NQ1 = size - 1;
         TSTAMP(3);
 

@@ -163,11 +163,11 @@ __device__ __forceinline__ Pre d_preamble(const MzrDev &d, int r, const double *
   return p;
 }
 
-// water_balance.f90:22-112 (non-lake, no abstraction)
-__device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, double Qlat, double Qout, double dt) {
+// water_balance.f90:22-112 (non-lake)
+__device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, double Qlat, double Qout, double wmAct, double dt) {
   const double dVol = vol1 - vol0;
   const double Qin = Qup * dt, Qlateral = Qlat * dt, precip = 0.0;
-  const double Qo = -1.0 * Qout * dt, Qtake = -1.0 * 0.0 * dt, evapo = 0.0;
+  const double Qo = -1.0 * Qout * dt, Qtake = -1.0 * wmAct * dt, evapo = 0.0;
   return dVol - (Qin + Qlateral + precip + Qtake + Qo + evapo);
 }
 
@@ -208,11 +208,41 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
     return;
   }
 
-  const Pre p = d_preamble(d, r, Qrow, qlat);
+  Pre p = d_preamble(d, r, Qrow, qlat);
   d.inflow[r] = p.q_up;
   double vol = d.vol[r];
   const double vol_prev = vol;        // REACH_VOL(0) = REACH_VOL(1)
   double vol0 = vol_prev;
+  // water management: abstraction from storage, then upstream inflow, then lateral flow; injection
+  // into the lateral flow (irf_route.f90:118-142, identical in mc/dfw/kwe)
+  const double wmflux = (d.is_flux_wm && d.wm) ? d.wm[(size_t)t * N + r] : 0.0;
+  double wmAct = wmflux;
+  if (d.is_flux_wm && wmflux != -9999.0) {
+    double Qabs = wmflux;
+    if (Qabs > 0) {
+      if (vol / dt > Qabs) {
+        vol = vol - Qabs * dt;
+      } else {
+        Qabs = Qabs - vol / dt;
+        vol = 0.0;
+        if (p.q_up > Qabs) {
+          p.q_up_mod = p.q_up - Qabs;
+        } else {
+          Qabs = Qabs - p.q_up;
+          p.q_up_mod = 0.0;
+          if (p.Qlat > Qabs) {
+            p.Qlat = p.Qlat - Qabs;
+          } else {
+            Qabs = Qabs - p.Qlat;
+            p.Qlat = 0.0;
+            wmAct = wmflux - Qabs;
+          }
+        }
+      }
+    } else {
+      p.Qlat = p.Qlat - Qabs;
+    }
+  }
   const double L = d.length[r];
   double Qout;
 
@@ -342,7 +372,8 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
   }
   Qrow[r] = Qout;
   d.vol[r] = vol; d.vol0[r] = vol0;
-  d.wb[r] = d_wb(vol, vol0, p.q_up, p.Qlat, Qout, dt);
+  d.wb[r] = d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt);
+  if (d.wmact) d.wmact[r] = wmAct;
   d.qsum[r] += Qout;
 }
 

@@ -47,7 +47,9 @@ struct MzrDev {
   // ---- configuration
   double dt, min_length_route, runoffMin, negRunoffTol, time_conv, length_conv, t_start;
   double T1_single;       // end of step for single-step windows (mzr_step passes TSEC(2) explicitly)
-  int hw_drain_point, doesBasinRoute;
+  int hw_drain_point, doesBasinRoute, is_flux_wm;
+  const double *wm;           // [W][N] REACH_WM_FLUX of the window (null unless is_flux_wm)
+  double *wmact;              // [N] REACH_WM_FLUX_actual of the method being launched
   // ---- hillslope
   int ntdhBas;
   const double *fracFuture;   // [ntdhBas]

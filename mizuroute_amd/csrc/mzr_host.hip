@@ -42,7 +42,7 @@ template <typename T> struct DBuf {
 struct RouteBufs {
   int method = -1;
   DBuf<double> Q;                                   // [maxWindow][N]
-  DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum;   // [N]
+  DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   long long nLaunches = 0, reachSteps = 0; double kernel_ms = 0.0;
@@ -53,6 +53,12 @@ __global__ void k_gather_rows(const double *src, double *dst, const int *ext2int
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (e < N && t < rows) dst[(size_t)t * N + e] = src[(size_t)t * N + ext2int[e]];
+}
+
+__global__ void k_scatter_rows(const double *src, double *dst, const int *ext2int, int N, int rows) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (e < N && t < rows) dst[(size_t)t * N + ext2int[e]] = src[(size_t)t * N + e];
 }
 
 __global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot) {
@@ -143,7 +149,8 @@ struct mzr_domain {
   DBuf<uint16_t> ntdh;
   std::vector<int> uhOff;
   // window buffers
-  DBuf<double> runoffW, qi, qlat, qr0Last, basS[2], scratchOut;
+  DBuf<double> runoffW, qi, qlat, qr0Last, basS[2], scratchOut, wm;
+  int wmSteps = 0;
   int basCur = 0;
   int lastW = 0;
   bool havePrevQlat = false;
@@ -185,6 +192,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
+  d.is_flux_wm = h->cfg.is_flux_wm; d.wm = (h->cfg.is_flux_wm && h->wmSteps > 0) ? h->wm.p : nullptr;
   d.ntdhBas = h->ntdhBas; d.fracFuture = h->fracFuture.p;
   d.qi = h->qi.p; d.qlat = h->qlat.p;
   d.basS0 = h->basS[h->basCur].p; d.basS1 = h->basS[h->basCur ^ 1].p;
@@ -201,7 +209,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
 void setRoute(mzr_handle h, MzrDev &d, int ix) {
   RouteBufs &rb = h->route[ix];
   d.Q = rb.Q.p; d.vol = rb.vol.p; d.vol0 = rb.vol0.p; d.inflow = rb.inflow.p; d.ele = rb.ele.p;
-  d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p;
+  d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -224,6 +232,7 @@ int checkDeviceError(mzr_handle h) {
                                                                                   : "kwt_rch/kinwav_rch/RUPDATE/array bounds exceeded"; break;
     case 14: what = "kwt_rch/no waiting particle left in reach"; break;
     case 15: what = "kwt_rch/interp_rch/bad bounds"; break;
+    case 17: what = "kwt_rch/extract_from_rch/interp_rch/bad bounds"; break;
   }
   char buf[512];
   snprintf(buf, sizeof buf, "main_routing/route_network/%s [reach index %d id %d, window step %d]", what, ext + 1, id, e.step);
@@ -492,6 +501,7 @@ int mzr_init_state(mzr_handle h) {
     h->qlat.alloc((W + 1) * N); h->qlat.zero();
     h->qr0Last.alloc(N); h->qr0Last.zero();
     h->scratchOut.alloc(W * N);
+    if (h->cfg.is_flux_wm) { h->wm.alloc(W * N); h->wm.zero(); h->wmSteps = 0; }
     h->err.alloc(1); h->err.zero();
     if (h->nHalo) {
       h->imN.alloc(W * h->nHalo); h->imN.zero();
@@ -506,7 +516,7 @@ int mzr_init_state(mzr_handle h) {
       const int m = rb.method;
       rb.Q.alloc(W * N); rb.Q.zero();
       if (h->nHalo) { rb.imQ.alloc(W * h->nHalo); rb.imQ.zero(); }
-      for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum}) { b->alloc(N); b->zero(); }
+      for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
       if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); }
       if (m == MZR_IRF) {
@@ -541,6 +551,7 @@ int mzr_init_state(mzr_handle h) {
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
+  if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
   hipStream_t st = h->stream;
@@ -575,8 +586,22 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     rb.reachSteps += (long long)N * W;
   }
-  h->lastW = W; h->stepsDone += W;
+  h->lastW = W; h->stepsDone += W; h->wmSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
+  return 0;
+}
+
+int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_wm_flux/state not initialised") : 1;
+  if (!h->cfg.is_flux_wm) return fail(h, 20, "mzr_set_wm_flux/is_flux_wm is off in the configuration");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_wm_flux/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  const int N = h->N;
+  (void)hipMemcpyAsync(h->scratchOut.p, flux, (size_t)nSteps * N * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  dim3 block(256), grid((N + 255) / 256, nSteps);
+  hipLaunchKernelGGL(k_scatter_rows, grid, block, 0, h->stream, h->scratchOut.p, h->wm.p, h->d_ext2int.p, N, nSteps);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, 92, "mzr_set_wm_flux/device error");
+  h->wmSteps = nSteps;
   return 0;
 }
 

@@ -27,13 +27,14 @@ MODULE mzr_c
     real(c_double)  :: time_conv, length_conv
     integer(c_int)  :: maxWindow
     integer(c_int)  :: device
+    integer(c_int)  :: is_flux_wm
   end type mzr_config
 
   public :: mzr_default_config, mzr_create, mzr_destroy, mzr_last_error, mzr_set_network, mzr_set_param, &
             mzr_set_uh, mzr_set_frac_future, mzr_init_state, mzr_step, mzr_run, mzr_sync, mzr_get_flux, &
             mzr_get_window_q, mzr_get_mean_q, mzr_get_kwt_state, mzr_set_kwt_state, mzr_get_irf_state, &
             mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule, mzr_set_boundary, mzr_boundary_size, &
-            mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev
+            mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux
   public :: mzr_message
 
   INTERFACE
@@ -173,6 +174,12 @@ MODULE mzr_c
       import :: c_ptr, c_int
       type(c_ptr), value :: h, rec_dev
       integer(c_int), value :: nSteps, nSrc, haloBase
+    end function
+    integer(c_int) function mzr_set_wm_flux(h, nSteps, flux) bind(C, name='mzr_set_wm_flux')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), intent(in) :: flux(*)
     end function
     integer(c_int) function mzr_run_dev(h, nSteps, t_start, runoff_dev) bind(C, name='mzr_run_dev')
       import :: c_ptr, c_int, c_double

@@ -62,6 +62,9 @@ int orc_step(orc_t *o, double T0, double T1, const double *runoff /* [H] */,
 /* nSteps steps; Qout/volOut [nSteps][nRoutes][N] (may be NULL); returns first ierr */
 int orc_run(orc_t *o, int nSteps, double t_start, const double *runoff /* [nSteps][H] */,
             double *Qout, double *volOut);
+/* same with water-management flux wmflux[nSteps][N] (REACH_WM_FLUX; needs is_flux_wm = 1) */
+int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux,
+               double *Qout, double *volOut);
 const char *orc_last_error(const orc_t *o);
 
 int orc_get_flux(const orc_t *o, int route, int which, double *out /* [N] */);

@@ -307,12 +307,17 @@ int orc_step(orc_t *o, double T0, double T1, const double *runoff, const double 
   return 0;
 }
 
+int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux, double *Qout, double *volOut);
 int orc_run(orc_t *o, int nSteps, double t_start, const double *runoff, double *Qout, double *volOut) {
+  return orc_run_wm(o, nSteps, t_start, runoff, NULL, Qout, volOut);
+}
+
+int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux, double *Qout, double *volOut) {
   int N = o->N;
   for (int it = 0; it < nSteps; it++) {
     double T0 = t_start + (double)it * o->dt;
     double T1 = T0 + o->dt;
-    int ierr = orc_step(o, T0, T1, runoff + (size_t)it * o->H, NULL);
+    int ierr = orc_step(o, T0, T1, runoff + (size_t)it * o->H, wmflux ? wmflux + (size_t)it * N : NULL);
     if (ierr) return ierr;
     for (int ix = 0; ix < o->nRoutes; ix++) {
       size_t base = ((size_t)it * o->nRoutes + ix) * N;

@@ -41,6 +41,7 @@ def lib():
         L.orc_set_uh.argtypes = [C.c_void_p, C.c_int, dp, C.c_void_p, C.c_void_p]
         L.orc_step.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, C.c_void_p]
         L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, C.c_void_p]
+        L.orc_run_wm.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, C.c_void_p, C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_get_flux.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
@@ -92,12 +93,16 @@ class Oracle:
     def step(self, T0, T1, runoff):
         return lib().orc_step(self.h, float(T0), float(T1), np.ascontiguousarray(runoff, dtype=np.float64), None)
 
-    def run(self, runoff, t_start=0.0, want_vol=False):
+    def run(self, runoff, t_start=0.0, want_vol=False, wm_flux=None):
         runoff = np.ascontiguousarray(runoff, dtype=np.float64)
         n = runoff.shape[0]
         Q = np.zeros((n, len(self.methods), self.N))
         V = np.zeros((n, len(self.methods), self.N)) if want_vol else None
-        rc = lib().orc_run(self.h, n, float(t_start), runoff, Q.ctypes.data, V.ctypes.data if want_vol else None)
+        if wm_flux is not None:
+            rc = lib().orc_run_wm(self.h, n, float(t_start), runoff, np.ascontiguousarray(wm_flux, dtype=np.float64),
+                                  Q.ctypes.data, V.ctypes.data if want_vol else None)
+        else:
+            rc = lib().orc_run(self.h, n, float(t_start), runoff, Q.ctypes.data, V.ctypes.data if want_vol else None)
         if rc:
             raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
         return (Q, V) if want_vol else Q

@@ -35,12 +35,12 @@ PROGRAM ref_driver
   character(len=1024) :: fcase, fout, arg
   integer(i4b) :: uin, uout, magic, version
   integer(i4b) :: N, H, nSteps, methodsIn(6), nUpTot, nHruTot, nOrder, nBranch
-  integer(i4b) :: uhSource, ntdhBasIn, nUhTotIn, dumpEvery
+  integer(i4b) :: uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm
   real(dp)     :: fshape, tscale, velo, diff, t_start
   integer(i4b), allocatable :: downIndex(:), reachId(:), upOffset(:), upIndex(:), upGood(:)
   integer(i4b), allocatable :: hruOffset(:), hruIndex(:), orderOffset(:), branchOffset(:), seg(:)
   integer(i4b), allocatable :: uhOffsetIn(:)
-  real(dp), allocatable :: hruWeight(:), par(:,:), fracIn(:), uhIn(:), runoff(:,:)
+  real(dp), allocatable :: hruWeight(:), par(:,:), fracIn(:), uhIn(:), runoff(:,:), wmflux(:,:)
   real(dp), allocatable :: lengths(:)
   type(dlength), allocatable :: seg_uh(:)
 
@@ -75,7 +75,7 @@ PROGRAM ref_driver
     write(*,*) 'bad case-file magic', magic; stop 3
   end if
   read(uin) N, H, nSteps, nRoutes, methodsIn, doesBasinRoute, hw_drain_point, nUpTot, nHruTot, &
-            nOrder, nBranch, uhSource, ntdhBasIn, nUhTotIn, dumpEvery
+            nOrder, nBranch, uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm
   read(uin) dt, min_length_route, runoffMin, fshape, tscale, velo, diff, t_start
   allocate(downIndex(N), reachId(N), upOffset(N+1), upIndex(nUpTot), upGood(nUpTot))
   allocate(hruOffset(N+1), hruIndex(nHruTot), hruWeight(nHruTot), par(N,11))
@@ -89,10 +89,14 @@ PROGRAM ref_driver
   end if
   allocate(runoff(H, nSteps))
   read(uin) runoff
+  if (isFluxWm == 1) then
+    allocate(wmflux(N, nSteps))
+    read(uin) wmflux
+  end if
   close(uin)
 
   ! ---- configuration the reference keeps in public_var / globalData (read_control.f90:580-600)
-  is_lake_sim = .false.; is_flux_wm = .false.; is_vol_wm = .false.; tracer = .false.
+  is_lake_sim = .false.; is_flux_wm = (isFluxWm == 1); is_vol_wm = .false.; tracer = .false.
   qmodOption = 0
   time_conv = 1._dp; length_conv = 1._dp
   allocate(routeMethods(nRoutes))
@@ -220,7 +224,12 @@ PROGRAM ref_driver
   end do
 
   allocate(ixRch(N)); ixRch = [(i, i=1,N)]
-  allocate(basinRunoff(H), basinEvapo(0), basinPrecip(0), basinSolute(0), reachflux(0), reachvol(0))
+  allocate(basinRunoff(H), basinEvapo(0), basinPrecip(0), basinSolute(0), reachvol(0))
+  if (isFluxWm == 1) then
+    allocate(reachflux(N))
+  else
+    allocate(reachflux(0))
+  end if
   allocate(qout(N, nRoutes), volout(N, nRoutes), qr1(N))
 
   open(newunit=uout, file=trim(fout), access='stream', form='unformatted', status='replace', action='write')
@@ -234,6 +243,7 @@ PROGRAM ref_driver
     TSEC(1) = t_start + real(it-1, dp)*dt       ! init_model_data.f90:311-312,600
     TSEC(2) = TSEC(1) + dt
     basinRunoff = runoff(:, it)
+    if (isFluxWm == 1) reachflux = wmflux(:, it)
     call system_clock(c0, crate)
     call main_route(basinRunoff, basinEvapo, basinPrecip, basinSolute, reachflux, reachvol, ixRch, &
                     river_basin, NETOPO, RPARAM, RCHFLX, RCHSTA, gage_obs, ierr, message)

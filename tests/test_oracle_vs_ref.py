@@ -58,3 +58,35 @@ def test_openmp_schedule_gives_same_answer():
     assert np.array_equal(a["Q"], b["Q"])
     c = refrun.run_case(net, ro, 3600.0, [2, 1], nthreads=4, schedule=refrun.streamorder_schedule(net))
     assert np.array_equal(a["Q"], c["Q"])
+
+
+def test_water_management_bit_exact(oracle_lib):
+    """is_flux_wm: abstraction cascade, injection and missing values in IRF/KW/MC/DW; for KWT a small
+    abstraction (incl. the reference's celerity index shift in extract_from_rch) is bit-exact and an
+    injection makes the reference fail in qexmul_rch -- the oracle must fail with the same code."""
+    net = make_network(400, seed=31)
+    net.params["MINFLOW"] = np.full(net.N, 1e-4)
+    steps = 40
+    ro = make_runoff(net.H, steps, seed=5, storm_prob=0.05, storm_amp=3e-6)
+    rng = np.random.default_rng(3)
+    wm = np.zeros((steps, net.N))
+    sel = rng.random(net.N) < 0.3
+    wm[:, sel] = rng.uniform(0.0, 0.5, sel.sum())[None, :] * (1 + np.sin(np.arange(steps))[:, None])
+    wm[:, rng.random(net.N) < 0.1] = -0.1
+    wm[:, rng.random(net.N) < 0.03] = -9999.0
+    methods = [1, 3, 4, 5]
+    out = refrun.run_case(net, ro, 3600.0, methods, wm_flux=wm)
+    assert out["ierr"] == 0
+    orc = oracle_lib.Oracle(net, 3600.0, methods, out["frac_future"], out["uh_offset"], out["uh"], is_flux_wm=1)
+    Q, V = orc.run(ro, want_vol=True, wm_flux=wm)
+    assert np.array_equal(Q, out["Q"]) and np.array_equal(V, out["VOL"])
+    for label, val, expect_err in (("abstraction", -0.001, 0), ("injection", 0.2, 20)):
+        wk = np.zeros((steps, net.N)); wk[:, rng.random(net.N) < 0.2] = val
+        out = refrun.run_case(net, ro, 3600.0, [2], wm_flux=wk)
+        assert out["ierr"] == expect_err, (label, out["stdout"])
+        orc = oracle_lib.Oracle(net, 3600.0, [2], out["frac_future"], out["uh_offset"], out["uh"], is_flux_wm=1)
+        if expect_err == 0:
+            assert np.array_equal(orc.run(ro, wm_flux=wk), out["Q"])
+        else:
+            with pytest.raises(RuntimeError, match="ierr=20"):
+                orc.run(ro, wm_flux=wk)
