@@ -93,6 +93,24 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev);
    for the next window of nSteps steps */
 int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase);
 
+/* Lakes and reservoirs (lake_route.f90:28-472; <is_lake_sim> = T).  lakeReach[nLake] 1-based;
+   modelType 0 endorheic, 1 Doll03, 2 Hanasaki06, 3 HYPE (lake_route.f90:14-17);
+   par[MZR_NLAKEPAR][nLake], rows in the order of RPARAM's lake fields (dataTypes.f90:196-254):
+   D03_MaxStorage D03_Coefficient D03_Power D03_S0 | HYP_E_emr E_lim E_min E_zero Qrate_emr Erate_emr
+   Qrate_prim Qrate_amp Qrate_phs prim_F A_avg Qsim_mode | H06_Smax alpha envfact S_ini c1 c2 exponent
+   denominator c_compare frac_Sdead E_rel_ini | H06_I_Jan..Dec | H06_D_Jan..Dec | H06_purpose I_mem_F
+   D_mem_F I_mem_L D_mem_L.   calendarId 0 noleap/365_day, 1 standard/gregorian.
+   Not supported: target-volume lakes (is_vol_wm) and the Hanasaki demand memory (H06_D_mem_F).
+   With several routing methods each method keeps its own copy of the mutable Hanasaki
+   parameters (the reference shares them through RPARAM).  Call after mzr_set_network. */
+#define MZR_NLAKEPAR 56
+int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, const int *lakeReach,
+                  const int *modelType, const double *par);
+/* lake forcing of the NEXT window: evaporation and precipitation [nSteps][nHru] in the runoff units,
+   and month / day / day-of-year of simDatetime(1) for every step */
+int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip,
+                         const int *month, const int *day, const int *dayofyear);
+
 /* cold start (init_model_data.f90:399-505); must follow the setters above */
 int mzr_init_state(mzr_handle h);
 

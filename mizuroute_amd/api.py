@@ -50,7 +50,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux"]
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing"]
 
 
 def load_library():
@@ -94,6 +94,8 @@ def load_library():
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
+    L.mzr_set_lakes.argtypes = [vp, ci, ci, ci, ip, ip, dp]
+    L.mzr_set_lake_forcing.argtypes = [vp, ci, dp, dp, ip, ip, ip]
     L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
     L.mzr_get_window_q.argtypes = [vp, ci, dp]
     L.mzr_get_mean_q.argtypes = [vp, ci, dp, ci]
@@ -122,7 +124,7 @@ class RoutingDomain:
 
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
                  hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
-                 export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0):
+                 export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0, lakes=None):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -154,6 +156,10 @@ class RoutingDomain:
         if uh_offset is not None:
             self.uh_offset = i32(uh_offset)
             self._check(L.mzr_set_uh(self.h, self.uh_offset, f64(uh)))
+        self.lakes = lakes
+        if lakes is not None:
+            self._check(L.mzr_set_lakes(self.h, int(lakes["input_option"]), int(lakes["calendar_id"]), len(lakes["reach"]),
+                                        i32(lakes["reach"]), i32(lakes["model_type"]), f64(lakes["par"])))
         self.n_export = 0 if export_reaches is None else len(export_reaches)
         self.n_halo = 0 if halo_reaches is None else len(halo_reaches)
         if self.n_export or self.n_halo:
@@ -195,6 +201,8 @@ class RoutingDomain:
         done = 0
         while done < n:
             w = min(self.max_window, n - done)
+            if self.lakes is not None:
+                self.set_lake_forcing(done, w)
             if self.is_flux_wm:
                 self._check(self.L.mzr_set_wm_flux(self.h, w, np.ascontiguousarray(wm_flux[done:done + w], dtype=np.float64)))
             self._check(self.L.mzr_run(self.h, w, float(t_start) + done * self.dt, runoff[done:done + w]))
@@ -204,6 +212,19 @@ class RoutingDomain:
                 out[done:done + w, ix, :] = buf
             done += w
         return out
+
+    def set_lake_forcing(self, first, w):
+        """Upload evaporation/precipitation and the calendar of steps [first, first+w) of self.lakes."""
+        lk = self.lakes
+        ymd = np.asarray(lk["ymd"][first:first + w], dtype=np.int64)
+        mdays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])
+        leap = (lk["calendar_id"] == 1) & (((ymd[:, 0] % 4 == 0) & (ymd[:, 0] % 100 != 0)) | (ymd[:, 0] % 400 == 0))
+        cum = np.concatenate([[0], np.cumsum(mdays)])[ymd[:, 1] - 1]
+        doy = cum + ymd[:, 2] + (leap & (ymd[:, 1] > 2))
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        self._check(self.L.mzr_set_lake_forcing(self.h, int(w), c(lk["evap"][first:first + w], np.float64),
+                                                c(lk["precip"][first:first + w], np.float64), c(ymd[:, 1], np.int32),
+                                                c(ymd[:, 2], np.int32), c(doy, np.int32)))
 
     def run_device(self, n_steps, t_start, runoff_dev_ptr):
         """Asynchronous window on device-resident runoff [n_steps, nHru] (e.g. a torch tensor's data_ptr())."""

@@ -5,7 +5,7 @@ Read by mizuroute_amd/fortran/mzr_demo.f90 (the Fortran host demo of the C-ABI) 
 harness that drives the reference solvers.  Layout (all int32 / float64):
   magic 'MZRC', version
   N, H, nSteps, nRoutes, routeMethods[6], doesBasinRoute, hw_drain_point, nUp, nHru, nOrder, nBranch,
-  uhSource, ntdhBas, nUh, dumpEvery, isFluxWm
+  uhSource, ntdhBas, nUh, dumpEvery, isFluxWm, isLakeSim
   dt, min_length_route, runoffMin, fshape, tscale, velo, diff, t_start
   downIndex[N] reachId[N] upOffset[N+1] upIndex[nUp] upGood[nUp] hruOffset[N+1] hruIndex[nHru] hruWeight[nHru]
   par[11][N]   (RiverNetwork.PARAM_ORDER)
@@ -13,6 +13,10 @@ harness that drives the reference solvers.  Layout (all int32 / float64):
   if uhSource == 1: fracFuture[ntdhBas] uhOffset[N+1] uh[nUh]
   runoff[nSteps][H]
   if isFluxWm == 1: wmflux[nSteps][N]   (REACH_WM_FLUX, + abstraction / - injection, m3/s)
+  if isLakeSim == 1: LakeInputOption, calendarId (0 noleap, 1 standard), nLake,
+                     ymd[nSteps][3] (year, month, day of every step),
+                     lakeReach[nLake] (1-based), lakeModelType[nLake], lakePar[NLAKEPAR][nLake],
+                     evap[nSteps][H], precip[nSteps][H]
 """
 from __future__ import annotations
 
@@ -21,6 +25,19 @@ import struct
 import numpy as np
 
 MAGIC_IN = 1297765955
+
+# lake parameter rows (RPARAM fields, dataTypes.f90:196-254), in this order
+LAKE_PAR = ("D03_MaxStorage", "D03_Coefficient", "D03_Power", "D03_S0",
+            "HYP_E_emr", "HYP_E_lim", "HYP_E_min", "HYP_E_zero", "HYP_Qrate_emr", "HYP_Erate_emr", "HYP_Qrate_prim",
+            "HYP_Qrate_amp", "HYP_Qrate_phs", "HYP_prim_F", "HYP_A_avg", "HYP_Qsim_mode",
+            "H06_Smax", "H06_alpha", "H06_envfact", "H06_S_ini", "H06_c1", "H06_c2", "H06_exponent", "H06_denominator",
+            "H06_c_compare", "H06_frac_Sdead", "H06_E_rel_ini",
+            "H06_I_Jan", "H06_I_Feb", "H06_I_Mar", "H06_I_Apr", "H06_I_May", "H06_I_Jun", "H06_I_Jul", "H06_I_Aug",
+            "H06_I_Sep", "H06_I_Oct", "H06_I_Nov", "H06_I_Dec",
+            "H06_D_Jan", "H06_D_Feb", "H06_D_Mar", "H06_D_Apr", "H06_D_May", "H06_D_Jun", "H06_D_Jul", "H06_D_Aug",
+            "H06_D_Sep", "H06_D_Oct", "H06_D_Nov", "H06_D_Dec",
+            "H06_purpose", "H06_I_mem_F", "H06_D_mem_F", "H06_I_mem_L", "H06_D_mem_L")
+NLAKEPAR = len(LAKE_PAR)
 
 
 def serial_schedule(net):
@@ -32,18 +49,21 @@ def serial_schedule(net):
 
 def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_point=2,
                min_length_route=0.0, runoff_min=0.0, fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0,
-               t_start=0.0, uh=None, schedule=None, dump_every=1, wm_flux=None):
+               t_start=0.0, uh=None, schedule=None, dump_every=1, wm_flux=None, lakes=None):
+    """lakes: None or dict(input_option, calendar_id, ymd[nSteps,3], reach[nLake] (1-based), model_type[nLake],
+    par[NLAKEPAR, nLake], evap[nSteps,H], precip[nSteps,H])."""
     """uh: None -> the harness calls the reference's basinUH/make_uh; else (frac, uhOffset, uh)."""
     runoff = np.ascontiguousarray(runoff, dtype=np.float64)
     n_steps = runoff.shape[0]
     orderOffset, branchOffset, seg = schedule if schedule is not None else serial_schedule(net)
     m = list(methods) + [-1] * (6 - len(methods))
     with open(path, "wb") as f:
-        f.write(struct.pack("<2i", MAGIC_IN, 2))
+        f.write(struct.pack("<2i", MAGIC_IN, 3))
         ints = [net.N, net.H, n_steps, len(methods)] + m + [does_basin_route, hw_drain_point,
                 int(net.upOffset[-1]), int(net.hruOffset[-1]), len(orderOffset) - 1, len(branchOffset) - 1,
                 1 if uh is not None else 0, len(uh[0]) if uh is not None else 0,
-                int(uh[1][-1]) if uh is not None else 0, int(dump_every), 1 if wm_flux is not None else 0]
+                int(uh[1][-1]) if uh is not None else 0, int(dump_every), 1 if wm_flux is not None else 0,
+                1 if lakes is not None else 0]
         f.write(struct.pack(f"<{len(ints)}i", *ints))
         f.write(struct.pack("<8d", dt, min_length_route, runoff_min, fshape, tscale, velo, diff, t_start))
         for a in (net.downIndex, net.reachId, net.upOffset, net.upIndex, net.upGood, net.hruOffset, net.hruIndex):
@@ -61,5 +81,14 @@ def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_poin
         f.write(runoff.astype("<f8").tobytes())
         if wm_flux is not None:
             f.write(np.ascontiguousarray(wm_flux, dtype="<f8").tobytes())
+        if lakes is not None:
+            nl = len(lakes["reach"])
+            f.write(struct.pack("<3i", int(lakes["input_option"]), int(lakes["calendar_id"]), nl))
+            f.write(np.ascontiguousarray(lakes["ymd"], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(lakes["reach"], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(lakes["model_type"], dtype="<i4").tobytes())
+            f.write(np.ascontiguousarray(lakes["par"], dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(lakes["evap"], dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(lakes["precip"], dtype="<f8").tobytes())
 
 

@@ -23,6 +23,7 @@
 // Bound by HBM traffic of the particle rows: see DESIGN.md for the bytes-per-reach-step model.
 #include <float.h>
 #include "mzr_device.h"
+#include "lake_device.h"
 
 namespace {
 
@@ -349,7 +350,18 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
       }
     }
   }
-  if (live && !halo) {
+  bool lake = false, upLake = false;
+  if (live && !halo && d.lakeSlot) {
+    const int ls = d.lakeSlot[r];
+    if (ls >= 0) {   // lake reach: lake_route replaces kwt_rch; it keeps one sentinel particle (init_model_data.f90:431-439)
+      lake = true;
+      double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
+      const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat_cur[r], vol, vol0, ele, wb, wmAct);
+      Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
+      if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0; }
+    }
+  }
+  if (live && !halo && !lake) {
     qlat_r = qlat_cur[r];
     ng = d.nGood[r];
     if (ng == 0) {   // headwater: kwt_route.f90:181-205
@@ -366,12 +378,15 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
       n_own = d.kwN[r];
       int NUPR = 0;
       IMAX = nup;
-      for (int i = 0; i < nup; ++i) {
+      if (d.lakeSlot) for (int i = 0; i < nup; ++i) if (d.lakeSlot[u0 + i] >= 0) upLake = true;
+      if (upLake && nup > 1) { mzr_raise(d, 10, r, t, 18); }   // lake outlet reach should have one upstream lake, :551-553
+      for (int i = 0; i < nup && !upLake; ++i) {
         if (d.nGood[u0 + i] > 0) { ++NUPR; const int nr = obN[u0 + i]; IMAX += nr - 1; st_up += nr + 1; }
       }
       NUPS = nup + NUPR;
       const int NJ0 = n_own == 0 ? 0 : n_own - 1;
-      need = NJ0 + 1 + (NUPS == 1 ? 1 : IMAX);
+      need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
+      if (upLake && nup > 1) need = 0;
       if (need > KWT_POOL) { mzr_raise(d, 60, r, t, 10); need = 0; }
     }
   }
@@ -409,7 +424,9 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
 
         // ---- qexmul_rch
         int ND;
-        if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
+        if (upLake) {      // lake outflow enters the river as one particle, getusq_rch :554-559
+          Qw[NJ + 1] = Qrow[u0] / RW; Tw[NJ + 1] = T1; ND = 1;
+        } else if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
           Qw[NJ + 1] = qlat_cur[u0] / RW; Tw[NJ + 1] = T1; ND = 1;
         } else if (nup <= 2) {   // binary confluence
           ND = kwt_merge_binary(nup, u0, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1);

@@ -15,6 +15,7 @@
 // on different time steps of the window in the same launch (time-skewed level sweep).
 // These solvers are FP64 transcendental-bound (Newton iterations with pow), not HBM-bound.
 #include "mzr_device.h"
+#include "lake_device.h"
 
 namespace {
 
@@ -193,6 +194,17 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
   }
   const double qlat = d.qlat[(size_t)(t + 1) * N + r];
   const double dt = d.dt;
+
+  if (METHOD != 0 && d.lakeSlot) {   // lake reach: lake_route replaces the reach solver (main_route.f90:375-381)
+    const int ls = d.lakeSlot[r];
+    if (ls >= 0) {
+      double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
+      const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat, vol, vol0, ele, wb, wmAct);
+      Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
+      if (d.wmact) d.wmact[r] = wmAct;
+      return;
+    }
+  }
 
   if (METHOD == 0) {   // SUM: all upstreams, regardless of goodBas (accum_runoff.f90:60-75)
     double q = qlat;

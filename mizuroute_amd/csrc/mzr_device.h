@@ -20,6 +20,7 @@
 #define MZR_NMOL_KW  20   // init_model_data.f90:386-394
 #define MZR_NMOL_MC  2
 #define MZR_NMOL_DW  20
+#define MZR_NLAKEPAR_DEV 56
 
 // error record written by the first failing lane (atomicCAS on code)
 struct MzrErr { int code; int reach; int step; int where; };
@@ -74,6 +75,17 @@ struct MzrDev {
   double *kwQ, *kwTI, *kwTR;  // [MZR_KW_CAP][N]
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
   double *obQ, *obT;          // [2][MZR_OB_CAP][N]
+  // ---- lakes (null / 0 without lakes)
+  const int *lakeSlot;        // [N] lake index of a lake reach, -1 otherwise
+  const int *lakeModel;       // [nLake]
+  const double *lakePar;      // [MZR_NLAKEPAR_DEV][nLake]
+  double *lakeMut;            // [25][nLake] of the method being launched: I_months, D_months, E_rel_ini
+  double *lakeRing;           // [nLake][12][lakeL] Hanasaki inflow memory of the method being launched
+  int *lakeHead;              // [nLake][13] ring heads per month, [12] = initialised flag
+  const double *lakeEvap, *lakePrecip;   // [W][nLake] m3/s
+  const int *calMonth, *calDay, *calDoy; // [W]
+  int nLake, LakeInputOption, calendarId, lakeL;
+  long long iTime0;           // iTime of window step 0 is iTime0 + 1
   // ---- partition boundary (null / 0 in an unpartitioned domain)
   const int *haloSlot;        // [N] slot of a halo reach, -1 otherwise
   const int *exportSlot;      // [N] slot of an export reach, -1 otherwise

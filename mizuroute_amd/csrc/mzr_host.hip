@@ -21,6 +21,8 @@
 #include "mzr_device.h"
 
 void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
+void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
+                             double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
 void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, hipStream_t stream);
 
@@ -45,6 +47,7 @@ struct RouteBufs {
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
+  DBuf<double> lakeMut, lakeRing; DBuf<int> lakeHead;   // per-method mutable Hanasaki parameters / inflow memory
   long long nLaunches = 0, reachSteps = 0; double kernel_ms = 0.0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
@@ -159,6 +162,11 @@ struct mzr_domain {
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
   DBuf<MzrKwtStat> kwtStat;
   DBuf<unsigned long long> dbgCycles;
+  // lakes
+  int nLake = 0, LakeInputOption = 0, calendarId = 0, lakeL = 0, lakeSteps = 0;
+  std::vector<double> h_lakePar; std::vector<int> h_lakeModel, h_lakeSlot;
+  DBuf<int> lakeSlot, lakeModel, lakeReachInt, calMonth, calDay, calDoy;
+  DBuf<double> lakePar, lakeEvap, lakePrecip, lakeFE, lakeFP;
   // partition boundary
   int nExp = 0, nHalo = 0;
   std::vector<int> h_expInt, h_haloInt, h_haloGood;
@@ -167,7 +175,7 @@ struct mzr_domain {
   DBuf<MzrErr> err;
   RouteBufs route[6];
   bool profiling = false;
-  long long stepsDone = 0;
+  long long stepsDone = 0, totalSteps = 0;
 };
 
 namespace {
@@ -200,6 +208,10 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
   d.kwtStat = h->kwtStat.p; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
+  d.lakeSlot = h->nLake ? h->lakeSlot.p : nullptr; d.lakeModel = h->lakeModel.p; d.lakePar = h->lakePar.p;
+  d.lakeEvap = h->lakeEvap.p; d.lakePrecip = h->lakePrecip.p; d.calMonth = h->calMonth.p; d.calDay = h->calDay.p; d.calDoy = h->calDoy.p;
+  d.nLake = h->nLake; d.LakeInputOption = h->LakeInputOption; d.calendarId = h->calendarId; d.lakeL = h->lakeL;
+  d.iTime0 = h->totalSteps;
   d.haloSlot = h->nHalo ? h->haloSlot.p : nullptr; d.exportSlot = h->nExp ? h->exportSlot.p : nullptr;
   d.nHalo = h->nHalo; d.nExp = h->nExp; d.Wmax = h->cfg.maxWindow;
   d.imN = h->imN.p; d.imOQ = h->imOQ.p; d.imOT = h->imOT.p;
@@ -210,6 +222,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   RouteBufs &rb = h->route[ix];
   d.Q = rb.Q.p; d.vol = rb.vol.p; d.vol0 = rb.vol0.p; d.inflow = rb.inflow.p; d.ele = rb.ele.p;
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
+  d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -233,6 +246,7 @@ int checkDeviceError(mzr_handle h) {
     case 14: what = "kwt_rch/no waiting particle left in reach"; break;
     case 15: what = "kwt_rch/interp_rch/bad bounds"; break;
     case 17: what = "kwt_rch/extract_from_rch/interp_rch/bad bounds"; break;
+    case 18: what = "kwt_rch/getusq_rch/lake outlet reach should have one upstream lake"; break;
   }
   char buf[512];
   snprintf(buf, sizeof buf, "main_routing/route_network/%s [reach index %d id %d, window step %d]", what, ext + 1, id, e.step);
@@ -423,6 +437,50 @@ int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
   return 0;
 }
 
+int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, const int *lakeReach, const int *modelType, const double *par) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_lakes/network not set") : 1;
+  (void)hipSetDevice(h->cfg.device);
+  const int N = h->N;
+  std::vector<int> slot(N, -1), lri(nLake, 0);
+  h->h_lakeModel.assign(modelType, modelType + nLake);
+  h->h_lakePar.assign(par, par + (size_t)MZR_NLAKEPAR * nLake);
+  int L = 0;
+  for (int l = 0; l < nLake; ++l) {
+    const int e = lakeReach[l] - 1;
+    if (e < 0 || e >= N) return fail(h, 20, "mzr_set_lakes/lake reach index out of range");
+    if (modelType[l] < 0 || modelType[l] > 3) return fail(h, 20, "lake_route/unable to identify the parametric lake model type");
+    slot[h->ext2int[e]] = l; lri[l] = h->ext2int[e];
+    if (par[(size_t)53 * nLake + l] != 0.0) return fail(h, 20, "mzr_set_lakes/Hanasaki demand memory (H06_D_mem_F) is not supported");
+    if (modelType[l] == 2 && par[(size_t)52 * nLake + l] != 0.0)
+      L = std::max(L, (int)std::floor(par[(size_t)54 * nLake + l] * 31 * 86400.0 / h->cfg.dt));
+  }
+  try {
+    h->nLake = nLake; h->LakeInputOption = LakeInputOption; h->calendarId = calendarId; h->lakeL = L;
+    h->h_lakeSlot = slot;
+    h->lakeSlot.upload(slot); h->lakeModel.upload(h->h_lakeModel); h->lakePar.upload(h->h_lakePar); h->lakeReachInt.upload(lri);
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_lakes/" + e); }
+  h->haveState = false;
+  return 0;
+}
+
+int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, const int *month, const int *day, const int *dayofyear) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_lake_forcing/state not initialised") : 1;
+  if (!h->nLake) return fail(h, 20, "mzr_set_lake_forcing/no lakes in this domain");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_lake_forcing/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t st = h->stream;
+  (void)hipMemcpyAsync(h->lakeFE.p, evap, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(h->lakeFP.p, precip, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(h->calMonth.p, month, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(h->calDay.p, day, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(h->calDoy.p, dayofyear, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
+  MzrDev d; fillDev(h, d);
+  mzr_launch_lake_forcing(d, h->lakeReachInt.p, h->lakeFE.p, h->lakeFP.p, h->lakeEvap.p, h->lakePrecip.p, nSteps, st);
+  if (hipStreamSynchronize(st) != hipSuccess) return fail(h, 92, "mzr_set_lake_forcing/device error");
+  h->lakeSteps = nSteps;
+  return checkDeviceError(h);
+}
+
 int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach, const int *haloGood) {
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_boundary/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
@@ -503,6 +561,11 @@ int mzr_init_state(mzr_handle h) {
     h->scratchOut.alloc(W * N);
     if (h->cfg.is_flux_wm) { h->wm.alloc(W * N); h->wm.zero(); h->wmSteps = 0; }
     h->err.alloc(1); h->err.zero();
+    if (h->nLake) {
+      h->lakeEvap.alloc(W * h->nLake); h->lakePrecip.alloc(W * h->nLake); h->lakeEvap.zero(); h->lakePrecip.zero();
+      h->lakeFE.alloc(W * h->H); h->lakeFP.alloc(W * h->H);
+      h->calMonth.alloc(W); h->calDay.alloc(W); h->calDoy.alloc(W);
+    }
     if (h->nHalo) {
       h->imN.alloc(W * h->nHalo); h->imN.zero();
       h->imOQ.alloc(W * MZR_OB_CAP * h->nHalo); h->imOT.alloc(W * MZR_OB_CAP * h->nHalo); h->imOQ.zero(); h->imOT.zero();
@@ -516,6 +579,15 @@ int mzr_init_state(mzr_handle h) {
       const int m = rb.method;
       rb.Q.alloc(W * N); rb.Q.zero();
       if (h->nHalo) { rb.imQ.alloc(W * h->nHalo); rb.imQ.zero(); }
+      if (h->nLake) {   // mutable Hanasaki parameters start from the static ones: I_months, D_months, E_rel_ini
+        std::vector<double> mut((size_t)25 * h->nLake);
+        for (int l = 0; l < h->nLake; ++l) {
+          for (int m2 = 0; m2 < 24; ++m2) mut[(size_t)m2 * h->nLake + l] = h->h_lakePar[(size_t)(27 + m2) * h->nLake + l];
+          mut[(size_t)24 * h->nLake + l] = h->h_lakePar[(size_t)26 * h->nLake + l];
+        }
+        rb.lakeMut.upload(mut);
+        if (h->lakeL > 0) { rb.lakeRing.alloc((size_t)h->nLake * 12 * h->lakeL); rb.lakeRing.zero(); rb.lakeHead.alloc((size_t)h->nLake * 13); rb.lakeHead.zero(); }
+      }
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
       if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); }
@@ -544,7 +616,7 @@ int mzr_init_state(mzr_handle h) {
     }
   } catch (const std::string &e) { return fail(h, 91, "mzr_init_state/" + e); }
   if (hipDeviceSynchronize() != hipSuccess) return fail(h, 92, "mzr_init_state/device error");
-  h->haveState = true; h->stepsDone = 0; h->lastW = 0;
+  h->haveState = true; h->stepsDone = 0; h->lastW = 0; h->totalSteps = 0;
   return 0;
 }
 
@@ -552,6 +624,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
+  if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
   hipStream_t st = h->stream;
@@ -586,7 +659,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     rb.reachSteps += (long long)N * W;
   }
-  h->lastW = W; h->stepsDone += W; h->wmSteps = 0;
+  h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
   return 0;
 }
@@ -723,7 +796,8 @@ int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry
       const size_t o = (size_t)e * MZR_WCAP + k;
       if (k < n[i]) {
         qwave[o] = q[(size_t)k * N + i]; tentry[o] = ti[(size_t)k * N + i]; texit[o] = tr[(size_t)k * N + i];
-        routed[o] = (k == 0 && h->h_nGood[i] > 0) ? 1 : 0;   // element 0 = last routed particle
+        const bool lake = !h->h_lakeSlot.empty() && h->h_lakeSlot[i] >= 0;   // a lake keeps one sentinel particle
+        routed[o] = (k == 0 && h->h_nGood[i] > 0 && !lake) ? 1 : 0;          // element 0 = last routed particle
       } else { qwave[o] = tentry[o] = texit[o] = -9999.0; routed[o] = 0; }
     }
   }

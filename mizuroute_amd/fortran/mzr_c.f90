@@ -34,7 +34,8 @@ MODULE mzr_c
             mzr_set_uh, mzr_set_frac_future, mzr_init_state, mzr_step, mzr_run, mzr_sync, mzr_get_flux, &
             mzr_get_window_q, mzr_get_mean_q, mzr_get_kwt_state, mzr_set_kwt_state, mzr_get_irf_state, &
             mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule, mzr_set_boundary, mzr_boundary_size, &
-            mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux
+            mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
+            mzr_set_lakes, mzr_set_lake_forcing
   public :: mzr_message
 
   INTERFACE
@@ -180,6 +181,20 @@ MODULE mzr_c
       type(c_ptr), value :: h
       integer(c_int), value :: nSteps
       real(c_double), intent(in) :: flux(*)
+    end function
+    integer(c_int) function mzr_set_lakes(h, LakeInputOption, calendarId, nLake, lakeReach, modelType, par) bind(C, name='mzr_set_lakes')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: LakeInputOption, calendarId, nLake
+      integer(c_int), intent(in) :: lakeReach(*), modelType(*)
+      real(c_double), intent(in) :: par(*)
+    end function
+    integer(c_int) function mzr_set_lake_forcing(h, nSteps, evap, precip, month, day, dayofyear) bind(C, name='mzr_set_lake_forcing')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), intent(in) :: evap(*), precip(*)
+      integer(c_int), intent(in) :: month(*), day(*), dayofyear(*)
     end function
     integer(c_int) function mzr_run_dev(h, nSteps, t_start, runoff_dev) bind(C, name='mzr_run_dev')
       import :: c_ptr, c_int, c_double

@@ -9,7 +9,7 @@ PROGRAM mzr_demo
   integer, parameter :: dp = c_double
   character(len=1024) :: fcase, fout
   integer(c_int) :: magic, version, N, nHru, nSteps, nRoutes, methodsIn(6), doesBasinRoute, hw_drain_point
-  integer(c_int) :: nUpTot, nHruTot, nOrder, nBranch, uhSource, ntdhBas, nUhTot, dumpEvery, isFluxWm, ierr
+  integer(c_int) :: nUpTot, nHruTot, nOrder, nBranch, uhSource, ntdhBas, nUhTot, dumpEvery, isFluxWm, isLakeSim, ierr
   real(dp) :: dt, min_length_route, runoffMin, fshape, tscale, velo, diff, t_start
   integer(c_int), allocatable :: downIndex(:), reachId(:), upOffset(:), upIndex(:), upGood(:), hruOffset(:), hruIndex(:)
   integer(c_int), allocatable :: orderOffset(:), branchOffset(:), seg(:), uhOffset(:)
@@ -25,7 +25,7 @@ PROGRAM mzr_demo
   open(newunit=uin, file=trim(fcase), access='stream', form='unformatted', status='old', action='read')
   read(uin) magic, version
   read(uin) N, nHru, nSteps, nRoutes, methodsIn, doesBasinRoute, hw_drain_point, nUpTot, nHruTot, nOrder, nBranch, &
-            uhSource, ntdhBas, nUhTot, dumpEvery, isFluxWm
+            uhSource, ntdhBas, nUhTot, dumpEvery, isFluxWm, isLakeSim
   read(uin) dt, min_length_route, runoffMin, fshape, tscale, velo, diff, t_start
   allocate(downIndex(N), reachId(N), upOffset(N+1), upIndex(nUpTot), upGood(nUpTot), hruOffset(N+1), hruIndex(nHruTot))
   allocate(hruWeight(nHruTot), par(N,11), orderOffset(nOrder+1), branchOffset(nBranch+1), seg(N))

@@ -195,3 +195,88 @@ def make_runoff(H: int, n_steps: int, seed: int = 7, t0: int = 0, base: float = 
     amp = rng2.random((n_steps, H))
     ro += np.where(pulses < storm_prob, storm_amp * amp * amp, 0.0)
     return np.ascontiguousarray(ro)
+
+
+def step_dates(n_steps: int, dt: float, start=(2001, 1, 1), calendar_id: int = 0) -> np.ndarray:
+    """(year, month, day) of the START of every step; calendar_id 0 = noleap, 1 = standard."""
+    mdays = [31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31]
+    y, mo, d = start
+    out = np.zeros((n_steps, 3), dtype=np.int32)
+    sec = 0.0
+    for t in range(n_steps):
+        out[t] = (y, mo, d)
+        sec += dt
+        while sec >= 86400.0:
+            sec -= 86400.0
+            leap = calendar_id == 1 and ((y % 4 == 0 and y % 100 != 0) or y % 400 == 0)
+            nd = mdays[mo - 1] + (1 if (mo == 2 and leap) else 0)
+            d += 1
+            if d > nd:
+                d = 1; mo += 1
+                if mo > 12:
+                    mo = 1; y += 1
+    return out
+
+
+def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: float = 0.02, calendar_id: int = 0,
+               input_option: int = 0, memory: bool = False, start=(2001, 1, 1)) -> dict:
+    """Synthetic lakes/reservoirs (Doll 70 %, Hanasaki 25 %, HYPE 5 %, plus an
+    endorheic one), parameters in the ranges of docs/source/users_guide/lake.rst.  A lake must be
+    the only upstream of its outlet reach (kwt_route.f90:551-553)."""
+    from .casefile import LAKE_PAR, NLAKEPAR
+    rng = np.random.default_rng(seed)
+    down0 = net.downIndex.astype(np.int64) - 1
+    nup = np.diff(net.upOffset)
+    elig = np.nonzero(((down0 < 0) | (nup[np.maximum(down0, 0)] == 1)) & (nup > 0))[0]
+    # no lake directly below another lake's outlet chain collision: keep lakes non-adjacent
+    rng.shuffle(elig)
+    chosen, taken = [], set()
+    for r in elig:
+        if len(chosen) >= max(4, int(frac * net.N)):
+            break
+        d = int(down0[r])
+        ups = set(int(u) - 1 for u in net.upIndex[net.upOffset[r]:net.upOffset[r + 1]])
+        if r in taken or d in taken or (ups & taken):
+            continue
+        chosen.append(int(r)); taken.update([int(r), d] + list(ups))
+    reach = np.array(sorted(chosen), dtype=np.int32) + 1
+    nl = reach.size
+    u = rng.random(nl)
+    model = np.where(u < 0.65, 1, np.where(u < 0.9, 2, np.where(u < 0.97, 3, 0))).astype(np.int32)
+    if nl >= 3:
+        model[:3] = [1, 2, 3]                          # make sure every type occurs
+    # an endorheic lake has no outflow, so it can only sit at an outlet (KWT aborts on zero flow below it)
+    is_out = down0[reach - 1] < 0
+    model = np.where((model == 0) & ~is_out, 1, model).astype(np.int32)
+    if is_out.any():
+        model[np.nonzero(is_out)[0][0]] = 0
+    ix = {k: i for i, k in enumerate(LAKE_PAR)}
+    par = np.zeros((NLAKEPAR, nl))
+    area = net.params["TOTAREA"][reach - 1]
+    qmean = 2e-8 * area                                 # rough mean inflow [m3/s]
+    par[ix["D03_MaxStorage"]] = qmean * 86400.0 * rng.uniform(20, 200, nl)
+    par[ix["D03_Coefficient"]] = rng.uniform(0.005, 0.05, nl)
+    par[ix["D03_Power"]] = rng.uniform(1.0, 2.0, nl)
+    par[ix["D03_S0"]] = par[ix["D03_MaxStorage"]] * rng.uniform(0.0, 0.2, nl)
+    par[ix["HYP_E_zero"]] = 0.0; par[ix["HYP_E_min"]] = 2.0; par[ix["HYP_E_lim"]] = 6.0; par[ix["HYP_E_emr"]] = 9.0
+    par[ix["HYP_A_avg"]] = qmean * 86400.0 * 30 / 9.0 + 1e4
+    par[ix["HYP_Qrate_emr"]] = qmean * 3; par[ix["HYP_Erate_emr"]] = 1.5
+    par[ix["HYP_Qrate_prim"]] = qmean * 1.2; par[ix["HYP_Qrate_amp"]] = 0.3; par[ix["HYP_Qrate_phs"]] = 100
+    par[ix["HYP_prim_F"]] = 1; par[ix["HYP_Qsim_mode"]] = (rng.random(nl) < 0.5)
+    par[ix["H06_Smax"]] = qmean * 86400.0 * rng.uniform(30, 600, nl)
+    par[ix["H06_alpha"]] = 0.85; par[ix["H06_envfact"]] = 0.1; par[ix["H06_S_ini"]] = par[ix["H06_Smax"]] * 0.8
+    par[ix["H06_c1"]] = 0.1; par[ix["H06_c2"]] = 0.9; par[ix["H06_exponent"]] = 2.0; par[ix["H06_denominator"]] = 0.5
+    par[ix["H06_c_compare"]] = 0.5; par[ix["H06_frac_Sdead"]] = 0.1; par[ix["H06_E_rel_ini"]] = 1.0
+    season = 1.0 + 0.5 * np.sin(2 * np.pi * (np.arange(12) + 0.5) / 12.0)
+    for mth in range(12):
+        par[ix["H06_I_Jan"] + mth] = qmean * season[mth]
+        par[ix["H06_D_Jan"] + mth] = qmean * 0.3 * season[(mth + 6) % 12]
+    par[ix["H06_purpose"]] = (rng.random(nl) < 0.5)
+    par[ix["H06_I_mem_F"]] = 1.0 if memory else 0.0
+    par[ix["H06_D_mem_F"]] = 0.0
+    par[ix["H06_I_mem_L"]] = 1; par[ix["H06_D_mem_L"]] = 1
+    rngf = np.random.default_rng(seed + 77)
+    precip = 3e-8 * (1.0 + rngf.random((n_steps, net.H)))
+    evap = 2e-8 * (1.0 + rngf.random((n_steps, net.H)))
+    return dict(input_option=input_option, calendar_id=calendar_id, ymd=step_dates(n_steps, dt, start, calendar_id),
+                reach=reach, model_type=model, par=par, evap=evap, precip=precip)

@@ -118,7 +118,7 @@ def make_uh(length: np.ndarray, dt: float, velo: float, diff: float):
         L = length[i]
         if velo > 0.0:
             pot = ((velo * sec - L) ** 2.0) / (4.0 * diff * sec)
-            H = np.where(pot > 69.0, 0.0, 1.0 / (2.0 * np.sqrt(math.pi * diff * sec)) * L * np.exp(-np.minimum(pot, 700.0)))
+            H = np.where(pot > 69.0, 0.0, 1.0 / (2.0 * np.sqrt(3.14159265359 * diff * sec)) * L * np.exp(-np.minimum(pot, 700.0)))
         else:
             H = np.zeros(nHr)
         inte = float(np.cumsum(H)[-1])

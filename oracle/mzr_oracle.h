@@ -65,6 +65,16 @@ int orc_run(orc_t *o, int nSteps, double t_start, const double *runoff /* [nStep
 /* same with water-management flux wmflux[nSteps][N] (REACH_WM_FLUX; needs is_flux_wm = 1) */
 int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux,
                double *Qout, double *volOut);
+/* lakes: lakeReach[nLake] 1-based, modelType 0 endorheic / 1 Doll03 / 2 Hanasaki06 / 3 HYPE,
+   par[ORC_NLAKEPAR=56][nLake] (row order: mizuroute_amd/casefile.py LAKE_PAR) */
+int orc_set_lakes(orc_t *o, int LakeInputOption, int calendarId, int nLake, const int *lakeReach,
+                  const int *modelType, const double *par);
+/* one step with lake forcing: evap/precip [H] m/s; month, day, dayofyear of simDatetime(1) */
+int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const double *wmflux,
+                  const double *evap, const double *precip, int month, int day, int dayofyear);
+int orc_run_lake(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux,
+                 const double *evap, const double *precip, const int *ymd /* [nSteps][3] */,
+                 double *Qout, double *volOut);
 const char *orc_last_error(const orc_t *o);
 
 int orc_get_flux(const orc_t *o, int route, int which, double *out /* [N] */);

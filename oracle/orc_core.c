@@ -150,7 +150,8 @@ static void hru_irf(orc_t *o, int r) {
   int n = o->ntdhBas;
   double *qf = o->QFUTURE + (size_t)r * n;
   o->BASIN_QR0[r] = o->BASIN_QR1[r];
-  for (int j = 0; j < n; j++) qf[j] = qf[j] + o->fracFuture[j] * o->BASIN_QI[r];
+  const int lake = o->is_lake_sim && o->lakeSlot[r] >= 0;   /* impulse for lakes, basinUH.f90:116-119 */
+  for (int j = 0; j < n; j++) qf[j] = qf[j] + (lake ? (j == 0 ? 1.0 : 0.0) : o->fracFuture[j]) * o->BASIN_QI[r];
   o->BASIN_QR1[r] = qf[0];
   for (int j = 1; j < n; j++) qf[j - 1] = qf[j];
   qf[n - 1] = 0.0;
@@ -274,13 +275,25 @@ int orc_irf_rch(orc_t *o, int r) {
 
 /* main_route.f90:29-268 + route_network 273-409 */
 int orc_step(orc_t *o, double T0, double T1, const double *runoff, const double *wmflux) {
+  return orc_step_lake(o, T0, T1, runoff, wmflux, NULL, NULL, 1, 1, 1);
+}
+
+int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const double *wmflux,
+                  const double *evap, const double *precip, int month, int day, int dayofyear) {
   int N = o->N, ierr = 0;
+  o->iTime += 1; o->month = month; o->day = day; o->dayofyear = dayofyear;
   o->msg[0] = 0;
   if (o->is_flux_wm && wmflux) { for (int r = 0; r < N; r++) o->REACH_WM_FLUX[r] = wmflux[r]; }
   else { for (int r = 0; r < N; r++) o->REACH_WM_FLUX[r] = 0.0; }
   double *reachRunoff = (double *)xcalloc(N, sizeof(double));
   ierr = basin2reach(o, runoff, reachRunoff);
   if (ierr) { free(reachRunoff); return ierr; }
+  if (o->is_lake_sim) {   /* main_route.f90:172-200: evaporation and precipitation through the same mapping */
+    if (!evap || !precip) { free(reachRunoff); snprintf(o->msg, sizeof o->msg, "main_routing/lake simulation needs evaporation and precipitation"); return 20; }
+    ierr = basin2reach(o, evap, o->basinEvapo);
+    if (!ierr) ierr = basin2reach(o, precip, o->basinPrecip);
+    if (ierr) { free(reachRunoff); return ierr; }
+  }
   if (o->doesBasinRoute == 1) {
     for (int r = 0; r < N; r++) o->BASIN_QI[r] = reachRunoff[r];
     for (int r = 0; r < N; r++) hru_irf(o, r);
@@ -293,6 +306,11 @@ int orc_step(orc_t *o, double T0, double T1, const double *runoff, const double 
     int m = o->methods[ix];
     for (int k = 0; k < N; k++) {
       int r = o->order[k];
+      if (o->is_lake_sim && o->lakeSlot[r] >= 0 && m != ORC_SUM) {   /* main_route.f90:375-381 */
+        ierr = orc_lake_route(o, r, m);
+        if (ierr) return ierr;
+        continue;
+      }
       switch (m) {
         case ORC_SUM: ierr = orc_sum_rch(o, r); break;
         case ORC_IRF: ierr = orc_irf_rch(o, r); break;
@@ -318,6 +336,28 @@ int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const
     double T0 = t_start + (double)it * o->dt;
     double T1 = T0 + o->dt;
     int ierr = orc_step(o, T0, T1, runoff + (size_t)it * o->H, wmflux ? wmflux + (size_t)it * N : NULL);
+    if (ierr) return ierr;
+    for (int ix = 0; ix < o->nRoutes; ix++) {
+      size_t base = ((size_t)it * o->nRoutes + ix) * N;
+      if (Qout)   for (int r = 0; r < N; r++) Qout[base + r] = o->route[(size_t)ix * N + r].REACH_Q;
+      if (volOut) for (int r = 0; r < N; r++) volOut[base + r] = o->route[(size_t)ix * N + r].REACH_VOL[1];
+    }
+  }
+  return 0;
+}
+
+int orc_run_lake(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux,
+                 const double *evap, const double *precip, const int *ymd, double *Qout, double *volOut) {
+  static const int mdays[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+  int N = o->N;
+  for (int it = 0; it < nSteps; it++) {
+    double T0 = t_start + (double)it * o->dt, T1 = T0 + o->dt;
+    const int y = ymd[3 * it], mo = ymd[3 * it + 1], d = ymd[3 * it + 2];
+    int doy = d;
+    const int leap = o->calendarId == 1 && ((y % 4 == 0 && y % 100 != 0) || y % 400 == 0);
+    for (int k = 0; k < mo - 1; k++) doy += mdays[k] + (k == 1 && leap ? 1 : 0);
+    int ierr = orc_step_lake(o, T0, T1, runoff + (size_t)it * o->H, wmflux ? wmflux + (size_t)it * N : NULL,
+                             evap + (size_t)it * o->H, precip + (size_t)it * o->H, mo, d, doy);
     if (ierr) return ierr;
     for (int ix = 0; ix < o->nRoutes; ix++) {
       size_t base = ((size_t)it * o->nRoutes + ix) * N;

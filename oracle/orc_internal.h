@@ -7,7 +7,8 @@
 #define ORC_NMOL_KW 20              /* init_model_data.f90:386-394 */
 #define ORC_NMOL_MC 2
 #define ORC_NMOL_DW 20
-#define ORC_KWSTORE 40              /* storage per reach for KWAVE (size <= MAXQPAR+1) */
+#define ORC_KWSTORE 40
+#define ORC_NLAKEPAR 56             /* mizuroute_amd/casefile.py LAKE_PAR order */              /* storage per reach for KWAVE (size <= MAXQPAR+1) */
 
 /* dataTypes.f90:291-302 (QM is always -9999 on this path and is not stored) */
 typedef struct { double QF, TI, TR; int RF; } orc_fpoint;
@@ -40,6 +41,13 @@ struct orc {
   double *QFUTURE_IRF;  /* concatenated per uhOff */
   orc_fpoint *kw; int *nkw;   /* [N][ORC_KWSTORE]; nkw = -1 unallocated */
   double *molKW, *molMC, *molDW;
+  /* lakes (lake_route.f90); lakeSlot[r] = -1 for river reaches */
+  int is_lake_sim, LakeInputOption, calendarId, nLake;
+  int *lakeSlot, *lakeModel, *lakeInlet;
+  double *lakePar;           /* [nLake][ORC_NLAKEPAR] (mutable: H06 monthly means, E_rel_ini) */
+  double *basinEvapo, *basinPrecip;   /* [N] m3/s */
+  double **qpast, **dpast; int *qpastLen, *dpastLen;   /* Hanasaki memory [12][L] per lake */
+  long long iTime; int month, day, dayofyear;
   /* KWT traffic statistics of the last step */
   long long w_in, w_up, w_out, n_head, n_route, n_edges;
   char msg[512];
@@ -64,6 +72,7 @@ int orc_irf_rch(orc_t *o, int r);
 int orc_mc_rch(orc_t *o, int r, double T0, double T1);
 int orc_dw_rch(orc_t *o, int r, int method);   /* ORC_DW or ORC_KW */
 int orc_kwt_rch(orc_t *o, int r, double T0, double T1);
+int orc_lake_route(orc_t *o, int r, int method);
 /* shared preamble of irf/mc/dw/kw (irf_route.f90:81-142) */
 void orc_preamble(orc_t *o, int r, int method, double *q_upstream, double *q_upstream_mod,
                   double *Qlat, int *isHW);

@@ -191,7 +191,19 @@ done:
 static int getusq_rch(orc_t *o, int JRCH, double T0, double T1, int *NK1_out, double **Q_JRCH, double **TENTRY, double **T_EXIT) {
   double DT = T1 - T0;
   int ND = 0; double *QD = NULL, *TD = NULL;
-  int ierr = qexmul_rch(o, JRCH, T0, T1, &ND, &QD, &TD);
+  int ierr = 0, isUpLake = 0, iUp = -1;
+  if (o->is_lake_sim) {   /* lake outflow enters the river as a single particle, :540-559 */
+    int nUps = o->upOff[JRCH + 1] - o->upOff[JRCH];
+    for (int e = o->upOff[JRCH]; e < o->upOff[JRCH + 1]; e++) if (o->lakeSlot[o->upIdx[e]] >= 0) { isUpLake = 1; iUp = o->upIdx[e]; }
+    if (isUpLake && nUps > 1) return fail(o, 10, "getusq_rch/lake outlet reach should have one upstream lake");
+  }
+  if (isUpLake) {
+    ND = 1; QD = (double *)malloc(sizeof(double)); TD = (double *)malloc(sizeof(double));
+    QD[0] = HYD(o, ORC_KWT, iUp).REACH_Q / o->par[ORC_P_WIDTH][JRCH];
+    TD[0] = T1;
+  } else {
+    ierr = qexmul_rch(o, JRCH, T0, T1, &ND, &QD, &TD);
+  }
   if (ierr) return ierr;
   orc_fpoint *K = KW(o, JRCH);
   if (o->nkw[JRCH] < 0) {   /* cold start, :587-596 */
@@ -453,7 +465,7 @@ int orc_kwt_rch(orc_t *o, int r, double T0, double T1) {
   o->w_out += NQ2 + 2;
   free(Q_JRCH); free(TENTRY); free(T_EXIT); free(FROUTE);
   /* outlet: strip routed particles itself, :325-344 */
-  if (o->down[r] < 0) {
+  if (o->down[r] < 0 || (o->is_lake_sim && o->lakeInlet[r])) {
     memmove(K, K + (NR + 1), (size_t)(NN + 1) * sizeof(orc_fpoint));
     o->nkw[r] = NN + 1;
   }

@@ -42,6 +42,8 @@ def lib():
         L.orc_step.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, C.c_void_p]
         L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, C.c_void_p]
         L.orc_run_wm.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, C.c_void_p, C.c_void_p]
+        L.orc_set_lakes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, dp]
+        L.orc_run_lake.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, dp, dp, ip, C.c_void_p, C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_get_flux.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
@@ -103,6 +105,27 @@ class Oracle:
                                   Q.ctypes.data, V.ctypes.data if want_vol else None)
         else:
             rc = lib().orc_run(self.h, n, float(t_start), runoff, Q.ctypes.data, V.ctypes.data if want_vol else None)
+        if rc:
+            raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
+        return (Q, V) if want_vol else Q
+
+    def set_lakes(self, lakes):
+        """lakes: dict as mizuroute_amd.casefile.write_case(lakes=...)."""
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        self._lakes = lakes
+        return lib().orc_set_lakes(self.h, int(lakes["input_option"]), int(lakes["calendar_id"]), len(lakes["reach"]),
+                                   c(lakes["reach"], np.int32), c(lakes["model_type"], np.int32), c(lakes["par"], np.float64))
+
+    def run_lake(self, runoff, lakes, t_start=0.0, want_vol=False, wm_flux=None):
+        runoff = np.ascontiguousarray(runoff, dtype=np.float64)
+        n = runoff.shape[0]
+        Q = np.zeros((n, len(self.methods), self.N))
+        V = np.zeros((n, len(self.methods), self.N)) if want_vol else None
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        wm = c(wm_flux, np.float64) if wm_flux is not None else None
+        rc = lib().orc_run_lake(self.h, n, float(t_start), runoff, wm.ctypes.data if wm is not None else None,
+                                c(lakes["evap"], np.float64), c(lakes["precip"], np.float64), c(lakes["ymd"], np.int32),
+                                Q.ctypes.data, V.ctypes.data if want_vol else None)
         if rc:
             raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
         return (Q, V) if want_vol else Q

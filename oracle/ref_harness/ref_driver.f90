@@ -11,6 +11,8 @@ PROGRAM ref_driver
   USE nrtype
   USE public_var
   USE dataTypes,  ONLY: RCHTOPO, RCHPRP, STRFLX, STRSTA, subbasin_omp, dlength
+  USE datetime_data, ONLY: datetime
+  USE globalData, ONLY: simDatetime
   USE globalData, ONLY: rch_routes, nRoutes, routeMethods, onRoute, &
                         idxSUM, idxIRF, idxKWT, idxKW, idxMC, idxDW, &
                         iTime, TSEC, nMolecule, isColdStart, FRAC_FUTURE, &
@@ -35,7 +37,9 @@ PROGRAM ref_driver
   character(len=1024) :: fcase, fout, arg
   integer(i4b) :: uin, uout, magic, version
   integer(i4b) :: N, H, nSteps, methodsIn(6), nUpTot, nHruTot, nOrder, nBranch
-  integer(i4b) :: uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm
+  integer(i4b) :: uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm, isLakeSim, calendarId, nLake, il
+  integer(i4b), allocatable :: ymd(:,:), lakeReach(:), lakeModel(:)
+  real(dp), allocatable :: lakePar(:,:), evap(:,:), precip(:,:)
   real(dp)     :: fshape, tscale, velo, diff, t_start
   integer(i4b), allocatable :: downIndex(:), reachId(:), upOffset(:), upIndex(:), upGood(:)
   integer(i4b), allocatable :: hruOffset(:), hruIndex(:), orderOffset(:), branchOffset(:), seg(:)
@@ -75,7 +79,7 @@ PROGRAM ref_driver
     write(*,*) 'bad case-file magic', magic; stop 3
   end if
   read(uin) N, H, nSteps, nRoutes, methodsIn, doesBasinRoute, hw_drain_point, nUpTot, nHruTot, &
-            nOrder, nBranch, uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm
+            nOrder, nBranch, uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm, isLakeSim
   read(uin) dt, min_length_route, runoffMin, fshape, tscale, velo, diff, t_start
   allocate(downIndex(N), reachId(N), upOffset(N+1), upIndex(nUpTot), upGood(nUpTot))
   allocate(hruOffset(N+1), hruIndex(nHruTot), hruWeight(nHruTot), par(N,11))
@@ -93,10 +97,20 @@ PROGRAM ref_driver
     allocate(wmflux(N, nSteps))
     read(uin) wmflux
   end if
+  if (isLakeSim == 1) then
+    read(uin) LakeInputOption, calendarId, nLake
+    allocate(ymd(3, nSteps), lakeReach(nLake), lakeModel(nLake), lakePar(nLake, 56), evap(H, nSteps), precip(H, nSteps))
+    read(uin) ymd, lakeReach, lakeModel, lakePar, evap, precip
+    if (calendarId == 0) then
+      calendar = 'noleap'
+    else
+      calendar = 'standard'
+    end if
+  end if
   close(uin)
 
   ! ---- configuration the reference keeps in public_var / globalData (read_control.f90:580-600)
-  is_lake_sim = .false.; is_flux_wm = (isFluxWm == 1); is_vol_wm = .false.; tracer = .false.
+  is_lake_sim = (isLakeSim == 1); is_flux_wm = (isFluxWm == 1); is_vol_wm = .false.; tracer = .false.
   qmodOption = 0
   time_conv = 1._dp; length_conv = 1._dp
   allocate(routeMethods(nRoutes))
@@ -181,6 +195,46 @@ PROGRAM ref_driver
     RPARAM(i)%UPSAREA = par(i,10) - par(i,9)
   end do
 
+  ! ---- lakes: flags, parameters (process_ntopo.f90:479-494; lake inlet = immediate downstream is a lake,
+  !      network_topo.f90:958-981)
+  if (is_lake_sim) then
+    do il = 1, nLake
+      i = lakeReach(il)
+      NETOPO(i)%ISLAKE = .true.
+      NETOPO(i)%LAKEMODELTYPE = lakeModel(il)
+      if (onRoute(impulseResponseFunc)) then
+        NETOPO(i)%UH = 0._dp; NETOPO(i)%UH(1) = 1._dp          ! process_ntopo.f90:501-505
+      end if
+      RPARAM(i)%D03_MaxStorage = lakePar(il,1);  RPARAM(i)%D03_Coefficient = lakePar(il,2)
+      RPARAM(i)%D03_Power = lakePar(il,3);       RPARAM(i)%D03_S0 = lakePar(il,4)
+      RPARAM(i)%HYP_E_emr = lakePar(il,5);       RPARAM(i)%HYP_E_lim = lakePar(il,6);   RPARAM(i)%HYP_E_min = lakePar(il,7)
+      RPARAM(i)%HYP_E_zero = lakePar(il,8);      RPARAM(i)%HYP_Qrate_emr = lakePar(il,9); RPARAM(i)%HYP_Erate_emr = lakePar(il,10)
+      RPARAM(i)%HYP_Qrate_prim = lakePar(il,11); RPARAM(i)%HYP_Qrate_amp = lakePar(il,12)
+      RPARAM(i)%HYP_Qrate_phs = nint(lakePar(il,13)); RPARAM(i)%HYP_prim_F = (lakePar(il,14) /= 0._dp)
+      RPARAM(i)%HYP_A_avg = lakePar(il,15);      RPARAM(i)%HYP_Qsim_mode = (lakePar(il,16) /= 0._dp)
+      RPARAM(i)%H06_Smax = lakePar(il,17);       RPARAM(i)%H06_alpha = lakePar(il,18);  RPARAM(i)%H06_envfact = lakePar(il,19)
+      RPARAM(i)%H06_S_ini = lakePar(il,20);      RPARAM(i)%H06_c1 = lakePar(il,21);     RPARAM(i)%H06_c2 = lakePar(il,22)
+      RPARAM(i)%H06_exponent = lakePar(il,23);   RPARAM(i)%H06_denominator = lakePar(il,24); RPARAM(i)%H06_c_compare = lakePar(il,25)
+      RPARAM(i)%H06_frac_Sdead = lakePar(il,26); RPARAM(i)%H06_E_rel_ini = lakePar(il,27)
+      RPARAM(i)%H06_I_Jan = lakePar(il,28); RPARAM(i)%H06_I_Feb = lakePar(il,29); RPARAM(i)%H06_I_Mar = lakePar(il,30)
+      RPARAM(i)%H06_I_Apr = lakePar(il,31); RPARAM(i)%H06_I_May = lakePar(il,32); RPARAM(i)%H06_I_Jun = lakePar(il,33)
+      RPARAM(i)%H06_I_Jul = lakePar(il,34); RPARAM(i)%H06_I_Aug = lakePar(il,35); RPARAM(i)%H06_I_Sep = lakePar(il,36)
+      RPARAM(i)%H06_I_Oct = lakePar(il,37); RPARAM(i)%H06_I_Nov = lakePar(il,38); RPARAM(i)%H06_I_Dec = lakePar(il,39)
+      RPARAM(i)%H06_D_Jan = lakePar(il,40); RPARAM(i)%H06_D_Feb = lakePar(il,41); RPARAM(i)%H06_D_Mar = lakePar(il,42)
+      RPARAM(i)%H06_D_Apr = lakePar(il,43); RPARAM(i)%H06_D_May = lakePar(il,44); RPARAM(i)%H06_D_Jun = lakePar(il,45)
+      RPARAM(i)%H06_D_Jul = lakePar(il,46); RPARAM(i)%H06_D_Aug = lakePar(il,47); RPARAM(i)%H06_D_Sep = lakePar(il,48)
+      RPARAM(i)%H06_D_Oct = lakePar(il,49); RPARAM(i)%H06_D_Nov = lakePar(il,50); RPARAM(i)%H06_D_Dec = lakePar(il,51)
+      RPARAM(i)%H06_purpose = nint(lakePar(il,52)); RPARAM(i)%H06_I_mem_F = (lakePar(il,53) /= 0._dp)
+      RPARAM(i)%H06_D_mem_F = (lakePar(il,54) /= 0._dp)
+      RPARAM(i)%H06_I_mem_L = nint(lakePar(il,55)); RPARAM(i)%H06_D_mem_L = nint(lakePar(il,56))
+    end do
+    do i = 1, N
+      if (downIndex(i) > 0) then
+        if (NETOPO(downIndex(i))%ISLAKE) NETOPO(i)%LAKINLT = .true.
+      end if
+    end do
+  end if
+
   ! ---- cold-start state (init_model_data.f90:399-505)
   isColdStart = .true.
   do i = 1, N
@@ -197,6 +251,11 @@ PROGRAM ref_driver
     end do
     if (onRoute(impulseResponseFunc)) then
       allocate(RCHFLX(i)%QFUTURE_IRF(size(NETOPO(i)%UH))); RCHFLX(i)%QFUTURE_IRF = 0._dp
+    end if
+    if (onRoute(kinematicWaveTracking) .and. is_lake_sim .and. NETOPO(i)%ISLAKE) then   ! init_model_data.f90:431-439
+      allocate(RCHSTA(i)%LKW_ROUTE%KWAVE(0:0))
+      RCHSTA(i)%LKW_ROUTE%KWAVE(0)%QF=-9999; RCHSTA(i)%LKW_ROUTE%KWAVE(0)%TI=-9999; RCHSTA(i)%LKW_ROUTE%KWAVE(0)%TR=-9999
+      RCHSTA(i)%LKW_ROUTE%KWAVE(0)%RF=.False.; RCHSTA(i)%LKW_ROUTE%KWAVE(0)%QM=-9999
     end if
     if (onRoute(kinematicWave)) then
       allocate(RCHSTA(i)%KW_ROUTE%molecule%Q(nMolecule%KW_ROUTE)); RCHSTA(i)%KW_ROUTE%molecule%Q = 0._dp
@@ -224,7 +283,12 @@ PROGRAM ref_driver
   end do
 
   allocate(ixRch(N)); ixRch = [(i, i=1,N)]
-  allocate(basinRunoff(H), basinEvapo(0), basinPrecip(0), basinSolute(0), reachvol(0))
+  allocate(basinRunoff(H), basinSolute(0), reachvol(0))
+  if (is_lake_sim) then
+    allocate(basinEvapo(H), basinPrecip(H))
+  else
+    allocate(basinEvapo(0), basinPrecip(0))
+  end if
   if (isFluxWm == 1) then
     allocate(reachflux(N))
   else
@@ -244,6 +308,10 @@ PROGRAM ref_driver
     TSEC(2) = TSEC(1) + dt
     basinRunoff = runoff(:, it)
     if (isFluxWm == 1) reachflux = wmflux(:, it)
+    if (is_lake_sim) then
+      basinEvapo = evap(:, it); basinPrecip = precip(:, it)
+      simDatetime(1) = datetime(ymd(1,it), ymd(2,it), ymd(3,it), 0, 0, 0._dp, calendar=trim(calendar))
+    end if
     call system_clock(c0, crate)
     call main_route(basinRunoff, basinEvapo, basinPrecip, basinSolute, reachflux, reachvol, ixRch, &
                     river_basin, NETOPO, RPARAM, RCHFLX, RCHSTA, gage_obs, ierr, message)

@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from mizuroute_amd.synthetic import make_network, make_runoff  # noqa: E402
+from mizuroute_amd.synthetic import make_lakes, make_network, make_runoff  # noqa: E402
 from oracle import refrun  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,13 +31,23 @@ CASES = {
     # KWT with a daily step: every particle leaves within the step, long merged trains
     "tree200_kwt_daily": dict(N=200, seed=404, methods=[2], dt=86400.0, steps=40, net_kw={},
                               ro_kw=dict(storm_prob=0.3, storm_amp=5e-7)),
+    # BASELINE config 4 flavour: lakes and reservoirs (endorheic, Doll, Hanasaki with inflow memory, HYPE),
+    # precipitation + evaporation + runoff into the lakes, standard calendar across a leap day
+    # (one method per case: the reference shares the mutable Hanasaki parameters between methods)
+    "lakes500_kwt": dict(N=500, seed=505, methods=[2], dt=21600.0, steps=80, net_kw=dict(n_outlets=5),
+                         ro_kw=dict(storm_prob=0.05, storm_amp=3e-6),
+                         lake_kw=dict(seed=6, frac=0.03, memory=True, input_option=2, calendar_id=1, start=(2004, 2, 20))),
+    "lakes300_dw": dict(N=300, seed=506, methods=[5], dt=21600.0, steps=60, net_kw=dict(n_outlets=3),
+                        ro_kw=dict(storm_prob=0.05, storm_amp=3e-6),
+                        lake_kw=dict(seed=7, frac=0.04, memory=False, input_option=0, calendar_id=0, start=(2001, 12, 25))),
 }
 
 
 def save_case(name, spec):
     net = make_network(spec["N"], seed=spec["seed"], **spec["net_kw"])
     ro = make_runoff(net.H, spec["steps"], seed=spec["seed"] + 1, **spec["ro_kw"])
-    out = refrun.run_case(net, ro, spec["dt"], spec["methods"])
+    lakes = make_lakes(net, spec["steps"], spec["dt"], **spec["lake_kw"]) if "lake_kw" in spec else None
+    out = refrun.run_case(net, ro, spec["dt"], spec["methods"], lakes=lakes)
     assert out["ierr"] == 0, out["stdout"]
     d = dict(N=net.N, H=net.H, dt=spec["dt"], methods=np.array(spec["methods"], np.int32),
              downIndex=net.downIndex, reachId=net.reachId, upOffset=net.upOffset, upIndex=net.upIndex,
@@ -45,6 +55,9 @@ def save_case(name, spec):
              params=net.param_matrix(), runoff=ro,
              frac_future=out["frac_future"], uh_offset=out["uh_offset"], uh=out["uh"],
              ref_Q=out["Q"], ref_VOL=out["VOL"], ref_QR1=out["QR1"], ref_basin_qfuture=out["basin_qfuture"])
+    if lakes is not None:
+        for k, v in lakes.items():
+            d["lake_" + k] = np.asarray(v)
     for m, st in out["state"].items():
         for k, v in st.items():
             d[f"ref_state_{m}_{k}"] = v
@@ -56,5 +69,7 @@ def save_case(name, spec):
 if __name__ == "__main__":
     if not refrun.available():
         refrun.build()
+    only = sys.argv[1:]
     for name, spec in CASES.items():
-        save_case(name, spec)
+        if not only or name in only:
+            save_case(name, spec)

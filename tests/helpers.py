@@ -6,7 +6,7 @@ import numpy as np
 from mizuroute_amd.synthetic import RiverNetwork
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["cameo50_irf", "tree150_all", "tree400_kwt", "tree200_kwt_daily"]
+GOLDEN_CASES = ["cameo50_irf", "tree150_all", "tree400_kwt", "tree200_kwt_daily", "lakes500_kwt", "lakes300_dw"]
 REL_TOL = 1e-6          # BASELINE.json north_star: discharge within 1e-6 relative of the reference
 
 
@@ -18,6 +18,13 @@ def load_golden(name):
                        hruOffset=z["hruOffset"], hruIndex=z["hruIndex"], hruWeight=z["hruWeight"],
                        params={k: par[i].copy() for i, k in enumerate(RiverNetwork.PARAM_ORDER)})
     return net, z
+
+
+def golden_lakes(z):
+    """lakes dict of a fixture (None if the case has no lakes)."""
+    if "lake_reach" not in z.files:
+        return None
+    return {k[5:]: (int(z[k]) if z[k].ndim == 0 else z[k]) for k in z.files if k.startswith("lake_")}
 
 
 def rel_err(a, b, floor=1e-9):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import mizuroute_amd as m
-from helpers import GOLDEN_CASES, REL_TOL, load_golden, parity_report
+from helpers import GOLDEN_CASES, REL_TOL, golden_lakes, load_golden, parity_report
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def domain_from_golden(net, z, **kw):
     methods = [int(x) for x in z["methods"]]
     return m.RoutingDomain(net, float(z["dt"]), methods, frac_future=z["frac_future"],
-                           uh_offset=z["uh_offset"], uh=z["uh"], **kw)
+                           uh_offset=z["uh_offset"], uh=z["uh"], lakes=golden_lakes(z), **kw)
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -49,6 +49,10 @@ def test_matches_reference_golden(name, window, hip_lib):
         for got, key in ((qf, "qf"), (ti, "ti"), (tr, "tr")):
             ref = z[f"ref_state_2_{key}"]
             assert np.allclose(got[mask], ref[mask], rtol=REL_TOL, atol=0), key
+    if golden_lakes(z) is not None:       # lake storage follows the reference, too
+        for meth in methods:
+            if meth != 0:
+                assert np.allclose(dom.flux(meth, m.api.F_VOL1), z[f"ref_state_{meth}_VOL1"], rtol=REL_TOL, atol=1e-6), meth
     for meth in (3, 4, 5):
         if meth in methods:
             assert np.allclose(dom.mol_state(meth), z[f"ref_state_{meth}_mol"], rtol=REL_TOL, atol=1e-300)

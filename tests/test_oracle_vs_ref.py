@@ -90,3 +90,22 @@ def test_water_management_bit_exact(oracle_lib):
         else:
             with pytest.raises(RuntimeError, match="ierr=20"):
                 orc.run(ro, wm_flux=wk)
+
+
+@pytest.mark.parametrize("memory,opt,cal,start", [(False, 0, 0, (2001, 2, 20)), (True, 2, 1, (2004, 2, 20)), (False, 1, 0, (2001, 12, 20))])
+def test_lakes_bit_exact(memory, opt, cal, start, oracle_lib):
+    """Lakes and reservoirs (endorheic, Doll03, Hanasaki06 with/without inflow memory, HYPE), every
+    LakeInputOption, both calendars: the oracle reproduces the reference bit for bit, KWT included."""
+    from mizuroute_amd.synthetic import make_lakes
+    net = make_network(800, seed=41, n_outlets=6)
+    steps, dt = 60, 21600.0
+    ro = make_runoff(net.H, steps, seed=5, storm_prob=0.05, storm_amp=3e-6)
+    lakes = make_lakes(net, steps, dt, seed=5, frac=0.02, memory=memory, input_option=opt, calendar_id=cal, start=start)
+    assert set(lakes["model_type"]) == {0, 1, 2, 3}
+    for methods in ([1, 3, 4, 5, 0], [2]):
+        out = refrun.run_case(net, ro, dt, methods, lakes=lakes)
+        assert out["ierr"] == 0, out["stdout"]
+        orc = oracle_lib.Oracle(net, dt, methods, out["frac_future"], out["uh_offset"], out["uh"])
+        orc.set_lakes(lakes)
+        Q, V = orc.run_lake(ro, lakes, want_vol=True)
+        assert np.array_equal(Q, out["Q"]) and np.array_equal(V, out["VOL"]), methods
