@@ -40,35 +40,67 @@ __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
   else d.qlat[(size_t)(t + 1) * d.N + r] = rr;            // main_route.f90:223-226
 }
 
-// grid: x over reaches, y over steps: BASIN_QR(1) of step t
-__global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
-  if (r >= d.N) return;
-  if (d.haloSlot && d.haloSlot[r] >= 0) return;
-  const int n = d.ntdhBas, N = d.N;
-  double acc = (t < n) ? d.basS0[(size_t)t * N + r] : 0.0;
-  if (d.lakeSlot && d.lakeSlot[r] >= 0) {   // lakes: impulse response, basinUH.f90:116-119
-    d.qlat[(size_t)(t + 1) * N + r] = acc + 1.0 * d.qi[(size_t)t * N + r];
-    return;
+// Register-tiled fold: one lane produces HT consecutive outputs of one reach, so every BASIN_QI
+// value is loaded once per HT outputs instead of once per output (the convolution has ~200 taps at
+// dt = 1 h), with the HT coefficients it meets kept in a sliding register window.  `first` is the
+// step (k_hillslope_out) or virtual step W+j (k_hillslope_state) of output 0; contributions are
+// still added oldest-first per output, so results are unchanged.
+#define HT 8
+template <bool STATE>
+__device__ __forceinline__ void hillslope_tile(const MzrDev &d, int r, int first, int count) {
+  const int n = d.ntdhBas, N = d.N, W = d.W;
+  const bool lake = d.lakeSlot && d.lakeSlot[r] >= 0;   // lakes: impulse response, basinUH.f90:116-119
+  double acc[HT], f[HT];
+#pragma unroll
+  for (int j = 0; j < HT; ++j) { const int tv = first + j; acc[j] = (j < count && tv < n) ? d.basS0[(size_t)tv * N + r] : 0.0; }
+  const int tauHi = STATE ? W - 1 : first + count - 1;          // newest input any output of the tile sees
+  int tauLo = first - n + 1; if (tauLo < 0) tauLo = 0;           // oldest input of output 0
+  if (!lake) {
+    // f[j] = F[first + j - tau] (0 outside [0, n-1])
+#pragma unroll
+    for (int j = 0; j < HT; ++j) { const int k = first + j - tauLo; f[j] = (k >= 0 && k < n) ? d.fracFuture[k] : 0.0; }
+    for (int tau = tauLo; tau <= tauHi; ++tau) {
+      const double q = d.qi[(size_t)tau * N + r];
+#pragma unroll
+      for (int j = 0; j < HT; ++j) {
+        const int k = first + j - tau;                             // tap index of output j
+        if (k >= 0 && k < n && (STATE || tau <= first + j)) acc[j] = acc[j] + f[j] * q;
+      }
+      // slide the window: tap index of every output drops by one
+#pragma unroll
+      for (int j = HT - 1; j > 0; --j) f[j] = f[j - 1];
+      const int k0 = first - tau - 1;
+      f[0] = (k0 >= 0 && k0 < n) ? d.fracFuture[k0] : 0.0;
+    }
+  } else if (!STATE) {
+#pragma unroll
+    for (int j = 0; j < HT; ++j) if (j < count) acc[j] = acc[j] + 1.0 * d.qi[(size_t)(first + j) * N + r];
   }
-  const int tau0 = t - n + 1 > 0 ? t - n + 1 : 0;
-  for (int tau = tau0; tau <= t; ++tau) acc = acc + d.fracFuture[t - tau] * d.qi[(size_t)tau * N + r];
-  d.qlat[(size_t)(t + 1) * N + r] = acc;
+#pragma unroll
+  for (int j = 0; j < HT; ++j) {
+    if (j >= count) continue;
+    if (STATE) d.basS1[(size_t)(first - W + j) * N + r] = acc[j];
+    else d.qlat[(size_t)(first + j + 1) * N + r] = acc[j];
+  }
 }
 
-// grid: x over reaches, y over register slots j: QFUTURE(j+1) after the window
+// grid: x over reaches, y over tiles of HT steps: BASIN_QR(1) of steps [y*HT, y*HT+HT)
+__global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= d.N) return;
+  if (d.haloSlot && d.haloSlot[r] >= 0) return;
+  const int t0 = blockIdx.y * HT;
+  const int count = d.W - t0 < HT ? d.W - t0 : HT;
+  hillslope_tile<false>(d, r, t0, count);
+}
+
+// grid: x over reaches, y over tiles of HT register slots: QFUTURE(j+1) after the window
 __global__ void __launch_bounds__(256) k_hillslope_state(MzrDev d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
   if (r >= d.N) return;
-  const int n = d.ntdhBas, N = d.N, W = d.W;
-  const int tv = W + j;                       // step at which this slot would be emitted
-  double acc = (tv < n) ? d.basS0[(size_t)tv * N + r] : 0.0;
-  if (d.lakeSlot && d.lakeSlot[r] >= 0) { d.basS1[(size_t)j * N + r] = acc; return; }
-  const int tau0 = tv - n + 1 > 0 ? tv - n + 1 : 0;
-  for (int tau = tau0; tau < W; ++tau) acc = acc + d.fracFuture[tv - tau] * d.qi[(size_t)tau * N + r];
-  d.basS1[(size_t)j * N + r] = acc;
+  const int j0 = blockIdx.y * HT;
+  const int count = d.ntdhBas - j0 < HT ? d.ntdhBas - j0 : HT;
+  hillslope_tile<true>(d, r, d.W + j0, count);
 }
 
 // evaporation / precipitation of the lake reaches through the HRU mapping (main_route.f90:172-200);
@@ -109,8 +141,9 @@ void mzr_launch_basin(const MzrDev &d, hipStream_t stream) {
   dim3 block(256), grid((d.N + 255) / 256, d.W);
   hipLaunchKernelGGL(k_basin2reach, grid, block, 0, stream, d);
   if (d.doesBasinRoute == 1) {
-    hipLaunchKernelGGL(k_hillslope_out, grid, block, 0, stream, d);
-    dim3 gridS((d.N + 255) / 256, d.ntdhBas);
+    dim3 gridO((d.N + 255) / 256, (d.W + HT - 1) / HT);
+    hipLaunchKernelGGL(k_hillslope_out, gridO, block, 0, stream, d);
+    dim3 gridS((d.N + 255) / 256, (d.ntdhBas + HT - 1) / HT);
     hipLaunchKernelGGL(k_hillslope_state, gridS, block, 0, stream, d);
   }
 }

@@ -310,6 +310,8 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
 // One wavefront per block.  Each lane first works out how many work-array entries its reach needs
 // (own particles + everything its upstreams routed), the wave carves the LDS pool with a prefix
 // sum, and lanes that do not fit wait for the next round of the same wave.
+// FULL = false compiles out lakes, water management and partition boundaries (the common case).
+template <bool FULL>
 __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, int rEnd) {
   __shared__ double sQ[KWT_POOL], sT[KWT_POOL], sX[KWT_POOL];
   __shared__ unsigned short sL[KWT_POOL];
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
   int need = 0, nup = 0, u0 = 0, ng = 0, n_own = 0, NUPS = 0, IMAX = 0;
   double qlat_r = 0.0;
   bool halo = false;
-  if (live && d.haloSlot) {   // tributary outlet computed in another partition: replay its imported record
+  if (FULL && live && d.haloSlot) {   // tributary outlet computed in another partition: replay its imported record
     const int hs = d.haloSlot[r];
     if (hs >= 0) {
       halo = true;
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
     }
   }
   bool lake = false, upLake = false;
-  if (live && !halo && d.lakeSlot) {
+  if (FULL && live && !halo && d.lakeSlot) {
     const int ls = d.lakeSlot[r];
     if (ls >= 0) {   // lake reach: lake_route replaces kwt_rch; it keeps one sentinel particle (init_model_data.f90:431-439)
       lake = true;
@@ -369,7 +371,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
       d.qsum[r] += qlat_r;
       d.inflow[r] = 0.0;
       if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0; }
-      if (d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
+      if (FULL && d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
       st_head = 1;
     } else {
       st_route = 1;
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
       n_own = d.kwN[r];
       int NUPR = 0;
       IMAX = nup;
-      if (d.lakeSlot) for (int i = 0; i < nup; ++i) if (d.lakeSlot[u0 + i] >= 0) upLake = true;
+      if (FULL && d.lakeSlot) for (int i = 0; i < nup; ++i) if (d.lakeSlot[u0 + i] >= 0) upLake = true;
       if (upLake && nup > 1) { mzr_raise(d, 10, r, t, 18); }   // lake outlet reach should have one upstream lake, :551-553
       for (int i = 0; i < nup && !upLake; ++i) {
         if (d.nGood[u0 + i] > 0) { ++NUPR; const int nr = obN[u0 + i]; IMAX += nr - 1; st_up += nr + 1; }
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
         }
         // ---- extract_from_rch :351-455 (water abstraction / injection on the particles).  Its
         // recomputed exit times are overwritten by kinwav below, so only the flows change.
-        if (d.is_flux_wm && d.wm) {
+        if (FULL && d.is_flux_wm && d.wm) {
           const double Qtake = d.wm[(size_t)t * N + r];
           if (Qtake != -9999.0) {
             double Qavg;
@@ -648,7 +650,7 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
         const double TIMEI = tN + ((tN1 - tN) / dTx) * (T_END - xN);
         const int NN2 = NQ2 - NR;
         // tributary outlet of a partition: the same record goes to the time-indexed export buffer
-        const int es = d.exportSlot ? d.exportSlot[r] : -1;
+        const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         if (es >= 0) {
           const size_t nE = d.nExp;
           d.exN[(size_t)t * nE + es] = NR + 2;
@@ -693,5 +695,7 @@ void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, 
   const int n = rEnd - rBegin;
   if (n <= 0) return;
   dim3 block(64), grid((n + 63) / 64);
-  hipLaunchKernelGGL(k_stage_kwt, grid, block, 0, stream, d, s, rBegin, rEnd);
+  const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
+  if (full) hipLaunchKernelGGL(k_stage_kwt<true>, grid, block, 0, stream, d, s, rBegin, rEnd);
+  else hipLaunchKernelGGL(k_stage_kwt<false>, grid, block, 0, stream, d, s, rBegin, rEnd);
 }
