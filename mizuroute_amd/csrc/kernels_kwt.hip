@@ -305,13 +305,14 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
-#define KWT_POOL 1024   // particles of LDS work space per wavefront (3 x 8 B + 2 B each)
+// particles of LDS work space per wavefront (3 x 8 B + 2 B each): 1024 (26 KB, 6 wavefronts per CU)
+// when a launch has fewer wavefronts than the chip can hold, 768 (20 KB, 8 per CU) for larger domains
 
 // One wavefront per block.  Each lane first works out how many work-array entries its reach needs
 // (own particles + everything its upstreams routed), the wave carves the LDS pool with a prefix
 // sum, and lanes that do not fit wait for the next round of the same wave.
 // FULL = false compiles out lakes, water management and partition boundaries (the common case).
-template <bool FULL>
+template <bool FULL, int KWT_POOL>
 __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, int rEnd) {
   __shared__ double sQ[KWT_POOL], sT[KWT_POOL], sX[KWT_POOL];
   __shared__ unsigned short sL[KWT_POOL];
@@ -696,6 +697,8 @@ void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, 
   if (n <= 0) return;
   dim3 block(64), grid((n + 63) / 64);
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
-  if (full) hipLaunchKernelGGL(k_stage_kwt<true>, grid, block, 0, stream, d, s, rBegin, rEnd);
-  else hipLaunchKernelGGL(k_stage_kwt<false>, grid, block, 0, stream, d, s, rBegin, rEnd);
+  const bool big = d.N > 250000;      // more wavefronts per launch than 6 per CU can hold at once
+  if (full) hipLaunchKernelGGL((k_stage_kwt<true, 1024>), grid, block, 0, stream, d, s, rBegin, rEnd);
+  else if (big) hipLaunchKernelGGL((k_stage_kwt<false, 768>), grid, block, 0, stream, d, s, rBegin, rEnd);
+  else hipLaunchKernelGGL((k_stage_kwt<false, 1024>), grid, block, 0, stream, d, s, rBegin, rEnd);
 }
