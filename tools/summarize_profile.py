@@ -12,7 +12,13 @@ import csv
 import json
 import os
 import shutil
+import re
 import sys
+
+
+def kname(full):
+    """'void k_stage_kwt<false, 1024>(MzrDev, ...)' -> 'k_stage_kwt' (template instances pooled)."""
+    return re.sub(r"<.*", "", full.split("(")[0].replace("void ", "")).strip()
 
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
@@ -31,14 +37,14 @@ def pmc(name, counter):
     for row in csv.DictReader(open(path)):
         if row.get("Counter_Name") != counter:
             continue
-        k = row["Kernel_Name"].split("(")[0]
+        k = kname(row["Kernel_Name"])
         agg[k] += float(row["Counter_Value"]); cnt[k] += 1
     return agg, cnt
 
 
 fetch, nf = pmc("pmc_fetch", "FETCH_SIZE")
 write, nw = pmc("pmc_write", "WRITE_SIZE")
-stats = {r["Name"].split("(")[0]: r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv")))}
+stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv")))}
 lines = [f"# Profile {tag}", "",
          "Command: `python bench.py --no-cpu-baseline --window 1024 --steps 1024 --warmup 256` under",
          "`rocprofv3 --kernel-trace --stats` and, separately, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.", "",
