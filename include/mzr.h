@@ -146,11 +146,15 @@ int mzr_get_basin_state(mzr_handle h, double *qfuture /* [nRch][n] */);
 
 /* schedule / measurement introspection */
 int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
-/* kernel-time accounting of the routing sweep since the last reset:
-   launches and summed device time [ms] (HIP events on the handle's stream) per method */
-int mzr_set_profiling(mzr_handle h, int on);
+/* measurement modes (bit mask, default 0):
+   1  kernel-time accounting of the routing sweep: launches and summed device time [ms] per method
+      (HIP events around every stage launch on the handle's stream), read with mzr_get_timing;
+   2  KWT particle-traffic counters (device atomics -- perturbs timing; use on a separate window),
+      read with mzr_get_kwt_traffic */
+int mzr_set_profiling(mzr_handle h, int mode);
 int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset);
-/* particle traffic counters of the KWT sweep since the last reset (for the roofline model) */
+/* particle traffic counters of the KWT sweep since the last reset (for the roofline model);
+   counted only while profiling mode 2 is on */
 int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long long *w_out,
                         long long *n_head, long long *n_route, long long *n_edges, int reset);
 

@@ -292,8 +292,10 @@ class RoutingDomain:
         self._check(self.L.mzr_get_schedule(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def set_profiling(self, on):
-        self._check(self.L.mzr_set_profiling(self.h, int(bool(on))))
+    def set_profiling(self, mode):
+        """mode: 0 off, 1 HIP events around every stage launch (timing()), 2 KWT particle-traffic
+        counters (kwt_traffic(); device atomics, not for timed runs), 3 both."""
+        self._check(self.L.mzr_set_profiling(self.h, int(mode)))
 
     def timing(self, method, reset=False):
         n, ms, rs = C.c_longlong(0), C.c_double(0), C.c_longlong(0)

@@ -1,5 +1,6 @@
-// Lagrangian kinematic-wave tracking (KWT) stage kernel for gfx950: one lane per reach, one launch
-// per stage of the time-skewed level sweep (see kernels_route.hip for the schedule).
+// Lagrangian kinematic-wave tracking (KWT) stage kernel for gfx950: a GROUP of G lanes per routed
+// reach, one launch per stage of the time-skewed level sweep (see kernels_route.hip for the
+// schedule).
 //
 // Replaces kwt_rch and its helpers, route/build/src/kwt_route.f90:
 //   kwt_rch 36-346, getusq_rch 461-613, qexmul_rch 619-993, remove_rch 999-1123,
@@ -17,9 +18,31 @@
 //    step t in the same launch.
 //  * Expected exit times of a reach's own waiting particles are recomputed by kinwav every step,
 //    so only TR of element 0 is read back; the others are written for restart files only.
-//  * Work arrays (own particles + merged upstream particles) live in LDS: each wavefront carves a
-//    1024-particle pool among its 64 reaches by need (prefix sum), no private-memory arrays.
 //
+// Execution model.  The reference algorithm is a chain of short sequential passes over a list of
+// 10..60 particles per reach.  One lane per reach leaves a wavefront waiting on its slowest lane
+// (the reach that thins 40 particles down to 20 while its neighbours hold 5), so a reach is worked
+// on by G = 8 adjacent lanes instead and every pass is rewritten as a data-parallel step over the
+// particles, with DPP reductions inside the group where the reference takes a minimum:
+//    merge     each upstream particle finds its rank in the other tributary's list and
+//              interpolates that tributary at its own time (qexmul_rch's k-way cursor walk);
+//    remove    interpolation errors for all particles at once, group arg-min per removal, only the
+//              two neighbours are re-evaluated (on two lanes);
+//    kinwav    celerities (the x**0.4 of every particle) in parallel, shock search = group arg-min
+//              of the pairwise crossing points, the particle list after routing is rebuilt with a
+//              bit-mask prefix count instead of the running ICOUNT;
+//    interp    time-step average: short serial sum (same order as the reference).
+// Arithmetic per particle is the reference's statement by statement; where the order of a sequence
+// of operations is observable (ties of MINLOC, summation order) it is kept.  Inputs for which the
+// parallel form is not equivalent (duplicate times across tributaries, unordered times, more
+// than two upstream reaches, more than 64 particles before thinning) take a serial path on lane
+// 0 of the group that follows the reference loop literally.
+// Headwater, lake and halo reaches are O(1) and take one lane each in the trailing blocks of the
+// same launch (the host lists routed and light reaches separately, stage-major).
+//
+// Layout: particle rows are contiguous per reach (kwQ[r][20], obQ[parity][r][21]) so that the G
+// lanes of a group read and write one 160-byte row together; work arrays live in LDS, carved
+// among the groups of a wavefront by need.
 // Bound by HBM traffic of the particle rows: see DESIGN.md for the bytes-per-reach-step model.
 #include <float.h>
 #include "mzr_device.h"
@@ -119,55 +142,103 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 }  // namespace
 
+
+// ---- group primitives: G adjacent lanes (G = 4, 8 or 16, aligned) cooperate on one reach ----------
+namespace {
+
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// Butterfly over the group: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror and
+// row_mirror (once both quads / both halves agree, the mirrored lane holds the other side's value).
+#define MZR_DPP_XOR1 0xB1
+#define MZR_DPP_XOR2 0x4E
+#define MZR_DPP_HALF_MIRROR 0x141
+#define MZR_DPP_MIRROR 0x140
+
+// G = 64 (one reach per wavefront): rows of 16 lanes are reduced with DPP, the four row results are
+// combined through v_readlane, and everything "uniform" lives in scalar registers.
+template <int G> __device__ __forceinline__ int uni(int v) { return G == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+template <int G> __device__ __forceinline__ double uni(double v) {
+  if (G != 64) return v;
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int G, class F> __device__ __forceinline__ double grp_reduce_d(double v, F op) {
+  v = op(v, dpp_d<MZR_DPP_XOR1>(v));
+  v = op(v, dpp_d<MZR_DPP_XOR2>(v));
+  if (G >= 8) v = op(v, dpp_d<MZR_DPP_HALF_MIRROR>(v));
+  if (G >= 16) v = op(v, dpp_d<MZR_DPP_MIRROR>(v));
+  if (G == 64) v = op(op(readlane_d(v, 0), readlane_d(v, 16)), op(readlane_d(v, 32), readlane_d(v, 48)));
+  return v;
+}
+template <int G> __device__ __forceinline__ double grp_min(double v) { return grp_reduce_d<G>(v, [](double a, double b) { return b < a ? b : a; }); }
+// number of lanes of the group whose flag is set
+template <int G> __device__ __forceinline__ int grp_count(bool p) {
+  const unsigned long long b = __ballot(p);
+  if (G == 64) return __popcll(b);
+  const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+  return __popcll((b >> gbase) & ((1ull << (G & 63)) - 1ull));
+}
+template <int G> __device__ __forceinline__ bool grp_any(bool p) {
+  const unsigned long long b = __ballot(p);
+  if (G == 64) return b != 0ull;
+  const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+  return ((b >> gbase) & ((1ull << (G & 63)) - 1ull)) != 0ull;
+}
+// arg-min over the group of (v, i); LAST = false: ties -> smallest i (MINLOC), true: ties -> largest i
+template <int G, bool LAST> __device__ __forceinline__ void grp_argmin(double &v, int &i) {
+  auto step = [&](double ov, int oi) {
+    const bool take = ov < v || (ov == v && (LAST ? oi > i : oi < i));
+    v = take ? ov : v; i = take ? oi : i;
+  };
+  step(dpp_d<MZR_DPP_XOR1>(v), dpp_i<MZR_DPP_XOR1>(i));
+  step(dpp_d<MZR_DPP_XOR2>(v), dpp_i<MZR_DPP_XOR2>(i));
+  if (G >= 8) step(dpp_d<MZR_DPP_HALF_MIRROR>(v), dpp_i<MZR_DPP_HALF_MIRROR>(i));
+  if (G >= 16) step(dpp_d<MZR_DPP_MIRROR>(v), dpp_i<MZR_DPP_MIRROR>(i));
+  if (G == 64) {
+    const double v0 = readlane_d(v, 0), v1 = readlane_d(v, 16), v2 = readlane_d(v, 32), v3 = readlane_d(v, 48);
+    const int i0 = __builtin_amdgcn_readlane(i, 0), i1 = __builtin_amdgcn_readlane(i, 16), i2 = __builtin_amdgcn_readlane(i, 32), i3 = __builtin_amdgcn_readlane(i, 48);
+    v = v0; i = i0; step(v1, i1); step(v2, i2); step(v3, i3);
+  }
+}
+// value held by the first lane of the group
+template <int G> __device__ __forceinline__ int grp_first(int v) {
+  if (G == 64) return __builtin_amdgcn_readfirstlane(v);
+  return __shfl(v, (int)(threadIdx.x & 63) & ~(G - 1), 64);
+}
+
+// LDS traffic of one group is ordered by the hardware (one wavefront, in-order LDS queue); this
+// only keeps the compiler from moving accesses across a phase boundary.
+__device__ __forceinline__ void grp_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+}  // namespace
+
 // ------------------------------------------------------------------------------------------------
-// qexmul_rch (:619-993) for the binary confluence (at most two upstream reaches), the shape of
-// almost every reach of a river network.  The reference's generic k-way merge then reduces to:
-//   * every upstream contributes its hillslope series {BASIN_QR(0)@T0, BASIN_QR(1)@T1}: a straight
-//     line, whose only own particle sits at T1 and is the LAST thing merged (MINLOC ties go to
-//     the lowest series index, and the basin series come first);
-//   * each non-headwater upstream contributes its routed particles (exit time < T1) and the
-//     interpolated end-of-step particle at exactly T1;
-//   so the output is the 2-way merge of the routed particles in time order (duplicated times
-//   emitted once), each with the other series interpolated at that time, followed by one particle
-//   at T1.  Arithmetic (scaling by width ratio, slope/prediction form, summation order over the
-//   series) is the reference's, statement by statement (:929-957).
-// The two particles bracketing each cursor live in registers and the next one is prefetched, so
-// the global-memory latency of the outbox overlaps the arithmetic of the current particle.
-__device__ __forceinline__ int kwt_merge_binary(int nup, int u0, double RW, double T0, double T1,
-                                                const uint8_t *nGood, const double *width,
-                                                const double *qlat_prev, const double *qlat_cur, const int *obN,
-                                                const double *obQ, const double *obT, int N, double *QD, double *TD) {
-  const double bsc = 1.0 / RW;               // UWIDTH(basin) = 1
-  const double dT10 = T1 - T0;
-  double b0q0, b0q1, b0sl, b1q0 = 0.0, b1sl = 0.0;
-  {
-    b0q0 = qlat_prev[u0]; b0q1 = qlat_cur[u0]; b0sl = (b0q1 - b0q0) / dT10;
-    if (nup > 1) { b1q0 = qlat_prev[u0 + 1]; const double q1 = qlat_cur[u0 + 1]; b1sl = (q1 - b1q0) / dT10; }
-  }
-  // reach series A (first non-headwater upstream in UREACHI order) and B (second)
-  int ns = 0, uA = 0, uB = 0;
-  if (nGood[u0] > 0) { uA = u0; ns = 1; }
-  if (nup > 1 && nGood[u0 + 1] > 0) { if (ns == 0) uA = u0 + 1; else uB = u0 + 1; ++ns; }
-  int nrA = 0, nrB = 0, kA = 1, kB = 1;
-  double scA = 0.0, qbA = 0.0, tbA = 0.0, qeA = 0.0, teA = DBL_MAX, qnA = 0.0, tnA = 0.0;
-  double scB = 0.0, qbB = 0.0, tbB = 0.0, qeB = 0.0, teB = DBL_MAX, qnB = 0.0, tnB = 0.0;
-  if (ns > 0) {
-    nrA = obN[uA]; scA = width[uA] / RW;
-    qbA = obQ[uA]; tbA = obT[uA]; qeA = obQ[(size_t)N + uA]; teA = obT[(size_t)N + uA];
-    if (nrA > 2) { qnA = obQ[(size_t)2 * N + uA]; tnA = obT[(size_t)2 * N + uA]; }
-  }
-  if (ns > 1) {
-    nrB = obN[uB]; scB = width[uB] / RW;
-    qbB = obQ[uB]; tbB = obT[uB]; qeB = obQ[(size_t)N + uB]; teB = obT[(size_t)N + uB];
-    if (nrB > 2) { qnB = obQ[(size_t)2 * N + uB]; tnB = obT[(size_t)2 * N + uB]; }
-  }
-  if ((ns > 0 && nrA < 2) || (ns > 1 && nrB < 2)) return -40;   // upstream published nothing
-  int IPRT = 0;
+// qexmul_rch (:619-993) for the binary confluence, literal cursor walk over the STAGED upstream
+// series (LDS copies of the outbox rows, index 0 = last particle routed before this step, 1..nr-2
+// = particles routed in this step, nr-1 = end-of-step particle at T1).  Serial path of the group
+// kernel: taken when the parallel rank/interpolate form is not equivalent (duplicate or unordered
+// times) and to produce the reference's error codes.
+// Every upstream also contributes its hillslope series {BASIN_QR(0)@T0, BASIN_QR(1)@T1}: a
+// straight line whose only own particle sits at T1 and is the LAST thing merged (MINLOC ties go to
+// the lowest series index, and the basin series come first).
+struct KwtBasin { double b0q0, b0q1, b0sl, b1q0, b1sl, bsc; };
+
+__device__ __forceinline__ int kwt_merge_binary_serial(int nup, int ns, int nrA, int nrB, const double *SAq, const double *SAt,
+                                                    const double *SBq, const double *SBt, double scA, double scB,
+                                                    const KwtBasin &bs, double T0, double T1, double *QD, double *TD) {
+  int kA = 1, kB = 1, IPRT = 0;
   double TIME_LAST = -DBL_MAX;
   for (;;) {
-    // next routed particle of each series: indices 1 .. nr-2 (index nr-1 is the end-of-step particle)
-    const double cA = (ns > 0 && kA <= nrA - 2) ? teA : DBL_MAX;
-    const double cB = (ns > 1 && kB <= nrB - 2) ? teB : DBL_MAX;
+    const double cA = (ns > 0 && kA <= nrA - 2) ? SAt[kA] : DBL_MAX;
+    const double cB = (ns > 1 && kB <= nrB - 2) ? SBt[kB] : DBL_MAX;
     if (cA == DBL_MAX && cB == DBL_MAX) break;
     const bool pickA = cA <= cB;               // MINLOC: ties -> lower series index
     const double CT = pickA ? cA : cB;
@@ -175,61 +246,59 @@ __device__ __forceinline__ int kwt_merge_binary(int nup, int u0, double RW, doub
     if (CT < TIME_LAST) return -30;
     if (CT != TIME_LAST) {
       double Q_AGG = 0.0;
-      Q_AGG = Q_AGG + (b0q0 + b0sl * (CT - T0)) * bsc;
-      if (nup > 1) Q_AGG = Q_AGG + (b1q0 + b1sl * (CT - T0)) * bsc;
+      Q_AGG = Q_AGG + (bs.b0q0 + bs.b0sl * (CT - T0)) * bs.bsc;
+      if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
       {
         double SFLOW;
-        if (pickA) SFLOW = qeA * scA;
+        if (pickA) SFLOW = SAq[kA] * scA;
         else {
-          if (teA < CT || tbA > CT) return -40;
-          const double SLOPE = (qeA - qbA) / (teA - tbA);
-          SFLOW = (qbA + SLOPE * (CT - tbA)) * scA;
+          const double tb = SAt[kA - 1], te = SAt[kA], qb = SAq[kA - 1], qe = SAq[kA];
+          if (te < CT || tb > CT) return -40;
+          const double SLOPE = (qe - qb) / (te - tb);
+          SFLOW = (qb + SLOPE * (CT - tb)) * scA;
         }
         Q_AGG = Q_AGG + SFLOW;
       }
       if (ns > 1) {
         double SFLOW;
-        if (!pickA) SFLOW = qeB * scB;
+        if (!pickA) SFLOW = SBq[kB] * scB;
         else {
-          if (teB < CT || tbB > CT) return -40;
-          const double SLOPE = (qeB - qbB) / (teB - tbB);
-          SFLOW = (qbB + SLOPE * (CT - tbB)) * scB;
+          const double tb = SBt[kB - 1], te = SBt[kB], qb = SBq[kB - 1], qe = SBq[kB];
+          if (te < CT || tb > CT) return -40;
+          const double SLOPE = (qe - qb) / (te - tb);
+          SFLOW = (qb + SLOPE * (CT - tb)) * scB;
         }
         Q_AGG = Q_AGG + SFLOW;
       }
       QD[IPRT] = Q_AGG; TD[IPRT] = CT; TIME_LAST = CT; ++IPRT;
     }
-    if (pickA) {
-      qbA = qeA; tbA = teA; qeA = qnA; teA = tnA; ++kA;
-      if (kA + 1 <= nrA - 1) { qnA = obQ[(size_t)(kA + 1) * N + uA]; tnA = obT[(size_t)(kA + 1) * N + uA]; }
-    } else {
-      qbB = qeB; tbB = teB; qeB = qnB; teB = tnB; ++kB;
-      if (kB + 1 <= nrB - 1) { qnB = obQ[(size_t)(kB + 1) * N + uB]; tnB = obT[(size_t)(kB + 1) * N + uB]; }
-    }
+    if (pickA) ++kA; else ++kB;
   }
   {   // the particle at T1, led by the first basin series
     const double CT = T1;
     double Q_AGG = 0.0;
-    Q_AGG = Q_AGG + b0q1 * bsc;
-    if (nup > 1) Q_AGG = Q_AGG + (b1q0 + b1sl * (CT - T0)) * bsc;
+    Q_AGG = Q_AGG + bs.b0q1 * bs.bsc;
+    if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
     if (ns > 0) {
-      if (teA < CT || tbA > CT) return -40;
-      const double SLOPE = (qeA - qbA) / (teA - tbA);
-      Q_AGG = Q_AGG + (qbA + SLOPE * (CT - tbA)) * scA;
+      const double tb = SAt[kA - 1], te = SAt[kA], qb = SAq[kA - 1], qe = SAq[kA];
+      if (te < CT || tb > CT) return -40;
+      const double SLOPE = (qe - qb) / (te - tb);
+      Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scA;
     }
     if (ns > 1) {
-      if (teB < CT || tbB > CT) return -40;
-      const double SLOPE = (qeB - qbB) / (teB - tbB);
-      Q_AGG = Q_AGG + (qbB + SLOPE * (CT - tbB)) * scB;
+      const double tb = SBt[kB - 1], te = SBt[kB], qb = SBq[kB - 1], qe = SBq[kB];
+      if (te < CT || tb > CT) return -40;
+      const double SLOPE = (qe - qb) / (te - tb);
+      Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scB;
     }
     QD[IPRT] = Q_AGG; TD[IPRT] = CT; ++IPRT;
   }
   return IPRT;
 }
 
-// Confluences of more than two reaches are rare: their merge stays out of line with the series
-// cursors in private memory and every particle fetched from the outbox on demand, so that the
-// common (binary) path keeps a small register footprint.
+// Confluences of more than two reaches are rare: the reference's k-way merge runs on lane 0 of the
+// group, out of line, with the series cursors in private memory and every particle fetched from
+// the outbox on demand.
 __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double RW, double T0, double T1,
                                               const uint8_t *nGood, const double *width, const double *qlat_prev,
                                               const double *qlat_cur, const int *obN, const double *obQ,
@@ -245,11 +314,11 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
     if (nGood[u] > 0) {
       const int si = nup + IUPR; ++IUPR;
       const int nr = obN[u];
-      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = obT[(size_t)N + u];
+      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = obT[MZR_OBI(1, u)];
     }
   }
-  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : obQ[(size_t)k * N + su[i]]; };
-  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : obT[(size_t)k * N + su[i]]; };
+  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : obQ[MZR_OBI(k, su[i])]; };
+  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : obT[MZR_OBI(k, su[i])]; };
   unsigned done = 0;
   const unsigned all = (1u << NUPS) - 1u;
   int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff;
@@ -301,216 +370,405 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
 }
 
 #ifdef MZR_KWT_TIMING
+#define KCOUNT(i, v) do { if (gl == 0) atomicAdd(&d.dbgCycles[i], (unsigned long long)(v)); } while (0)
 #define TSTAMP(i) do { const long long _n = clock64(); if ((threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[i], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
 #else
+#define KCOUNT(i, v) do { } while (0)
 #define TSTAMP(i) do { } while (0)
 #endif
-// particles of LDS work space per wavefront (3 x 8 B + 2 B each): 1024 (26 KB, 6 wavefronts per CU)
-// when a launch has fewer wavefronts than the chip can hold, 768 (20 KB, 8 per CU) for larger domains
 
-// One wavefront per block.  Each lane first works out how many work-array entries its reach needs
-// (own particles + everything its upstreams routed), the wave carves the LDS pool with a prefix
-// sum, and lanes that do not fit wait for the next round of the same wave.
-// FULL = false compiles out lakes, water management and partition boundaries (the common case).
-template <bool FULL, int KWT_POOL>
-__global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, int rEnd) {
-  __shared__ double sQ[KWT_POOL], sT[KWT_POOL], sX[KWT_POOL];
-  __shared__ unsigned short sL[KWT_POOL];
-  const int r = rBegin + blockIdx.x * 64 + threadIdx.x;
+namespace {
+
+struct KwtStep {   // what a lane needs to know about its reach and window step
+  int t, par;
+  double T0, T1;
+  double *Qrow;
+  const double *qlat_prev, *qlat_cur;
+};
+__device__ __forceinline__ KwtStep kwt_step(const MzrDev &d, int t) {
+  KwtStep k;
+  const int tt = t < 0 ? 0 : t;
+  k.t = t; k.par = tt & 1;
+  k.T0 = d.t_start + (double)tt * d.dt;
+  k.T1 = (d.W == 1) ? d.T1_single : k.T0 + d.dt;   // mzr_step passes TSEC(2) explicitly
+  k.Qrow = d.Q + (size_t)tt * d.N;
+  k.qlat_prev = d.qlat + (size_t)tt * d.N;          // BASIN_QR(0)
+  k.qlat_cur = d.qlat + (size_t)(tt + 1) * d.N;     // BASIN_QR(1)
+  return k;
+}
+
+// Reaches that do not route particles: headwaters (kwt_route.f90:181-205), lake reaches
+// (lake_route replaces kwt_rch) and halo reaches of a partition (replay of the imported record).
+template <bool FULL>
+__device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int ltEnd) {
   const int N = d.N;
-  unsigned long long st_in = 0, st_up = 0, st_out = 0, st_head = 0, st_route = 0, st_edges = 0;
-  int t = -1;
-  const bool live = (r < rEnd) && ((t = s - d.sigma[r]) >= 0) && (t < d.W);
-  const double T0 = d.t_start + (double)(t < 0 ? 0 : t) * d.dt;
-  const double T1 = (d.W == 1) ? d.T1_single : T0 + d.dt;   // mzr_step passes TSEC(2) explicitly
+  unsigned long long st_head = 0;
+  if (item < ltEnd) {
+    const int r = d.kwtLight[item];
+    const int t = s - d.sigma[r];
+    if (t >= 0 && t < d.W) {
+      const KwtStep k = kwt_step(d, t);
+      bool done = false;
+      if (FULL && d.haloSlot) {   // tributary outlet computed in another partition
+        const int hs = d.haloSlot[r];
+        if (hs >= 0) {
+          done = true;
+          const size_t nH = d.nHalo;
+          k.Qrow[r] = d.imQ[(size_t)t * nH + hs];
+          const int n = d.imN[(size_t)t * nH + hs];
+          d.obN[(size_t)k.par * N + r] = n;
+          double *oq = d.obQ + (size_t)k.par * MZR_OB_CAP * N, *ot = d.obT + (size_t)k.par * MZR_OB_CAP * N;
+          for (int j = 0; j <= n && n > 0; ++j) {
+            oq[MZR_OBI(j, r)] = d.imOQ[((size_t)t * MZR_OB_CAP + j) * nH + hs];
+            ot[MZR_OBI(j, r)] = d.imOT[((size_t)t * MZR_OB_CAP + j) * nH + hs];
+          }
+        }
+      }
+      if (FULL && !done && d.lakeSlot) {
+        const int ls = d.lakeSlot[r];
+        if (ls >= 0) {   // a lake keeps one sentinel particle (init_model_data.f90:431-439)
+          done = true;
+          double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
+          const double Q = mzr_lake::lake_route(d, r, t, ls, k.Qrow, k.qlat_cur[r], vol, vol0, ele, wb, wmAct);
+          k.Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
+          if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
+        }
+      }
+      if (!done) {   // headwater
+        const double qlat_r = k.qlat_cur[r];
+        k.Qrow[r] = qlat_r;
+        d.qsum[r] += qlat_r;
+        d.inflow[r] = 0.0;
+        if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
+        if (FULL && d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
+        st_head = 1;
+      }
+    }
+  }
+  if (d.kwtStat) {
+    const unsigned long long e = wave_sum(st_head);
+    if ((threadIdx.x & 63) == 0 && e) atomicAdd(&d.kwtStat->n_head, e);
+  }
+}
+
+}  // namespace
+
+// One wavefront per block, RPW = 64/G routed reaches per wavefront.  Each group first works out how
+// many work-array entries its reach needs (own particles + everything its upstreams routed), the
+// wave carves the LDS pool among its groups, and groups that do not fit wait for the next round.
+// FULL = false compiles out lakes, water management and partition boundaries (the common case).
+// Values named "uniform" below are computed redundantly by all lanes of a group.
+#ifndef MZR_KWT_OCC
+#define MZR_KWT_OCC 4
+#endif
+#ifndef MZR_KWT_G
+#define MZR_KWT_G 64   // lanes per routed reach
+#endif
+template <bool FULL, bool GEN, int G, int POOL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
+  constexpr int RPW = 64 / G;
+  constexpr int KS = (MZR_KW_CAP + G - 1) / G;   // slots per lane for <= 20 entries
+  constexpr int OS = (MZR_OB_CAP + G - 1) / G;   // ... for one outbox row
+  __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
+  if (!GEN && (int)blockIdx.x >= nHvBlocks) {
+    kwt_light<FULL>(d, s, ltBegin + ((int)blockIdx.x - nHvBlocks) * 64 + (int)threadIdx.x, ltEnd);
+    return;
+  }
+  const int lane = threadIdx.x, gl = lane & (G - 1), grp = lane / G;
+  const int item = hvBegin + (int)blockIdx.x * RPW + grp;
+  const int N = d.N;
+  // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line)
+  const bool have = item < hvEnd;
+  const MzrKwtRec rec = d.kwtRouted[have ? item : hvEnd - 1];
+  const int r = uni<G>(rec.r);
+  const int t = uni<G>(have ? s - rec.sigma : -1);
+  const bool live = t >= 0 && t < d.W;
+  const KwtStep ks = kwt_step(d, t);
+  const double T0 = ks.T0, T1 = ks.T1;
   const double T_START = T0, T_END = T1;                    // RSTEP = 0
-  double *Qrow = d.Q + (size_t)(t < 0 ? 0 : t) * N;
-  const double *qlat_prev = d.qlat + (size_t)(t < 0 ? 0 : t) * N;       // BASIN_QR(0)
-  const double *qlat_cur = d.qlat + (size_t)((t < 0 ? 0 : t) + 1) * N;  // BASIN_QR(1)
-  const int par = t & 1;
+  double *Qrow = ks.Qrow;
+  const double *qlat_prev = ks.qlat_prev, *qlat_cur = ks.qlat_cur;
+  const int par = ks.par;
   const int *obN = d.obN + (size_t)par * N;
   const double *obQ = d.obQ + (size_t)par * MZR_OB_CAP * N;
   const double *obT = d.obT + (size_t)par * MZR_OB_CAP * N;
-
+  const int nup = uni<G>((int)rec.nup), ng = uni<G>((int)(rec.flags & 15)), u0 = uni<G>(rec.u0);
+  const unsigned upGood = uni<G>((int)rec.upGood), goodMask = uni<G>((int)rec.goodMask);
+  const bool isOut = (uni<G>((int)rec.flags) & 0x80) != 0;
+  const bool upLake = FULL && (uni<G>((int)rec.flags) & 0x40) != 0;   // an upstream reach is a lake
+  const double RW = rec.width, K = rec.K, cw = rec.CW, XMX = rec.length, scA = rec.scA, scB = rec.scB;
+  // reach series A / B: first and second non-headwater upstream in UREACHI order
+  const int ns = __popc(upGood);
+  const int uA = u0 + (upGood ? __ffs(upGood) - 1 : 0);
+  const int uB = u0 + ((upGood & (upGood - 1u)) ? __ffs(upGood & (upGood - 1u)) - 1 : 0);
+  int st_in = 0, st_up = 0, st_out = 0, st_route = 0, st_edges = 0;
 #ifdef MZR_KWT_TIMING
   long long _tprev = clock64();
 #endif
-  int need = 0, nup = 0, u0 = 0, ng = 0, n_own = 0, NUPS = 0, IMAX = 0;
-  double qlat_r = 0.0;
-  bool halo = false;
-  if (FULL && live && d.haloSlot) {   // tributary outlet computed in another partition: replay its imported record
-    const int hs = d.haloSlot[r];
-    if (hs >= 0) {
-      halo = true;
-      const size_t nH = d.nHalo;
-      Qrow[r] = d.imQ[(size_t)t * nH + hs];
-      const int n = d.imN[(size_t)t * nH + hs];
-      d.obN[(size_t)par * N + r] = n;
-      double *oq = d.obQ + (size_t)par * MZR_OB_CAP * N, *ot = d.obT + (size_t)par * MZR_OB_CAP * N;
-      for (int k = 0; k <= n && n > 0; ++k) {
-        oq[(size_t)k * N + r] = d.imOQ[((size_t)t * MZR_OB_CAP + k) * nH + hs];
-        ot[(size_t)k * N + r] = d.imOT[((size_t)t * MZR_OB_CAP + k) * nH + hs];
-      }
-    }
-  }
-  bool lake = false, upLake = false;
-  if (FULL && live && !halo && d.lakeSlot) {
-    const int ls = d.lakeSlot[r];
-    if (ls >= 0) {   // lake reach: lake_route replaces kwt_rch; it keeps one sentinel particle (init_model_data.f90:431-439)
-      lake = true;
-      double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
-      const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat_cur[r], vol, vol0, ele, wb, wmAct);
-      Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
-      if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0; }
-    }
-  }
-  if (live && !halo && !lake) {
-    qlat_r = qlat_cur[r];
-    ng = d.nGood[r];
-    if (ng == 0) {   // headwater: kwt_route.f90:181-205
-      Qrow[r] = qlat_r;
-      d.qsum[r] += qlat_r;
-      d.inflow[r] = 0.0;
-      if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[r] = -9999.0; d.kwTI[r] = -9999.0; d.kwTR[r] = -9999.0; }
-      if (FULL && d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
-      st_head = 1;
-    } else {
-      st_route = 1;
-      nup = d.nUp[r]; u0 = d.upStart[r];
-      st_edges = nup;
-      n_own = d.kwN[r];
-      int NUPR = 0;
-      IMAX = nup;
-      if (FULL && d.lakeSlot) for (int i = 0; i < nup; ++i) if (d.lakeSlot[u0 + i] >= 0) upLake = true;
-      if (upLake && nup > 1) { mzr_raise(d, 10, r, t, 18); }   // lake outlet reach should have one upstream lake, :551-553
-      for (int i = 0; i < nup && !upLake; ++i) {
-        if (d.nGood[u0 + i] > 0) { ++NUPR; const int nr = obN[u0 + i]; IMAX += nr - 1; st_up += nr + 1; }
-      }
-      NUPS = nup + NUPR;
-      const int NJ0 = n_own == 0 ? 0 : n_own - 1;
-      need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
-      if (upLake && nup > 1) need = 0;
-      if (need > KWT_POOL) { mzr_raise(d, 60, r, t, 10); need = 0; }
-    }
-  }
 
+  // ---- round trip 2: everything that depends on the step, issued together -- particle counts,
+  // hillslope inflow of the upstream basins, upstream discharge, own particle row (getusq_rch
+  // :598-608; element 0 = last routed particle) and, for the binary confluence, the outbox rows of
+  // the upstream reaches.  Rows are fixed-size, so they are read whole before their counts are known.
+  int need = 0, n_own = 0, NUPS = 0, IMAX = 0, nrA = 0, nrB = 0;
+  double X0 = 0.0, qlat_r = 0.0, q_up = 0.0;
+  KwtBasin bs;
+  bs.bsc = 1.0 / RW; bs.b0q0 = bs.b0q1 = bs.b0sl = bs.b1q0 = bs.b1sl = 0.0;   // UWIDTH(basin) = 1
+  double q[KS], ti[KS], aq[OS], at[OS], bq[OS], bt[OS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) q[j] = ti[j] = 0.0;
+#pragma unroll
+  for (int j = 0; j < OS; ++j) aq[j] = at[j] = bq[j] = bt[j] = 0.0;
+  if (live) {
+    int n_own_v = d.kwN[r], nrA_v = 0, nrB_v = 0;
+    if (!GEN && !upLake) { if (ns > 0) nrA_v = obN[uA]; if (ns > 1) nrB_v = obN[uB]; }
+    X0 = d.kwTR[MZR_KWI(0, r)];
+    qlat_r = qlat_cur[r];
+    double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
+    bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
+    if (nup > 1) { bs.b1q0 = qlat_prev[u0 + 1]; b1q1 = qlat_cur[u0 + 1]; }
+    if (!GEN) { up0 = Qrow[u0]; if (nup > 1) up1 = Qrow[u0 + 1]; }
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
+      q[j] = d.kwQ[MZR_KWI(kk, r)]; ti[j] = d.kwTI[MZR_KWI(kk, r)];
+    }
+    if (!GEN && !upLake) {
+#pragma unroll
+      for (int j = 0; j < OS; ++j) {
+        const int k = gl + j * G, kk = k < MZR_OB_CAP ? k : 0;
+        if (ns > 0) { aq[j] = obQ[MZR_OBI(kk, uA)]; at[j] = obT[MZR_OBI(kk, uA)]; }
+        if (ns > 1) { bq[j] = obQ[MZR_OBI(kk, uB)]; bt[j] = obT[MZR_OBI(kk, uB)]; }
+      }
+    }
+    // ---- uniform: the work-array need
+    n_own = uni<G>(n_own_v); nrA = uni<G>(nrA_v); nrB = uni<G>(nrB_v);
+    st_route = 1; st_edges = nup;
+    IMAX = nup;
+    int NUPR = 0;
+    bool empty = false;
+    if (upLake && nup > 1) mzr_raise(d, 10, r, t, 18);   // lake outlet reach should have one upstream lake, :551-553
+    if (!upLake) {
+      if (!GEN) {
+        if (ns > 0) { if (nrA < 2) empty = true; ++NUPR; IMAX += nrA - 1; st_up += nrA + 1; }   // nr < 2: upstream published nothing
+        if (ns > 1) { if (nrB < 2) empty = true; ++NUPR; IMAX += nrB - 1; st_up += nrB + 1; }
+      } else {
+        for (int i = 0; i < nup; ++i) {
+          if ((upGood >> i) & 1u) {
+            const int nr = uni<G>(obN[u0 + i]);
+            if (nr < 2) empty = true;
+            ++NUPR; IMAX += nr - 1; st_up += nr + 1;
+          }
+        }
+      }
+    }
+    NUPS = nup + NUPR;
+    const int NJ0 = n_own == 0 ? 0 : n_own - 1;
+    need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
+    if (upLake && nup > 1) need = 0;
+    if (empty) { mzr_raise(d, 40, r, t, 11); need = 0; }
+    if (need > POOL) { mzr_raise(d, 60, r, t, 10); need = 0; }
+    const double dT10 = T1 - T0;
+    bs.b0sl = (bs.b0q1 - bs.b0q0) / dT10;
+    if (nup > 1) bs.b1sl = (b1q1 - bs.b1q0) / dT10;
+    // upstream discharge, kwt_rch :163-174
+    if (!GEN) {
+      if (ng > 0 && (goodMask & 1u)) q_up = q_up + up0;
+      if (ng > 1 && (goodMask & 2u)) q_up = q_up + up1;
+    } else {
+      for (int i = 0; i < ng; ++i) { if (!((goodMask >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
+    }
+  }
   TSTAMP(0);
+
   bool pending = need > 0;
   while (__any(pending)) {
-    // wave-wide inclusive prefix sum of the pending lanes' needs
-    int incl = pending ? need : 0;
+    // carve the pool: exclusive prefix sum of the pending groups' needs
+    const int mine = pending ? need : 0;
+    int off = 0, run = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += v; }
-    const bool go = pending && incl <= KWT_POOL;
+    for (int g = 0; g < RPW; ++g) {
+      const int v = __builtin_amdgcn_readlane(mine, g * G);
+      if (g == grp) off = run;
+      run += v;
+    }
+    const bool go = pending && off + need <= POOL;
+    if (pending && !go) KCOUNT(10, 1);
     if (go) {
       pending = false;
-      const int off = incl - need;
-      double *Qw = sQ + off, *Tw = sT + off, *Xw = sX + off;
-      unsigned short *Lw = sL + off;
+      KCOUNT(11, 1); KCOUNT(12, need);
+      double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
       do {
-        const double RW = d.width[r];
-        // ---- own particles (getusq_rch :598-608); element 0 = last routed particle
         const bool cold = (n_own == 0);
         const int NJ = cold ? 0 : n_own - 1;
-        double X0 = cold ? 0.0 : d.kwTR[r];
-        for (int k = 0; k < n_own; k += 4) {   // four particles per trip: eight loads in flight before the LDS writes
-          double q[4], ti[4];
+        const bool binary = !GEN && !upLake && NUPS != 1;   // GEN: launch over the confluences of more than two reaches
+        if (cold) X0 = 0.0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int kk = k + j < n_own ? k + j : n_own - 1;
-            q[j] = d.kwQ[(size_t)kk * N + r]; ti[j] = d.kwTI[(size_t)kk * N + r];
+        for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
+        if (binary) {
+#pragma unroll
+          for (int j = 0; j < OS; ++j) {
+            const int k = gl + j * G;
+            if (ns > 0 && k < nrA) { Xw[k] = aq[j]; Yw[k] = at[j]; }
+            if (ns > 1 && k < nrB) { Xw[nrA + k] = bq[j]; Yw[nrA + k] = bt[j]; }
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if (k + j < n_own) { Qw[k + j] = q[j]; Tw[k + j] = ti[j]; }
         }
         st_in = n_own;
+        grp_sync();
 
         // ---- qexmul_rch
         int ND;
+        double *QD = Qw + NJ + 1, *TD = Tw + NJ + 1;
         if (upLake) {      // lake outflow enters the river as one particle, getusq_rch :554-559
-          Qw[NJ + 1] = Qrow[u0] / RW; Tw[NJ + 1] = T1; ND = 1;
+          if (gl == 0) { QD[0] = Qrow[u0] / RW; TD[0] = T1; }
+          ND = 1;
         } else if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
-          Qw[NJ + 1] = qlat_cur[u0] / RW; Tw[NJ + 1] = T1; ND = 1;
-        } else if (nup <= 2) {   // binary confluence
-          ND = kwt_merge_binary(nup, u0, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1);
+          if (gl == 0) { QD[0] = bs.b0q1 / RW; TD[0] = T1; }
+          ND = 1;
+        } else if (binary) {
+          // Output = 2-way merge of the routed particles in time order, each with the other series
+          // interpolated at its time, followed by one particle at T1 (:929-957).  Rank of a
+          // particle = its index in its own series + the number of particles of the other series
+          // that the cursor walk consumes before it (ties: series A first).
+          const double *SAq = Xw, *SAt = Yw, *SBq = Xw + nrA, *SBt = Yw + nrA;
+          const int nA = ns > 0 ? nrA - 2 : 0, nB = ns > 1 ? nrB - 2 : 0;
+          ND = nA + nB + 1;
+          bool slow = false;
+          for (int m = gl; m < ND; m += G) {
+            double CT, Q_AGG = 0.0;
+            int pos = m;
+            if (m == nA + nB) {   // the particle at T1, led by the first basin series
+              CT = T1;
+              Q_AGG = Q_AGG + bs.b0q1 * bs.bsc;
+              if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
+              if (ns > 0) {
+                const double tb = SAt[nA], te = SAt[nA + 1], qb = SAq[nA], qe = SAq[nA + 1];
+                if (te < CT || tb > CT) slow = true;
+                const double SLOPE = (qe - qb) / (te - tb);
+                Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scA;
+              }
+              if (ns > 1) {
+                const double tb = SBt[nB], te = SBt[nB + 1], qb = SBq[nB], qe = SBq[nB + 1];
+                if (te < CT || tb > CT) slow = true;
+                const double SLOPE = (qe - qb) / (te - tb);
+                Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scB;
+              }
+            } else {
+              const bool isA = m < nA;
+              const int i = isA ? m + 1 : m - nA + 1;                 // index in the own series
+              const double *St = isA ? SAt : SBt, *Sq = isA ? SAq : SBq;
+              const double *Ot = isA ? SBt : SAt, *Oq = isA ? SBq : SAq;
+              const int nO = isA ? nB : nA;
+              const bool other = isA ? ns > 1 : true;
+              CT = St[i];
+              if (!(CT < T1)) slow = true;                            // error 40 in the cursor walk
+              if (i > 1 && !(St[i - 1] < CT)) slow = true;            // duplicate or unordered
+              int cnt = 0;
+              for (int j = 1; j <= nO; ++j) { const double to = Ot[j]; cnt += (isA ? to < CT : to <= CT) ? 1 : 0; if (to == CT) slow = true; }
+              pos = (i - 1) + cnt;
+              Q_AGG = Q_AGG + (bs.b0q0 + bs.b0sl * (CT - T0)) * bs.bsc;
+              if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
+              double SOWN = Sq[i] * (isA ? scA : scB), SOTH = 0.0;
+              if (other) {
+                const double tb = Ot[cnt], te = Ot[cnt + 1], qb = Oq[cnt], qe = Oq[cnt + 1];
+                if (te < CT || tb > CT) slow = true;
+                const double SLOPE = (qe - qb) / (te - tb);
+                SOTH = (qb + SLOPE * (CT - tb)) * (isA ? scB : scA);
+              }
+              // summation order of the series: A, then B (:929-957)
+              if (isA) { Q_AGG = Q_AGG + SOWN; if (other) Q_AGG = Q_AGG + SOTH; }
+              else { Q_AGG = Q_AGG + SOTH; Q_AGG = Q_AGG + SOWN; }
+            }
+            QD[pos] = Q_AGG; TD[pos] = CT;
+          }
+          if (grp_any<G>(slow)) {
+            KCOUNT(8, 1);
+            grp_sync();
+            int nd = 0;
+            if (gl == 0) nd = kwt_merge_binary_serial(nup, ns, nrA, nrB, SAq, SAt, SBq, SBt, scA, scB, bs, T0, T1, QD, TD);
+            ND = grp_first<G>(nd);
+          }
         } else {
-          ND = kwt_merge_generic(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, Qw + NJ + 1, Tw + NJ + 1, IMAX);
+          int nd = -60;
+          if (GEN && gl == 0) nd = kwt_merge_generic(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, QD, TD, IMAX);
+          ND = grp_first<G>(nd);
         }
         TSTAMP(1);
         if (ND < 0) { mzr_raise(d, -ND, r, t, 11); break; }
+        grp_sync();
         if (cold) {   // getusq_rch :587-596
           const double DT = T1 - T0;
-          Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; X0 = T0 - DT * 0;
+          if (gl == 0) { Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; }
+          X0 = T0 - DT * 0;
+          grp_sync();
         }
         int size = NJ + 1 + ND;
 
         {   // kwt_rch :163-174
-          double mn = Qw[0];
-          for (int k = 1; k < size; ++k) { const double q = Qw[k]; mn = q < mn ? q : mn; }
+          double mn = DBL_MAX;
+          for (int k = gl; k < size; k += G) { const double q = Qw[k]; mn = q < mn ? q : mn; }
+          mn = grp_min<G>(mn);
           if (mn < 0.0) { mzr_raise(d, 20, r, t, 12); break; }
-          double q_up = 0.0;
-          const uint32_t gm = d.goodMask[r];
-          for (int i = 0; i < ng; ++i) { if (!((gm >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
-          d.inflow[r] = q_up;
+          if (gl == 0) d.inflow[r] = q_up;
         }
-
         TSTAMP(2);
-#ifdef MZR_KWT_TIMING
-        {
-          const unsigned long long bm = __ballot(size > MZR_MAXQPAR_DEV);
-          if (size > MZR_MAXQPAR_DEV) { atomicAdd(&d.dbgCycles[8], 1ull); atomicAdd(&d.dbgCycles[9], (unsigned long long)(size - MZR_MAXQPAR_DEV)); atomicMax(&d.dbgCycles[10], (unsigned long long)size); atomicAdd(&d.dbgCycles[12], (unsigned long long)size); }
-          if (bm && (int)(threadIdx.x & 63) == __ffsll(bm) - 1) { atomicAdd(&d.dbgCycles[11], 1ull); atomicAdd(&d.dbgCycles[13], (unsigned long long)__popcll(bm)); }
-          atomicAdd(&d.dbgCycles[14], (unsigned long long)size); atomicAdd(&d.dbgCycles[15], 1ull);
-        }
-#endif
+
         // ---- remove_rch :999-1123: drop the particle with the least interpolation error until < MAXQPAR
         if (size > MZR_MAXQPAR_DEV) {
+          KCOUNT(13, 1); KCOUNT(14, size - MZR_MAXQPAR_DEV);
           const int NPRT = size - 1;
-          for (int i = 0; i <= NPRT; ++i) Lw[i] = (unsigned short)(((i - 1) & 0xff) | ((i + 1) << 8));
-          Xw[NPRT] = DBL_MAX; Xw[0] = DBL_MAX;
-          {
-            double qa = Qw[0], ta = Tw[0], qb2 = Qw[1], tb2 = Tw[1];
-            for (int i = 1; i <= NPRT - 1; ++i) {
-              const double qc = Qw[i + 1], tc = Tw[i + 1];
-              Xw[i] = fabs(interp3(tb2, qa, qc, ta, tc) - qb2);
-              qa = qb2; ta = tb2; qb2 = qc; tb2 = tc;
-            }
+          const bool big = NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
+          for (int i = gl; i <= NPRT; i += G) {
+            double e = DBL_MAX;
+            if (i >= 1 && i < NPRT) e = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
+            Xw[i] = e;
           }
+          grp_sync();
+          unsigned long long mask = NPRT >= 63 ? ~0ull : ((2ull << NPRT) - 1ull);   // bits 0..NPRT
           int MPRT = NPRT;
           while (MPRT >= MZR_MAXQPAR_DEV) {
-            int ISEL = 0; double emin = DBL_MAX;
-            {   // first minimum of ABSERR over 1..NPRT (removed entries hold +Inf); four LDS reads in flight
-              int i = 1;
-              for (; i + 3 <= NPRT; i += 4) {
-                const double e0 = Xw[i], e1 = Xw[i + 1], e2 = Xw[i + 2], e3 = Xw[i + 3];
-                if (e0 < emin) { emin = e0; ISEL = i; }
-                if (e1 < emin) { emin = e1; ISEL = i + 1; }
-                if (e2 < emin) { emin = e2; ISEL = i + 2; }
-                if (e3 < emin) { emin = e3; ISEL = i + 3; }
-              }
-              for (; i <= NPRT; ++i) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
-            }
+            double emin = DBL_MAX; int ISEL = 0;
+            for (int i = gl; i <= NPRT; i += G) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
+            grp_argmin<G, false>(emin, ISEL);           // first minimum of ABSERR (removed entries hold +Inf)
+            ISEL = uni<G>(ISEL);
             if (ISEL == 0) break;                         // no finite interpolation error left (NaN/Inf input)
-            const unsigned short ls = Lw[ISEL];
-            const int pm = ls & 0xff, pn = ls >> 8;     // INDEX1(ISEL-1), INDEX1(ISEL+1)
-            const double qm = Qw[pm], tm = Tw[pm], qn = Qw[pn], tn = Tw[pn];
-            if (pm > 0) {
-              const int INEG = Lw[pm] & 0xff;
-              Xw[pm] = fabs(interp3(tm, Qw[INEG], qn, Tw[INEG], tn) - qm);
+            auto prevA = [&](int c) -> int {
+              if (!big) return 63 - __clzll((long long)(mask & ((1ull << c) - 1ull)));
+              int i = c - 1; while (i > 0 && (i == ISEL || Xw[i] == INFINITY)) --i; return i;
+            };
+            auto nextA = [&](int c) -> int {
+              if (!big) return __ffsll((long long)(mask & ~((2ull << c) - 1ull))) - 1;
+              int i = c + 1; while (i < NPRT && (i == ISEL || Xw[i] == INFINITY)) ++i; return i;
+            };
+            mask &= ~(1ull << (ISEL & 63));
+            const int pm = prevA(ISEL), pn = nextA(ISEL);   // INDEX1(ISEL-1), INDEX1(ISEL+1)
+            // the two neighbours are re-evaluated against their new neighbours, one on even and one on odd lanes
+            const bool side = gl & 1;
+            const int c = side ? pn : pm;
+            const bool valid = side ? pn < NPRT : pm > 0;
+            double e = 0.0;
+            if (valid) {
+              const int a = prevA(c), b = nextA(c);
+              e = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
             }
-            if (pn < NPRT) {
-              const int IPOS = Lw[pn] >> 8;
-              Xw[pn] = fabs(interp3(tn, qm, Qw[IPOS], tm, Tw[IPOS]) - qn);
-            }
-            Xw[ISEL] = INFINITY;                        // removed: never the minimum again
-            Lw[pm] = (unsigned short)((Lw[pm] & 0xff) | (pn << 8));
-            Lw[pn] = (unsigned short)((Lw[pn] & 0xff00) | pm);
+            grp_sync();
+            if (valid && gl < 2) Xw[c] = e;
+            if (gl == 0) Xw[ISEL] = INFINITY;              // removed: never the minimum again
             --MPRT;
+            grp_sync();
           }
           if (MPRT >= MZR_MAXQPAR_DEV) { mzr_raise(d, 62, r, t, 16); break; }
-          int k = 0;
-          for (int i = 0; i <= NPRT; i = Lw[i] >> 8) { Qw[k] = Qw[i]; Tw[k] = Tw[i]; ++k; }
+          if (!big) {   // compact into the two free arrays, then swap roles
+            for (int i = gl; i <= NPRT; i += G) {
+              if ((mask >> i) & 1ull) { const int k = __popcll(mask & ((1ull << i) - 1ull)); Yw[k] = Qw[i]; Xw[k] = Tw[i]; }
+            }
+            double *p = Qw; Qw = Yw; Yw = p; p = Tw; Tw = Xw; Xw = p;
+          } else if (gl == 0) {
+            int k = 0;
+            for (int i = 0; i <= NPRT; ++i) if (Xw[i] != INFINITY) { Qw[k] = Qw[i]; Tw[k] = Tw[i]; ++k; }
+          }
           size = MPRT + 1;
+          grp_sync();
         }
         // ---- extract_from_rch :351-455 (water abstraction / injection on the particles).  Its
         // recomputed exit times are overwritten by kinwav below, so only the flows change.
@@ -519,36 +777,41 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           if (Qtake != -9999.0) {
             double Qavg;
             if (d_interp_rch(Tw, Qw, size, T_START, T_END, &Qavg)) { mzr_raise(d, 1, r, t, 17); break; }
+            grp_sync();
             const double totQ = Qavg * RW;
             if (Qtake > 0.0) {
               const double Qfrac = Qtake / totQ;
-              for (int i = 1; i < size; ++i) Qw[i] = Qw[i] * (1.0 + Qfrac);
+              for (int i = 1 + gl; i < size; i += G) Qw[i] = Qw[i] * (1.0 + Qfrac);
             } else if (Qtake < 0.0 && fabs(Qtake) < totQ) {
               const double Qfrac = fabs(Qtake) / totQ;
-              for (int i = 1; i < size; ++i) Qw[i] = Qw[i] * (1.0 - Qfrac);
+              for (int i = 1 + gl; i < size; i += G) Qw[i] = Qw[i] * (1.0 - Qfrac);
             } else {
               const double mf = d.minflow[r];
-              for (int i = 0; i < size; ++i) Qw[i] = mf;
+              for (int i = gl; i < size; i += G) Qw[i] = mf;
             }
+            grp_sync();
           }
         }
-        const int NQ1 = size - 1;
         TSTAMP(3);
 
-        // ---- kinwav_rch :1130-1439 on particles 1..NQ1, in place:
+        // ---- kinwav_rch :1130-1439 on particles 1..NI (NI <= 19 after thinning):
         //   Xw[i]   wave celerity of the group whose first particle is i   (WC)
-        //   alive   bit i set while particle i still heads a group
+        //   Yw[i]   1/WC during the shock search, then the exit time of the group headed by i
+        //   alive   bit i set while particle i still heads a group (uniform)
         //   Xw[i+1] entry time of a merged group (T1 after :1335); flows of a merged group are the
         //           min / max over its members (:1329-1330), recomputed when needed
+        const int NI = size - 1;
         int NQ2 = 0;
         {
-          const double K = d.kwK[r];        // sqrt(R_SLOPE)/R_MAN_N           (host, once)
-          const double cw = d.kwCW[r];      // ALFA*K**(1/ALFA), ALFA = 5/3     (host, once)
-          const double XMX = d.length[r];
-          const int NI = NQ1;
-          for (int i = 1; i <= NI; ++i) Xw[i] = cw * pow_0p4(Qw[i]);
+          // K = sqrt(R_SLOPE)/R_MAN_N, cw = ALFA*K**(1/ALFA) with ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
+#pragma unroll
+          for (int j = 0; j < KS; ++j) {
+            const int i = gl + j * G;
+            if (i >= 1 && i <= NI) { const double wc = cw * pow_0p4(Qw[i]); Xw[i] = wc; Yw[i] = 1.0 / wc; }
+          }
+          grp_sync();
           TSTAMP(4);
-          unsigned alive = NI >= 31 ? 0xfffffffeu : ((1u << (NI + 1)) - 2u);   // bits 1..NI
+          unsigned alive = (2u << NI) - 2u;   // bits 1..NI
           auto nextHead = [&](int h) -> int {           // next group head after h, or NI+1
             const unsigned m = alive & ~((2u << h) - 1u);
             return m ? __ffs(m) - 1 : NI + 1;
@@ -557,124 +820,183 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
           if (NI > 1) {
             double X = 0.0;
             for (;;) {
-              double XB = XMX; int IXB = 0, JXBsel = 0;
-              int jw = 1, iw = nextHead(1);
-              double wcj = Xw[jw], tj = groupT(jw, iw);
-              while (iw <= NI) {
-                const int inx = nextHead(iw);
-                const double wci = Xw[iw], ti = groupT(iw, inx);
-                // earlier wave faster and later entry: XXB < 0 <= X (or WDIFF == 0) -> no break, no division
-                if (!(wci == 0.0 || wcj == 0.0) && !(wcj > wci && ti > tj)) {
-                  const double WDIFF = 1.0 / wcj - 1.0 / wci;
-                  if (!(WDIFF == 0.0) && !(wci == wcj)) {
-                    const double XXB = (ti - tj) / WDIFF;
-                    if (!(XXB < X || XXB > XB)) { XB = XXB; IXB = iw; JXBsel = jw; }
+              // crossing point of every pair of neighbouring groups; the reference keeps the smallest
+              // one in [X, XMX], the later pair on ties (:1301-1320)
+              double XB = DBL_MAX; int JXB = 0;
+#pragma unroll
+              for (int sl = 0; sl < KS; ++sl) {
+                const int jw = gl + sl * G;
+                if (jw >= 1 && jw <= NI && ((alive >> jw) & 1u)) {
+                  const int iw = nextHead(jw);
+                  if (iw <= NI) {
+                    const int inx = nextHead(iw);
+                    const double wcj = Xw[jw], wci = Xw[iw], tj = groupT(jw, iw), ti = groupT(iw, inx);
+                    // earlier wave faster and later entry: XXB < 0 <= X (or WDIFF == 0) -> no break, no division
+                    if (!(wci == 0.0 || wcj == 0.0) && !(wcj > wci && ti > tj)) {
+                      const double WDIFF = Yw[jw] - Yw[iw];
+                      if (!(WDIFF == 0.0) && !(wci == wcj)) {
+                        const double XXB = (ti - tj) / WDIFF;
+                        if (!(XXB < X || XXB > XMX) && XXB <= XB) { XB = XXB; JXB = jw; }
+                      }
+                    }
                   }
                 }
-                jw = iw; wcj = wci; tj = ti; iw = inx;
               }
-              if (XB == XMX) break;
+              grp_argmin<G, true>(XB, JXB);
+              JXB = uni<G>(JXB); XB = uni<G>(XB);
+              if (JXB == 0 || XB == XMX) break;
               // merge group IXB into group JXB (:1325-1346)
-              const int JXB = JXBsel;
+              KCOUNT(15, 1);
+              const int IXB = nextHead(JXB);
               const int endI = nextHead(IXB);
               double q2 = Qw[JXB], q1 = Qw[JXB];
               for (int j = JXB + 1; j < endI; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
-              const double A2 = pow_0p6(q2 / K);
-              const double A1 = pow_0p6(q1 / K);
+              const double a = pow_0p6(((gl & 1) ? q1 : q2) / K);   // A2 on even, A1 on odd lanes
+              const double b = dpp_d<MZR_DPP_XOR1>(a);
+              const double A2 = (gl & 1) ? b : a, A1 = (gl & 1) ? a : b;
               const double CM = (q2 - q1) / (A2 - A1);
               const double tJ = groupT(JXB, IXB);
               const double wcJ = Xw[JXB];
               alive &= ~(1u << IXB);
-              Xw[JXB + 1] = tJ + XB / wcJ - XB / CM;
-              Xw[JXB] = CM;
+              grp_sync();
+              if (gl == 0) { Xw[JXB + 1] = tJ + XB / wcJ - XB / CM; Xw[JXB] = CM; Yw[JXB] = 1.0 / CM; }
               X = XB;
+              grp_sync();
             }
           }
           TSTAMP(5);
-          int ICOUNT = 0, bad = 0;
-          double xprev = 0.0;
-          auto rUpdate = [&](double QNEW, double TOLD, double TNEW) {   // :1409-1437
-            ++ICOUNT;
-            if (ICOUNT > NI) { bad = 60; return; }
-            double te = TNEW;
-            if (ICOUNT > 1) { if (te <= xprev) te = xprev + 1.0; }
-            if (ICOUNT == 1 && te <= T_START) te = T_START + 1.0;
-            Qw[ICOUNT] = QNEW; Tw[ICOUNT] = TOLD; Xw[ICOUNT] = te; xprev = te;
-          };
-          int h = 1;
-          int hn = NI >= 1 ? nextHead(1) : NI + 1;
-          double wc = NI >= 1 ? Xw[1] : 0.0, tg = NI >= 1 ? groupT(1, hn) : 0.0;
-          double TEXIT = (NI >= 1 && !(wc < DBL_MIN)) ? fmin(XMX / wc + tg, DBL_MAX) : 0.0;
-          while (h <= NI && !bad) {
-            // look ahead to the next group before this group's slots are overwritten
-            const int hnn = hn <= NI ? nextHead(hn) : NI + 1;
-            const double wcn = hn <= NI ? Xw[hn] : 0.0;
-            const double tgn = hn <= NI ? groupT(hn, hnn) : 0.0;
-            if (wc < DBL_MIN) { bad = 20; break; }                       // zero flow :1365
-            double TNEXT = DBL_MAX;                                      // = TEXIT of the next group (:1372)
-            if (hn <= NI) TNEXT = fmin(XMX / wcn + tgn, DBL_MAX);
-            double q1 = Qw[h], q2 = q1;
-            for (int j = h + 1; j < hn; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
-            if (q1 != q2) {
-              if (TEXIT < T_END) {
-                const double TEXIT2 = fmin(TEXIT + 1.0, TEXIT + 0.5 * (fmin(TNEXT, T_END) - TEXIT));
-                if (TEXIT2 == TEXIT) { bad = 30; break; }
-                rUpdate(q1, tg, TEXIT);
-                if (bad) break;
-                rUpdate(q2, tg, TEXIT2);
-              } else {
-                for (int J = h; J < hn && !bad; ++J) rUpdate(Qw[J], Tw[J], TEXIT);
-              }
-            } else {
-              rUpdate(q1, tg, TEXIT);
+          // exit time of every group (:1363-1372)
+          bool zero = false;
+#pragma unroll
+          for (int sl = 0; sl < KS; ++sl) {
+            const int h = gl + sl * G;
+            if (h >= 1 && h <= NI && ((alive >> h) & 1u)) {
+              const double wc = Xw[h];
+              if (wc < DBL_MIN) zero = true;                                // zero flow :1365
+              else Yw[h] = fmin(XMX / wc + groupT(h, nextHead(h)), DBL_MAX);
             }
-            h = hn; hn = hnn; wc = wcn; tg = tgn; TEXIT = TNEXT;
           }
-          if (bad) { mzr_raise(d, bad, r, t, 13); break; }
-          NQ2 = ICOUNT;
+          if (grp_any<G>(zero)) { mzr_raise(d, 20, r, t, 13); break; }
+          grp_sync();
+          // The routed list (rUpdate :1409-1437): a group of one particle stays one particle; a
+          // merged group becomes two particles when it leaves within the step (:1381-1386), all
+          // its members with a common exit time when it does not (:1388-1392), one particle when
+          // its flows are all equal.  ICOUNT of a group = heads before it + what merged groups
+          // before it add.
+          const unsigned mergedHeads = alive & ~(alive >> 1) & ((1u << NI) - 1u);
+          int hS[KS], adj[KS], extra = 0;
+#pragma unroll
+          for (int sl = 0; sl < KS; ++sl) {
+            const int J = gl + sl * G;
+            hS[sl] = (J >= 1 && J <= NI) ? 31 - __clz((int)(alive & ((2u << J) - 1u))) : 0;
+            adj[sl] = 0;
+          }
+          for (unsigned m = mergedHeads; m; m &= m - 1u) {
+            const int g = __ffs(m) - 1, hn = nextHead(g);
+            double q1 = Qw[g], q2 = q1;
+            for (int j = g + 1; j < hn; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
+            const int c = uni<G>((q1 != q2) ? (Yw[g] < T_END ? 2 : hn - g) : 1);
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) if (hS[sl] > g) adj[sl] += c - 1;
+            extra += c - 1;
+          }
+          NQ2 = __popc(alive) + extra;
+          int oI[KS]; double oQ[KS], oT[KS], oX[KS];
+          bool bad30 = false;
+#pragma unroll
+          for (int sl = 0; sl < KS; ++sl) {
+            const int J = gl + sl * G;
+            oI[sl] = 0; oQ[sl] = 0.0; oT[sl] = 0.0; oX[sl] = 0.0;
+            if (J >= 1 && J <= NI) {
+              const int h = hS[sl], hn = nextHead(h);
+              const int base = __popc(alive & ((1u << h) - 1u)) + 1 + adj[sl];
+              if (hn - h == 1) { oI[sl] = base; oQ[sl] = Qw[J]; oT[sl] = Tw[J]; oX[sl] = Yw[J]; }
+              else {
+                double q1 = Qw[h], q2 = q1;
+                for (int j = h + 1; j < hn; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
+                const double TEXIT = Yw[h], tg = Xw[h + 1];
+                if (q1 != q2) {
+                  if (TEXIT < T_END) {
+                    const double TNEXT = hn <= NI ? Yw[hn] : DBL_MAX;           // = TEXIT of the next group (:1372)
+                    const double TEXIT2 = fmin(TEXIT + 1.0, TEXIT + 0.5 * (fmin(TNEXT, T_END) - TEXIT));
+                    if (TEXIT2 == TEXIT) bad30 = true;
+                    if (J == h) { oI[sl] = base; oQ[sl] = q1; oT[sl] = tg; oX[sl] = TEXIT; }
+                    else if (J == h + 1) { oI[sl] = base + 1; oQ[sl] = q2; oT[sl] = tg; oX[sl] = TEXIT2; }
+                  } else { oI[sl] = base + (J - h); oQ[sl] = Qw[J]; oT[sl] = Tw[J]; oX[sl] = TEXIT; }
+                } else if (J == h) { oI[sl] = base; oQ[sl] = q1; oT[sl] = tg; oX[sl] = TEXIT; }
+              }
+            }
+          }
+          if (grp_any<G>(bad30)) { mzr_raise(d, 30, r, t, 13); break; }
+          grp_sync();
+#pragma unroll
+          for (int sl = 0; sl < KS; ++sl) {
+            if (oI[sl] > 0) {
+              double te = oX[sl];
+              if (oI[sl] == 1 && te <= T_START) te = T_START + 1.0;
+              Qw[oI[sl]] = oQ[sl]; Tw[oI[sl]] = oT[sl]; Xw[oI[sl]] = te;
+            }
+          }
+          if (gl == 0) Xw[0] = X0;
+          grp_sync();
+          // exit times must increase: te <= previous -> previous + 1 s (:1423-1426); sequential only when it happens
+          bool viol = false;
+#pragma unroll
+          for (int sl = 0; sl < KS; ++sl) { const int k2 = gl + sl * G; if (k2 >= 2 && k2 <= NQ2 && Xw[k2] <= Xw[k2 - 1]) viol = true; }
+          if (grp_any<G>(viol)) {
+            KCOUNT(9, 1);
+            if (gl == 0) for (int k2 = 2; k2 <= NQ2; ++k2) { const double xp = Xw[k2 - 1]; if (Xw[k2] <= xp) Xw[k2] = xp + 1.0; }
+            grp_sync();
+          }
         }
-
         TSTAMP(6);
+
         // ---- time-step average and housekeeping, kwt_rch :257-311
-        Xw[0] = X0;
         int NR = 0;
-        for (int i = 1; i <= NQ2; ++i) NR += Xw[i] < T_END ? 1 : 0;   // count(FROUTE)-1
+#pragma unroll
+        for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         double QNEW;
         if (d_interp_rch(Xw, Qw, NR + 2, T_START, T_END, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
         const double Qout = QNEW * RW + qlat_r;
-        Qrow[r] = Qout;
-        d.qsum[r] += Qout;
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
         const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
         const double TIMEI = tN + ((tN1 - tN) / dTx) * (T_END - xN);
         const int NN2 = NQ2 - NR;
-        // tributary outlet of a partition: the same record goes to the time-indexed export buffer
+        if (gl == 0) { Qrow[r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; }
+        // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
-        if (es >= 0) {
-          const size_t nE = d.nExp;
-          d.exN[(size_t)t * nE + es] = NR + 2;
-          double *eq = d.exOQ + (size_t)t * MZR_OB_CAP * nE, *et = d.exOT + (size_t)t * MZR_OB_CAP * nE;
-          for (int k = 0; k <= NR; ++k) { eq[(size_t)k * nE + es] = Qw[k]; et[(size_t)k * nE + es] = Xw[k]; }
-          eq[(size_t)(NR + 1) * nE + es] = Q_END; et[(size_t)(NR + 1) * nE + es] = T_END;
-          eq[(size_t)(NR + 2) * nE + es] = qN1;   et[(size_t)(NR + 2) * nE + es] = xN1;
-        }
-        // outbox for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
-        if (!d.isOutlet[r]) {
+        const bool outbox = !isOut;
+        if (outbox || es >= 0) {
           int *obNw = d.obN + (size_t)par * N;
-          double *obQw = d.obQ + (size_t)par * MZR_OB_CAP * N;
-          double *obTw = d.obT + (size_t)par * MZR_OB_CAP * N;
-          obNw[r] = NR + 2;
-          for (int k = 0; k <= NR; ++k) { obQw[(size_t)k * N + r] = Qw[k]; obTw[(size_t)k * N + r] = Xw[k]; }
-          obQw[(size_t)(NR + 1) * N + r] = Q_END; obTw[(size_t)(NR + 1) * N + r] = T_END;
-          obQw[(size_t)(NR + 2) * N + r] = qN1;   obTw[(size_t)(NR + 2) * N + r] = xN1;
+          double *obQw = d.obQ + (size_t)par * MZR_OB_CAP * N, *obTw = d.obT + (size_t)par * MZR_OB_CAP * N;
+          if (gl == 0 && outbox) obNw[r] = NR + 2;
+          if (gl == 0 && es >= 0) d.exN[(size_t)t * d.nExp + es] = NR + 2;
+#pragma unroll
+          for (int j = 0; j < OS; ++j) {
+            const int k2 = gl + j * G;
+            if (k2 <= NR + 2) {
+              const double q = k2 <= NR ? Qw[k2] : k2 == NR + 1 ? Q_END : qN1;
+              const double x = k2 <= NR ? Xw[k2] : k2 == NR + 1 ? T_END : xN1;
+              if (outbox) { obQw[MZR_OBI(k2, r)] = q; obTw[MZR_OBI(k2, r)] = x; }
+              if (es >= 0) {   // tributary outlet of a partition: the same record goes to the time-indexed export buffer
+                const size_t nE = d.nExp;
+                d.exOQ[((size_t)t * MZR_OB_CAP + k2) * nE + es] = q; d.exOT[((size_t)t * MZR_OB_CAP + k2) * nE + es] = x;
+              }
+            }
+          }
         }
         // at-rest state: KWAVE(NR+1:NQ2+1)
-        d.kwN[r] = NN2 + 1;
-        d.kwQ[r] = Q_END; d.kwTI[r] = TIMEI; d.kwTR[r] = T_END;
-        for (int j = 1; j <= NN2; ++j) {
-          d.kwQ[(size_t)j * N + r] = Qw[NR + j]; d.kwTI[(size_t)j * N + r] = Tw[NR + j]; d.kwTR[(size_t)j * N + r] = Xw[NR + j];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const int k2 = gl + j * G;
+          if (k2 <= NN2) {
+            const bool first = k2 == 0;
+            d.kwQ[MZR_KWI(k2, r)] = first ? Q_END : Qw[NR + k2];
+            d.kwTI[MZR_KWI(k2, r)] = first ? TIMEI : Tw[NR + k2];
+            d.kwTR[MZR_KWI(k2, r)] = first ? T_END : Xw[NR + k2];
+          }
         }
         st_out = NQ2 + 2;
         TSTAMP(7);
@@ -682,23 +1004,31 @@ __global__ void __launch_bounds__(64) k_stage_kwt(MzrDev d, int s, int rBegin, i
     }
   }
   if (d.kwtStat) {
-    const unsigned long long a = wave_sum(st_in), b = wave_sum(st_up), c = wave_sum(st_out);
-    const unsigned long long e = wave_sum(st_head), f = wave_sum(st_route), g = wave_sum(st_edges);
-    if ((threadIdx.x & 63) == 0 && (e | f)) {
+    const bool lead = gl == 0;
+    const unsigned long long a = wave_sum(lead ? st_in : 0), b = wave_sum(lead ? st_up : 0), c = wave_sum(lead ? st_out : 0);
+    const unsigned long long f = wave_sum(lead ? st_route : 0), g = wave_sum(lead ? st_edges : 0);
+    if (lane == 0 && f) {
       atomicAdd(&d.kwtStat->w_in, a); atomicAdd(&d.kwtStat->w_up, b); atomicAdd(&d.kwtStat->w_out, c);
-      atomicAdd(&d.kwtStat->n_head, e); atomicAdd(&d.kwtStat->n_route, f); atomicAdd(&d.kwtStat->n_edges, g);
+      atomicAdd(&d.kwtStat->n_route, f); atomicAdd(&d.kwtStat->n_edges, g);
     }
   }
 }
 
-void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, hipStream_t stream) {
-  (void)wk;
-  const int n = rEnd - rBegin;
-  if (n <= 0) return;
-  dim3 block(64), grid((n + 63) / 64);
+void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream) {
+  constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = G == 64 ? 64 : 48 * RPW, POOLG = G == 64 ? 256 : POOL;
+  const int nHv = hvEnd - hvBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
-  const bool big = d.N > 250000;      // more wavefronts per launch than 6 per CU can hold at once
-  if (full) hipLaunchKernelGGL((k_stage_kwt<true, 1024>), grid, block, 0, stream, d, s, rBegin, rEnd);
-  else if (big) hipLaunchKernelGGL((k_stage_kwt<false, 768>), grid, block, 0, stream, d, s, rBegin, rEnd);
-  else hipLaunchKernelGGL((k_stage_kwt<false, 1024>), grid, block, 0, stream, d, s, rBegin, rEnd);
+  dim3 block(64);
+  if (nHv > 0 || nLt > 0) {
+    const int nHvBlocks = (nHv + RPW - 1) / RPW;
+    dim3 grid(nHvBlocks + (nLt + 63) / 64);
+    if (full) hipLaunchKernelGGL((k_stage_kwt<true, false, G, POOL>), grid, block, 0, stream, d, s, hvBegin, hvEnd, ltBegin, ltEnd, nHvBlocks);
+    else hipLaunchKernelGGL((k_stage_kwt<false, false, G, POOL>), grid, block, 0, stream, d, s, hvBegin, hvEnd, ltBegin, ltEnd, nHvBlocks);
+  }
+  if (nGn > 0) {   // confluences of more than two reaches: the reference's k-way merge on one lane of the group
+    MzrDev dg = d; dg.kwtRouted = d.kwtGeneric;
+    dim3 grid((nGn + RPW - 1) / RPW);
+    if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, G, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, 0, 0, (int)grid.x);
+    else hipLaunchKernelGGL((k_stage_kwt<false, true, G, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, 0, 0, (int)grid.x);
+  }
 }

@@ -6,9 +6,10 @@
 //   * the immediate upstreams of reach r are the contiguous range [upStart[r], upStart[r]+nUp[r])
 //     in UREACHI order                             -> no index list, neighbouring lanes read
 //                                                     neighbouring upstream rows.
-// Ragged per-reach state (KWT particles, IRF convolution windows, sub-reach molecules) is stored
-// "row-major by slot": element k of reach r lives at [k*N + r], so lanes of a wavefront that walk
-// their rows in step touch consecutive addresses.
+// Ragged per-reach state of the one-lane-per-reach solvers (IRF convolution windows, sub-reach
+// molecules) is stored "row-major by slot": element k of reach r lives at [k*N + r], so lanes of a
+// wavefront that walk their rows in step touch consecutive addresses.  KWT particle rows are
+// worked on by a group of lanes per reach and are contiguous per reach instead (MZR_KWI / MZR_OBI).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,6 +17,8 @@
 #define MZR_MAXQPAR_DEV 20 // MAXQPAR, public_var.f90:36
 #define MZR_KW_CAP   20   // at-rest particles per reach (MAXQPAR, public_var.f90:36)
 #define MZR_OB_CAP   21   // outbox entries per reach: KWAVE(0:NR+1) + first non-routed
+#define MZR_KWI(k, r) ((size_t)(r) * MZR_KW_CAP + (k))   // particle k of reach r in kwQ/kwTI/kwTR
+#define MZR_OBI(k, r) ((size_t)(r) * MZR_OB_CAP + (k))   // entry k of reach r in one parity of obQ/obT
 #define MZR_MAXUP    8    // immediate upstreams handled by the KWT merge
 #define MZR_NMOL_KW  20   // init_model_data.f90:386-394
 #define MZR_NMOL_MC  2
@@ -24,6 +27,21 @@
 
 // error record written by the first failing lane (atomicCAS on code)
 struct MzrErr { int code; int reach; int step; int where; };
+
+// Static description of a reach that routes KWT particles, packed by the host into one 64-byte line
+// (kwt_route.f90 reads the same values from NETOPO / RPARAM): everything the kernel would otherwise
+// fetch through dependent loads.
+struct MzrKwtRec {
+  int r, sigma, u0;           // reach (internal index), its stage, first immediate upstream
+  uint8_t nup;                // size(UREACHI)
+  uint8_t flags;              // bits 0-3 count(goodBas), bit 6 an upstream reach is a lake, bit 7 outlet (DREACHK <= 0)
+  uint8_t upGood;             // bit i: upstream i has upstream reaches of its own (publishes an outbox)
+  uint8_t goodMask;           // bit i: goodBas(i+1)
+  double width, K, CW, length;   // R_WIDTH, sqrt(R_SLOPE)/R_MAN_N, ALFA*K**(1/ALFA), RLENGTH
+  double scA, scB;            // R_WIDTH of the first / second non-headwater upstream over R_WIDTH (:929)
+};
+
+static_assert(sizeof(MzrKwtRec) == 64, "MzrKwtRec is one 64-byte line");
 
 // kwt traffic counters (particles), accumulated with wave-level reductions
 struct MzrKwtStat { unsigned long long w_in, w_up, w_out, n_head, n_route, n_edges; };
@@ -72,9 +90,12 @@ struct MzrDev {
   double *mol;                // [nMol][N]
   // ---- KWT
   int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
-  double *kwQ, *kwTI, *kwTR;  // [MZR_KW_CAP][N]
+  double *kwQ, *kwTI, *kwTR;  // [N][MZR_KW_CAP]
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
-  double *obQ, *obT;          // [2][MZR_OB_CAP][N]
+  double *obQ, *obT;          // [2][N][MZR_OB_CAP]
+  const MzrKwtRec *kwtRouted;    // reaches that route particles (at most two upstream reaches), stage-major (a group of lanes each)
+  const MzrKwtRec *kwtGeneric;   // ... with more than two upstream reaches
+  const int *kwtLight;        // headwater, lake and halo reaches, stage-major (one lane each)
   // ---- lakes (null / 0 without lakes)
   const int *lakeSlot;        // [N] lake index of a lake reach, -1 otherwise
   const int *lakeModel;       // [nLake]

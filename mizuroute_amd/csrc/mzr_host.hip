@@ -24,7 +24,7 @@ void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
                              double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
-void mzr_launch_stage_kwt(const MzrDev &d, int wk, int s, int rBegin, int rEnd, hipStream_t stream);
+void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream);
 
 namespace {
 
@@ -158,7 +158,9 @@ struct mzr_domain {
   int lastW = 0;
   bool havePrevQlat = false;
   // kwt
-  DBuf<int> kwN, obN;
+  DBuf<int> kwN, obN, kwtLight;
+  DBuf<MzrKwtRec> kwtRouted, kwtGeneric;
+  std::vector<int> kwtRoutedOff, kwtGenericOff, kwtLightOff;   // [nStages+1] offsets of each stage in the two lists
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
   DBuf<MzrKwtStat> kwtStat;
   DBuf<unsigned long long> dbgCycles;
@@ -169,12 +171,13 @@ struct mzr_domain {
   DBuf<double> lakePar, lakeEvap, lakePrecip, lakeFE, lakeFP;
   // partition boundary
   int nExp = 0, nHalo = 0;
-  std::vector<int> h_expInt, h_haloInt, h_haloGood;
+  std::vector<int> h_expInt, h_haloInt, h_haloGood, h_haloSlot;
   DBuf<int> haloSlot, exportSlot, expInt, haloInt, imN, exN;
   DBuf<double> imOQ, imOT, exOQ, exOT;
   DBuf<MzrErr> err;
   RouteBufs route[6];
-  bool profiling = false;
+  bool profiling = false;       // HIP events around every stage launch
+  bool countTraffic = false;    // KWT particle-traffic counters (atomics: not for timed runs)
   long long stepsDone = 0, totalSteps = 0;
 };
 
@@ -207,7 +210,8 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
-  d.kwtStat = h->kwtStat.p; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
+  d.kwtRouted = h->kwtRouted.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
+  d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
   d.lakeSlot = h->nLake ? h->lakeSlot.p : nullptr; d.lakeModel = h->lakeModel.p; d.lakePar = h->lakePar.p;
   d.lakeEvap = h->lakeEvap.p; d.lakePrecip = h->lakePrecip.p; d.calMonth = h->calMonth.p; d.calDay = h->calDay.p; d.calDoy = h->calDoy.p;
   d.nLake = h->nLake; d.LakeInputOption = h->LakeInputOption; d.calendarId = h->calendarId; d.lakeL = h->lakeL;
@@ -504,6 +508,7 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
   }
   try {
     h->nExp = nExport; h->nHalo = nHalo;
+    h->h_haloSlot = hs;
     h->haloSlot.upload(hs); h->exportSlot.upload(es);
     h->expInt.upload(h->h_expInt); h->haloInt.upload(h->h_haloInt);
     h->h_nGood = ng; h->nGood.upload(ng);
@@ -597,11 +602,52 @@ int mzr_init_state(mzr_handle h) {
       }
       if (m == MZR_KWT) {
         if ((size_t)h->h_slope.size() != N || (size_t)h->h_mann.size() != N) return fail(h, 20, "mzr_init_state/R_SLOPE and R_MAN_N must be set before KWT state is initialised");
+        std::vector<double> K(N), CW(N);
         {   // kinwav_rch constants, kwt_route.f90:1273-1274,1290: evaluated once, with the host libm
           const double ALFA = 5.0 / 3.0;
-          std::vector<double> K(N), CW(N);
           for (size_t i = 0; i < N; ++i) { K[i] = std::sqrt(h->h_slope[i]) / h->h_mann[i]; CW[i] = ALFA * std::pow(K[i], 1.0 / ALFA); }
           h->kwK.upload(K); h->kwCW.upload(CW);
+        }
+        {   // reaches that route particles get a group of lanes each, the O(1) ones a lane each
+          std::vector<double> width(N), length(N);
+          (void)hipMemcpy(width.data(), h->par[2].p, N * sizeof(double), hipMemcpyDeviceToHost);
+          (void)hipMemcpy(length.data(), h->par[4].p, N * sizeof(double), hipMemcpyDeviceToHost);
+          std::vector<int> upStart(N); std::vector<uint32_t> gmask(N); std::vector<uint8_t> isOut(N);
+          (void)hipMemcpy(upStart.data(), h->upStart.p, N * sizeof(int), hipMemcpyDeviceToHost);
+          (void)hipMemcpy(gmask.data(), h->goodMask.p, N * sizeof(uint32_t), hipMemcpyDeviceToHost);
+          (void)hipMemcpy(isOut.data(), h->isOutlet.p, N * sizeof(uint8_t), hipMemcpyDeviceToHost);
+          std::vector<MzrKwtRec> routed, generic; std::vector<int> light;
+          h->kwtRoutedOff.assign(h->nStages + 1, 0); h->kwtGenericOff.assign(h->nStages + 1, 0); h->kwtLightOff.assign(h->nStages + 1, 0);
+          for (int sg = 0; sg < h->nStages; ++sg) {
+            h->kwtRoutedOff[sg] = (int)routed.size(); h->kwtGenericOff[sg] = (int)generic.size(); h->kwtLightOff[sg] = (int)light.size();
+            for (int i = h->stageStart[sg]; i < h->stageStart[sg + 1]; ++i) {
+              const bool halo = h->nHalo && !h->h_haloSlot.empty() && h->h_haloSlot[i] >= 0;
+              const bool lake = !h->h_lakeSlot.empty() && h->h_lakeSlot[i] >= 0;
+              if (halo || lake || h->h_nGood[i] == 0) { light.push_back(i); continue; }
+              MzrKwtRec rc; memset(&rc, 0, sizeof rc);
+              rc.r = i; rc.sigma = sg; rc.u0 = upStart[i]; rc.nup = h->h_nUp[i];
+              rc.flags = (uint8_t)(h->h_nGood[i] & 15) | (isOut[i] ? 0x80 : 0);
+              rc.goodMask = (uint8_t)(gmask[i] & 0xff);
+              int nsr = 0;
+              for (int k = 0; k < rc.nup; ++k) {
+                const int u = rc.u0 + k;
+                if (!h->h_lakeSlot.empty() && h->h_lakeSlot[u] >= 0) rc.flags |= 0x40;
+                if (h->h_nGood[u] > 0) {
+                  rc.upGood |= (uint8_t)(1u << k);
+                  if (nsr == 0) rc.scA = width[u] / width[i]; else if (nsr == 1) rc.scB = width[u] / width[i];
+                  ++nsr;
+                }
+              }
+              rc.width = width[i]; rc.K = K[i]; rc.CW = CW[i]; rc.length = length[i];
+              if (rc.nup > 2) generic.push_back(rc); else routed.push_back(rc);
+            }
+          }
+          h->kwtRoutedOff[h->nStages] = (int)routed.size(); h->kwtGenericOff[h->nStages] = (int)generic.size(); h->kwtLightOff[h->nStages] = (int)light.size();
+          MzrKwtRec none; memset(&none, 0, sizeof none);
+          if (routed.empty()) routed.push_back(none);
+          if (generic.empty()) generic.push_back(none);
+          if (light.empty()) light.push_back(0);
+          h->kwtRouted.upload(routed); h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
         }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
@@ -652,7 +698,9 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         }
         (void)hipEventRecord(rb.events[rb.evUsed].first, st);
       }
-      if (rb.method == MZR_KWT) mzr_launch_stage_kwt(d, h->wk, s, rB, rE, st);
+      if (rb.method == MZR_KWT)
+        mzr_launch_stage_kwt(d, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1],
+                             h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
       else mzr_launch_stage(rb.method, d, s, rB, rE, st);
       if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, st); ++rb.evUsed; }
       ++rb.nLaunches;
@@ -795,7 +843,7 @@ int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry
     for (int k = 0; k < MZR_WCAP; ++k) {
       const size_t o = (size_t)e * MZR_WCAP + k;
       if (k < n[i]) {
-        qwave[o] = q[(size_t)k * N + i]; tentry[o] = ti[(size_t)k * N + i]; texit[o] = tr[(size_t)k * N + i];
+        qwave[o] = q[MZR_KWI(k, i)]; tentry[o] = ti[MZR_KWI(k, i)]; texit[o] = tr[MZR_KWI(k, i)];
         const bool lake = !h->h_lakeSlot.empty() && h->h_lakeSlot[i] >= 0;   // a lake keeps one sentinel particle
         routed[o] = (k == 0 && h->h_nGood[i] > 0 && !lake) ? 1 : 0;          // element 0 = last routed particle
       } else { qwave[o] = tentry[o] = texit[o] = -9999.0; routed[o] = 0; }
@@ -817,7 +865,7 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
     n[i] = numWaves[e];
     for (int k = 0; k < numWaves[e]; ++k) {
       const size_t o = (size_t)e * MZR_WCAP + k;
-      q[(size_t)k * N + i] = qwave[o]; ti[(size_t)k * N + i] = tentry[o]; tr[(size_t)k * N + i] = texit[o];
+      q[MZR_KWI(k, i)] = qwave[o]; ti[MZR_KWI(k, i)] = tentry[o]; tr[MZR_KWI(k, i)] = texit[o];
     }
   }
   (void)hipMemcpy(h->kwN.p, n.data(), N * sizeof(int), hipMemcpyHostToDevice);
@@ -877,7 +925,7 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {
   return 0;
 }
 
-int mzr_set_profiling(mzr_handle h, int on) { if (!h) return 1; h->profiling = on != 0; return 0; }
+int mzr_set_profiling(mzr_handle h, int mode) { if (!h) return 1; h->profiling = (mode & 1) != 0; h->countTraffic = (mode & 2) != 0; return 0; }
 
 int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset) {
   if (!h) return 1;

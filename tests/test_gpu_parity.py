@@ -93,6 +93,7 @@ def test_kwt_vs_oracle_fresh_case(N, seed, dt, kw, hip_lib, oracle_lib):
     assert rep["max_rel"] <= REL_TOL, rep
     assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
     # particle-traffic counters used by the roofline model agree with the oracle's for the last step
+    dom.set_profiling(2)
     dom.kwt_traffic(reset=True)
     orc_t0 = None
     ro2 = m.make_runoff(net.H, 1, seed=seed + 2)
