@@ -167,6 +167,9 @@ template <int G> __device__ __forceinline__ double uni(double v) {
   if (G != 64) return v;
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+// lanes i <-> i^16 inside each half of the wavefront (ds_swizzle bit mode: and 0x1f, xor 0x10)
+__device__ __forceinline__ int swz16_i(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x401F); }
+__device__ __forceinline__ double swz16_d(double v) { return __hiloint2double(swz16_i(__double2hiint(v)), swz16_i(__double2loint(v))); }
 __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
@@ -175,6 +178,7 @@ template <int G, class F> __device__ __forceinline__ double grp_reduce_d(double 
   v = op(v, dpp_d<MZR_DPP_XOR2>(v));
   if (G >= 8) v = op(v, dpp_d<MZR_DPP_HALF_MIRROR>(v));
   if (G >= 16) v = op(v, dpp_d<MZR_DPP_MIRROR>(v));
+  if (G == 32) v = op(v, swz16_d(v));
   if (G == 64) v = op(op(readlane_d(v, 0), readlane_d(v, 16)), op(readlane_d(v, 32), readlane_d(v, 48)));
   return v;
 }
@@ -202,6 +206,7 @@ template <int G, bool LAST> __device__ __forceinline__ void grp_argmin(double &v
   step(dpp_d<MZR_DPP_XOR2>(v), dpp_i<MZR_DPP_XOR2>(i));
   if (G >= 8) step(dpp_d<MZR_DPP_HALF_MIRROR>(v), dpp_i<MZR_DPP_HALF_MIRROR>(i));
   if (G >= 16) step(dpp_d<MZR_DPP_MIRROR>(v), dpp_i<MZR_DPP_MIRROR>(i));
+  if (G == 32) step(swz16_d(v), swz16_i(i));
   if (G == 64) {
     const double v0 = readlane_d(v, 0), v1 = readlane_d(v, 16), v2 = readlane_d(v, 32), v3 = readlane_d(v, 48);
     const int i0 = __builtin_amdgcn_readlane(i, 0), i1 = __builtin_amdgcn_readlane(i, 16), i2 = __builtin_amdgcn_readlane(i, 32), i3 = __builtin_amdgcn_readlane(i, 48);
@@ -459,10 +464,10 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 // FULL = false compiles out lakes, water management and partition boundaries (the common case).
 // Values named "uniform" below are computed redundantly by all lanes of a group.
 #ifndef MZR_KWT_OCC
-#define MZR_KWT_OCC 4
+#define MZR_KWT_OCC 3
 #endif
 #ifndef MZR_KWT_G
-#define MZR_KWT_G 64   // lanes per routed reach
+#define MZR_KWT_G 16   // lanes per routed reach (4, 8, 16, 32 or 64)
 #endif
 template <bool FULL, bool GEN, int G, int POOL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
@@ -1015,7 +1020,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
 }
 
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream) {
-  constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = G == 64 ? 64 : 48 * RPW, POOLG = G == 64 ? 256 : POOL;
+  constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = G >= 32 ? 64 * RPW : 48 * RPW, POOLG = G >= 32 ? 256 : POOL;
   const int nHv = hvEnd - hvBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
   dim3 block(64);
