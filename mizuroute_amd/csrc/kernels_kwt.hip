@@ -376,7 +376,7 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
 
 #ifdef MZR_KWT_TIMING
 #define KCOUNT(i, v) do { if (gl == 0) atomicAdd(&d.dbgCycles[i], (unsigned long long)(v)); } while (0)
-#define TSTAMP(i) do { const long long _n = clock64(); if ((threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[i], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
+#define TSTAMP(i) do { const long long _n = clock64(); if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[i], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
 #else
 #define KCOUNT(i, v) do { } while (0)
 #define TSTAMP(i) do { } while (0)
@@ -466,21 +466,26 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 3
 #endif
+#ifndef MZR_KWT_WPB
+#define MZR_KWT_WPB 1   // wavefronts per block (independent of each other; fewer workgroups to dispatch)
+#endif
 #ifndef MZR_KWT_G
 #define MZR_KWT_G 16   // lanes per routed reach (4, 8, 16, 32 or 64)
 #endif
 template <bool FULL, bool GEN, int G, int POOL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
+__global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
   constexpr int RPW = 64 / G;
   constexpr int KS = (MZR_KW_CAP + G - 1) / G;   // slots per lane for <= 20 entries
   constexpr int OS = (MZR_OB_CAP + G - 1) / G;   // ... for one outbox row
-  __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
+  constexpr int WPB = MZR_KWT_WPB;
+  __shared__ double sA[WPB * POOL], sB[WPB * POOL], sC[WPB * POOL], sD[WPB * POOL];
+  __shared__ double sCtx[WPB * RPW][8];   // per reach: values needed again late (X0, BASIN_QR(1), K, cw, RLENGTH, R_WIDTH)
   if (!GEN && (int)blockIdx.x >= nHvBlocks) {
-    kwt_light<FULL>(d, s, ltBegin + ((int)blockIdx.x - nHvBlocks) * 64 + (int)threadIdx.x, ltEnd);
+    kwt_light<FULL>(d, s, ltBegin + ((int)blockIdx.x - nHvBlocks) * 64 * WPB + (int)threadIdx.x, ltEnd);
     return;
   }
-  const int lane = threadIdx.x, gl = lane & (G - 1), grp = lane / G;
-  const int item = hvBegin + (int)blockIdx.x * RPW + grp;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
+  const int item = hvBegin + ((int)blockIdx.x * WPB + wv) * RPW + grp;
   const int N = d.N;
   // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line)
   const bool have = item < hvEnd;
@@ -501,12 +506,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
   const unsigned upGood = uni<G>((int)rec.upGood), goodMask = uni<G>((int)rec.goodMask);
   const bool isOut = (uni<G>((int)rec.flags) & 0x80) != 0;
   const bool upLake = FULL && (uni<G>((int)rec.flags) & 0x40) != 0;   // an upstream reach is a lake
-  const double RW = rec.width, K = rec.K, cw = rec.CW, XMX = rec.length, scA = rec.scA, scB = rec.scB;
+  const double RW = rec.width, scA = rec.scA, scB = rec.scB;
   // reach series A / B: first and second non-headwater upstream in UREACHI order
   const int ns = __popc(upGood);
   const int uA = u0 + (upGood ? __ffs(upGood) - 1 : 0);
   const int uB = u0 + ((upGood & (upGood - 1u)) ? __ffs(upGood & (upGood - 1u)) - 1 : 0);
-  int st_in = 0, st_up = 0, st_out = 0, st_route = 0, st_edges = 0;
 #ifdef MZR_KWT_TIMING
   long long _tprev = clock64();
 #endif
@@ -516,7 +520,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
   // :598-608; element 0 = last routed particle) and, for the binary confluence, the outbox rows of
   // the upstream reaches.  Rows are fixed-size, so they are read whole before their counts are known.
   int need = 0, n_own = 0, NUPS = 0, IMAX = 0, nrA = 0, nrB = 0;
-  double X0 = 0.0, qlat_r = 0.0, q_up = 0.0;
+  double q_up = 0.0;
+  int st_up = 0;
   KwtBasin bs;
   bs.bsc = 1.0 / RW; bs.b0q0 = bs.b0q1 = bs.b0sl = bs.b1q0 = bs.b1sl = 0.0;   // UWIDTH(basin) = 1
   double q[KS], ti[KS], aq[OS], at[OS], bq[OS], bt[OS];
@@ -527,8 +532,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
   if (live) {
     int n_own_v = d.kwN[r], nrA_v = 0, nrB_v = 0;
     if (!GEN && !upLake) { if (ns > 0) nrA_v = obN[uA]; if (ns > 1) nrB_v = obN[uB]; }
-    X0 = d.kwTR[MZR_KWI(0, r)];
-    qlat_r = qlat_cur[r];
+    const double X0 = d.kwTR[MZR_KWI(0, r)];
+    const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
     if (nup > 1) { bs.b1q0 = qlat_prev[u0 + 1]; b1q1 = qlat_cur[u0 + 1]; }
@@ -548,7 +553,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
     }
     // ---- uniform: the work-array need
     n_own = uni<G>(n_own_v); nrA = uni<G>(nrA_v); nrB = uni<G>(nrB_v);
-    st_route = 1; st_edges = nup;
     IMAX = nup;
     int NUPR = 0;
     bool empty = false;
@@ -583,6 +587,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
     } else {
       for (int i = 0; i < ng; ++i) { if (!((goodMask >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
     }
+    if (gl == 0) {
+      d.inflow[r] = q_up;
+      double *c = sCtx[wv * RPW + grp];
+      c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
+      c[1] = qlat_r; c[2] = rec.K; c[3] = rec.CW; c[4] = rec.length; c[5] = RW;
+      if (d.kwtStat) {
+        atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own); atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
+        atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
+      }
+    }
   }
   TSTAMP(0);
 
@@ -599,15 +613,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
     }
     const bool go = pending && off + need <= POOL;
     if (pending && !go) KCOUNT(10, 1);
+#ifdef MZR_KWT_TIMING
+    if (go && (blockIdx.x & 15) == 0 && gl == 0) { atomicAdd(&d.dbgCycles[11], 1ull); atomicAdd(&d.dbgCycles[12], (unsigned long long)need); }
+#endif
     if (go) {
       pending = false;
-      KCOUNT(11, 1); KCOUNT(12, need);
-      double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
+      double *Qw = sA + wv * POOL + off, *Tw = sB + wv * POOL + off, *Xw = sC + wv * POOL + off, *Yw = sD + wv * POOL + off;
       do {
         const bool cold = (n_own == 0);
         const int NJ = cold ? 0 : n_own - 1;
         const bool binary = !GEN && !upLake && NUPS != 1;   // GEN: launch over the confluences of more than two reaches
-        if (cold) X0 = 0.0;
 #pragma unroll
         for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
         if (binary) {
@@ -618,7 +633,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
             if (ns > 1 && k < nrB) { Xw[nrA + k] = bq[j]; Yw[nrA + k] = bt[j]; }
           }
         }
-        st_in = n_own;
         grp_sync();
 
         // ---- qexmul_rch
@@ -704,7 +718,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
         if (cold) {   // getusq_rch :587-596
           const double DT = T1 - T0;
           if (gl == 0) { Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; }
-          X0 = T0 - DT * 0;
           grp_sync();
         }
         int size = NJ + 1 + ND;
@@ -714,7 +727,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
           for (int k = gl; k < size; k += G) { const double q = Qw[k]; mn = q < mn ? q : mn; }
           mn = grp_min<G>(mn);
           if (mn < 0.0) { mzr_raise(d, 20, r, t, 12); break; }
-          if (gl == 0) d.inflow[r] = q_up;
         }
         TSTAMP(2);
 
@@ -809,6 +821,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
         int NQ2 = 0;
         {
           // K = sqrt(R_SLOPE)/R_MAN_N, cw = ALFA*K**(1/ALFA) with ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
+          const double K = sCtx[wv * RPW + grp][2], cw = sCtx[wv * RPW + grp][3], XMX = sCtx[wv * RPW + grp][4];
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
@@ -942,7 +955,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
               Qw[oI[sl]] = oQ[sl]; Tw[oI[sl]] = oT[sl]; Xw[oI[sl]] = te;
             }
           }
-          if (gl == 0) Xw[0] = X0;
+          if (gl == 0) Xw[0] = sCtx[wv * RPW + grp][0];
           grp_sync();
           // exit times must increase: te <= previous -> previous + 1 s (:1423-1426); sequential only when it happens
           bool viol = false;
@@ -963,21 +976,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         double QNEW;
         if (d_interp_rch(Xw, Qw, NR + 2, T_START, T_END, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
-        const double Qout = QNEW * RW + qlat_r;
+        const double Qout = QNEW * sCtx[wv * RPW + grp][5] + sCtx[wv * RPW + grp][1];
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
         const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
         const double TIMEI = tN + ((tN1 - tN) / dTx) * (T_END - xN);
         const int NN2 = NQ2 - NR;
-        if (gl == 0) { Qrow[r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; }
+        // addresses of the result rows are rebuilt from the step index here rather than kept in
+        // registers since the loads at the top
+        int tq = t;
+        if (G < 64) asm volatile("" : "+v"(tq));
+        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; }
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         const bool outbox = !isOut;
         if (outbox || es >= 0) {
-          int *obNw = d.obN + (size_t)par * N;
-          double *obQw = d.obQ + (size_t)par * MZR_OB_CAP * N, *obTw = d.obT + (size_t)par * MZR_OB_CAP * N;
+          const int pq = tq & 1;
+          int *obNw = d.obN + (size_t)pq * N;
+          double *obQw = d.obQ + (size_t)pq * MZR_OB_CAP * N, *obTw = d.obT + (size_t)pq * MZR_OB_CAP * N;
           if (gl == 0 && outbox) obNw[r] = NR + 2;
-          if (gl == 0 && es >= 0) d.exN[(size_t)t * d.nExp + es] = NR + 2;
+          if (gl == 0 && es >= 0) d.exN[(size_t)tq * d.nExp + es] = NR + 2;
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
             const int k2 = gl + j * G;
@@ -987,7 +1005,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
               if (outbox) { obQw[MZR_OBI(k2, r)] = q; obTw[MZR_OBI(k2, r)] = x; }
               if (es >= 0) {   // tributary outlet of a partition: the same record goes to the time-indexed export buffer
                 const size_t nE = d.nExp;
-                d.exOQ[((size_t)t * MZR_OB_CAP + k2) * nE + es] = q; d.exOT[((size_t)t * MZR_OB_CAP + k2) * nE + es] = x;
+                d.exOQ[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = q; d.exOT[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = x;
               }
             }
           }
@@ -1003,18 +1021,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT
             d.kwTR[MZR_KWI(k2, r)] = first ? T_END : Xw[NR + k2];
           }
         }
-        st_out = NQ2 + 2;
+        if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
         TSTAMP(7);
       } while (0);
-    }
-  }
-  if (d.kwtStat) {
-    const bool lead = gl == 0;
-    const unsigned long long a = wave_sum(lead ? st_in : 0), b = wave_sum(lead ? st_up : 0), c = wave_sum(lead ? st_out : 0);
-    const unsigned long long f = wave_sum(lead ? st_route : 0), g = wave_sum(lead ? st_edges : 0);
-    if (lane == 0 && f) {
-      atomicAdd(&d.kwtStat->w_in, a); atomicAdd(&d.kwtStat->w_up, b); atomicAdd(&d.kwtStat->w_out, c);
-      atomicAdd(&d.kwtStat->n_route, f); atomicAdd(&d.kwtStat->n_edges, g);
     }
   }
 }
@@ -1023,16 +1032,17 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gn
   constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = G >= 32 ? 64 * RPW : 48 * RPW, POOLG = G >= 32 ? 256 : POOL;
   const int nHv = hvEnd - hvBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
-  dim3 block(64);
+  constexpr int WPB = MZR_KWT_WPB;
+  dim3 block(64 * WPB);
   if (nHv > 0 || nLt > 0) {
-    const int nHvBlocks = (nHv + RPW - 1) / RPW;
-    dim3 grid(nHvBlocks + (nLt + 63) / 64);
+    const int nHvBlocks = (nHv + RPW * WPB - 1) / (RPW * WPB);
+    dim3 grid(nHvBlocks + (nLt + 64 * WPB - 1) / (64 * WPB));
     if (full) hipLaunchKernelGGL((k_stage_kwt<true, false, G, POOL>), grid, block, 0, stream, d, s, hvBegin, hvEnd, ltBegin, ltEnd, nHvBlocks);
     else hipLaunchKernelGGL((k_stage_kwt<false, false, G, POOL>), grid, block, 0, stream, d, s, hvBegin, hvEnd, ltBegin, ltEnd, nHvBlocks);
   }
   if (nGn > 0) {   // confluences of more than two reaches: the reference's k-way merge on one lane of the group
     MzrDev dg = d; dg.kwtRouted = d.kwtGeneric;
-    dim3 grid((nGn + RPW - 1) / RPW);
+    dim3 grid((nGn + RPW * WPB - 1) / (RPW * WPB));
     if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, G, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, 0, 0, (int)grid.x);
     else hipLaunchKernelGGL((k_stage_kwt<false, true, G, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, 0, 0, (int)grid.x);
   }

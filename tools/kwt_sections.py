@@ -24,5 +24,5 @@ names = ["0 setup/need", "1 load own + merge", "2 min/inflow", "3 remove", "4 ce
 tot = sum(buf[i] for i in range(8))
 for i, n in enumerate(names):
     print(f"{n:22s} {buf[i]:16d}  {100.0*buf[i]/tot:5.1f}%")
-print("slow merges", buf[8], "exit-time fixes", buf[9], "deferred to next round", buf[10], "routed reach-steps", buf[11],
+print("slow merges", buf[8], "exit-time fixes", buf[9], "deferred to next round", buf[10], "sampled routed reach-steps (1/16 of blocks)", buf[11],
       "mean LDS need", buf[12] / max(1, buf[11]), "thinned", buf[13], "particles removed", buf[14], "shock merges", buf[15])
