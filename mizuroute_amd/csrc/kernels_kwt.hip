@@ -213,6 +213,13 @@ template <int G, bool LAST> __device__ __forceinline__ void grp_argmin(double &v
     v = v0; i = i0; step(v1, i1); step(v2, i2); step(v3, i3);
   }
 }
+// flags of the group's lanes as a bit mask (bit 0 = first lane of the group)
+template <int G> __device__ __forceinline__ unsigned long long grp_bits(bool p) {
+  const unsigned long long b = __ballot(p);
+  if (G == 64) return b;
+  const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+  return (b >> gbase) & ((1ull << (G & 63)) - 1ull);
+}
 // value held by the first lane of the group
 template <int G> __device__ __forceinline__ int grp_first(int v) {
   if (G == 64) return __builtin_amdgcn_readfirstlane(v);
@@ -372,6 +379,59 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
     if (done == all) break;
   }
   return IPRT;
+}
+
+// interp_rch (:1444-1622) by a group of lanes, one averaging interval.  The two index searches are
+// ballots, every trapezoid is evaluated by the lane of its right end point, and only the running
+// sum (same order as the reference) is sequential.  TERM is scratch for NOLD values.
+template <int G, int KS>
+__device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *QOLD, double *TERM, int NOLD, double T0, double T1,
+                                              int gl, double *QNEW) {
+#define T(i) TOLD[(i) - 1]
+#define Q(i) QOLD[(i) - 1]
+  if (T(1) > T0 || T(NOLD) < T1) return 1;
+  int IBEG = 1, IEND = 1;
+  bool fb = false, fe = false;
+#pragma unroll
+  for (int sl = 0; sl < KS; ++sl) {
+    const int i = gl + sl * G + 1;
+    const double ti = i <= NOLD ? T(i) : 0.0;
+    const unsigned long long mb = grp_bits<G>(i >= 2 && i <= NOLD && T0 <= ti), me = grp_bits<G>(i <= NOLD && T1 <= ti);
+    if (!fb && mb) { IBEG = sl * G + __ffsll((long long)mb); fb = true; }
+    if (!fe && me) { IEND = sl * G + __ffsll((long long)me); fe = true; }
+  }
+  if (T1 < T(IBEG)) {
+    const double SLOPE = (Q(IBEG) - Q(IBEG - 1)) / (T(IBEG) - T(IBEG - 1));
+    const double QEST0 = SLOPE * (T0 - T(IBEG - 1)) + Q(IBEG - 1);
+    const double QEST1 = SLOPE * (T1 - T(IBEG - 1)) + Q(IBEG - 1);
+    *QNEW = 0.5 * (QEST0 + QEST1);
+    return 0;
+  }
+#pragma unroll
+  for (int sl = 0; sl < KS; ++sl) {
+    const int i = gl + sl * G + 1;
+    if (i > IBEG && i <= IEND) TERM[i - 1] = (T(i) - T(i - 1)) * 0.5 * (Q(i - 1) + Q(i));
+  }
+  double AREAB = 0.0, AREAE = 0.0, AREAM = 0.0;
+  if (T0 < T(IBEG)) {
+    const double SLOPE = (Q(IBEG) - Q(IBEG - 1)) / (T(IBEG) - T(IBEG - 1));
+    const double QEST0 = SLOPE * (T0 - T(IBEG - 1)) + Q(IBEG - 1);
+    AREAB = (T(IBEG) - T0) * 0.5 * (QEST0 + Q(IBEG));
+  }
+  if (T1 < T(IEND)) {
+    const double SLOPE = (Q(IEND) - Q(IEND - 1)) / (T(IEND) - T(IEND - 1));
+    const double QEST1 = SLOPE * (T1 - T(IEND - 1)) + Q(IEND - 1);
+    AREAE = (T1 - T(IEND - 1)) * 0.5 * (Q(IEND - 1) + QEST1);
+  }
+  grp_sync();
+  if (IBEG < IEND) {
+    for (int IMID = IBEG + 1; IMID < IEND; ++IMID) AREAM = AREAM + TERM[IMID - 1];
+    if (T1 == T(IEND) && T0 < T(IEND - 1)) AREAM = AREAM + TERM[IEND - 1];
+  }
+#undef T
+#undef Q
+  *QNEW = (AREAB + AREAE + AREAM) / (T1 - T0);
+  return 0;
 }
 
 #ifdef MZR_KWT_TIMING
@@ -975,7 +1035,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
         for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         double QNEW;
-        if (d_interp_rch(Xw, Qw, NR + 2, T_START, T_END, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
+        if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
         const double Qout = QNEW * sCtx[wv * RPW + grp][5] + sCtx[wv * RPW + grp][1];
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
@@ -986,7 +1046,11 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
         // registers since the loads at the top
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
+#ifdef X_NOQSUM
+        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] = Qout; d.kwN[r] = NN2 + 1; }
+#else
         if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; }
+#endif
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         const bool outbox = !isOut;
@@ -1018,7 +1082,11 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
             const bool first = k2 == 0;
             d.kwQ[MZR_KWI(k2, r)] = first ? Q_END : Qw[NR + k2];
             d.kwTI[MZR_KWI(k2, r)] = first ? TIMEI : Tw[NR + k2];
+#ifndef X_NOTR
             d.kwTR[MZR_KWI(k2, r)] = first ? T_END : Xw[NR + k2];
+#else
+            if (first) d.kwTR[MZR_KWI(k2, r)] = T_END;
+#endif
           }
         }
         if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
