@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--reaches", type=int, default=N_REACH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
 
     import torch
@@ -200,14 +202,16 @@ def main():
     # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
     # every stage launch on the library's stream, on the window that follows the timed region
     roof = None
-    if world > 1:      # every rank takes part in the profiled window (the exchange is collective)
+    if args.no_roofline:
+        pass
+    elif world > 1:      # every rank takes part in the profiled window (the exchange is collective)
         if rank != 0:
             ro_prof = gen(W, args.warmup + args.steps)
             torch.cuda.synchronize()
             dist.barrier()
             run_steps(ro_prof, args.warmup + args.steps)
             sync_all()
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         dom.timing(m.KWT, reset=True)
         dom.set_profiling(1)
         ro_prof = gen(W, args.warmup + args.steps)
@@ -221,13 +225,13 @@ def main():
     # particle-traffic counters (device atomics) are collected on one more window so that they do
     # not disturb the event-timed launches; bytes per reach-step of that window x the reach-steps
     # of the timed window = algorithmic bytes of the timed window
-    if world > 1 and rank != 0:
+    if world > 1 and rank != 0 and not args.no_roofline:
         ro_cnt = gen(W, args.warmup + args.steps + W)
         torch.cuda.synchronize()
         dist.barrier()
         run_steps(ro_cnt, args.warmup + args.steps + W)
         sync_all()
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:
         dom.set_profiling(2)
         dom.kwt_traffic(reset=True)
         ro_cnt = gen(W, args.warmup + args.steps + W)
