@@ -518,13 +518,12 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 
 }  // namespace
 
-// One wavefront per block, RPW = 64/G routed reaches per wavefront.  Each group first works out how
-// many work-array entries its reach needs (own particles + everything its upstreams routed), the
-// wave carves the LDS pool among its groups, and groups that do not fit wait for the next round.
+// RPW = 64/G routed reaches per wavefront, each with a fixed slice of the LDS work arrays (own
+// particles + everything its upstreams routed).
 // FULL = false compiles out lakes, water management and partition boundaries (the common case).
 // Values named "uniform" below are computed redundantly by all lanes of a group.
 #ifndef MZR_KWT_OCC
-#define MZR_KWT_OCC 3
+#define MZR_KWT_OCC 5
 #endif
 #ifndef MZR_KWT_WPB
 #define MZR_KWT_WPB 1   // wavefronts per block (independent of each other; fewer workgroups to dispatch)
@@ -538,6 +537,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
   constexpr int KS = (MZR_KW_CAP + G - 1) / G;   // slots per lane for <= 20 entries
   constexpr int OS = (MZR_OB_CAP + G - 1) / G;   // ... for one outbox row
   constexpr int WPB = MZR_KWT_WPB;
+  constexpr int GP = POOL / RPW;   // work-array entries per reach
   __shared__ double sA[WPB * POOL], sB[WPB * POOL], sC[WPB * POOL], sD[WPB * POOL];
   __shared__ double sCtx[WPB * RPW][8];   // per reach: values needed again late (X0, BASIN_QR(1), K, cw, RLENGTH, R_WIDTH)
   if (!GEN && (int)blockIdx.x >= nHvBlocks) {
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
     need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
     if (upLake && nup > 1) need = 0;
     if (empty) { mzr_raise(d, 40, r, t, 11); need = 0; }
-    if (need > POOL) { mzr_raise(d, 60, r, t, 10); need = 0; }
+    if (need > GP) { mzr_raise(d, 60, r, t, 10); need = 0; }
     const double dT10 = T1 - T0;
     bs.b0sl = (bs.b0q1 - bs.b0q0) / dT10;
     if (nup > 1) bs.b1sl = (b1q1 - bs.b1q0) / dT10;
@@ -660,25 +660,12 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
   }
   TSTAMP(0);
 
-  bool pending = need > 0;
-  while (__any(pending)) {
-    // carve the pool: exclusive prefix sum of the pending groups' needs
-    const int mine = pending ? need : 0;
-    int off = 0, run = 0;
-#pragma unroll
-    for (int g = 0; g < RPW; ++g) {
-      const int v = __builtin_amdgcn_readlane(mine, g * G);
-      if (g == grp) off = run;
-      run += v;
-    }
-    const bool go = pending && off + need <= POOL;
-    if (pending && !go) KCOUNT(10, 1);
-#ifdef MZR_KWT_TIMING
-    if (go && (blockIdx.x & 15) == 0 && gl == 0) { atomicAdd(&d.dbgCycles[11], 1ull); atomicAdd(&d.dbgCycles[12], (unsigned long long)need); }
-#endif
-    if (go) {
-      pending = false;
-      double *Qw = sA + wv * POOL + off, *Tw = sB + wv * POOL + off, *Xw = sC + wv * POOL + off, *Yw = sD + wv * POOL + off;
+  // work arrays: a fixed slice of the wavefront's LDS pool per group (GP entries: a binary
+  // confluence needs at most 20 + 1 + 2 + 2*19 of them)
+  if (need > 0) {
+    {
+      const int off = (wv * RPW + grp) * GP;
+      double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
       do {
         const bool cold = (n_own == 0);
         const int NJ = cold ? 0 : n_own - 1;
@@ -1097,7 +1084,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
 }
 
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream) {
-  constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = G >= 32 ? 64 * RPW : 48 * RPW, POOLG = G >= 32 ? 256 : POOL;
+  constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = 60 * RPW, POOLG = 256 * RPW;   // binary confluence: 20 + 2 + 2 * 19 entries at most
   const int nHv = hvEnd - hvBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
   constexpr int WPB = MZR_KWT_WPB;
