@@ -183,6 +183,59 @@ def make_network(N: int, seed: int = 20240529, depth: int | None = None, n_outle
                         hruIndex=hruIndex, hruWeight=hruWeight, params=params)
 
 
+def make_star_network(k: int = 5, depth: int = 6, seed: int = 0, identical: bool = True) -> RiverNetwork:
+    """k perfect binary trees of `depth` levels whose roots meet in ONE confluence reach that drains
+    to an outlet reach.  Reaches of the same tree and level share all parameters, so that with
+    spatially uniform runoff sibling tributaries deliver particles with identical times (the
+    duplicate-time branch of qexmul_rch), while the k trees differ from each other, so that the
+    k-way confluence receives k particle lists.  identical=False draws every reach's parameters
+    independently instead: no duplicate times, every list grows to MAXQPAR, and the k-way confluence
+    holds more than 64 particles before remove_rch."""
+    rng = np.random.default_rng(seed)
+    per = 2 ** depth - 1
+    N = k * per + 2
+    down = np.zeros(N, dtype=np.int64)               # 1-based, 0 = outlet
+    level = np.zeros(N, dtype=np.int64)
+    tree = np.zeros(N, dtype=np.int64)
+    conf, outlet = N - 2, N - 1
+    down[conf] = outlet + 1
+    for j in range(k):
+        base = j * per
+        for i in range(per):                         # heap order: children of i are 2i+1, 2i+2
+            down[base + i] = (conf if i == 0 else base + (i - 1) // 2) + 1
+            level[base + i] = int(np.floor(np.log2(i + 1)))
+            tree[base + i] = j
+    level[conf] = level[outlet] = -1
+    tree[conf] = tree[outlet] = k
+    downIndex = down.astype(np.int32)
+    upOffset, upIndex = build_upstream_csr(downIndex)
+    lvl_len = np.clip(np.exp(rng.normal(np.log(3000.0), 0.4, (k + 1, depth + 1))), 500.0, 12000.0)
+    lvl_slope = np.exp(rng.uniform(np.log(5e-4), np.log(2e-2), (k + 1, depth + 1)))
+    length = lvl_len[tree, level + 1]
+    slope = lvl_slope[tree, level + 1]
+    if not identical:
+        length = np.clip(np.exp(rng.normal(np.log(3000.0), 0.6, N)), 200.0, 30000.0)
+        slope = np.exp(rng.uniform(np.log(1e-4), np.log(5e-2), N))
+    basarea = np.full(N, 2.5e7) * (1.0 + 0.1 * tree)
+    totarea = basarea.copy()
+    down0 = downIndex.astype(np.int64) - 1
+    dist = hops_to_outlet(down0)
+    for d in range(int(dist.max()), 0, -1):
+        idx = np.nonzero(dist == d)[0]
+        np.add.at(totarea, down0[idx], totarea[idx])
+    width = 0.001 * np.sqrt(totarea)
+    rdepth = np.full(N, HIGH_DEPTH)
+    side = np.zeros(N)
+    params = dict(R_SLOPE=slope, R_MAN_N=np.full(N, 0.01), R_WIDTH=width, R_DEPTH=rdepth,
+                  RLENGTH=length, R_STORAGE=rdepth * width * length, SIDE_SLOPE=side,
+                  FLDP_SLOPE=np.full(N, 1000.0), BASAREA=basarea, TOTAREA=totarea, MINFLOW=np.zeros(N))
+    upGood = np.ones(upIndex.size, dtype=np.int32)
+    return RiverNetwork(N=N, H=N, downIndex=downIndex, reachId=np.arange(1001, 1001 + N, dtype=np.int32),
+                        upOffset=upOffset, upIndex=upIndex, upGood=upGood,
+                        hruOffset=np.arange(N + 1, dtype=np.int32), hruIndex=np.arange(1, N + 1, dtype=np.int32),
+                        hruWeight=np.ones(N), params=params)
+
+
 def make_runoff(H: int, n_steps: int, seed: int = 7, t0: int = 0, base: float = 1e-8,
                 storm_prob: float = 0.01, storm_amp: float = 1e-6) -> np.ndarray:
     """runoff[t, h] in m/s: low seasonal base flow plus sparse storm pulses."""

@@ -89,6 +89,9 @@ int orc_get_basin_state(const orc_t *o, double *qfuture /* [N][ntdhBas] */);
 int orc_get_kwt_traffic(const orc_t *o, long long *w_in, long long *w_up, long long *w_out,
                         long long *n_head, long long *n_route, long long *n_edges);
 
+/* counts of the less common kwt_rch branches taken since creation, out[9] (see orc_internal.h) */
+int orc_get_kwt_paths(const orc_t *o, long long *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -441,6 +441,11 @@ int orc_get_basin_state(const orc_t *o, double *qfuture) {
   return 0;
 }
 
+int orc_get_kwt_paths(const orc_t *o, long long *out) {
+  for (int i = 0; i < ORC_NPATHS; i++) out[i] = o->paths[i];
+  return 0;
+}
+
 int orc_get_kwt_traffic(const orc_t *o, long long *w_in, long long *w_up, long long *w_out,
                         long long *n_head, long long *n_route, long long *n_edges) {
   *w_in = o->w_in; *w_up = o->w_up; *w_out = o->w_out;

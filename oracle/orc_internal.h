@@ -8,6 +8,7 @@
 #define ORC_NMOL_MC 2
 #define ORC_NMOL_DW 20
 #define ORC_KWSTORE 40
+#define ORC_NPATHS 9
 #define ORC_NLAKEPAR 56             /* mizuroute_amd/casefile.py LAKE_PAR order */              /* storage per reach for KWAVE (size <= MAXQPAR+1) */
 
 /* dataTypes.f90:291-302 (QM is always -9999 on this path and is not stored) */
@@ -50,6 +51,11 @@ struct orc {
   long long iTime; int month, day, dayofyear;
   /* KWT traffic statistics of the last step */
   long long w_in, w_up, w_out, n_head, n_route, n_edges;
+  /* how often the less common branches of kwt_rch ran since creation (test coverage evidence):
+     0 shock merges, 1 merged group leaving within the step, 2 merged group staying, 3 exit-time +1 s fixes,
+     4 duplicate times dropped in qexmul, 5 remove_rch calls, 6 ... with more than 64 particles,
+     7 confluences of more than two reaches merged, 8 first-particle T_START+1 fixes */
+  long long paths[ORC_NPATHS];
   char msg[512];
 };
 

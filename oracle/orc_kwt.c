@@ -65,6 +65,7 @@ static int qexmul_rch(orc_t *o, int JRCH, double T0, double T1, int *ND_out, dou
   int NUPS = NUPB + NUPR;
   double RW = o->par[ORC_P_WIDTH][JRCH];
   o->n_edges += NUPB;
+  if (NUPB > 2 && NUPS > 1) o->paths[7]++;
 
   if (NUPS == 1) {   /* one upstream basin that is a headwater, :743-759 */
     double *QD = (double *)malloc(sizeof(double)), *TD = (double *)malloc(sizeof(double));
@@ -136,6 +137,7 @@ static int qexmul_rch(orc_t *o, int JRCH, double T0, double T1, int *ND_out, dou
         } else {
           double TIME_OLD = IPRT >= 1 ? TD[IPRT - 1] : -DBL_MAX;
           if (CTIME[JUPS] < TIME_OLD) { ierr = fail(o, 30, "qexmul_rch/expect process in order of time"); }
+          if (!ierr && CTIME[JUPS] == TIME_OLD && CTIME[JUPS] < T1) o->paths[4]++;   /* not the common end-of-step time */
           if (!ierr && CTIME[JUPS] != TIME_OLD) {
             double Q_AGG = 0.0;
             for (int i = 0; i < NUPS; i++) {
@@ -310,6 +312,7 @@ static int kinwav_rch(orc_t *o, int JRCH, double T_START, double T_END, double *
         IXB = IW;
       }
       if (XB == XMX) break;
+      o->paths[0]++;
       NN = NN - 1;
       int JXB = IXB - 1;
       NM = NI - NN; (void)NM;
@@ -333,8 +336,8 @@ static int kinwav_rch(orc_t *o, int JRCH, double T_START, double T_END, double *
     ICOUNT++;                                                                                 \
     if (ICOUNT > NI) { ierr = fail(o, 60, "kinwav_rch/RUPDATE/array bounds exceeded"); break; } \
     Q_JRCH[ICOUNT - 1] = (QNEW); TENTRY[ICOUNT - 1] = (TOLD); T_EXIT[ICOUNT - 1] = (TNEW);    \
-    if (ICOUNT > 1) { if (T_EXIT[ICOUNT - 1] <= T_EXIT[ICOUNT - 2]) T_EXIT[ICOUNT - 1] = T_EXIT[ICOUNT - 2] + 1.0; } \
-    if (ICOUNT == 1 && T_EXIT[ICOUNT - 1] <= T_START) T_EXIT[ICOUNT - 1] = T_START + 1.0;     \
+    if (ICOUNT > 1) { if (T_EXIT[ICOUNT - 1] <= T_EXIT[ICOUNT - 2]) { T_EXIT[ICOUNT - 1] = T_EXIT[ICOUNT - 2] + 1.0; o->paths[3]++; } } \
+    if (ICOUNT == 1 && T_EXIT[ICOUNT - 1] <= T_START) { T_EXIT[ICOUNT - 1] = T_START + 1.0; o->paths[8]++; } \
     if (T_EXIT[ICOUNT - 1] < T_END) FROUTE[ICOUNT - 1] = 1;                                   \
   } while (0)
   for (int IROUTE = 1; IROUTE <= NN && !ierr; IROUTE++) {
@@ -349,10 +352,12 @@ static int kinwav_rch(orc_t *o, int JRCH, double T_START, double T_END, double *
       if (TEXIT < T_END) {
         double TEXIT2 = fmin(TEXIT + 1.0, TEXIT + 0.5 * (fmin(TNEXT, T_END) - TEXIT));
         if (TEXIT2 == TEXIT) { ierr = fail(o, 30, "kinwav_rch/TEXIT equals TEXIT2 in kinwav"); break; }
+        o->paths[1]++;
         RUPDATE(Q1[IROUTE], T1[IROUTE], TEXIT);
         if (ierr) break;
         RUPDATE(Q2[IROUTE], T1[IROUTE], TEXIT2);
       } else {
+        o->paths[2]++;
         for (int JROUTE = 1; JROUTE <= NI && !ierr; JROUTE++) {
           if (MF[JROUTE] == IROUTE) RUPDATE(Q0[JROUTE], T0[JROUTE], TEXIT);
         }
@@ -429,6 +434,7 @@ int orc_kwt_rch(orc_t *o, int r, double T0, double T1) {
     return 0;
   }
   if (size > ORC_MAXQPAR) {
+    o->paths[5]++; if (size > 64) o->paths[6]++;
     ierr = remove_rch(ORC_MAXQPAR, &size, &Q_JRCH, &TENTRY, &T_EXIT);
     if (ierr) return ierr;
   }

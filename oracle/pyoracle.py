@@ -37,6 +37,7 @@ def lib():
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, dp, dp]
         L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_get_kwt_paths.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.orc_config.argtypes = [C.c_void_p, C.c_double, C.c_int, ip, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
         L.orc_set_uh.argtypes = [C.c_void_p, C.c_int, dp, C.c_void_p, C.c_void_p]
         L.orc_step.argtypes = [C.c_void_p, C.c_double, C.c_double, dp, C.c_void_p]
@@ -156,6 +157,15 @@ class Oracle:
         out = np.zeros((self.N, self.ntdh))
         lib().orc_get_basin_state(self.h, out)
         return out
+
+    PATHS = ("shock_merges", "merged_leaving", "merged_staying", "exit_time_fixes", "duplicate_times",
+             "removes", "removes_over_64", "confluences_over_2", "tstart_fixes")
+
+    def kwt_paths(self):
+        """How often the less common branches of kwt_rch ran since creation (coverage evidence for the parity tests)."""
+        v = (C.c_longlong * 9)()
+        lib().orc_get_kwt_paths(self.h, v)
+        return dict(zip(self.PATHS, list(v)))
 
     def kwt_traffic(self):
         v = [C.c_longlong(0) for _ in range(6)]

@@ -44,3 +44,25 @@ def parity_report(ref, got, floor=1e-9):
                 p999=float(np.quantile(r, 0.999)) if r.size else 0.0,
                 frac_within=float((r <= REL_TOL).mean()) if r.size else 1.0,
                 bit_identical=float((ref == got).mean()))
+
+
+def star_case(kind):
+    """Inputs that drive kwt_rch through branches ordinary networks rarely reach.
+    'duplicates': symmetric tributaries + uniform runoff -> equal particle times across tributaries
+                  (qexmul_rch drops the duplicate, kwt_route.f90:916-918) and shocks;
+    'over64':     a five-way confluence of saturated tributaries with a daily step -> more than 64
+                  particles enter remove_rch at once."""
+    import numpy as np
+    from mizuroute_amd.synthetic import make_star_network, make_runoff
+    if kind == "duplicates":
+        net = make_star_network(5, 6, seed=5, identical=True)
+        steps, dt = 120, 3600.0
+        rng = np.random.default_rng(9)
+        t = np.arange(steps)
+        series = 2e-8 * (1 + np.sin(2 * np.pi * t / 24.0)) + np.where(rng.random(steps) < 0.15, 3e-6 * rng.random(steps), 0.0) + 1e-9
+        ro = np.ascontiguousarray(np.repeat(series[:, None], net.H, axis=1))
+    else:
+        net = make_star_network(5, 6, seed=5, identical=False)
+        steps, dt = 30, 86400.0
+        ro = make_runoff(net.H, steps, seed=3, storm_prob=0.05, storm_amp=3e-6)
+    return net, ro, dt

@@ -92,6 +92,8 @@ def test_kwt_vs_oracle_fresh_case(N, seed, dt, kw, hip_lib, oracle_lib):
     print("kwt fresh", N, dt, rep, "stages", dom.schedule())
     assert rep["max_rel"] <= REL_TOL, rep
     assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
+    paths = orc.kwt_paths()   # the storms do drive kinwav_rch through its shock branches
+    assert paths["shock_merges"] > 0 and paths["merged_leaving"] > 0 and paths["removes"] > 0, paths
     # particle-traffic counters used by the roofline model agree with the oracle's for the last step
     dom.set_profiling(2)
     dom.kwt_traffic(reset=True)
@@ -101,6 +103,28 @@ def test_kwt_vs_oracle_fresh_case(N, seed, dt, kw, hip_lib, oracle_lib):
     dom.step(steps * dt, (steps + 1) * dt, ro2[0])
     to, tg = orc.kwt_traffic(), dom.kwt_traffic()
     assert to == tg, (to, tg)
+
+
+@pytest.mark.parametrize("kind,must", [("duplicates", ("duplicate_times", "shock_merges", "merged_leaving", "merged_staying", "exit_time_fixes")),
+                                       ("over64", ("removes_over_64", "confluences_over_2"))])
+def test_kwt_rare_branches_vs_oracle(kind, must, hip_lib, oracle_lib):
+    """Serial fall-back paths of the lane-group kernel: duplicate particle times across tributaries
+    (cursor-walk merge), exit-time ordering fixes, shock merges, the k-way merge of a confluence
+    of more than two reaches and thinning of more than 64 particles."""
+    from helpers import star_case
+    net, ro, dt = star_case(kind)
+    ff = np.array([0.5, 0.3, 0.2])
+    orc = oracle_lib.Oracle(net, dt, [2], ff)
+    Qo = orc.run(ro)
+    paths = orc.kwt_paths()
+    for k in must:
+        assert paths[k] > 0, (k, paths)
+    dom = m.RoutingDomain(net, dt, [m.KWT], frac_future=ff, max_window=32)
+    Qg = dom.run(ro)
+    rep = parity_report(Qo[:, 0], Qg[:, 0])
+    print("kwt rare branches", kind, rep, paths)
+    assert rep["max_rel"] <= REL_TOL, rep
+    assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
 
 
 def test_eulerian_methods_vs_oracle_fresh_case(hip_lib, oracle_lib):

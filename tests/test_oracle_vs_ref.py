@@ -40,6 +40,21 @@ def test_all_methods_bit_exact(N, seed, dt, steps, kw, oracle_lib):
     assert np.array_equal(nw, out["state"][2]["nw"])
 
 
+@pytest.mark.parametrize("kind,must", [("duplicates", ("duplicate_times", "shock_merges", "merged_leaving", "merged_staying", "exit_time_fixes")),
+                                       ("over64", ("removes_over_64", "confluences_over_2"))])
+def test_kwt_rare_branches_bit_exact(kind, must, oracle_lib):
+    from helpers import star_case
+    net, ro, dt = star_case(kind)
+    out = refrun.run_case(net, ro, dt, [2])
+    assert out["ierr"] == 0
+    orc = oracle_lib.Oracle(net, dt, [2], out["frac_future"], out["uh_offset"], out["uh"])
+    assert np.array_equal(orc.run(ro), out["Q"])
+    assert np.array_equal(orc.kwt_state()[0], out["state"][2]["nw"])
+    paths = orc.kwt_paths()
+    for k in must:
+        assert paths[k] > 0, (k, paths)     # the case does exercise the branch
+
+
 def test_hw_drain_top_and_no_basin_route(oracle_lib):
     net = make_network(300, seed=9)
     ro = make_runoff(net.H, 50, seed=19, storm_prob=0.05)
