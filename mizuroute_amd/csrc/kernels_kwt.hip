@@ -196,22 +196,23 @@ template <int G> __device__ __forceinline__ bool grp_any(bool p) {
   const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
   return ((b >> gbase) & ((1ull << (G & 63)) - 1ull)) != 0ull;
 }
-// arg-min over the group of (v, i); LAST = false: ties -> smallest i (MINLOC), true: ties -> largest i
+template <int G, bool MAXI> __device__ __forceinline__ int grp_minmax_i(int v) {
+  auto op = [](int a, int b) { return MAXI ? (b > a ? b : a) : (b < a ? b : a); };
+  v = op(v, dpp_i<MZR_DPP_XOR1>(v));
+  v = op(v, dpp_i<MZR_DPP_XOR2>(v));
+  if (G >= 8) v = op(v, dpp_i<MZR_DPP_HALF_MIRROR>(v));
+  if (G >= 16) v = op(v, dpp_i<MZR_DPP_MIRROR>(v));
+  if (G == 32) v = op(v, swz16_i(v));
+  if (G == 64) v = op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+  return v;
+}
+// arg-min over the group of (v, i): the minimum value first, then among the lanes that hold it the
+// smallest index (LAST = false, MINLOC) or the largest (LAST = true).  i >= 0.
 template <int G, bool LAST> __device__ __forceinline__ void grp_argmin(double &v, int &i) {
-  auto step = [&](double ov, int oi) {
-    const bool take = ov < v || (ov == v && (LAST ? oi > i : oi < i));
-    v = take ? ov : v; i = take ? oi : i;
-  };
-  step(dpp_d<MZR_DPP_XOR1>(v), dpp_i<MZR_DPP_XOR1>(i));
-  step(dpp_d<MZR_DPP_XOR2>(v), dpp_i<MZR_DPP_XOR2>(i));
-  if (G >= 8) step(dpp_d<MZR_DPP_HALF_MIRROR>(v), dpp_i<MZR_DPP_HALF_MIRROR>(i));
-  if (G >= 16) step(dpp_d<MZR_DPP_MIRROR>(v), dpp_i<MZR_DPP_MIRROR>(i));
-  if (G == 32) step(swz16_d(v), swz16_i(i));
-  if (G == 64) {
-    const double v0 = readlane_d(v, 0), v1 = readlane_d(v, 16), v2 = readlane_d(v, 32), v3 = readlane_d(v, 48);
-    const int i0 = __builtin_amdgcn_readlane(i, 0), i1 = __builtin_amdgcn_readlane(i, 16), i2 = __builtin_amdgcn_readlane(i, 32), i3 = __builtin_amdgcn_readlane(i, 48);
-    v = v0; i = i0; step(v1, i1); step(v2, i2); step(v3, i3);
-  }
+  const double m = grp_min<G>(v);
+  const int c = (v == m) ? i : (LAST ? -1 : 0x7fffffff);
+  i = grp_minmax_i<G, LAST>(c);
+  v = m;
 }
 // flags of the group's lanes as a bit mask (bit 0 = first lane of the group)
 template <int G> __device__ __forceinline__ unsigned long long grp_bits(bool p) {
@@ -811,8 +812,8 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
             const int c = side ? pn : pm;
             const bool valid = side ? pn < NPRT : pm > 0;
             double e = 0.0;
-            if (valid) {
-              const int a = prevA(c), b = nextA(c);
+            if (valid) {   // pm: between INDEX1(pm-1) and pn; pn: between pm and INDEX1(pn+1)
+              const int a = side ? pm : prevA(pm), b = side ? nextA(pn) : pn;
               e = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
             }
             grp_sync();
