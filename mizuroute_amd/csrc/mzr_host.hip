@@ -160,6 +160,8 @@ struct mzr_domain {
   // kwt
   DBuf<int> kwN, obN, kwtLight;
   DBuf<MzrKwtRec> kwtRouted, kwtGeneric;
+  std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list (regrouped by load now and then)
+  long long kwtWindows = 0;                    // KWT windows run since mzr_init_state
   std::vector<int> kwtRoutedOff, kwtGenericOff, kwtLightOff;   // [nStages+1] offsets of each stage in the two lists
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
   DBuf<MzrKwtStat> kwtStat;
@@ -648,6 +650,7 @@ int mzr_init_state(mzr_handle h) {
           if (generic.empty()) generic.push_back(none);
           if (light.empty()) light.push_back(0);
           h->kwtRouted.upload(routed); h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
+          h->h_kwtRouted = routed; h->kwtWindows = 0;
         }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
@@ -666,12 +669,47 @@ int mzr_init_state(mzr_handle h) {
   return 0;
 }
 
+// The order of the reaches inside a stage is free.  A wavefront works on 64/G reaches in lockstep and
+// pays for its busiest one (thinning iterations, second particle slot), and how many particles a
+// reach holds changes slowly, so every now and then the routed list of each stage is regrouped by
+// the particle counts of the last step: saturated reaches share wavefronts, light ones do too.
+static void kwt_regroup(mzr_handle h) {
+  if (h->h_kwtRouted.size() < 2 || !h->kwN.p) return;
+  (void)hipStreamSynchronize(h->stream);
+  const int N = h->N;
+  std::vector<int> n(N), ob((size_t)2 * N);
+  (void)hipMemcpy(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(ob.data(), h->obN.p, (size_t)2 * N * sizeof(int), hipMemcpyDeviceToHost);
+  auto load = [&](const MzrKwtRec &rc) {
+    int l = n[rc.r];
+    for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) l += std::max(ob[rc.u0 + k], ob[(size_t)N + rc.u0 + k]);
+    return l;
+  };
+  std::vector<MzrKwtRec> &v = h->h_kwtRouted;
+  std::vector<std::pair<int, int>> key;
+  std::vector<MzrKwtRec> tmp;
+  for (int sg = 0; sg < h->nStages; ++sg) {
+    const int a = h->kwtRoutedOff[sg], b = h->kwtRoutedOff[sg + 1];
+    if (b - a < 2) continue;
+    key.clear();
+    for (int i = a; i < b; ++i) key.emplace_back(-load(v[i]), i);
+    std::sort(key.begin(), key.end());
+    tmp.assign(v.begin() + a, v.begin() + b);
+    for (int i = a; i < b; ++i) v[i] = tmp[key[i - a].second - a];
+  }
+  (void)hipMemcpy(h->kwtRouted.p, v.data(), v.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+}
+
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   (void)hipSetDevice(h->cfg.device);
+  if (h->kwN.p && W > 1) {   // regroup after the first two windows, then every 8th
+    if (h->kwtWindows == 1 || h->kwtWindows == 2 || (h->kwtWindows & 7) == 0) kwt_regroup(h);
+    ++h->kwtWindows;
+  }
   const int N = h->N;
   hipStream_t st = h->stream;
   MzrDev d; fillDev(h, d);
