@@ -15,62 +15,72 @@
 // fold for the virtual output times W..W+n-2.
 #include "mzr_device.h"
 
-// grid: x over reaches, y over steps of the window
+// grid: x over reaches, y over tiles of BT steps of the window (the HRU list of a reach is read once per tile)
+#define BT 8
 __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
+  const int t0 = blockIdx.y * BT;
   if (r >= d.N) return;
   if (d.haloSlot && d.haloSlot[r] >= 0) return;     // lateral inflow of a halo reach is imported
-  const double *ro = d.runoff + (size_t)t * d.H;
   const int e0 = d.hruOff[r], e1 = d.hruOff[r + 1];
-  double rr;
-  if (e1 > e0) {
-    double acc = 0.0;
-    for (int e = e0; e < e1; ++e) {
-      const double v = ro[d.hruIdx[e]];
-      if (v < d.negRunoffTol) mzr_raise(d, 20, r, t, 1);   // process_remap.f90:397-402
-      acc = acc + d.hruW[e] * v * d.time_conv * d.length_conv;
+  const double area = d.basarea[r];
+  double acc[BT];
+#pragma unroll
+  for (int j = 0; j < BT; ++j) acc[j] = 0.0;
+  for (int e = e0; e < e1; ++e) {
+    const int hx = d.hruIdx[e];
+    const double w = d.hruW[e];
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      if (t0 + j < d.W) {
+        const double v = d.runoff[(size_t)(t0 + j) * d.H + hx];
+        if (v < d.negRunoffTol) mzr_raise(d, 20, r, t0 + j, 1);   // process_remap.f90:397-402
+        acc[j] = acc[j] + w * v * d.time_conv * d.length_conv;
+      }
     }
-    if (acc < d.runoffMin) acc = d.runoffMin;
-    rr = acc * d.basarea[r];
-  } else {
-    rr = d.runoffMin;
   }
-  if (d.doesBasinRoute == 1) d.qi[(size_t)t * d.N + r] = rr;
-  else d.qlat[(size_t)(t + 1) * d.N + r] = rr;            // main_route.f90:223-226
+#pragma unroll
+  for (int j = 0; j < BT; ++j) {
+    const int t = t0 + j;
+    if (t >= d.W) continue;
+    double rr;
+    if (e1 > e0) {
+      double a = acc[j];
+      if (a < d.runoffMin) a = d.runoffMin;
+      rr = a * area;
+    } else {
+      rr = d.runoffMin;
+    }
+    if (d.doesBasinRoute == 1) d.qi[(size_t)t * d.N + r] = rr;
+    else d.qlat[(size_t)(t + 1) * d.N + r] = rr;            // main_route.f90:223-226
+  }
 }
 
 // Register-tiled fold: one lane produces HT consecutive outputs of one reach, so every BASIN_QI
 // value is loaded once per HT outputs instead of once per output (the convolution has ~200 taps at
-// dt = 1 h), with the HT coefficients it meets kept in a sliding register window.  `first` is the
-// step (k_hillslope_out) or virtual step W+j (k_hillslope_state) of output 0; contributions are
-// still added oldest-first per output, so results are unchanged.
-#define HT 8
+// dt = 1 h).  The coefficients sit in LDS, zero-padded by HT on both sides, and are read with a
+// wave-uniform address: tap k of output j at input tau is F[first + j - tau], outside [0, n) it is
+// 0 and the (exact) addition of 0*q stands in for the reference's "no contribution yet".  `first`
+// is the step (k_hillslope_out) or virtual step W+j (k_hillslope_state) of output 0; contributions
+// are still added oldest-first per output, so results are unchanged.
+#define HT 32
+#define MZR_MAX_NTDH_BAS 2048
 template <bool STATE>
-__device__ __forceinline__ void hillslope_tile(const MzrDev &d, int r, int first, int count) {
+__device__ __forceinline__ void hillslope_tile(const MzrDev &d, const double *Fpad, int r, int first, int count, bool active) {
   const int n = d.ntdhBas, N = d.N, W = d.W;
+  if (!active) return;
   const bool lake = d.lakeSlot && d.lakeSlot[r] >= 0;   // lakes: impulse response, basinUH.f90:116-119
-  double acc[HT], f[HT];
+  double acc[HT];
 #pragma unroll
   for (int j = 0; j < HT; ++j) { const int tv = first + j; acc[j] = (j < count && tv < n) ? d.basS0[(size_t)tv * N + r] : 0.0; }
   const int tauHi = STATE ? W - 1 : first + count - 1;          // newest input any output of the tile sees
   int tauLo = first - n + 1; if (tauLo < 0) tauLo = 0;           // oldest input of output 0
   if (!lake) {
-    // f[j] = F[first + j - tau] (0 outside [0, n-1])
-#pragma unroll
-    for (int j = 0; j < HT; ++j) { const int k = first + j - tauLo; f[j] = (k >= 0 && k < n) ? d.fracFuture[k] : 0.0; }
     for (int tau = tauLo; tau <= tauHi; ++tau) {
       const double q = d.qi[(size_t)tau * N + r];
+      const double *F = Fpad + HT + (first - tau);               // F[j] = tap of output j (wave-uniform address)
 #pragma unroll
-      for (int j = 0; j < HT; ++j) {
-        const int k = first + j - tau;                             // tap index of output j
-        if (k >= 0 && k < n && (STATE || tau <= first + j)) acc[j] = acc[j] + f[j] * q;
-      }
-      // slide the window: tap index of every output drops by one
-#pragma unroll
-      for (int j = HT - 1; j > 0; --j) f[j] = f[j - 1];
-      const int k0 = first - tau - 1;
-      f[0] = (k0 >= 0 && k0 < n) ? d.fracFuture[k0] : 0.0;
+      for (int j = 0; j < HT; ++j) acc[j] = acc[j] + F[j] * q;
     }
   } else if (!STATE) {
 #pragma unroll
@@ -84,23 +94,32 @@ __device__ __forceinline__ void hillslope_tile(const MzrDev &d, int r, int first
   }
 }
 
+// FRAC_FUTURE into LDS, zero-padded by HT entries on both sides
+__device__ __forceinline__ void hillslope_coeffs(const MzrDev &d, double *Fpad) {
+  const int n = d.ntdhBas;
+  for (int k = threadIdx.x; k < n + 2 * HT; k += blockDim.x) Fpad[k] = (k >= HT && k < HT + n) ? d.fracFuture[k - HT] : 0.0;
+  __syncthreads();
+}
+
 // grid: x over reaches, y over tiles of HT steps: BASIN_QR(1) of steps [y*HT, y*HT+HT)
 __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
+  __shared__ double Fpad[MZR_MAX_NTDH_BAS + 2 * HT];
+  hillslope_coeffs(d, Fpad);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= d.N) return;
-  if (d.haloSlot && d.haloSlot[r] >= 0) return;
+  const bool active = r < d.N && !(d.haloSlot && d.haloSlot[r] >= 0);
   const int t0 = blockIdx.y * HT;
   const int count = d.W - t0 < HT ? d.W - t0 : HT;
-  hillslope_tile<false>(d, r, t0, count);
+  hillslope_tile<false>(d, Fpad, r, t0, count, active);
 }
 
 // grid: x over reaches, y over tiles of HT register slots: QFUTURE(j+1) after the window
 __global__ void __launch_bounds__(256) k_hillslope_state(MzrDev d) {
+  __shared__ double Fpad[MZR_MAX_NTDH_BAS + 2 * HT];
+  hillslope_coeffs(d, Fpad);
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= d.N) return;
   const int j0 = blockIdx.y * HT;
   const int count = d.ntdhBas - j0 < HT ? d.ntdhBas - j0 : HT;
-  hillslope_tile<true>(d, r, d.W + j0, count);
+  hillslope_tile<true>(d, Fpad, r, d.W + j0, count, r < d.N);
 }
 
 // evaporation / precipitation of the lake reaches through the HRU mapping (main_route.f90:172-200);
@@ -138,7 +157,7 @@ void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const dou
 }
 
 void mzr_launch_basin(const MzrDev &d, hipStream_t stream) {
-  dim3 block(256), grid((d.N + 255) / 256, d.W);
+  dim3 block(256), grid((d.N + 255) / 256, (d.W + BT - 1) / BT);
   hipLaunchKernelGGL(k_basin2reach, grid, block, 0, stream, d);
   if (d.doesBasinRoute == 1) {
     dim3 gridO((d.N + 255) / 256, (d.W + HT - 1) / HT);

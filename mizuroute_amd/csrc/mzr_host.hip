@@ -437,6 +437,7 @@ int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh) {
 
 int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
   if (!h || n < 1) return 1;
+  if (n > 2048) return fail(h, 20, "mzr_set_frac_future/more than 2048 hillslope unit-hydrograph ordinates");
   (void)hipSetDevice(h->cfg.device);
   h->ntdhBas = n;
   try { h->fracFuture.upload(std::vector<double>(frac, frac + n)); } catch (const std::string &e) { return fail(h, 91, "mzr_set_frac_future/" + e); }
