@@ -61,6 +61,8 @@ PROGRAM ref_driver
   integer(i4b) :: ierr, i, j, k, ix, it, nu, nh, io, ib, nb, nr, nw, ntdh, first_err, first_err_step
   integer(i8b) :: c0, c1, crate
   real(dp)     :: wall
+  integer      :: nSkip, envstat
+  character(len=32) :: envbuf
   character(len=strLen) :: message
   real(dp), allocatable :: wbuf(:,:)
   integer(i4b), allocatable :: ibuf(:)
@@ -302,6 +304,10 @@ PROGRAM ref_driver
   ! ---- time loop (standalone/route_runoff.f90:80-108 without I/O)
   first_err = 0; first_err_step = 0
   wall = 0._dp
+  nSkip = 0     ! leading steps that run but are not timed (spin-up), from the environment
+  call get_environment_variable('MZR_REF_SKIP', envbuf, status=envstat)
+  if (envstat == 0) read(envbuf, *, iostat=envstat) nSkip
+  if (envstat /= 0 .or. nSkip < 0 .or. nSkip >= nSteps) nSkip = 0
   do it = 1, nSteps
     iTime = it
     TSEC(1) = t_start + real(it-1, dp)*dt       ! init_model_data.f90:311-312,600
@@ -316,7 +322,7 @@ PROGRAM ref_driver
     call main_route(basinRunoff, basinEvapo, basinPrecip, basinSolute, reachflux, reachvol, ixRch, &
                     river_basin, NETOPO, RPARAM, RCHFLX, RCHSTA, gage_obs, ierr, message)
     call system_clock(c1)
-    wall = wall + real(c1-c0, dp)/real(crate, dp)
+    if (it > nSkip) wall = wall + real(c1-c0, dp)/real(crate, dp)
     if (ierr == 0 .and. harness_last_err /= 0) then
       ierr = harness_last_err; message = harness_last_msg
     end if
@@ -405,5 +411,5 @@ PROGRAM ref_driver
   end do
   close(uout)
   write(*,'(a,i0,a,i0,a,i0,a,f10.4,a,es12.4)') 'ref_route: N=', N, ' steps=', nSteps, ' threads=', nThreads, &
-        ' wall_s=', wall, ' reach_steps_per_s=', real(N,dp)*real(nSteps,dp)*real(nRoutes,dp)/max(wall,1.e-9_dp)
+        ' wall_s=', wall, ' reach_steps_per_s=', real(N,dp)*real(nSteps-nSkip,dp)*real(nRoutes,dp)/max(wall,1.e-9_dp)
 END PROGRAM ref_driver

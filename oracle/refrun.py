@@ -142,14 +142,15 @@ def read_output(path, methods):
     return out
 
 
-def run_case(net, runoff, dt, methods, nthreads=1, keep=None, **kw):
-    """Write a case, run the reference harness, return the parsed dump (+ 'stdout')."""
+def run_case(net, runoff, dt, methods, nthreads=1, keep=None, time_from=0, **kw):
+    """Write a case, run the reference harness, return the parsed dump (+ 'stdout').
+    time_from: leading steps that run but are excluded from reach_steps_per_s (spin-up)."""
     if not available():
         raise FileNotFoundError(EXE)
     tmpdir = keep or tempfile.mkdtemp(prefix="mzrref_")
     case, outp = os.path.join(tmpdir, "case.bin"), os.path.join(tmpdir, "out.bin")
     write_case(case, net, runoff, dt, methods, **kw)
-    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads))
+    env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), MZR_REF_SKIP=str(int(time_from)))
     res = subprocess.run([EXE, case, outp, str(nthreads)], capture_output=True, text=True, env=env)
     if res.returncode != 0:
         raise RuntimeError(f"ref_route failed rc={res.returncode}: {res.stdout}\n{res.stderr}")
