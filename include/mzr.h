@@ -123,6 +123,25 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff);
    handle's stream, errors surface at the next mzr_sync / mzr_get_* call */
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev);
 int mzr_sync(mzr_handle h);
+
+/* Forcing remap in front of basin2reach (get_basin_runoff.f90:86-98 -> process_remap.f90:32-316),
+   for when the hydrologic model's runoff is not on the river-network HRUs.  The mapping-file arrays
+   are passed as the reference holds them (dataTypes.f90:132-143; 1-based indices, -9999 =
+   integerMissing):  kind 1 = runoff on n1 polygons (remap_1D_runoff; qhru_ix, and optionally
+   qhru_id[nOverlap] / src_id[n1] for the reference's id check, ierr 20);  kind 2 = runoff on an
+   n1 x n2 grid stored like the reference's sim2d(n1,n2) (remap_2D_runoff; i_index, j_index).
+   hru_ix[nMap] = position of each mapping row's HRU in the runoff rows given to mzr_run*. */
+int mzr_set_remap(mzr_handle h, int kind, int nMap, const int *hru_ix, const int *num_qhru, int nOverlap,
+                  const int *qhru_ix, const int *i_index, const int *j_index, const double *weight,
+                  int n1, int n2, const long long *qhru_id, const long long *src_id);
+/* runoff already on the river-network HRUs but in file order (sort_flux, process_remap.f90:268-316):
+   ix_in[nSrc] = 1-based HRU position of every file entry (-9999: not in the network) */
+int mzr_set_sort_map(mzr_handle h, int nSrc, const int *ix_in, int remove_negatives);
+/* src_dev [nSteps][n1] or [nSteps][n2][n1] -> dst_dev [nSteps][nHru], both in device memory,
+   asynchronous on the handle's stream */
+int mzr_remap_runoff_dev(mzr_handle h, int nSteps, const double *src_dev, double *dst_dev);
+/* remap + mzr_run_dev in one call: the window's forcing never visits the host */
+int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_dev);
 /* water-management flux REACH_WM_FLUX for the NEXT window: flux[nSteps][nRch] in m3/s, caller's
    reach order; > 0 abstraction, < 0 injection for IRF/KW/MC/DW (irf_route.f90:118-142), Qtake for
    KWT (kwt_route.f90:351-455); -9999 = missing.  Only read when cfg.is_flux_wm = 1

@@ -5,7 +5,7 @@ There is no CPU fallback: creating a RoutingDomain without the library or withou
 """
 from .api import (RoutingDomain, MzrError, lib_path, load_library, build_library,
                   SUM, IRF, KWT, KW, MC, DW)
-from .synthetic import RiverNetwork, make_network, make_runoff, make_star_network
+from .synthetic import RiverNetwork, make_network, make_remap, make_runoff, make_source_runoff, make_star_network
 
 __all__ = ["RoutingDomain", "MzrError", "lib_path", "load_library", "build_library",
-           "RiverNetwork", "make_network", "make_runoff", "make_star_network", "SUM", "IRF", "KWT", "KW", "MC", "DW"]
+           "RiverNetwork", "make_network", "make_remap", "make_runoff", "make_source_runoff", "make_star_network", "SUM", "IRF", "KWT", "KW", "MC", "DW"]

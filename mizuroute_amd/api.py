@@ -50,7 +50,8 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing"]
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing",
+           "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev"]
 
 
 def load_library():
@@ -94,6 +95,10 @@ def load_library():
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
+    L.mzr_set_remap.argtypes = [vp, ci, ci, ip, ip, ci, vp, vp, vp, dp, ci, ci, vp, vp]
+    L.mzr_set_sort_map.argtypes = [vp, ci, ip, ci]
+    L.mzr_remap_runoff_dev.argtypes = [vp, ci, vp, vp]
+    L.mzr_run_src_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_set_lakes.argtypes = [vp, ci, ci, ci, ip, ip, dp]
     L.mzr_set_lake_forcing.argtypes = [vp, ci, dp, dp, ip, ip, ip]
     L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
@@ -291,6 +296,30 @@ class RoutingDomain:
         a, b = C.c_int(0), C.c_int(0)
         self._check(self.L.mzr_get_schedule(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    # ---- forcing remap (process_remap.f90:32-316)
+    def set_remap(self, mp):
+        """mp: mapping-file content as a dict (see synthetic.make_remap): hru_ix, num_qhru, weight, n1, n2
+        and qhru_ix [+ qhru_id, src_id] (polygon vector) or i_index, j_index (grid)."""
+        i32 = lambda k: np.ascontiguousarray(mp[k], dtype=np.int32) if k in mp else None
+        i64 = lambda k: np.ascontiguousarray(mp[k], dtype=np.int64) if k in mp else None
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        kind = 2 if mp.get("n2", 0) > 0 else 1
+        hix, num, w = i32("hru_ix"), i32("num_qhru"), np.ascontiguousarray(mp["weight"], dtype=np.float64)
+        q, ii, jj, qid, sid = i32("qhru_ix"), i32("i_index"), i32("j_index"), i64("qhru_id"), i64("src_id")
+        self._check(self.L.mzr_set_remap(self.h, kind, hix.size, hix, num, w.size, ptr(q), ptr(ii), ptr(jj), w,
+                                         int(mp["n1"]), int(mp.get("n2", 0)), ptr(qid), ptr(sid)))
+
+    def set_sort_map(self, ix_in, remove_negatives=True):
+        ix = np.ascontiguousarray(ix_in, dtype=np.int32)
+        self._check(self.L.mzr_set_sort_map(self.h, ix.size, ix, int(bool(remove_negatives))))
+
+    def remap_device(self, n_steps, src_dev_ptr, dst_dev_ptr):
+        self._check(self.L.mzr_remap_runoff_dev(self.h, int(n_steps), C.c_void_p(int(src_dev_ptr)), C.c_void_p(int(dst_dev_ptr))))
+
+    def run_source_device(self, n_steps, t_start, src_dev_ptr):
+        """remap + run of one window from the hydrologic model's own runoff layer (device memory)."""
+        self._check(self.L.mzr_run_src_dev(self.h, int(n_steps), float(t_start), C.c_void_p(int(src_dev_ptr))))
 
     def set_profiling(self, mode):
         """mode: 0 off, 1 HIP events around every stage launch (timing()), 2 KWT particle-traffic

@@ -533,7 +533,7 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 #define MZR_KWT_G 16   // lanes per routed reach (4, 8, 16, 32 or 64)
 #endif
 template <bool FULL, bool GEN, int G, int POOL>
-__global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
+__global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : MZR_KWT_OCC, GEN ? 2 : MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
   constexpr int RPW = 64 / G;
   constexpr int KS = (MZR_KW_CAP + G - 1) / G;   // slots per lane for <= 20 entries
   constexpr int OS = (MZR_OB_CAP + G - 1) / G;   // ... for one outbox row

@@ -24,6 +24,11 @@ void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
                              double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
+int mzr_remap_ld(int nSteps);
+void mzr_launch_remap(int H, int nSteps, int nSrc, const int *rowStart, const int *rowCnt, const int *srcIdx,
+                      const double *weight, const double *src, double *srcT, double *dst, hipStream_t stream);
+void mzr_launch_sort_flux(int H, int nSteps, int nSrc, const int *srcOf, int removeNegatives, const double *src, double *dst,
+                          hipStream_t stream);
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream);
 
 namespace {
@@ -176,6 +181,11 @@ struct mzr_domain {
   std::vector<int> h_expInt, h_haloInt, h_haloGood, h_haloSlot;
   DBuf<int> haloSlot, exportSlot, expInt, haloInt, imN, exN;
   DBuf<double> imOQ, imOT, exOQ, exOT;
+  // forcing remap (0 = none, 1 = polygon vector, 2 = grid, 3 = sort_flux)
+  int remapKind = 0, remapSrc = 0, remapRemoveNeg = 1;
+  DBuf<int> rmRowStart, rmRowCnt, rmSrcIdx;
+  DBuf<double> rmWeight, rmScratch;   // rmScratch: the window transposed to [cell][step]
+  size_t rmScratchLen = 0;
   DBuf<MzrErr> err;
   RouteBufs route[6];
   bool profiling = false;       // HIP events around every stage launch
@@ -794,6 +804,90 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
   const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
   if (rc) return rc;
   return mzr_sync(h);
+}
+
+int mzr_set_remap(mzr_handle h, int kind, int nMap, const int *hru_ix, const int *num_qhru, int nOverlap, const int *qhru_ix,
+                  const int *i_index, const int *j_index, const double *weight, int n1, int n2,
+                  const long long *qhru_id, const long long *src_id) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_remap/network not set") : 1;
+  if (kind != 1 && kind != 2) return fail(h, 20, "mzr_set_remap/kind must be 1 (polygon vector) or 2 (grid)");
+  if ((kind == 1 && !qhru_ix) || (kind == 2 && (!i_index || !j_index || n2 < 1)) || n1 < 1) return fail(h, 20, "mzr_set_remap/missing index arrays");
+  (void)hipSetDevice(h->cfg.device);
+  const int H = h->H, IMISS = -9999;   // integerMissing, public_var.f90:44
+  std::vector<int> rowStart(H, 0), rowCnt(H, -1), srcIdx((size_t)std::max(nOverlap, 1), -1);
+  long long cur = 0;   // the reference's running ixOverlap (0-based)
+  for (int i = 0; i < nMap; ++i) {
+    const int j = hru_ix[i];
+    if (j == IMISS) { if (num_qhru[i] != IMISS) cur += num_qhru[i]; continue; }   // process_remap.f90:189-194
+    if (j < 1 || j > H) return fail(h, 20, "mzr_set_remap/hru_ix out of range");
+    const int n = num_qhru[i] > 0 ? num_qhru[i] : 0;
+    if (cur + n > nOverlap) return fail(h, 20, "mzr_set_remap/num_qhru runs past the overlap arrays");
+    rowStart[j - 1] = (int)cur; rowCnt[j - 1] = n;      // a later row that names the same HRU overwrites it
+    for (int k = 0; k < n; ++k) {
+      const size_t e = (size_t)cur + k;
+      if (kind == 1) {
+        const int q = qhru_ix[e];
+        if (q == IMISS) { srcIdx[e] = -1; continue; }
+        if (q < 1 || q > n1) return fail(h, 20, "mzr_set_remap/qhru_ix out of range");
+        if (qhru_id && src_id && qhru_id[e] != src_id[q - 1])
+          return fail(h, 20, "remap_runoff/remap_1D_runoff/mismatch in HRU ids for polygons in the runoff layer");
+        srcIdx[e] = q - 1;
+      } else {
+        const int ii = i_index[e], jj = j_index[e];
+        srcIdx[e] = (ii < 1 || ii > n1 || jj < 1 || jj > n2) ? -1 : (jj - 1) * n1 + (ii - 1);
+      }
+    }
+    cur += n;
+  }
+  try {
+    h->rmRowStart.upload(rowStart); h->rmRowCnt.upload(rowCnt); h->rmSrcIdx.upload(srcIdx);
+    h->rmWeight.upload(std::vector<double>(weight, weight + std::max(nOverlap, 1)));
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_remap/" + e); }
+  h->remapKind = kind; h->remapSrc = kind == 1 ? n1 : n1 * n2;
+  return 0;
+}
+
+int mzr_set_sort_map(mzr_handle h, int nSrc, const int *ix_in, int remove_negatives) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_sort_map/network not set") : 1;
+  if (nSrc < 1 || !ix_in) return fail(h, 20, "mzr_set_sort_map/empty map");
+  (void)hipSetDevice(h->cfg.device);
+  std::vector<int> srcOf(h->H, -1);
+  for (int i = 0; i < nSrc; ++i) {
+    const int j = ix_in[i];
+    if (j == -9999) continue;                        // process_remap.f90:304-307
+    if (j < 1 || j > h->H) return fail(h, 20, "mzr_set_sort_map/index out of range");
+    srcOf[j - 1] = i;
+  }
+  try { h->rmRowStart.upload(srcOf); } catch (const std::string &e) { return fail(h, 91, "mzr_set_sort_map/" + e); }
+  h->remapKind = 3; h->remapSrc = nSrc; h->remapRemoveNeg = remove_negatives != 0;
+  return 0;
+}
+
+int mzr_remap_runoff_dev(mzr_handle h, int nSteps, const double *src_dev, double *dst_dev) {
+  if (!h || !h->remapKind) return h ? fail(h, 20, "mzr_remap_runoff/no mapping set (mzr_set_remap / mzr_set_sort_map)") : 1;
+  if (nSteps < 1) return fail(h, 20, "mzr_remap_runoff/nSteps must be positive");
+  (void)hipSetDevice(h->cfg.device);
+  if (h->remapKind == 3) mzr_launch_sort_flux(h->H, nSteps, h->remapSrc, h->rmRowStart.p, h->remapRemoveNeg, src_dev, dst_dev, h->stream);
+  else {
+    const size_t need = (size_t)h->remapSrc * mzr_remap_ld(nSteps);
+    if (need > h->rmScratchLen) {
+      (void)hipStreamSynchronize(h->stream);
+      try { h->rmScratch.alloc(need); } catch (const std::string &e) { return fail(h, 91, "mzr_remap_runoff/" + e); }
+      h->rmScratchLen = need;
+    }
+    mzr_launch_remap(h->H, nSteps, h->remapSrc, h->rmRowStart.p, h->rmRowCnt.p, h->rmSrcIdx.p, h->rmWeight.p, src_dev, h->rmScratch.p, dst_dev, h->stream);
+  }
+  if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_remap_runoff/kernel launch failed");
+  return 0;
+}
+
+int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_dev) {
+  if (!h) return 1;
+  if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
+  const int rc = mzr_remap_runoff_dev(h, nSteps, src_dev, h->runoffW.p);
+  if (rc) return rc;
+  return run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
 }
 
 int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {

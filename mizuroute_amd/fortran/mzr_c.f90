@@ -35,6 +35,7 @@ MODULE mzr_c
             mzr_get_window_q, mzr_get_mean_q, mzr_get_kwt_state, mzr_set_kwt_state, mzr_get_irf_state, &
             mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule, mzr_set_boundary, mzr_boundary_size, &
             mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
+            mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_lakes, mzr_set_lake_forcing
   public :: mzr_message
 
@@ -199,6 +200,33 @@ MODULE mzr_c
     integer(c_int) function mzr_run_dev(h, nSteps, t_start, runoff_dev) bind(C, name='mzr_run_dev')
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h, runoff_dev
+      integer(c_int), value :: nSteps
+      real(c_double), value :: t_start
+    end function
+    ! forcing remap (process_remap.f90:32-316): remap_data as the reference holds it; pass c_null_ptr for the
+    ! index arrays of the other kind and for the optional id arrays
+    integer(c_int) function mzr_set_remap(h, kind, nMap, hru_ix, num_qhru, nOverlap, qhru_ix, i_index, j_index, weight, &
+                                          n1, n2, qhru_id, src_id) bind(C, name='mzr_set_remap')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h, qhru_ix, i_index, j_index, qhru_id, src_id
+      integer(c_int), value :: kind, nMap, nOverlap, n1, n2
+      integer(c_int), intent(in) :: hru_ix(*), num_qhru(*)
+      real(c_double), intent(in) :: weight(*)
+    end function
+    integer(c_int) function mzr_set_sort_map(h, nSrc, ix_in, remove_negatives) bind(C, name='mzr_set_sort_map')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSrc, remove_negatives
+      integer(c_int), intent(in) :: ix_in(*)
+    end function
+    integer(c_int) function mzr_remap_runoff_dev(h, nSteps, src_dev, dst_dev) bind(C, name='mzr_remap_runoff_dev')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, src_dev, dst_dev
+      integer(c_int), value :: nSteps
+    end function
+    integer(c_int) function mzr_run_src_dev(h, nSteps, t_start, src_dev) bind(C, name='mzr_run_src_dev')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h, src_dev
       integer(c_int), value :: nSteps
       real(c_double), value :: t_start
     end function

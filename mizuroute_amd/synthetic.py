@@ -236,6 +236,59 @@ def make_star_network(k: int = 5, depth: int = 6, seed: int = 0, identical: bool
                         hruWeight=np.ones(N), params=params)
 
 
+IMISS = -9999   # integerMissing, public_var.f90:44
+
+
+def make_remap(H: int, n1: int, n2: int = 0, seed: int = 0, max_overlap: int = 6, missing_frac: float = 0.03) -> dict:
+    """A mapping file's content (dataTypes.f90:132-143) from a runoff layer to H river-network HRUs:
+    n2 = 0: the runoff layer is a vector of n1 polygons (remap_1D_runoff); n2 > 0: an n1 x n2 grid
+    (remap_2D_runoff).  Rows come in shuffled order, a few rows name HRUs that are not in the network
+    (hru_ix = integerMissing), a few overlaps name polygons/cells that are not in the runoff file,
+    most rows have weights that sum to one and some do not (the renormalisation branch)."""
+    rng = np.random.default_rng(seed)
+    n_extra = max(1, int(missing_frac * H))
+    hru_ix = np.concatenate([rng.permutation(H) + 1, np.full(n_extra, IMISS)]).astype(np.int32)
+    hru_ix = hru_ix[rng.permutation(hru_ix.size)]
+    nMap = hru_ix.size
+    num = rng.integers(0, max_overlap + 1, nMap).astype(np.int32)
+    num[rng.random(nMap) < 0.01] = 0
+    extra = np.nonzero(hru_ix == IMISS)[0]
+    if extra.size:
+        num[extra[0]] = IMISS                      # "num_qhru missing too": the cursor does not advance
+    n_ov = int(num[num > 0].sum())
+    w = rng.random(n_ov) + 0.05
+    row = np.repeat(np.arange(nMap)[num > 0], num[num > 0])
+    tot = np.bincount(row, weights=w, minlength=nMap)
+    norm = rng.random(nMap) < 0.8                   # these rows carry normalised weights
+    w = np.where(norm[row], w / tot[row], w)
+    out = dict(hru_ix=hru_ix, num_qhru=num, weight=w, n1=n1, n2=n2, H=H)
+    if n2 == 0:
+        q = rng.integers(1, n1 + 1, n_ov).astype(np.int32)
+        src_id = (rng.permutation(n1) + 700001).astype(np.int64)
+        qid = src_id[q - 1].copy()
+        q[rng.random(n_ov) < missing_frac] = IMISS
+        out.update(qhru_ix=q, qhru_id=qid, src_id=src_id)
+    else:
+        ii = rng.integers(1, n1 + 1, n_ov).astype(np.int32)
+        jj = rng.integers(1, n2 + 1, n_ov).astype(np.int32)
+        bad = rng.random(n_ov) < missing_frac        # cells outside the runoff grid
+        ii[bad & (rng.random(n_ov) < 0.5)] = n1 + 3
+        jj[bad & (ii <= n1)] = 0
+        out.update(i_index=ii, j_index=jj)
+    return out
+
+
+def make_source_runoff(n_steps: int, n1: int, n2: int = 0, seed: int = 0) -> np.ndarray:
+    """runoff of the hydrologic model's own layer, [n_steps, n1] or [n_steps, n2, n1] (grid rows in the
+    reference's memory order), with a few negative / fill values that the remap must skip."""
+    rng = np.random.default_rng(seed)
+    shape = (n_steps, n1) if n2 == 0 else (n_steps, n2, n1)
+    ro = 1e-8 * (1.0 + rng.random(shape)) + np.where(rng.random(shape) < 0.02, 1e-6 * rng.random(shape), 0.0)
+    ro[rng.random(shape) < 0.02] = -9999.0
+    ro[rng.random(shape) < 0.01] = -1e-7            # inside the tolerance (-1e-6): still used
+    return np.ascontiguousarray(ro)
+
+
 def make_runoff(H: int, n_steps: int, seed: int = 7, t0: int = 0, base: float = 1e-8,
                 storm_prob: float = 0.01, storm_amp: float = 1e-6) -> np.ndarray:
     """runoff[t, h] in m/s: low seasonal base flow plus sparse storm pulses."""

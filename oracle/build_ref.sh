@@ -29,6 +29,9 @@ for f in $SRCS; do
   OBJS="$OBJS $o"
 done
 $FC $FFLAGS $OBJS -o "$OUT/ref_route"
+# second harness: the reference's forcing remap (remap_runoff, sort_flux) on its own
+$FC $FFLAGS -c "$H/ref_remap_driver.f90" -o ref_remap_driver.o
+$FC $FFLAGS ${OBJS/ ref_driver.o/} ref_remap_driver.o -o "$OUT/ref_remap"
 $FC --version | head -1 > "$OUT/BUILD_INFO.txt"
 echo "flags: $FFLAGS" >> "$OUT/BUILD_INFO.txt"
-echo "built $OUT/ref_route"
+echo "built $OUT/ref_route $OUT/ref_remap"

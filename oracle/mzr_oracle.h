@@ -22,6 +22,7 @@
  *   dfw_route.f90:49-370, kwe_route.f90:46-363, advection_diffusion.f90:19-258   DW / KW
  *   hydraulic.f90:46-535       channel geometry, Newton normal depth, celerity, diffusivity
  *   water_balance.f90:22-112   per-reach water balance
+ *   process_remap.f90:58-316   forcing remap (remap_1D/2D_runoff, sort_flux) -- orc_remap.c
  */
 #ifndef MZR_ORACLE_H
 #define MZR_ORACLE_H
@@ -88,6 +89,14 @@ int orc_get_basin_state(const orc_t *o, double *qfuture /* [N][ntdhBas] */);
 /* statistics for the roofline model: particles read/written by KWT in the last step */
 int orc_get_kwt_traffic(const orc_t *o, long long *w_in, long long *w_up, long long *w_out,
                         long long *n_head, long long *n_route, long long *n_edges);
+
+/* forcing remap in front of basin2reach (process_remap.f90:58-316), one time step per call */
+int orc_remap_1d(int nMap, const int *hru_ix, const int *num_qhru, const int *qhru_ix,
+                 const long long *qhru_id, const long long *src_id, const double *weight,
+                 const double *sim, double *basinRunoff);
+int orc_remap_2d(int nMap, const int *hru_ix, const int *num_qhru, const int *i_index, const int *j_index,
+                 const double *weight, int n1, int n2, const double *sim2d, double *basinRunoff);
+int orc_sort_flux(int nIn, const int *ix_in, const double *flux_in, int remove_negatives, int nOut, double *sorted_flux);
 
 /* counts of the less common kwt_rch branches taken since creation, out[9] (see orc_internal.h) */
 int orc_get_kwt_paths(const orc_t *o, long long *out);

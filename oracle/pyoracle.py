@@ -171,3 +171,43 @@ class Oracle:
         v = [C.c_longlong(0) for _ in range(6)]
         lib().orc_get_kwt_traffic(self.h, *[C.byref(x) for x in v])
         return dict(zip(("w_in", "w_up", "w_out", "n_head", "n_route", "n_edges"), [x.value for x in v]))
+
+
+def _ip(a):
+    return np.ascontiguousarray(a, dtype=np.int32).ctypes.data_as(C.POINTER(C.c_int))
+
+
+def remap_runoff(mp, sim):
+    """process_remap.f90 remap_runoff over a series: sim [nSteps, n1] (1-D) or [nSteps, n2, n1] (grid);
+    returns (ierr, basinRunoff[nSteps, H]) with the array carried from step to step like the reference's."""
+    L = lib()
+    dp = C.POINTER(C.c_double); lp = C.POINTER(C.c_longlong)
+    sim = np.ascontiguousarray(sim, dtype=np.float64)
+    H = int(mp["H"]); nSteps = sim.shape[0]
+    out = np.zeros((nSteps, H)); cur = np.zeros(H)
+    w = np.ascontiguousarray(mp["weight"], dtype=np.float64)
+    hix, num = _ip(mp["hru_ix"]), _ip(mp["num_qhru"])
+    rc = 0
+    for t in range(nSteps):
+        if sim.ndim == 2:
+            qid = np.ascontiguousarray(mp["qhru_id"], dtype=np.int64); sid = np.ascontiguousarray(mp["src_id"], dtype=np.int64)
+            L.orc_remap_1d.restype = C.c_int
+            r = L.orc_remap_1d(C.c_int(len(mp["hru_ix"])), hix, num, _ip(mp["qhru_ix"]), qid.ctypes.data_as(lp), sid.ctypes.data_as(lp),
+                               w.ctypes.data_as(dp), sim[t].ctypes.data_as(dp), cur.ctypes.data_as(dp))
+        else:
+            r = L.orc_remap_2d(C.c_int(len(mp["hru_ix"])), hix, num, _ip(mp["i_index"]), _ip(mp["j_index"]), w.ctypes.data_as(dp),
+                               C.c_int(sim.shape[2]), C.c_int(sim.shape[1]), sim[t].ctypes.data_as(dp), cur.ctypes.data_as(dp))
+        rc = rc or r
+        out[t] = cur
+    return rc, out
+
+
+def sort_flux(ix_in, flux, H, remove_negatives=True):
+    """process_remap.f90 sort_flux over a series: flux [nSteps, nIn] -> [nSteps, H]."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    flux = np.ascontiguousarray(flux, dtype=np.float64)
+    out = np.zeros((flux.shape[0], H))
+    for t in range(flux.shape[0]):
+        L.orc_sort_flux(C.c_int(flux.shape[1]), _ip(ix_in), flux[t].ctypes.data_as(dp), C.c_int(int(remove_negatives)), C.c_int(H), out[t].ctypes.data_as(dp))
+    return out

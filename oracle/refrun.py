@@ -161,3 +161,50 @@ def run_case(net, runoff, dt, methods, nthreads=1, keep=None, time_from=0, **kw)
     if keep is None:
         os.remove(case); os.remove(outp); os.rmdir(tmpdir)
     return out
+
+
+# ---- forcing remap harness (oracle/_ref/ref_remap: the reference's remap_runoff / sort_flux) ----------
+EXE_REMAP = os.path.join(HERE, "_ref", "ref_remap")
+MAGIC_REMAP = 1380798800
+
+
+def remap_available() -> bool:
+    return os.path.exists(EXE_REMAP) and os.access(EXE_REMAP, os.X_OK)
+
+
+def run_remap(mp, sim, kind=None, remove_negatives=True):
+    """mp: dict from mizuroute_amd.synthetic.make_remap (kind 1/2) or dict(ix_in=..., H=...) (kind 3).
+    sim: [nSteps, n1] or [nSteps, n2, n1].  Returns (ierr, basinRunoff[nSteps, H])."""
+    if kind is None:
+        kind = 3 if "ix_in" in mp else (2 if mp.get("n2", 0) > 0 else 1)
+    nSteps = sim.shape[0]
+    n1 = sim.shape[-1]
+    n2 = sim.shape[1] if kind == 2 else 0
+    H = int(mp["H"])
+    tmpdir = tempfile.mkdtemp(prefix="mzrremap_")
+    case, outp = os.path.join(tmpdir, "case.bin"), os.path.join(tmpdir, "out.bin")
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).tobytes()
+    with open(case, "wb") as f:
+        nMap = len(mp["hru_ix"]) if kind != 3 else 0
+        nOv = len(mp["weight"]) if kind != 3 else 0
+        f.write(struct.pack("9i", MAGIC_REMAP, kind, nMap, nOv, n1, n2, H, nSteps, int(bool(remove_negatives))))
+        if kind in (1, 2):
+            f.write(i32(mp["hru_ix"])); f.write(i32(mp["num_qhru"]))
+            if kind == 1:
+                f.write(i32(mp["qhru_ix"]))
+                f.write(np.ascontiguousarray(mp["qhru_id"], dtype=np.int64).tobytes())
+                f.write(np.ascontiguousarray(mp["src_id"], dtype=np.int64).tobytes())
+            else:
+                f.write(i32(mp["i_index"])); f.write(i32(mp["j_index"]))
+            f.write(np.ascontiguousarray(mp["weight"], dtype=np.float64).tobytes())
+        else:
+            f.write(i32(mp["ix_in"]))
+        f.write(np.ascontiguousarray(sim, dtype=np.float64).tobytes())
+    res = subprocess.run([EXE_REMAP, case, outp], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"ref_remap failed rc={res.returncode}: {res.stdout}\n{res.stderr}")
+    raw = open(outp, "rb").read()
+    ierr = struct.unpack("i", raw[:4])[0]
+    out = np.frombuffer(raw, dtype=np.float64, offset=4, count=H * nSteps).reshape(nSteps, H).copy()
+    os.remove(case); os.remove(outp); os.rmdir(tmpdir)
+    return ierr, out

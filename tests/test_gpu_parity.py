@@ -305,3 +305,59 @@ def test_water_management_fluxes(hip_lib, oracle_lib):
     with pytest.raises(m.MzrError):
         dom2.L.mzr_run  # noqa: B018
         dom2._check(dom2.L.mzr_run(dom2.h, 1, 0.0, np.ascontiguousarray(ro[:1])))
+
+
+# ---- forcing remap (process_remap.f90:32-316): integer gather + ordered FP64 sums -> bit-exact -----------
+@pytest.mark.parametrize("n1,n2,seed", [(2500, 0, 4), (90, 64, 6)])
+def test_remap_runoff_vs_oracle(n1, n2, seed, hip_lib, oracle_lib):
+    import torch
+    from mizuroute_amd.synthetic import make_remap, make_source_runoff
+    net = m.make_network(3000, seed=2)
+    mp = make_remap(net.H, n1, n2, seed=seed)
+    steps = 21
+    sim = make_source_runoff(steps, n1, n2, seed=seed + 1)
+    rc, want = oracle_lib.remap_runoff(mp, sim)
+    assert rc == 0
+    kw = dict(frac_future=np.array([0.6, 0.4]), uh_offset=np.arange(0, 2 * net.N + 1, 2, dtype=np.int32),
+              uh=np.tile(np.array([0.7, 0.3]), net.N), max_window=32)   # IRF: HRUs without a mapping row carry zero runoff
+    dom = m.RoutingDomain(net, 3600.0, [m.IRF], **kw)
+    dom.set_remap(mp)
+    src = torch.from_numpy(sim).cuda()
+    dst = torch.full((steps, net.H), -1.0, dtype=torch.float64, device="cuda")
+    dom.remap_device(steps, src.data_ptr(), dst.data_ptr())
+    dom.sync()
+    assert np.array_equal(dst.cpu().numpy(), want)
+    # remap + routing in one call == routing of the remapped runoff
+    a = dom.run(want)
+    b = m.RoutingDomain(net, 3600.0, [m.IRF], **kw)
+    b.set_remap(mp)
+    b.run_source_device(steps, 0.0, src.data_ptr())
+    b.sync()
+    assert np.array_equal(b.window_q(m.IRF, steps), a[:, 0])
+    # the reference's id check surfaces as its error
+    bad = dict(mp)
+    if n2 == 0:
+        bad["qhru_id"] = mp["qhru_id"].copy()
+        bad["qhru_id"][int(np.nonzero(mp["qhru_ix"] > 0)[0][7])] += 1
+        with pytest.raises(m.MzrError) as e:
+            dom.set_remap(bad)
+        assert e.value.ierr == 20 and "mismatch in HRU ids" in str(e.value)
+
+
+def test_sort_flux_vs_oracle(hip_lib, oracle_lib):
+    import torch
+    from mizuroute_amd.synthetic import make_source_runoff
+    net = m.make_network(520, seed=2)
+    rng = np.random.default_rng(1)
+    ix = (rng.permutation(500) + 1).astype(np.int32)
+    ix[::17] = -9999
+    ix[3] = ix[4]
+    fl = make_source_runoff(5, 500, 0, seed=6)
+    dom = m.RoutingDomain(net, 3600.0, [m.IRF], frac_future=np.array([1.0]), uh_offset=np.arange(net.N + 1, dtype=np.int32), uh=np.ones(net.N))
+    src = torch.from_numpy(fl).cuda()
+    dst = torch.empty((5, net.H), dtype=torch.float64, device="cuda")
+    for rmneg in (True, False):
+        dom.set_sort_map(ix, rmneg)
+        dom.remap_device(5, src.data_ptr(), dst.data_ptr())
+        dom.sync()
+        assert np.array_equal(dst.cpu().numpy(), oracle_lib.sort_flux(ix, fl, net.H, remove_negatives=rmneg))

@@ -124,3 +124,46 @@ def test_lakes_bit_exact(memory, opt, cal, start, oracle_lib):
         orc.set_lakes(lakes)
         Q, V = orc.run_lake(ro, lakes, want_vol=True)
         assert np.array_equal(Q, out["Q"]) and np.array_equal(V, out["VOL"]), methods
+
+
+# ---- forcing remap (process_remap.f90:32-316) against the reference's own routines -------------------
+@pytest.mark.parametrize("H,n1,n2,seed", [(500, 700, 0, 3), (3000, 2500, 0, 4), (800, 40, 30, 5), (2000, 90, 64, 6)])
+def test_remap_runoff_bit_exact(H, n1, n2, seed, oracle_lib):
+    from mizuroute_amd.synthetic import make_remap, make_source_runoff
+    if not refrun.remap_available():
+        pytest.skip("oracle/_ref/ref_remap not built")
+    mp = make_remap(H, n1, n2, seed=seed)
+    sim = make_source_runoff(6, n1, n2, seed=seed + 1)
+    ierr, ref = refrun.run_remap(mp, sim)
+    rc, orc = oracle_lib.remap_runoff(mp, sim)
+    assert ierr == 0 and rc == 0
+    assert np.array_equal(ref, orc)
+    assert (orc != 0).mean() > 0.5
+
+
+def test_remap_id_mismatch_is_the_reference_error(oracle_lib):
+    from mizuroute_amd.synthetic import make_remap, make_source_runoff
+    if not refrun.remap_available():
+        pytest.skip("oracle/_ref/ref_remap not built")
+    mp = make_remap(300, 400, 0, seed=8)
+    k = int(np.nonzero(mp["qhru_ix"] > 0)[0][50])
+    mp["qhru_id"][k] += 1                      # process_remap.f90:217-220 -> ierr = 20
+    sim = make_source_runoff(2, 400, 0, seed=9)
+    ierr, _ = refrun.run_remap(mp, sim)
+    rc, _ = oracle_lib.remap_runoff(mp, sim)
+    assert ierr == 20 and rc == 20
+
+
+def test_sort_flux_bit_exact(oracle_lib):
+    from mizuroute_amd.synthetic import make_source_runoff
+    if not refrun.remap_available():
+        pytest.skip("oracle/_ref/ref_remap not built")
+    rng = np.random.default_rng(1)
+    ix = (rng.permutation(500) + 1).astype(np.int32)
+    ix[::17] = -9999
+    ix[3] = ix[4]                                 # two file entries for one HRU: the later one wins
+    fl = make_source_runoff(3, 500, 0, seed=6)
+    for rm in (True, False):
+        ierr, ref = refrun.run_remap(dict(ix_in=ix, H=520), fl, remove_negatives=rm)
+        assert ierr == 0
+        assert np.array_equal(ref, oracle_lib.sort_flux(ix, fl, 520, remove_negatives=rm))
