@@ -58,15 +58,18 @@ __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
 
 // Register-tiled fold: one lane produces HT consecutive outputs of one reach, so every BASIN_QI
 // value is loaded once per HT outputs instead of once per output (the convolution has ~200 taps at
-// dt = 1 h).  The coefficients sit in LDS, zero-padded by HT on both sides, and are read with a
-// wave-uniform address: tap k of output j at input tau is F[first + j - tau], outside [0, n) it is
+// dt = 1 h).  The coefficients sit in a copy zero-padded by HT on both sides (fracPad) and are read
+// with a wave-uniform address: tap k of output j at input tau is F[first + j - tau], outside [0, n) it is
 // 0 and the (exact) addition of 0*q stands in for the reference's "no contribution yet".  `first`
 // is the step (k_hillslope_out) or virtual step W+j (k_hillslope_state) of output 0; contributions
 // are still added oldest-first per output, so results are unchanged.
 #define HT 32
-#define MZR_MAX_NTDH_BAS 2048
+// wave-uniform reads through the scalar cache: a pointer into the constant address space makes the
+// compiler issue s_load for a uniform address, so the coefficients arrive in SGPRs and cost neither
+// LDS bandwidth (one LDS serves four SIMDs) nor vector registers
+typedef const double __attribute__((address_space(4))) *mzr_cptr;
 template <bool STATE>
-__device__ __forceinline__ void hillslope_tile(const MzrDev &d, const double *Fpad, int r, int first, int count, bool active) {
+__device__ __forceinline__ void hillslope_tile(const MzrDev &d, mzr_cptr Fpad, int r, int first, int count, bool active) {
   const int n = d.ntdhBas, N = d.N, W = d.W;
   if (!active) return;
   const bool lake = d.lakeSlot && d.lakeSlot[r] >= 0;   // lakes: impulse response, basinUH.f90:116-119
@@ -78,7 +81,7 @@ __device__ __forceinline__ void hillslope_tile(const MzrDev &d, const double *Fp
   if (!lake) {
     for (int tau = tauLo; tau <= tauHi; ++tau) {
       const double q = d.qi[(size_t)tau * N + r];
-      const double *F = Fpad + HT + (first - tau);               // F[j] = tap of output j (wave-uniform address)
+      mzr_cptr F = Fpad + HT + (first - tau);                    // F[j] = tap of output j (wave-uniform address)
 #pragma unroll
       for (int j = 0; j < HT; ++j) acc[j] = acc[j] + F[j] * q;
     }
@@ -94,17 +97,9 @@ __device__ __forceinline__ void hillslope_tile(const MzrDev &d, const double *Fp
   }
 }
 
-// FRAC_FUTURE into LDS, zero-padded by HT entries on both sides
-__device__ __forceinline__ void hillslope_coeffs(const MzrDev &d, double *Fpad) {
-  const int n = d.ntdhBas;
-  for (int k = threadIdx.x; k < n + 2 * HT; k += blockDim.x) Fpad[k] = (k >= HT && k < HT + n) ? d.fracFuture[k - HT] : 0.0;
-  __syncthreads();
-}
-
 // grid: x over reaches, y over tiles of HT steps: BASIN_QR(1) of steps [y*HT, y*HT+HT)
 __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
-  __shared__ double Fpad[MZR_MAX_NTDH_BAS + 2 * HT];
-  hillslope_coeffs(d, Fpad);
+  const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = r < d.N && !(d.haloSlot && d.haloSlot[r] >= 0);
   const int t0 = blockIdx.y * HT;
@@ -114,8 +109,7 @@ __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
 
 // grid: x over reaches, y over tiles of HT register slots: QFUTURE(j+1) after the window
 __global__ void __launch_bounds__(256) k_hillslope_state(MzrDev d) {
-  __shared__ double Fpad[MZR_MAX_NTDH_BAS + 2 * HT];
-  hillslope_coeffs(d, Fpad);
+  const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int j0 = blockIdx.y * HT;
   const int count = d.ntdhBas - j0 < HT ? d.ntdhBas - j0 : HT;

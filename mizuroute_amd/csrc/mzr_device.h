@@ -72,6 +72,7 @@ struct MzrDev {
   // ---- hillslope
   int ntdhBas;
   const double *fracFuture;   // [ntdhBas]
+  const double *fracPad;      // [32 + ntdhBas + 32] the same, zero-padded by the hillslope tile size on both sides
   const double *runoff;       // [W][H]
   double *qi;                 // [W][N] BASIN_QI per step
   double *qlat;               // [W+1][N] BASIN_QR(1); row 0 = value before the window

@@ -153,7 +153,7 @@ struct mzr_domain {
   }
   // unit hydrographs
   int ntdhBas = 0, maxtdh = 0;
-  DBuf<double> fracFuture, uh, irfQ;
+  DBuf<double> fracFuture, fracPad, uh, irfQ;
   DBuf<uint16_t> ntdh;
   std::vector<int> uhOff;
   // window buffers
@@ -216,7 +216,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
   d.is_flux_wm = h->cfg.is_flux_wm; d.wm = (h->cfg.is_flux_wm && h->wmSteps > 0) ? h->wm.p : nullptr;
-  d.ntdhBas = h->ntdhBas; d.fracFuture = h->fracFuture.p;
+  d.ntdhBas = h->ntdhBas; d.fracFuture = h->fracFuture.p; d.fracPad = h->fracPad.p;
   d.qi = h->qi.p; d.qlat = h->qlat.p;
   d.basS0 = h->basS[h->basCur].p; d.basS1 = h->basS[h->basCur ^ 1].p;
   d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
@@ -447,10 +447,14 @@ int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh) {
 
 int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
   if (!h || n < 1) return 1;
-  if (n > 2048) return fail(h, 20, "mzr_set_frac_future/more than 2048 hillslope unit-hydrograph ordinates");
   (void)hipSetDevice(h->cfg.device);
   h->ntdhBas = n;
-  try { h->fracFuture.upload(std::vector<double>(frac, frac + n)); } catch (const std::string &e) { return fail(h, 91, "mzr_set_frac_future/" + e); }
+  try {
+    h->fracFuture.upload(std::vector<double>(frac, frac + n));
+    std::vector<double> pad((size_t)n + 64, 0.0);
+    for (int k = 0; k < n; ++k) pad[32 + k] = frac[k];
+    h->fracPad.upload(pad);
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_frac_future/" + e); }
   return 0;
 }
 
