@@ -87,9 +87,9 @@ def cpu_baseline(net, frac, sample_steps, spinup_steps=72, budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=16384)
     ap.add_argument("--warmup", type=int, default=512)
-    ap.add_argument("--window", type=int, default=4096)
+    ap.add_argument("--window", type=int, default=8192)
     ap.add_argument("--reaches", type=int, default=N_REACH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",

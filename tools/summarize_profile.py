@@ -46,7 +46,7 @@ fetch, nf = pmc("pmc_fetch", "FETCH_SIZE")
 write, nw = pmc("pmc_write", "WRITE_SIZE")
 stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv")))}
 lines = [f"# Profile {tag}", "",
-         "Command: `python bench.py --no-cpu-baseline --no-roofline --window 4096 --steps 4096 --warmup 256` under",
+         "Command: `python bench.py --no-cpu-baseline --no-roofline --window 8192 --steps 8192 --warmup 256` under",
          "`rocprofv3 --kernel-trace --stats` and, separately, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.", "",
          "| kernel | calls | avg us | total ms | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (2*F+W) |",
          "|---|---|---|---|---|---|---|"]
@@ -67,8 +67,8 @@ lines += ["", "Bench line of the same build (un-profiled run):", "", "```", json
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 if "k_stage_kwt" in out:
     cfg = bench["config"]
-    json.dump(dict(tag=tag, reaches=cfg["reaches_per_gpu"], window=4096, hbm_bytes_per_launch=out["k_stage_kwt"]["hbm_bytes"],
+    json.dump(dict(tag=tag, reaches=cfg["reaches_per_gpu"], window=8192, hbm_bytes_per_launch=out["k_stage_kwt"]["hbm_bytes"],
                    fetch_kib_per_launch=out["k_stage_kwt"]["fetch_kib"], write_kib_per_launch=out["k_stage_kwt"]["write_kib"],
-                   note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes, bench.py --window 4096"),
+                   note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes, bench.py --window 8192"),
               open(os.path.join(dst, "kwt_hbm_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
