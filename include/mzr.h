@@ -162,6 +162,11 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
 int mzr_get_irf_state(mzr_handle h, double *qfuture /* CSR by uhOffset */);
 int mzr_get_mol_state(mzr_handle h, int method, double *q /* [nRch][nMolecule] */);
 int mzr_get_basin_state(mzr_handle h, double *qfuture /* [nRch][n] */);
+/* restart (read_restart.f90:152-742): the same layouts back in; basin_q = BASIN_QR(1) (either pointer may be NULL) */
+int mzr_set_irf_state(mzr_handle h, const double *qfuture /* CSR by uhOffset */);
+int mzr_set_mol_state(mzr_handle h, int method, const double *q /* [nRch][nMolecule] */);
+int mzr_set_basin_state(mzr_handle h, const double *qfuture /* [nRch][n] */, const double *basin_q /* [nRch] */);
+int mzr_set_volume(mzr_handle h, int method, const double *vol /* [nRch] REACH_VOL(1) */);
 
 /* schedule / measurement introspection */
 int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);

@@ -51,7 +51,8 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing",
-           "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev"]
+           "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
+           "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume"]
 
 
 def load_library():
@@ -95,6 +96,10 @@ def load_library():
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
+    L.mzr_set_irf_state.argtypes = [vp, dp]
+    L.mzr_set_mol_state.argtypes = [vp, ci, dp]
+    L.mzr_set_basin_state.argtypes = [vp, vp, vp]
+    L.mzr_set_volume.argtypes = [vp, ci, dp]
     L.mzr_set_remap.argtypes = [vp, ci, ci, ip, ip, ci, vp, vp, vp, dp, ci, ci, vp, vp]
     L.mzr_set_sort_map.argtypes = [vp, ci, ip, ci]
     L.mzr_remap_runoff_dev.argtypes = [vp, ci, vp, vp]
@@ -134,6 +139,7 @@ class RoutingDomain:
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
         self.dt = float(dt)
+        self.does_basin_route = int(does_basin_route)
         cfg = MzrConfig()
         L.mzr_default_config(C.byref(cfg))
         cfg.dt = float(dt); cfg.nRoutes = len(self.methods)
@@ -275,6 +281,22 @@ class RoutingDomain:
         c = lambda a, t: np.ascontiguousarray(a, dtype=t)
         self._check(self.L.mzr_set_kwt_state(self.h, c(nw, np.int32), c(qf, np.float64), c(ti, np.float64),
                                              c(tr, np.float64), c(rf, np.int32)))
+
+    # restart: the same layouts back in (read_restart.f90:152-742)
+    def set_irf_state(self, qfuture):
+        self._check(self.L.mzr_set_irf_state(self.h, np.ascontiguousarray(qfuture, dtype=np.float64)))
+
+    def set_mol_state(self, method, q):
+        self._check(self.L.mzr_set_mol_state(self.h, method, np.ascontiguousarray(q, dtype=np.float64)))
+
+    def set_basin_state(self, qfuture, basin_q):
+        a = None if qfuture is None else np.ascontiguousarray(qfuture, dtype=np.float64)
+        b = None if basin_q is None else np.ascontiguousarray(basin_q, dtype=np.float64)
+        ptr = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+        self._check(self.L.mzr_set_basin_state(self.h, ptr(a), ptr(b)))
+
+    def set_volume(self, method, vol):
+        self._check(self.L.mzr_set_volume(self.h, method, np.ascontiguousarray(vol, dtype=np.float64)))
 
     def irf_state(self):
         out = np.zeros(int(self.uh_offset[-1]))

@@ -1047,6 +1047,63 @@ int mzr_get_basin_state(mzr_handle h, double *qfuture) {
   return 0;
 }
 
+// ---- state setters (restart, read_restart.f90:152-742): caller order -> device (internal order)
+int mzr_set_irf_state(mzr_handle h, const double *qfuture) {
+  if (!h || !h->haveState || !h->irfQ.p) return h ? fail(h, 20, "mzr_set_irf_state/IRF not active") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N;
+  std::vector<double> v((size_t)h->maxtdh * N, 0.0);
+  for (int e = 0; e < N; ++e) {
+    const int i = h->ext2int[e];
+    for (int j = 0; j < h->uhOff[e + 1] - h->uhOff[e]; ++j) v[(size_t)j * N + i] = qfuture[h->uhOff[e] + j];
+  }
+  (void)hipMemcpy(h->irfQ.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  return 0;
+}
+
+int mzr_set_mol_state(mzr_handle h, int method, const double *q) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_mol_state/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0 || !h->route[ix].mol.p) return fail(h, 81, "mzr_set_mol_state/method not active");
+  const int N = h->N, nm = method == MZR_MC ? MZR_NMOL_MC : MZR_NMOL_KW;
+  std::vector<double> v((size_t)nm * N);
+  for (int e = 0; e < N; ++e) for (int j = 0; j < nm; ++j) v[(size_t)j * N + h->ext2int[e]] = q[(size_t)e * nm + j];
+  (void)hipMemcpy(h->route[ix].mol.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  return 0;
+}
+
+// qfuture[nRch][n] = hillslope QFUTURE, basin_q[nRch] = BASIN_QR(1) (read_restart.f90:190,246)
+int mzr_set_basin_state(mzr_handle h, const double *qfuture, const double *basin_q) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_basin_state/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N, n = h->ntdhBas;
+  if (qfuture) {
+    if (h->cfg.doesBasinRoute != 1) return fail(h, 20, "mzr_set_basin_state/hillslope routing not active");
+    std::vector<double> v((size_t)n * N);
+    for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) v[(size_t)j * N + h->ext2int[e]] = qfuture[(size_t)e * n + j];
+    (void)hipMemcpy(h->basS[h->basCur].p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
+  if (basin_q) {   // row lastW of qlat is BASIN_QR(1) of the last step; the next window starts from it
+    std::vector<double> v(N);
+    for (int e = 0; e < N; ++e) v[h->ext2int[e]] = basin_q[e];
+    (void)hipMemcpy(h->qlat.p + (size_t)h->lastW * N, v.data(), N * sizeof(double), hipMemcpyHostToDevice);
+  }
+  return 0;
+}
+
+// REACH_VOL(1) of a method (volume_<method> of the restart file)
+int mzr_set_volume(mzr_handle h, int method, const double *vol) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_volume/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_set_volume/method not active");
+  std::vector<double> v(h->N);
+  for (int e = 0; e < h->N; ++e) v[h->ext2int[e]] = vol[e];
+  (void)hipMemcpy(h->route[ix].vol.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  return 0;
+}
+
 // debug: per-section wave cycles of the KWT kernel (library built with -DMZR_KWT_TIMING)
 int mzr_debug_cycles(mzr_handle h, unsigned long long *out16, int reset) {
   if (!h || !h->dbgCycles.p) return 1;

@@ -36,6 +36,7 @@ MODULE mzr_c
             mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule, mzr_set_boundary, mzr_boundary_size, &
             mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
+            mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing
   public :: mzr_message
 
@@ -202,6 +203,28 @@ MODULE mzr_c
       type(c_ptr), value :: h, runoff_dev
       integer(c_int), value :: nSteps
       real(c_double), value :: t_start
+    end function
+    ! restart (read_restart.f90:152-742): state back in, the layouts of the getters
+    integer(c_int) function mzr_set_irf_state(h, qfuture) bind(C, name='mzr_set_irf_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      real(c_double), intent(in) :: qfuture(*)
+    end function
+    integer(c_int) function mzr_set_mol_state(h, method, q) bind(C, name='mzr_set_mol_state')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method
+      real(c_double), intent(in) :: q(*)
+    end function
+    integer(c_int) function mzr_set_basin_state(h, qfuture, basin_q) bind(C, name='mzr_set_basin_state')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, qfuture, basin_q
+    end function
+    integer(c_int) function mzr_set_volume(h, method, vol) bind(C, name='mzr_set_volume')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method
+      real(c_double), intent(in) :: vol(*)
     end function
     ! forcing remap (process_remap.f90:32-316): remap_data as the reference holds it; pass c_null_ptr for the
     ! index arrays of the other kind and for the optional id arrays

@@ -361,3 +361,44 @@ def test_sort_flux_vs_oracle(hip_lib, oracle_lib):
         dom.remap_device(5, src.data_ptr(), dst.data_ptr())
         dom.sync()
         assert np.array_equal(dst.cpu().numpy(), oracle_lib.sort_flux(ix, fl, net.H, remove_negatives=rmneg))
+
+
+# ---- restart / history files (ncfiles.py): state through a file == state kept on the device ----------
+def test_restart_continues_bit_exact(tmp_path, hip_lib):
+    from mizuroute_amd import ncfiles, uh as uhmod
+    net = m.make_network(2500, seed=17)
+    dt, n1, n2 = 3600.0, 40, 35
+    ro = m.make_runoff(net.H, n1 + n2, seed=18, storm_prob=0.03, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    methods = [m.KWT, m.IRF, m.KW, m.MC, m.DW]
+    mk = lambda: m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=48)
+    whole = mk()
+    Qw = np.concatenate([whole.run(ro[:n1]), whole.run(ro[n1:], t_start=n1 * dt)])
+    a = mk()
+    a.run(ro[:n1])
+    path = str(tmp_path / "case.r.nc")
+    ncfiles.write_restart(path, a, net.reachId, ((n1 - 1) * dt, n1 * dt), restart_time=n1 * dt)
+    b = mk()
+    tb = ncfiles.read_restart(path, b)
+    assert tb[1] == n1 * dt
+    Qb = b.run(ro[n1:], t_start=tb[1])
+    assert np.array_equal(Qb, Qw[n1:])
+    for meth in methods:
+        assert np.array_equal(b.flux(meth, m.api.F_VOL1), whole.flux(meth, m.api.F_VOL1)), meth
+    assert np.array_equal(b.kwt_state()[0], whole.kwt_state()[0])
+    # history: interval means accumulated on the device, written as float32
+    hpath = str(tmp_path / "case.h.nc")
+    c = mk()
+    hw = ncfiles.HistoryWriter(hpath, net.reachId, methods)
+    for k in range(3):
+        Q = c.run(ro[k * 24:(k + 1) * 24], t_start=k * 24 * dt)
+        hw.append((k + 1) * 24 * dt, c)
+        want = Q.mean(axis=0)
+    hw.close()
+    from scipy.io import netcdf_file
+    f = netcdf_file(hpath, "r", mmap=False)
+    got = f.variables["KWTroutedRunoff"][:]
+    assert got.shape == (3, net.N)
+    assert np.allclose(got[2], want[0], rtol=1e-6)
+    f.close()
