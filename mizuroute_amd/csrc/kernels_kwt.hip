@@ -229,7 +229,7 @@ template <int G> __device__ __forceinline__ int grp_first(int v) {
 
 // LDS traffic of one group is ordered by the hardware (one wavefront, in-order LDS queue); this
 // only keeps the compiler from moving accesses across a phase boundary.
-__device__ __forceinline__ void grp_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void grp_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
 }  // namespace
 
@@ -649,8 +649,8 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
       for (int i = 0; i < ng; ++i) { if (!((goodMask >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
     }
     if (gl == 0) {
-      d.inflow[r] = q_up;
       double *c = sCtx[wv * RPW + grp];
+      c[6] = q_up;                     // REACH_INFLOW, stored with the other results at the end
       c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
       c[1] = qlat_r; c[2] = rec.K; c[3] = rec.CW; c[4] = rec.length; c[5] = RW;
       if (d.kwtStat) {
@@ -1037,7 +1037,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
 #ifdef X_NOQSUM
         if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] = Qout; d.kwN[r] = NN2 + 1; }
 #else
-        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; }
+        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; d.inflow[r] = sCtx[wv * RPW + grp][6]; }
 #endif
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
