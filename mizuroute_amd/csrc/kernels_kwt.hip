@@ -524,33 +524,21 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 // FULL = false compiles out lakes, water management and partition boundaries (the common case).
 // Values named "uniform" below are computed redundantly by all lanes of a group.
 #ifndef MZR_KWT_OCC
-#define MZR_KWT_OCC 5
+#define MZR_KWT_OCC 4
 #endif
-#ifndef MZR_KWT_WPB
-#define MZR_KWT_WPB 1   // wavefronts per block (independent of each other; fewer workgroups to dispatch)
-#endif
-#ifndef MZR_KWT_G
-#define MZR_KWT_G 16   // lanes per routed reach (4, 8, 16, 32 or 64)
-#endif
-template <bool FULL, bool GEN, int G, int POOL>
-__global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : MZR_KWT_OCC, GEN ? 2 : MZR_KWT_OCC))) k_stage_kwt(MzrDev d, int s, int hvBegin, int hvEnd, int ltBegin, int ltEnd, int nHvBlocks) {
-  constexpr int RPW = 64 / G;
-  constexpr int KS = (MZR_KW_CAP + G - 1) / G;   // slots per lane for <= 20 entries
-  constexpr int OS = (MZR_OB_CAP + G - 1) / G;   // ... for one outbox row
-  constexpr int WPB = MZR_KWT_WPB;
-  constexpr int GP = POOL / RPW;   // work-array entries per reach
-  __shared__ double sA[WPB * POOL], sB[WPB * POOL], sC[WPB * POOL], sD[WPB * POOL];
-  __shared__ double sCtx[WPB * RPW][8];   // per reach: values needed again late (X0, BASIN_QR(1), K, cw, RLENGTH, R_WIDTH)
-  if (!GEN && (int)blockIdx.x >= nHvBlocks) {
-    kwt_light<FULL>(d, s, ltBegin + ((int)blockIdx.x - nHvBlocks) * 64 * WPB + (int)threadIdx.x, ltEnd);
-    return;
-  }
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
-  const int item = hvBegin + ((int)blockIdx.x * WPB + wv) * RPW + grp;
+// One reach by a group of G adjacent lanes with KS (OS) particle slots per lane for the own row
+// (an outbox row).  `off` = the group's slice of the LDS work arrays, `cap` = how many entries the
+// reach may need: a reach that needs more is left untouched and reported back (true), so that the
+// caller can give it a wider group.  ctx = 8 doubles of LDS for values needed again late.
+template <bool FULL, bool GEN, int G, int KS, int OS>
+__device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
+                                          int off, int cap, double *sA, double *sB, double *sC, double *sD, double *ctx) {
+  constexpr bool CAN_THIN = GEN || G * KS > MZR_MAXQPAR_DEV;   // a narrow group never holds enough particles to thin
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1);
   const int N = d.N;
+  bool ovf = false;
   // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line)
-  const bool have = item < hvEnd;
-  const MzrKwtRec rec = d.kwtRouted[have ? item : hvEnd - 1];
+  const MzrKwtRec rec = recs[have ? item : lastItem];
   const int r = uni<G>(rec.r);
   const int t = uni<G>(have ? s - rec.sigma : -1);
   const bool live = t >= 0 && t < d.W;
@@ -637,7 +625,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
     need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
     if (upLake && nup > 1) need = 0;
     if (empty) { mzr_raise(d, 40, r, t, 11); need = 0; }
-    if (need > GP) { mzr_raise(d, 60, r, t, 10); need = 0; }
+    if (need > cap) { ovf = true; need = 0; }
     const double dT10 = T1 - T0;
     bs.b0sl = (bs.b0q1 - bs.b0q0) / dT10;
     if (nup > 1) bs.b1sl = (b1q1 - bs.b1q0) / dT10;
@@ -649,11 +637,11 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
       for (int i = 0; i < ng; ++i) { if (!((goodMask >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
     }
     if (gl == 0) {
-      double *c = sCtx[wv * RPW + grp];
+      double *c = ctx;
       c[6] = q_up;                     // REACH_INFLOW, stored with the other results at the end
       c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
       c[1] = qlat_r; c[2] = rec.K; c[3] = rec.CW; c[4] = rec.length; c[5] = RW;
-      if (d.kwtStat) {
+      if (d.kwtStat && !ovf) {
         atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own); atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
         atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
       }
@@ -665,7 +653,6 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
   // confluence needs at most 20 + 1 + 2 + 2*19 of them)
   if (need > 0) {
     {
-      const int off = (wv * RPW + grp) * GP;
       double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
       do {
         const bool cold = (n_own == 0);
@@ -769,6 +756,9 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
           grp_sync();
         }
         int size = NJ + 1 + ND;
+#ifdef MZR_KWT_HIST
+        if (gl == 0 && (blockIdx.x & 15) == 0) { const int b = size <= 4 ? 0 : size <= 8 ? 1 : size <= 12 ? 2 : size <= 16 ? 3 : size <= 20 ? 4 : size <= 32 ? 5 : size <= 48 ? 6 : 7; atomicAdd(&d.dbgCycles[8 + b], 1ull); }
+#endif
 
         {   // kwt_rch :163-174
           double mn = DBL_MAX;
@@ -779,10 +769,10 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
         TSTAMP(2);
 
         // ---- remove_rch :999-1123: drop the particle with the least interpolation error until < MAXQPAR
-        if (size > MZR_MAXQPAR_DEV) {
+        if (CAN_THIN && size > MZR_MAXQPAR_DEV) {
           KCOUNT(13, 1); KCOUNT(14, size - MZR_MAXQPAR_DEV);
           const int NPRT = size - 1;
-          const bool big = NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
+          const bool big = GEN && NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
           for (int i = gl; i <= NPRT; i += G) {
             double e = DBL_MAX;
             if (i >= 1 && i < NPRT) e = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
@@ -869,7 +859,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
         int NQ2 = 0;
         {
           // K = sqrt(R_SLOPE)/R_MAN_N, cw = ALFA*K**(1/ALFA) with ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
-          const double K = sCtx[wv * RPW + grp][2], cw = sCtx[wv * RPW + grp][3], XMX = sCtx[wv * RPW + grp][4];
+          const double K = ctx[2], cw = ctx[3], XMX = ctx[4];
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
@@ -1003,7 +993,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
               Qw[oI[sl]] = oQ[sl]; Tw[oI[sl]] = oT[sl]; Xw[oI[sl]] = te;
             }
           }
-          if (gl == 0) Xw[0] = sCtx[wv * RPW + grp][0];
+          if (gl == 0) Xw[0] = ctx[0];
           grp_sync();
           // exit times must increase: te <= previous -> previous + 1 s (:1423-1426); sequential only when it happens
           bool viol = false;
@@ -1024,7 +1014,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         double QNEW;
         if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
-        const double Qout = QNEW * sCtx[wv * RPW + grp][5] + sCtx[wv * RPW + grp][1];
+        const double Qout = QNEW * ctx[5] + ctx[1];
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
         const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
@@ -1037,7 +1027,7 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
 #ifdef X_NOQSUM
         if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] = Qout; d.kwN[r] = NN2 + 1; }
 #else
-        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; d.inflow[r] = sCtx[wv * RPW + grp][6]; }
+        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; d.inflow[r] = ctx[6]; }
 #endif
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
@@ -1082,24 +1072,82 @@ __global__ void __launch_bounds__(64 * MZR_KWT_WPB) __attribute__((amdgpu_waves_
       } while (0);
     }
   }
+  return ovf;
 }
 
-void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream) {
-  constexpr int G = MZR_KWT_G, RPW = 64 / G, POOL = 60 * RPW, POOLG = 256 * RPW;   // binary confluence: 20 + 2 + 2 * 19 entries at most
-  const int nHv = hvEnd - hvBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
+// One launch = every routed, headwater, lake and halo reach of the stages that are active in this
+// launch.  Routed reaches come in two host-made classes (kwt_regroup): class A, 16 lanes per reach
+// (4 per wavefront), and class B, reaches that held at most 7 particles lately, 8 lanes per reach (8
+// per wavefront, one particle slot per lane, no thinning code).  A class-B reach that has grown
+// beyond that is picked up by 16-lane groups of the same wavefront right away, four at a time, so
+// the classification only has to be usually right.  GEN: confluences of more than two reaches.
+template <bool FULL, bool GEN, int POOL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : MZR_KWT_OCC, GEN ? 2 : MZR_KWT_OCC)))
+k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, int hbEnd, int nBBlocks, int ltBegin, int ltEnd) {
+  constexpr int GA = 16, RA = 64 / GA, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
+  constexpr int GB = 8, RB = 64 / GB, CAPB = GB - 1;   // entries 0..7: the outbox write reaches index NR+2 <= size
+  constexpr int GPA = POOL / RA, GPB = POOL / RB;
+  __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
+  __shared__ double sCtx[RB][8];   // per reach: values needed again late (X0, BASIN_QR(1), K, cw, RLENGTH, R_WIDTH, inflow)
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  if (!GEN && b >= nABlocks + nBBlocks) {
+    kwt_light<FULL>(d, s, ltBegin + (b - nABlocks - nBBlocks) * 64 + lane, ltEnd);
+    return;
+  }
+  const bool isB = !GEN && b >= nABlocks;
+  unsigned ovfMask = 0;      // class B: groups whose reach needs the wide path (wave-uniform)
+  if (isB) {
+    const int g8 = lane / GB;
+    const int item = hbBegin + (b - nABlocks) * RB + g8;
+    const bool ovf = kwt_reach<FULL, false, GB, 1, 1>(d, s, d.kwtRoutedB, item, item < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+    const unsigned long long bal = __ballot(ovf);
+#ifdef MZR_KWT_HIST
+    if ((lane & 7) == 0 && item < hbEnd) { atomicAdd(&d.dbgCycles[0], 1ull); if (ovf) atomicAdd(&d.dbgCycles[1], 1ull); }
+#endif
+#pragma unroll
+    for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
+    if (!ovfMask) return;
+  }
+  const int g16 = lane / GA;
+  if (!isB) {
+    const int item = haBegin + b * RA + g16;
+    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+    if (ovf) mzr_raise(d, 60, d.kwtRouted[item < haEnd ? item : haEnd - 1].r, s, 10);      // work array bounds exceeded
+    return;
+  }
+  // class-B reaches that have outgrown 8 lanes: four at a time; eight groups = at most two rounds (rare),
+  // written out instead of looped so that nothing of the wide path is carried around a loop
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if (round == 1 && !ovfMask) break;
+    unsigned m = ovfMask;
+    int sel = -1;
+    for (int k = 0; k <= g16 && m; ++k) { sel = (k == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
+    const bool have = sel >= 0;
+    const int item = hbBegin + (b - nABlocks) * RB + (have ? sel : 0);
+    for (int k = 0; k < RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
+    const bool ovf = kwt_reach<FULL, false, GA, KA, OA>(d, s, d.kwtRoutedB, item, have, hbEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+    if (ovf) mzr_raise(d, 60, d.kwtRoutedB[have ? item : hbEnd - 1].r, s, 10);
+  }
+}
+
+void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int gnBegin, int gnEnd,
+                          int ltBegin, int ltEnd, hipStream_t stream) {
+  constexpr int POOL = 240, POOLG = 1024;   // binary confluence: 20 + 2 + 2 * 19 = 60 entries per reach at most, 4 reaches
+  const int nA = haEnd - haBegin, nB = hbEnd - hbBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
-  constexpr int WPB = MZR_KWT_WPB;
-  dim3 block(64 * WPB);
-  if (nHv > 0 || nLt > 0) {
-    const int nHvBlocks = (nHv + RPW * WPB - 1) / (RPW * WPB);
-    dim3 grid(nHvBlocks + (nLt + 64 * WPB - 1) / (64 * WPB));
-    if (full) hipLaunchKernelGGL((k_stage_kwt<true, false, G, POOL>), grid, block, 0, stream, d, s, hvBegin, hvEnd, ltBegin, ltEnd, nHvBlocks);
-    else hipLaunchKernelGGL((k_stage_kwt<false, false, G, POOL>), grid, block, 0, stream, d, s, hvBegin, hvEnd, ltBegin, ltEnd, nHvBlocks);
+  dim3 block(64);
+  if (nA > 0 || nB > 0 || nLt > 0) {
+    const int nABlocks = (nA + 3) / 4, nBBlocks = (nB + 7) / 8;
+    dim3 grid(nABlocks + nBBlocks + (nLt + 63) / 64);
+    if (full) hipLaunchKernelGGL((k_stage_kwt<true, false, POOL>), grid, block, 0, stream, d, s, haBegin, haEnd, nABlocks, hbBegin, hbEnd, nBBlocks, ltBegin, ltEnd);
+    else hipLaunchKernelGGL((k_stage_kwt<false, false, POOL>), grid, block, 0, stream, d, s, haBegin, haEnd, nABlocks, hbBegin, hbEnd, nBBlocks, ltBegin, ltEnd);
   }
   if (nGn > 0) {   // confluences of more than two reaches: the reference's k-way merge on one lane of the group
     MzrDev dg = d; dg.kwtRouted = d.kwtGeneric;
-    dim3 grid((nGn + RPW * WPB - 1) / (RPW * WPB));
-    if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, G, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, 0, 0, (int)grid.x);
-    else hipLaunchKernelGGL((k_stage_kwt<false, true, G, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, 0, 0, (int)grid.x);
+    const int nBlocks = (nGn + 3) / 4;
+    dim3 grid(nBlocks);
+    if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0);
+    else hipLaunchKernelGGL((k_stage_kwt<false, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0);
   }
 }

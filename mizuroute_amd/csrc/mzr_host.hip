@@ -29,7 +29,8 @@ void mzr_launch_remap(int H, int nSteps, int nSrc, const int *rowStart, const in
                       const double *weight, const double *src, double *srcT, double *dst, hipStream_t stream);
 void mzr_launch_sort_flux(int H, int nSteps, int nSrc, const int *srcOf, int removeNegatives, const double *src, double *dst,
                           hipStream_t stream);
-void mzr_launch_stage_kwt(const MzrDev &d, int s, int hvBegin, int hvEnd, int gnBegin, int gnEnd, int ltBegin, int ltEnd, hipStream_t stream);
+void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int gnBegin, int gnEnd,
+                          int ltBegin, int ltEnd, hipStream_t stream);
 
 namespace {
 
@@ -164,8 +165,9 @@ struct mzr_domain {
   bool havePrevQlat = false;
   // kwt
   DBuf<int> kwN, obN, kwtLight;
-  DBuf<MzrKwtRec> kwtRouted, kwtGeneric;
-  std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list (regrouped by load now and then)
+  DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtGeneric;
+  std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
+  std::vector<int> kwtStageOff, kwtBOff;        // [nStages+1] stage offsets in h_kwtRouted / in the class-B list (kwtRoutedOff: class A)
   long long kwtWindows = 0;                    // KWT windows run since mzr_init_state
   std::vector<int> kwtRoutedOff, kwtGenericOff, kwtLightOff;   // [nStages+1] offsets of each stage in the two lists
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
@@ -222,7 +224,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
-  d.kwtRouted = h->kwtRouted.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
+  d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
   d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
   d.lakeSlot = h->nLake ? h->lakeSlot.p : nullptr; d.lakeModel = h->lakeModel.p; d.lakePar = h->lakePar.p;
   d.lakeEvap = h->lakeEvap.p; d.lakePrecip = h->lakePrecip.p; d.calMonth = h->calMonth.p; d.calDay = h->calDay.p; d.calDoy = h->calDoy.p;
@@ -664,8 +666,10 @@ int mzr_init_state(mzr_handle h) {
           if (routed.empty()) routed.push_back(none);
           if (generic.empty()) generic.push_back(none);
           if (light.empty()) light.push_back(0);
-          h->kwtRouted.upload(routed); h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
+          h->kwtRouted.upload(routed); h->kwtRoutedB.upload(routed); h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
           h->h_kwtRouted = routed; h->kwtWindows = 0;
+          h->kwtStageOff = h->kwtRoutedOff;                       // every routed reach starts in class A
+          h->kwtBOff.assign(h->nStages + 1, 0);
         }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
@@ -687,7 +691,8 @@ int mzr_init_state(mzr_handle h) {
 // The order of the reaches inside a stage is free.  A wavefront works on 64/G reaches in lockstep and
 // pays for its busiest one (thinning iterations, second particle slot), and how many particles a
 // reach holds changes slowly, so every now and then the routed list of each stage is regrouped by
-// the particle counts of the last step: saturated reaches share wavefronts, light ones do too.
+// the particle counts of the last step: saturated reaches share wavefronts, light ones do too, and
+// reaches that hold only a few particles go to the class that gives them 8 lanes instead of 16.
 static void kwt_regroup(mzr_handle h) {
   if (h->h_kwtRouted.size() < 2 || !h->kwN.p) return;
   (void)hipStreamSynchronize(h->stream);
@@ -695,24 +700,30 @@ static void kwt_regroup(mzr_handle h) {
   std::vector<int> n(N), ob((size_t)2 * N);
   (void)hipMemcpy(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost);
   (void)hipMemcpy(ob.data(), h->obN.p, (size_t)2 * N * sizeof(int), hipMemcpyDeviceToHost);
-  auto load = [&](const MzrKwtRec &rc) {
-    int l = n[rc.r];
-    for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) l += std::max(ob[rc.u0 + k], ob[(size_t)N + rc.u0 + k]);
+  // work-array entries the reach needed in the last step (the kernel's `need`), from the larger outbox parity
+  auto need = [&](const MzrKwtRec &rc) {
+    int l = std::max(n[rc.r], 1) + rc.nup;
+    for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) l += std::max(std::max(ob[rc.u0 + k], ob[(size_t)N + rc.u0 + k]) - 1, 0);
     return l;
   };
-  std::vector<MzrKwtRec> &v = h->h_kwtRouted;
+  // class B (8 lanes) holds 7 entries: reaches that needed at most 6 go there, one entry in reserve.
+  // MZR_KWT_CLASSB_MAX overrides the threshold (tests: 0 = nobody, 64 = everybody, through the fall-back).
+  int classBMax = 6;
+  if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
+  const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
+  std::vector<MzrKwtRec> A, B;
+  A.reserve(v.size()); B.reserve(v.size());
   std::vector<std::pair<int, int>> key;
-  std::vector<MzrKwtRec> tmp;
   for (int sg = 0; sg < h->nStages; ++sg) {
-    const int a = h->kwtRoutedOff[sg], b = h->kwtRoutedOff[sg + 1];
-    if (b - a < 2) continue;
+    h->kwtRoutedOff[sg] = (int)A.size(); h->kwtBOff[sg] = (int)B.size();
     key.clear();
-    for (int i = a; i < b; ++i) key.emplace_back(-load(v[i]), i);
+    for (int i = h->kwtStageOff[sg]; i < h->kwtStageOff[sg + 1]; ++i) key.emplace_back(-need(v[i]), i);
     std::sort(key.begin(), key.end());
-    tmp.assign(v.begin() + a, v.begin() + b);
-    for (int i = a; i < b; ++i) v[i] = tmp[key[i - a].second - a];
+    for (const auto &k : key) (-k.first <= classBMax ? B : A).push_back(v[k.second]);
   }
-  (void)hipMemcpy(h->kwtRouted.p, v.data(), v.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+  h->kwtRoutedOff[h->nStages] = (int)A.size(); h->kwtBOff[h->nStages] = (int)B.size();
+  if (!A.empty()) (void)hipMemcpy(h->kwtRouted.p, A.data(), A.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+  if (!B.empty()) (void)hipMemcpy(h->kwtRoutedB.p, B.data(), B.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
 }
 
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
@@ -721,8 +732,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   (void)hipSetDevice(h->cfg.device);
-  if (h->kwN.p && W > 1) {   // regroup after the first two windows, then every 8th
-    if (h->kwtWindows == 1 || h->kwtWindows == 2 || (h->kwtWindows & 7) == 0) kwt_regroup(h);
+  if (h->kwN.p && W > 1) {   // regroup after the first two windows (not before the first: no particles yet), then every 8th
+    if (h->kwtWindows == 1 || h->kwtWindows == 2 || (h->kwtWindows >= 8 && (h->kwtWindows & 7) == 0)) kwt_regroup(h);
     ++h->kwtWindows;
   }
   const int N = h->N;
@@ -752,8 +763,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         (void)hipEventRecord(rb.events[rb.evUsed].first, st);
       }
       if (rb.method == MZR_KWT)
-        mzr_launch_stage_kwt(d, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1],
-                             h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
+        mzr_launch_stage_kwt(d, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1],
+                             h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
       else mzr_launch_stage(rb.method, d, s, rB, rE, st);
       if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, st); ++rb.evUsed; }
       ++rb.nLaunches;

@@ -402,3 +402,20 @@ def test_restart_continues_bit_exact(tmp_path, hip_lib):
     assert got.shape == (3, net.N)
     assert np.allclose(got[2], want[0], rtol=1e-6)
     f.close()
+
+
+@pytest.mark.parametrize("class_b_max", ["0", "64"])
+def test_kwt_lane_classes_give_the_same_answer(class_b_max, hip_lib, monkeypatch):
+    """Routed reaches are served by 16 or by 8 lanes depending on a host-side guess of their particle
+    count; a wrong guess is caught in the wavefront (wide fall-back).  Forcing every reach into either
+    class must not change a bit."""
+    net = m.make_network(4000, seed=51)
+    ro = m.make_runoff(net.H, 120, seed=52, storm_prob=0.03, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    ref = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=30)
+    Qr = ref.run(ro)
+    monkeypatch.setenv("MZR_KWT_CLASSB_MAX", class_b_max)
+    dom = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=30)
+    Qd = dom.run(ro)
+    assert np.array_equal(Qd, Qr)
+    assert all(np.array_equal(a, b) for a, b in zip(dom.kwt_state(), ref.kwt_state()))

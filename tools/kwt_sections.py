@@ -21,8 +21,9 @@ ro = bench.device_runoff(torch, net.H, W, W, 7, dev); torch.cuda.synchronize()
 dom.run_device(W, W * 3600.0, ro.data_ptr()); dom.sync()
 dom.L.mzr_debug_cycles(dom.h, buf, 1)
 names = ["0 setup/need", "1 load own + merge", "2 min/inflow", "3 remove", "4 celerity pow", "5 shock search", "6 routing loop", "7 interp + stores"]
-tot = sum(buf[i] for i in range(8))
+tot = max(1, sum(buf[i] for i in range(8)))
 for i, n in enumerate(names):
     print(f"{n:22s} {buf[i]:16d}  {100.0*buf[i]/tot:5.1f}%")
 print("slow merges", buf[8], "exit-time fixes", buf[9], "deferred to next round", buf[10], "sampled routed reach-steps (1/16 of blocks)", buf[11],
       "mean LDS need", buf[12] / max(1, buf[11]), "thinned", buf[13], "particles removed", buf[14], "shock merges", buf[15])
+print("size histogram (<=4,<=8,<=12,<=16,<=20,<=32,<=48,>48; with -DMZR_KWT_HIST the counters 8..15 hold this instead):", [buf[8 + i] for i in range(8)])
