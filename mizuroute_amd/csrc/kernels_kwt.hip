@@ -523,17 +523,19 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 // particles + everything its upstreams routed).
 // FULL = false compiles out lakes, water management and partition boundaries (the common case).
 // Values named "uniform" below are computed redundantly by all lanes of a group.
+#ifndef MZR_KWT_KB
+#define MZR_KWT_KB 3   // particle slots per lane of the 8-lane class
+#endif
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 4
 #endif
 // One reach by a group of G adjacent lanes with KS (OS) particle slots per lane for the own row
 // (an outbox row).  `off` = the group's slice of the LDS work arrays, `cap` = how many entries the
 // reach may need: a reach that needs more is left untouched and reported back (true), so that the
-// caller can give it a wider group.  ctx = 8 doubles of LDS for values needed again late.
-template <bool FULL, bool GEN, int G, int KS, int OS>
+// caller can give it a wider group.  CAN_THIN = false leaves remove_rch out (cap <= MAXQPAR).  ctx = 8 doubles of LDS for values needed again late.
+template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN>
 __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
                                           int off, int cap, double *sA, double *sB, double *sC, double *sD, double *ctx) {
-  constexpr bool CAN_THIN = GEN || G * KS > MZR_MAXQPAR_DEV;   // a narrow group never holds enough particles to thin
   const int lane = threadIdx.x & 63, gl = lane & (G - 1);
   const int N = d.N;
   bool ovf = false;
@@ -1077,15 +1079,17 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
 
 // One launch = every routed, headwater, lake and halo reach of the stages that are active in this
 // launch.  Routed reaches come in two host-made classes (kwt_regroup): class A, 16 lanes per reach
-// (4 per wavefront), and class B, reaches that held at most 7 particles lately, 8 lanes per reach (8
-// per wavefront, one particle slot per lane, no thinning code).  A class-B reach that has grown
+// (4 per wavefront), and class B, reaches that needed at most 16 work-array entries lately, 8 lanes per
+// reach (8 per wavefront, no thinning code, capacity MAXQPAR entries).  A class-B reach that has grown
 // beyond that is picked up by 16-lane groups of the same wavefront right away, four at a time, so
 // the classification only has to be usually right.  GEN: confluences of more than two reaches.
 template <bool FULL, bool GEN, int POOL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : MZR_KWT_OCC, GEN ? 2 : MZR_KWT_OCC)))
 k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, int hbEnd, int nBBlocks, int ltBegin, int ltEnd) {
   constexpr int GA = 16, RA = 64 / GA, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
-  constexpr int GB = 8, RB = 64 / GB, CAPB = GB - 1;   // entries 0..7: the outbox write reaches index NR+2 <= size
+  constexpr int GB = 8, RB = 64 / GB, KB = MZR_KWT_KB;
+  // entries 0..GB*KB-1 (the outbox write reaches index NR+2 <= size), and never enough particles to thin
+  constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
   constexpr int GPA = POOL / RA, GPB = POOL / RB;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
   __shared__ double sCtx[RB][8];   // per reach: values needed again late (X0, BASIN_QR(1), K, cw, RLENGTH, R_WIDTH, inflow)
@@ -1099,7 +1103,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   if (isB) {
     const int g8 = lane / GB;
     const int item = hbBegin + (b - nABlocks) * RB + g8;
-    const bool ovf = kwt_reach<FULL, false, GB, 1, 1>(d, s, d.kwtRoutedB, item, item < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, false>(d, s, d.kwtRoutedB, item, item < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
     const unsigned long long bal = __ballot(ovf);
 #ifdef MZR_KWT_HIST
     if ((lane & 7) == 0 && item < hbEnd) { atomicAdd(&d.dbgCycles[0], 1ull); if (ovf) atomicAdd(&d.dbgCycles[1], 1ull); }
@@ -1111,7 +1115,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   const int g16 = lane / GA;
   if (!isB) {
     const int item = haBegin + b * RA + g16;
-    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
     if (ovf) mzr_raise(d, 60, d.kwtRouted[item < haEnd ? item : haEnd - 1].r, s, 10);      // work array bounds exceeded
     return;
   }
@@ -1126,7 +1130,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
     const bool have = sel >= 0;
     const int item = hbBegin + (b - nABlocks) * RB + (have ? sel : 0);
     for (int k = 0; k < RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
-    const bool ovf = kwt_reach<FULL, false, GA, KA, OA>(d, s, d.kwtRoutedB, item, have, hbEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+    const bool ovf = kwt_reach<FULL, false, GA, KA, OA, true>(d, s, d.kwtRoutedB, item, have, hbEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
     if (ovf) mzr_raise(d, 60, d.kwtRoutedB[have ? item : hbEnd - 1].r, s, 10);
   }
 }

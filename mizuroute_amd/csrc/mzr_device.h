@@ -95,7 +95,7 @@ struct MzrDev {
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
   double *obQ, *obT;          // [2][N][MZR_OB_CAP]
   const MzrKwtRec *kwtRouted;    // reaches that route particles (at most two upstream reaches), stage-major, class A: 16 lanes each
-  const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately held at most 7 particles, 8 lanes each (host regroups)
+  const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 16 work-array entries, 8 lanes each (host regroups)
   const MzrKwtRec *kwtGeneric;   // ... with more than two upstream reaches
   const int *kwtLight;        // headwater, lake and halo reaches, stage-major (one lane each)
   // ---- lakes (null / 0 without lakes)

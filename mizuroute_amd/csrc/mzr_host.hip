@@ -706,9 +706,9 @@ static void kwt_regroup(mzr_handle h) {
     for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) l += std::max(std::max(ob[rc.u0 + k], ob[(size_t)N + rc.u0 + k]) - 1, 0);
     return l;
   };
-  // class B (8 lanes) holds 7 entries: reaches that needed at most 6 go there, one entry in reserve.
+  // class B (8 lanes, capacity MAXQPAR entries, no thinning): reaches that needed at most 16 entries in the last step.
   // MZR_KWT_CLASSB_MAX overrides the threshold (tests: 0 = nobody, 64 = everybody, through the fall-back).
-  int classBMax = 6;
+  int classBMax = 16;
   if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
   const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
   std::vector<MzrKwtRec> A, B;
