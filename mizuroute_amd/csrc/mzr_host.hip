@@ -168,7 +168,7 @@ struct mzr_domain {
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtGeneric;
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff;        // [nStages+1] stage offsets in h_kwtRouted / in the class-B list (kwtRoutedOff: class A)
-  long long kwtWindows = 0;                    // KWT windows run since mzr_init_state
+  long long kwtWindows = 0, kwtStepsSince = 0; // KWT windows run since mzr_init_state, steps since the last regrouping
   std::vector<int> kwtRoutedOff, kwtGenericOff, kwtLightOff;   // [nStages+1] offsets of each stage in the two lists
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
   DBuf<MzrKwtStat> kwtStat;
@@ -667,7 +667,7 @@ int mzr_init_state(mzr_handle h) {
           if (generic.empty()) generic.push_back(none);
           if (light.empty()) light.push_back(0);
           h->kwtRouted.upload(routed); h->kwtRoutedB.upload(routed); h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
-          h->h_kwtRouted = routed; h->kwtWindows = 0;
+          h->h_kwtRouted = routed; h->kwtWindows = 0; h->kwtStepsSince = 0;
           h->kwtStageOff = h->kwtRoutedOff;                       // every routed reach starts in class A
           h->kwtBOff.assign(h->nStages + 1, 0);
         }
@@ -732,9 +732,10 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   (void)hipSetDevice(h->cfg.device);
-  if (h->kwN.p && W > 1) {   // regroup after the first two windows (not before the first: no particles yet), then every 8th
-    if (h->kwtWindows == 1 || h->kwtWindows == 2 || (h->kwtWindows >= 8 && (h->kwtWindows & 7) == 0)) kwt_regroup(h);
-    ++h->kwtWindows;
+  if (h->kwN.p) {   // regroup after the first two windows (not before the first: no particles yet), then every 8 windows / 512 steps
+    const bool early = W > 1 && (h->kwtWindows == 1 || h->kwtWindows == 2);
+    if (h->kwtWindows > 0 && (early || h->kwtStepsSince >= std::max(512LL, 8LL * W))) { kwt_regroup(h); h->kwtStepsSince = 0; }
+    ++h->kwtWindows; h->kwtStepsSince += W;
   }
   const int N = h->N;
   hipStream_t st = h->stream;
