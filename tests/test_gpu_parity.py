@@ -419,3 +419,39 @@ def test_kwt_lane_classes_give_the_same_answer(class_b_max, hip_lib, monkeypatch
     Qd = dom.run(ro)
     assert np.array_equal(Qd, Qr)
     assert all(np.array_equal(a, b) for a, b in zip(dom.kwt_state(), ref.kwt_state()))
+
+
+# ---- degenerate sizes: one reach, a chain of two, windows of one step, eight-way confluence ---------------
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 9])
+def test_tiny_networks_vs_oracle(N, hip_lib, oracle_lib):
+    net = m.make_network(N, seed=N)
+    ro = m.make_runoff(net.H, 30, seed=3, storm_prob=0.1, storm_amp=3e-6)
+    ff = np.array([0.6, 0.4])
+    uh_off, uhv = np.arange(net.N + 1, dtype=np.int32), np.ones(net.N)
+    methods = [m.KWT, m.IRF, m.DW]
+    orc = oracle_lib.Oracle(net, 3600.0, methods, ff, uh_off, uhv)
+    Qo = orc.run(ro)
+    for win in (1, 7, 64):
+        dom = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=win)
+        Qg = dom.run(ro)
+        for ix in range(len(methods)):
+            rep = parity_report(Qo[:, ix], Qg[:, ix])
+            assert rep["max_rel"] <= REL_TOL, (N, win, methods[ix], rep)
+        assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
+        dom.close()
+
+
+def test_eight_way_confluence_and_the_upstream_limit(hip_lib, oracle_lib):
+    from mizuroute_amd.synthetic import make_star_network
+    net = make_star_network(8, 3, seed=2, identical=False)      # eight tributaries meet in one reach: MZR_MAX_UPSTREAM
+    ro = m.make_runoff(net.H, 40, seed=5, storm_prob=0.05, storm_amp=3e-6)
+    ff = np.array([0.5, 0.5])
+    orc = oracle_lib.Oracle(net, 3600.0, [2], ff)
+    Qo = orc.run(ro)
+    dom = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=16)
+    rep = parity_report(Qo[:, 0], dom.run(ro)[:, 0])
+    assert rep["max_rel"] <= REL_TOL, rep
+    assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
+    with pytest.raises(m.MzrError) as e:                           # nine: refused at set-up, not silently wrong
+        m.RoutingDomain(make_star_network(9, 2, seed=2), 3600.0, [m.KWT], frac_future=ff)
+    assert "at most 8 immediate upstream" in str(e.value)
