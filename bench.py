@@ -169,10 +169,13 @@ def main():
                 ptrs = [r[done:done + w].data_ptr() for r in ros]
                 pt = ptrs[0] if router.trib is not None else 0
                 pm = ptrs[-1] if router.main is not None else 0
-                router.run_window(w, (t_first + done) * DT, pt, pm)
+                router.run_window(w, (t_first + done) * DT, pt, pm, keep=ros)
             done += w
 
     def sync_all():
+        if router is not None:
+            router.sync()            # flushes the window whose boundary exchange is still in flight
+            return
         for d, _ in doms:
             d.sync()
 

@@ -185,29 +185,43 @@ class PartitionedRouter:
             ms = self.main_spec
             self.main = make_domain(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good)
         self.n_routes = None
+        self._pending = None            # (w, t_start, runoff_main_ptr, record, keep) of the window whose exchange is still due
 
     def _rec_size(self, dom, w, n):
         return dom.boundary_size(w, n)
 
-    def run_window(self, w, t_start, runoff_trib_ptr, runoff_main_ptr):
+    def run_window(self, w, t_start, runoff_trib_ptr, runoff_main_ptr, keep=None):
         """One window of w steps.  Pointers are device pointers to [w, H_local] runoff of the
-        tributary domain and (rank 0) the mainstem domain."""
+        tributary domain and (rank 0) the mainstem domain; `keep` is any object that must stay alive
+        until the window has been routed everywhere (the tensors behind the pointers).
+
+        Pipelined by one window: the tributary domain starts window k at once, and only then the
+        boundary records of window k-1 travel (send on the tributary ranks; receive, import and
+        mainstem window k-1 on rank 0), so the exchange and the host time of the mainstem launches
+        hide behind the tributary sweep of window k.  sync() flushes the window still in flight.
+        All ranks must call run_window / sync in the same order."""
         part = self.part
-        rec = None
         n_exp = self.trib_spec.export_local.size
+        prev = self._pending
+        if prev is not None and self.trib is not None:
+            self.trib.sync()                              # window k-1 and its export are complete
+        rec = None
         if self.trib is not None:
             self.trib.run_device(w, t_start, runoff_trib_ptr)
             if n_exp and part.main is not None:
                 rec = self.alloc(self.trib.boundary_size(w, n_exp))
                 self.trib.export_boundary(rec.data_ptr())
-                self.trib.sync()
-        if part.main is None:
-            return
+        if prev is not None:
+            self._exchange(*prev)
+        self._pending = (w, t_start, runoff_main_ptr, rec, keep) if part.main is not None else None
+
+    def _exchange(self, w, t_start, runoff_main_ptr, rec, keep):
+        """Boundary records of a finished tributary window -> mainstem halos -> mainstem window."""
+        part = self.part
         if self.rank != 0:
             if rec is not None:
                 self.transport.send(rec, 0)
             return
-        # rank 0: collect every partition's record into the mainstem halos, then route the mainstem
         for p in range(part.n_parts):
             base, n = self.main_spec.halo_base[p]
             if n == 0:
@@ -222,6 +236,11 @@ class PartitionedRouter:
         self.main.run_device(w, t_start, runoff_main_ptr)
 
     def sync(self):
+        if self._pending is not None:
+            if self.trib is not None:
+                self.trib.sync()
+            prev, self._pending = self._pending, None
+            self._exchange(*prev)
         if self.trib is not None:
             self.trib.sync()
         if self.main is not None:

@@ -266,6 +266,39 @@ def test_partitioned_network_equals_whole(hip_lib):
     for ix, meth in enumerate(methods):
         assert np.array_equal(Q[:, ix], Qw[:, ix]), f"method {meth} differs between partitioned and whole-network runs"
 
+    # the same with the exchange pipelined by one window (no sync between windows, as bench.py runs it):
+    # interval means and the last window must come out the same
+    box.clear()
+    steps2 = 4 * W
+    ro2 = m.make_runoff(net.H, steps2, seed=10, storm_prob=0.05, storm_amp=3e-6)
+    whole2 = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=W)
+    Qw2 = whole2.run(ro2)
+    routers2 = []
+    for rank in range(nparts):
+        class T2:
+            def __init__(self, me): self.me = me
+            def send(self, t, dst): box.setdefault((self.me, dst), []).append(t.clone())
+            def recv(self, t, src): t.copy_(box[(src, 0)].pop(0)); torch.cuda.synchronize()
+        routers2.append(PartitionedRouter(P, rank, make, T2(rank), lambda n: torch.zeros(n, dtype=torch.float64, device="cuda"), W))
+    order = list(range(1, nparts)) + [0]
+    for w0 in range(0, steps2, W):
+        for rank in order:
+            r = routers2[rank]
+            rt = torch.from_numpy(np.ascontiguousarray(ro2[w0:w0 + W][:, r.trib_spec.hru_global])).to(dev) if r.trib is not None else None
+            rm = torch.from_numpy(np.ascontiguousarray(ro2[w0:w0 + W][:, r.main_spec.hru_global])).to(dev) if r.main is not None else None
+            r.run_window(W, w0 * 3600.0, rt.data_ptr() if rt is not None else 0, rm.data_ptr() if rm is not None else 0, keep=(rt, rm))
+    for rank in order:
+        routers2[rank].sync()
+    for rank in order:
+        r = routers2[rank]
+        for dom, spec in ((r.trib, r.trib_spec), (r.main, r.main_spec)):
+            if dom is None:
+                continue
+            g = spec.reach_global[:spec.n_real]
+            for ix, meth in enumerate(methods):
+                assert np.array_equal(dom.window_q(meth, W)[:, :spec.n_real], Qw2[-W:, ix][:, g]), (rank, meth)
+                assert np.array_equal(dom.mean_q(meth)[:spec.n_real], whole2.mean_q(meth)[g]), (rank, meth)
+
 
 def test_water_management_fluxes(hip_lib, oracle_lib):
     """is_flux_wm: abstraction cascade / injection in IRF, KW, MC, DW (irf_route.f90:118-142) and

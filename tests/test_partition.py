@@ -121,8 +121,15 @@ def _worker(rank, world, port, q):
     # replace the (no-op) device export by the fabricated record
     if router.trib is not None:
         router.alloc = lambda n, _d=router.trib: _d.fabricate(w) if n == _d.boundary_size(w, _d.exp.size) else torch.zeros(n, dtype=torch.float64)
+    # two windows: the exchange of window 0 rides behind the start of window 1, sync() flushes window 1
     router.run_window(w, 0.0, 0, 0)
+    if rank == 0 and P.main is not None:
+        assert domains["main"].ran == []                  # nothing has travelled yet
+    router.run_window(w, w * 3600.0, 0, 0)
     ok = True
+    if rank == 0 and P.main is not None:
+        ok &= domains["main"].ran == [(w, 0.0)]
+    router.sync()
     if rank == 0 and P.main is not None:
         main = domains["main"]
         for p in range(1, world):
@@ -133,7 +140,7 @@ def _worker(rank, world, port, q):
             ids = P.trib[p].net.reachId[P.trib[p].export_local - 1].astype(np.float64)
             expect = (np.arange(w)[:, None] * 1000.0 + ids[None, :]).ravel()
             ok &= bool(np.array_equal(got[p][: w * n].numpy(), expect))
-        ok &= main.ran == [(w, 0.0)]
+        ok &= main.ran == [(w, 0.0), (w, w * 3600.0)]
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
