@@ -134,6 +134,7 @@ __global__ void k_unpack_boundary(const double *rec, int R, int W, int nB, int N
 struct mzr_domain {
   mzr_config cfg;
   hipStream_t stream = nullptr;
+  bool highPriority = false;
   std::string msg;
   int N = 0, H = 0, nStages = 0, maxStageWidth = 0, wk = 64;
   bool haveNet = false, haveState = false;
@@ -524,6 +525,20 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
     if (h->h_nUp[i] != 0) return fail(h, 20, "mzr_set_boundary/a halo reach must not have upstream reaches in this domain");
     hs[i] = b; h->h_haloInt[b] = i; h->h_haloGood[b] = haloGood[b] != 0;
     ng[i] = haloGood[b] ? 1 : 0;      // what its downstream reach sees: count(goodBas) of the full network
+  }
+  if (nHalo > 0 && !h->highPriority) {
+    // a domain that consumes halo records is the mainstem of a partitioned network: few reaches, many
+    // stages, on the critical path of the next exchange, and it shares the GPU with a tributary domain
+    // whose launches fill every slot -- its small launches go to a high-priority stream
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
+      hipStream_t st2 = nullptr;
+      if (hipStreamCreateWithPriority(&st2, hipStreamNonBlocking, hi) == hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->stream);
+        h->stream = st2; h->highPriority = true;
+      }
+    }
   }
   try {
     h->nExp = nExport; h->nHalo = nHalo;
