@@ -6,10 +6,12 @@
 
 Workload (BASELINE.json configs[1]): synthetic HDMA-CONUS-like sub-basin, ~100k reaches per GPU,
 KWT routing (route_opt 2), dt = 3600 s, hillslope unit-hydrograph delay on (fshape 2.5,
-tscale 86400 s), cold start + W spin-up steps (untimed), then K timed steps.  A "step" is one
-simulation time step of the whole domain (one main_route call in the reference); the device
-executes them in time-skewed windows.  Forcing is generated on the device before the
-timed region, so `value` is the HBM-resident rate.
+tscale 86400 s).  A bench "step" is one pass of the hot path over one BATCH of synthetic forcing =
+one forcing window of `window_steps` model time steps (8192 by default; one main_route call per
+model time step in the reference; the device sweeps a window time-skewed over the stages,
+DESIGN.md 2): cold start, W untimed batches, then exactly K timed batches.  `value` counts MODEL
+time steps: reaches x K x window_steps / elapsed.  Forcing windows are generated on the device
+before the timed region (two of them, used alternately), so `value` is the HBM-resident rate.
 
 One JSON line on rank 0 with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel (KWT stage sweep): algorithmic bytes from the
@@ -87,9 +89,10 @@ def cpu_baseline(net, frac, sample_steps, spinup_steps=72, budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16384)
-    ap.add_argument("--warmup", type=int, default=512)
-    ap.add_argument("--window", type=int, default=8192)
+    ap.add_argument("--steps", type=int, default=2, help="timed batches (forcing windows)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed batches")
+    ap.add_argument("--window", type=int, default=0,
+                    help="model time steps per batch; 0 = 8192, fewer when --steps is large (about 2M model steps in total)")
     ap.add_argument("--reaches", type=int, default=N_REACH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
@@ -124,7 +127,12 @@ def main():
     # mizuroute_amd/partition.py); tributary partitions ship their outlet reaches' boundary records to
     # the mainstem owner (rank 0) once per window over RCCL point-to-point.
     frac = uhmod.basin_uh(DT, 2.5, 86400.0)
-    W = max(1, min(args.window, max(args.steps, 1)))
+    K, KW = max(1, args.steps), max(0, args.warmup)
+    W = args.window
+    if W <= 0:   # keep the whole run at about two million model time steps whatever K the caller asks for
+        W = 8192
+        while W > 128 and W * (K + KW) > (1 << 21):
+            W //= 2
     net = m.make_network(args.reaches * world, seed=20240529)
     router = None
     if world == 1:
@@ -159,18 +167,21 @@ def main():
     def gen(n_steps, t0):
         return [device_runoff(torch, H, n_steps, t0, 7 + rank + 101 * i, dev) for i, (_, H) in enumerate(doms)]
 
-    def run_steps(ros, t_first):
-        n, done = ros[0].shape[0], 0
-        while done < n:
-            w = min(W, n - done)
+    pool = [gen(W, 0), gen(W, W)]          # two forcing windows, used alternately
+    state = {"batch": 0}                    # batches routed so far (the simulation clock)
+
+    def run_batches(nb):
+        for _ in range(nb):
+            k = state["batch"]
+            ros = pool[k % 2]
+            t_start = k * W * DT
             if router is None:
-                dom.run_device(w, (t_first + done) * DT, ros[0][done:done + w].data_ptr())
+                dom.run_device(W, t_start, ros[0].data_ptr())
             else:
-                ptrs = [r[done:done + w].data_ptr() for r in ros]
-                pt = ptrs[0] if router.trib is not None else 0
-                pm = ptrs[-1] if router.main is not None else 0
-                router.run_window(w, (t_first + done) * DT, pt, pm, keep=ros)
-            done += w
+                pt = ros[0].data_ptr() if router.trib is not None else 0
+                pm = ros[-1].data_ptr() if router.main is not None else 0
+                router.run_window(W, t_start, pt, pm, keep=ros)
+            state["batch"] = k + 1
 
     def sync_all():
         if router is not None:
@@ -179,11 +190,8 @@ def main():
         for d, _ in doms:
             d.sync()
 
-    ro_warm = gen(args.warmup, 0) if args.warmup > 0 else None
-    ro_time = gen(args.steps, args.warmup)
     torch.cuda.synchronize()
-    if ro_warm is not None:
-        run_steps(ro_warm, 0)
+    run_batches(KW)
     sync_all()
     dom.timing(m.KWT, reset=True)
 
@@ -191,7 +199,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(ro_time, args.warmup)
+    run_batches(K)
     sync_all()
     torch.cuda.synchronize()
     if dist is not None:
@@ -202,7 +210,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    total_reach_steps = float(net.N) * args.steps
+    total_reach_steps = float(net.N) * K * W
     value = total_reach_steps / elapsed
 
     # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
@@ -212,19 +220,16 @@ def main():
         pass
     elif world > 1:      # every rank takes part in the profiled window (the exchange is collective)
         if rank != 0:
-            ro_prof = gen(W, args.warmup + args.steps)
-            torch.cuda.synchronize()
             dist.barrier()
-            run_steps(ro_prof, args.warmup + args.steps)
+            run_batches(1)
             sync_all()
     if rank == 0 and not args.no_roofline:
         dom.timing(m.KWT, reset=True)
         dom.set_profiling(1)
-        ro_prof = gen(W, args.warmup + args.steps)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        run_steps(ro_prof, args.warmup + args.steps)
+        run_batches(1)
         sync_all()
         dom.set_profiling(0)
         pt = dom.timing(m.KWT, reset=True)
@@ -232,19 +237,16 @@ def main():
     # not disturb the event-timed launches; bytes per reach-step of that window x the reach-steps
     # of the timed window = algorithmic bytes of the timed window
     if world > 1 and rank != 0 and not args.no_roofline:
-        ro_cnt = gen(W, args.warmup + args.steps + W)
-        torch.cuda.synchronize()
         dist.barrier()
-        run_steps(ro_cnt, args.warmup + args.steps + W)
+        run_batches(1)
         sync_all()
     if rank == 0 and not args.no_roofline:
         dom.set_profiling(2)
         dom.kwt_traffic(reset=True)
-        ro_cnt = gen(W, args.warmup + args.steps + W)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        run_steps(ro_cnt, args.warmup + args.steps + W)
+        run_batches(1)
         sync_all()
         dom.set_profiling(0)
         tr = dom.kwt_traffic(reset=True)
@@ -279,13 +281,15 @@ def main():
     if rank == 0:
         out = {
             "metric": "reaches*timesteps/s", "value": value, "unit": "reaches*timesteps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": K, "warmup": KW,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on",
                        "reaches_per_gpu": net.N // world, "reaches_total": net.N, "stages": n_stages,
-                       "max_stage_width": max_width, "window_steps": W,
-                       "simulated_years_per_wallclock_day": (args.steps * DT / 31536000.0) / (elapsed / 86400.0),
+                       "max_stage_width": max_width,
+                       "step": "one forcing window (batch) of window_steps model time steps",
+                       "window_steps": W, "model_timesteps_timed": K * W, "ms_per_model_timestep": elapsed / (K * W) * 1e3,
+                       "simulated_years_per_wallclock_day": (K * W * DT / 31536000.0) / (elapsed / 86400.0),
                        "kernel_time_fraction": tm["kernel_ms"] * 1e-3 / elapsed if tm["kernel_ms"] else None,
                        "parallelism": ("1 domain" if world == 1 else
                                        f"{world} sub-basin partitions (reference mainstem rule), mainstem on rank 0, "

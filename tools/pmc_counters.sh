@@ -2,7 +2,7 @@
 # usage: tools_pmc.sh <outdir> <counters...>   (run inside gpurun)
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 out=$1; shift
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -o pmc -- python bench.py --no-cpu-baseline --no-roofline --window 1024 --steps 1024 --warmup 256 $MZR_PMC_ARGS > gpurun_out/$out.log 2>&1
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -o pmc -- python bench.py --no-cpu-baseline --no-roofline --window 1024 --steps 1 --warmup 1 $MZR_PMC_ARGS > gpurun_out/$out.log 2>&1
 ls gpurun_out/$out | head
 python - <<PY
 import csv, glob, collections

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/$tag
 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
 tail -c 3000 gpurun_out/$tag/bench.json
-ARGS="--no-cpu-baseline --no-roofline --window 8192 --steps 8192 --warmup 256"
+ARGS="--no-cpu-baseline --no-roofline --window 8192 --steps 1 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/stats -o k -- python bench.py $ARGS > gpurun_out/$tag/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$tag/pmc_fetch -o k -- python bench.py $ARGS > gpurun_out/$tag/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/$tag/pmc_write -o k -- python bench.py $ARGS > gpurun_out/$tag/pmc_write.log 2>&1

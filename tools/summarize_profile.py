@@ -46,7 +46,7 @@ fetch, nf = pmc("pmc_fetch", "FETCH_SIZE")
 write, nw = pmc("pmc_write", "WRITE_SIZE")
 stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv")))}
 lines = [f"# Profile {tag}", "",
-         "Command: `python bench.py --no-cpu-baseline --no-roofline --window 8192 --steps 8192 --warmup 256` under",
+         "Command: `python bench.py --no-cpu-baseline --no-roofline --window 8192 --steps 1 --warmup 1` under",
          "`rocprofv3 --kernel-trace --stats` and, separately, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.", "",
          "| kernel | calls | avg us | total ms | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (2*F+W) |",
          "|---|---|---|---|---|---|---|"]
