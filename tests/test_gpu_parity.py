@@ -488,3 +488,20 @@ def test_eight_way_confluence_and_the_upstream_limit(hip_lib, oracle_lib):
     with pytest.raises(m.MzrError) as e:                           # nine: refused at set-up, not silently wrong
         m.RoutingDomain(make_star_network(9, 2, seed=2), 3600.0, [m.KWT], frac_future=ff)
     assert "at most 8 immediate upstream" in str(e.value)
+
+
+def test_long_single_step_run_equals_windows(hip_lib):
+    """mzr_step (one main_route call per model time step, the coupled-model use) regroups the KWT lane
+    classes every 512 steps; 600 single steps must equal the same steps run as windows."""
+    net = m.make_network(1500, seed=61)
+    steps, dt = 600, 3600.0
+    ro = m.make_runoff(net.H, steps, seed=62, storm_prob=0.03, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    a = m.RoutingDomain(net, dt, [m.KWT], frac_future=ff, max_window=64)
+    Qa = a.run(ro)
+    b = m.RoutingDomain(net, dt, [m.KWT], frac_future=ff, max_window=1)
+    for it in range(steps):
+        b.step(it * dt, (it + 1) * dt, ro[it])
+        if it % 97 == 0 or it == steps - 1:
+            assert np.array_equal(b.flux(m.KWT), Qa[it, 0]), it
+    assert all(np.array_equal(x, y) for x, y in zip(a.kwt_state(), b.kwt_state()))
