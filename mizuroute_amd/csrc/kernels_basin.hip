@@ -17,9 +17,9 @@
 
 // grid: x over reaches, y over tiles of BT steps of the window (the HRU list of a reach is read once per tile)
 #define BT 8
-__global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
+__global__ void __launch_bounds__(256) k_basin2reach(MzrDev d, int tBegin, int tEnd) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t0 = blockIdx.y * BT;
+  const int t0 = tBegin + blockIdx.y * BT;
   if (r >= d.N) return;
   if (d.haloSlot && d.haloSlot[r] >= 0) return;     // lateral inflow of a halo reach is imported
   const int e0 = d.hruOff[r], e1 = d.hruOff[r + 1];
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
     const double w = d.hruW[e];
 #pragma unroll
     for (int j = 0; j < BT; ++j) {
-      if (t0 + j < d.W) {
+      if (t0 + j < tEnd) {
         const double v = d.runoff[(size_t)(t0 + j) * d.H + hx];
         if (v < d.negRunoffTol) mzr_raise(d, 20, r, t0 + j, 1);   // process_remap.f90:397-402
         acc[j] = acc[j] + w * v * d.time_conv * d.length_conv;
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d) {
 #pragma unroll
   for (int j = 0; j < BT; ++j) {
     const int t = t0 + j;
-    if (t >= d.W) continue;
+    if (t >= tEnd) continue;
     double rr;
     if (e1 > e0) {
       double a = acc[j];
@@ -98,12 +98,12 @@ __device__ __forceinline__ void hillslope_tile(const MzrDev &d, mzr_cptr Fpad, i
 }
 
 // grid: x over reaches, y over tiles of HT steps: BASIN_QR(1) of steps [y*HT, y*HT+HT)
-__global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d) {
+__global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d, int tBegin, int tEnd) {
   const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = r < d.N && !(d.haloSlot && d.haloSlot[r] >= 0);
-  const int t0 = blockIdx.y * HT;
-  const int count = d.W - t0 < HT ? d.W - t0 : HT;
+  const int t0 = tBegin + blockIdx.y * HT;
+  const int count = tEnd - t0 < HT ? tEnd - t0 : HT;
   hillslope_tile<false>(d, Fpad, r, t0, count, active);
 }
 
@@ -150,13 +150,25 @@ void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const dou
   hipLaunchKernelGGL(k_lake_forcing, grid, block, 0, stream, d, lakeReachInt, evap, precip, lakeEvap, lakePrecip);
 }
 
-void mzr_launch_basin(const MzrDev &d, hipStream_t stream) {
-  dim3 block(256), grid((d.N + 255) / 256, (d.W + BT - 1) / BT);
-  hipLaunchKernelGGL(k_basin2reach, grid, block, 0, stream, d);
+// steps [tBegin, tEnd) of the window (tBegin a multiple of the tile sizes): the hillslope fold is causal,
+// so the window can be produced in chunks while the routing sweep already consumes the first ones
+void mzr_launch_basin_chunk(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream) {
+  const int n = tEnd - tBegin;
+  if (n <= 0) return;
+  dim3 block(256), grid((d.N + 255) / 256, (n + BT - 1) / BT);
+  hipLaunchKernelGGL(k_basin2reach, grid, block, 0, stream, d, tBegin, tEnd);
   if (d.doesBasinRoute == 1) {
-    dim3 gridO((d.N + 255) / 256, (d.W + HT - 1) / HT);
-    hipLaunchKernelGGL(k_hillslope_out, gridO, block, 0, stream, d);
-    dim3 gridS((d.N + 255) / 256, (d.ntdhBas + HT - 1) / HT);
-    hipLaunchKernelGGL(k_hillslope_state, gridS, block, 0, stream, d);
+    dim3 gridO((d.N + 255) / 256, (n + HT - 1) / HT);
+    hipLaunchKernelGGL(k_hillslope_out, gridO, block, 0, stream, d, tBegin, tEnd);
   }
+}
+// QFUTURE after the window (needs every BASIN_QI of the window)
+void mzr_launch_basin_state(const MzrDev &d, hipStream_t stream) {
+  if (d.doesBasinRoute != 1) return;
+  dim3 block(256), gridS((d.N + 255) / 256, (d.ntdhBas + HT - 1) / HT);
+  hipLaunchKernelGGL(k_hillslope_state, gridS, block, 0, stream, d);
+}
+void mzr_launch_basin(const MzrDev &d, hipStream_t stream) {
+  mzr_launch_basin_chunk(d, 0, d.W, stream);
+  mzr_launch_basin_state(d, stream);
 }

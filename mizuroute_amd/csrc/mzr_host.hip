@@ -21,6 +21,8 @@
 #include "mzr_device.h"
 
 void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
+void mzr_launch_basin_chunk(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
+void mzr_launch_basin_state(const MzrDev &d, hipStream_t stream);
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
                              double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
@@ -135,6 +137,8 @@ struct mzr_domain {
   mzr_config cfg;
   hipStream_t stream = nullptr;
   bool highPriority = false;
+  hipStream_t basinStream = nullptr;          // hillslope pre-pass of the later parts of a window, behind the sweep
+  std::vector<hipEvent_t> basinEvents;        // [0] window start, [c] chunk c ready, [last] state ready
   std::string msg;
   int N = 0, H = 0, nStages = 0, maxStageWidth = 0, wk = 64;
   bool haveNet = false, haveState = false;
@@ -308,6 +312,8 @@ int mzr_destroy(mzr_handle h) {
   (void)hipSetDevice(h->cfg.device);
   for (auto &rb : h->route) for (auto &e : rb.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
+  for (auto &e : h->basinEvents) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -760,7 +766,26 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // hold the imported row 0 of this window)
   if (h->lastW > 0)
     hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot);
-  mzr_launch_basin(d, st);
+  // hillslope pre-pass.  The fold is causal and launch s of the sweep only touches steps <= s, so only the
+  // first chunk has to be ready before the sweep starts; the others are produced on a second stream
+  // while the sweep runs and the sweep waits for chunk c right before launch s = c * chunk.
+  const int CH = 1024;
+  const int nChunks = (W + CH - 1) / CH;
+  const bool chunked = nChunks > 2;
+  if (!chunked) mzr_launch_basin(d, st);
+  else {
+    if (!h->basinStream) (void)hipStreamCreateWithFlags(&h->basinStream, hipStreamNonBlocking);
+    while ((int)h->basinEvents.size() < nChunks + 2) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->basinEvents.push_back(e); }
+    mzr_launch_basin_chunk(d, 0, CH, st);
+    (void)hipEventRecord(h->basinEvents[0], st);                       // everything before this window is done
+    (void)hipStreamWaitEvent(h->basinStream, h->basinEvents[0], 0);
+    for (int c = 1; c < nChunks; ++c) {
+      mzr_launch_basin_chunk(d, c * CH, std::min(W, (c + 1) * CH), h->basinStream);
+      (void)hipEventRecord(h->basinEvents[c], h->basinStream);
+    }
+    mzr_launch_basin_state(d, h->basinStream);
+    (void)hipEventRecord(h->basinEvents[nChunks], h->basinStream);
+  }
   if (h->cfg.doesBasinRoute == 1) h->basCur ^= 1;
   const int nS = h->nStages;
   for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
@@ -769,6 +794,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     const bool prof = h->profiling;
     if (prof) rb.evUsed = 0;
     for (int s = 0; s < nS + W - 1; ++s) {
+      if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
       const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
       const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
       if (rE <= rB) continue;
@@ -787,6 +813,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     rb.reachSteps += (long long)N * W;
   }
+  if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
   h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
   return 0;
