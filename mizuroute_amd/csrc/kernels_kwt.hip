@@ -1099,6 +1099,12 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
     return;
   }
   const bool isB = !GEN && b >= nABlocks;
+#ifdef MZR_KWT_HIST
+  const long long _w0 = clock64();
+#define WAVE_DONE(k) do { if (lane == 0 && (b & 7) == 0) { const unsigned long long dt_ = (unsigned long long)(clock64() - _w0); atomicAdd(&d.dbgCycles[3 * (k) + 2], dt_); atomicAdd(&d.dbgCycles[3 * (k) + 3], 1ull); atomicMax(&d.dbgCycles[3 * (k) + 4], dt_); } } while (0)
+#else
+#define WAVE_DONE(k) do { } while (0)
+#endif
   unsigned ovfMask = 0;      // class B: groups whose reach needs the wide path (wave-uniform)
   if (isB) {
     const int g8 = lane / GB;
@@ -1110,13 +1116,14 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
 #endif
 #pragma unroll
     for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
-    if (!ovfMask) return;
+    if (!ovfMask) { WAVE_DONE(1); return; }
   }
   const int g16 = lane / GA;
   if (!isB) {
     const int item = haBegin + b * RA + g16;
     const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
     if (ovf) mzr_raise(d, 60, d.kwtRouted[item < haEnd ? item : haEnd - 1].r, s, 10);      // work array bounds exceeded
+    WAVE_DONE(0);
     return;
   }
   // class-B reaches that have outgrown 8 lanes: four at a time; eight groups = at most two rounds (rare),

@@ -27,3 +27,5 @@ for i, n in enumerate(names):
 print("slow merges", buf[8], "exit-time fixes", buf[9], "deferred to next round", buf[10], "sampled routed reach-steps (1/16 of blocks)", buf[11],
       "mean LDS need", buf[12] / max(1, buf[11]), "thinned", buf[13], "particles removed", buf[14], "shock merges", buf[15])
 print("size histogram (<=4,<=8,<=12,<=16,<=20,<=32,<=48,>48; with -DMZR_KWT_HIST the counters 8..15 hold this instead):", [buf[8 + i] for i in range(8)])
+if buf[3] and buf[6]:
+    print("with -DMZR_KWT_HIST: class A waves mean %.0f max %d cycles (n=%d); class B waves mean %.0f max %d cycles (n=%d)" % (buf[2] / buf[3], buf[4], buf[3], buf[5] / buf[6], buf[7], buf[6]))
