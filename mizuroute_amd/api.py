@@ -134,7 +134,8 @@ class RoutingDomain:
 
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
                  hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
-                 export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0, lakes=None):
+                 export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0, lakes=None,
+                 time_conv=1.0, length_conv=1.0):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -148,6 +149,7 @@ class RoutingDomain:
         cfg.doesBasinRoute = int(does_basin_route); cfg.hw_drain_point = int(hw_drain_point)
         cfg.min_length_route = float(min_length_route); cfg.runoffMin = float(runoff_min)
         cfg.maxWindow = int(max_window); cfg.device = int(device); cfg.is_flux_wm = int(is_flux_wm)
+        cfg.time_conv = float(time_conv); cfg.length_conv = float(length_conv)   # runoff units -> m/s
         self.is_flux_wm = int(is_flux_wm)
         self.max_window = int(max_window)
         self.h = C.c_void_p()

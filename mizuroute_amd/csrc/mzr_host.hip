@@ -56,7 +56,7 @@ struct RouteBufs {
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing; DBuf<int> lakeHead;   // per-method mutable Hanasaki parameters / inflow memory
-  long long nLaunches = 0, reachSteps = 0; double kernel_ms = 0.0;
+  long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
 
@@ -701,7 +701,7 @@ int mzr_init_state(mzr_handle h) {
         h->kwtStat.alloc(1); h->kwtStat.zero();
         h->dbgCycles.alloc(16); h->dbgCycles.zero();
       }
-      rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0;
+      rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0; rb.meanSteps = 0;
     }
   } catch (const std::string &e) { return fail(h, 91, "mzr_init_state/" + e); }
   if (hipDeviceSynchronize() != hipSuccess) return fail(h, 92, "mzr_init_state/device error");
@@ -812,6 +812,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       ++rb.nLaunches;
     }
     rb.reachSteps += (long long)N * W;
+    rb.meanSteps += W;
   }
   if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
   h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0;
@@ -1012,9 +1013,9 @@ int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset) {
   const int ix = idxOf(h, method);
   if (ix < 0) return fail(h, 81, "mzr_get_mean_q/method not active");
   rc = pullRow(h, h->route[ix].qsum.p, out); if (rc) return rc;
-  const double n = (double)std::max<long long>(1, h->stepsDone);
+  const double n = (double)std::max<long long>(1, h->route[ix].meanSteps);      // steps accumulated in THIS method's sum
   for (int e = 0; e < h->N; ++e) out[e] /= n;
-  if (reset) { h->route[ix].qsum.zero(h->stream); h->stepsDone = 0; (void)hipStreamSynchronize(h->stream); }
+  if (reset) { h->route[ix].qsum.zero(h->stream); h->route[ix].meanSteps = 0; (void)hipStreamSynchronize(h->stream); }
   return 0;
 }
 

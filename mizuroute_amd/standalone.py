@@ -1,0 +1,243 @@
+"""Stand-alone run from a mizuRoute control file: the host side that the reference's
+`route_runoff.exe <control file>` provides (standalone/route_runoff.f90, read_control.f90,
+read_param.f90, process_ntopo.f90 / network_topo.f90 set-up, get_basin_runoff.f90 forcing,
+historyFile.f90, write_restart_pio.f90), in front of the device hot path.
+
+    python -m mizuroute_amd.standalone <control_file> [--window W]
+
+Scope (what a run of the reference's SAMPLE.control needs, nothing more):
+  * control file `<tag> value ! comment` (read_control.f90) and the parameter namelist
+    &HSLOPE fshape,tscale / &IRF_UH velo,diff / &KWT mann_n,wscale (read_param.f90);
+  * river network from `<fname_ntopOld>`: ids, downstream ids, length, slope, HRU ids / areas / their
+    segment (names through the <varname_*> dictionary; defaults of popMetadat.f90:124-170), with the
+    augmentation the reference computes at start-up: upstream lists (network_topo.f90), HRU weights =
+    area fractions (:188), BASAREA / TOTAREA (:748-764), goodBas (:771-775), hydraulic geometry
+    R_WIDTH = wscale*sqrt(TOTAREA), R_DEPTH = high_depth without flood plain, R_MAN_N = mann_n,
+    R_STORAGE (process_ntopo.f90:174-205), slope floor min_slope (:360), unit hydrographs (uh.py);
+  * forcing from `<fname_qsim>` (one NetCDF file, or a text file listing them) on the simulation
+    step (dt_ro == dt_qsim; the general time mapping timeMap_sim_forc is not implemented), on the
+    river-network HRUs in file order (is_remap = F -> sort_flux) or remapped (is_remap = T, 1-D);
+  * history file(s) `<case_name>.h.<start>.nc` at `<outputFrequency>` (a multiple of the step or
+    `daily`), one file per run (`<newFileFrequency> single`), restart in / out (`<fname_state_in>`,
+    `<restart_write> last`).
+NetCDF files are classic (CDF-1/2) through scipy -- the image has no netCDF-4/HDF5 library.  The file
+conventions are taken from the reference's sources and documentation; they are not pinned by running
+the reference's own I/O (it needs ParallelIO).
+"""
+from __future__ import annotations
+
+import datetime as _dt
+import os
+import re
+import sys
+
+import numpy as np
+from scipy.io import netcdf_file
+
+from . import api, ncfiles, uh as uhmod
+from .synthetic import HIGH_DEPTH, RiverNetwork, build_upstream_csr, hops_to_outlet
+
+MIN_SLOPE = 1.0e-6            # public_var.f90:30
+VERY_SMALL = np.finfo(np.float64).tiny
+DEFAULT_NAMES = dict(varname_area="area", varname_length="length", varname_slope="slope", varname_HRUid="HRUid",
+                     varname_hruSegId="hruSegId", varname_segId="segId", varname_downSegId="downSegId")
+
+
+def read_control(path: str) -> dict:
+    """`<tag>  value   ! comment` lines (read_control.f90); later tags win."""
+    out = {}
+    for line in open(path):
+        s = line.strip()
+        if not s.startswith("<"):
+            continue
+        m = re.match(r"<([^>]+)>\s*([^!]*)", s)
+        if m:
+            out[m.group(1).strip()] = m.group(2).strip()
+    return out
+
+
+def read_param_nml(path: str) -> dict:
+    """&HSLOPE / &IRF_UH / &KWT namelist groups with scalar values (read_param.f90)."""
+    out = dict(fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0, mann_n=0.01, wscale=0.001, dscale=0.0036)
+    for k, v in re.findall(r"(\w+)\s*=\s*([-+0-9.eEdD]+)", open(path).read()):
+        out[k] = float(v.replace("d", "e").replace("D", "e"))
+    return out
+
+
+def _truth(s: str) -> bool:
+    return s.strip().upper() in ("T", ".TRUE.", "TRUE")
+
+
+def _parse_time(s: str) -> _dt.datetime:
+    s = s.strip()
+    for fmt in ("%Y-%m-%d %H:%M:%S", "%Y-%m-%d %H:%M", "%Y-%m-%d"):
+        try:
+            return _dt.datetime.strptime(s, fmt)
+        except ValueError:
+            pass
+    raise ValueError(f"cannot parse time '{s}'")
+
+
+def _time_axis(var) -> np.ndarray:
+    """Seconds since 1970-01-01 of a CF time variable (`<unit> since <date>`)."""
+    units = var.units.decode() if isinstance(var.units, bytes) else var.units
+    m = re.match(r"\s*(\w+)\s+since\s+(.*)", units)
+    scale = {"seconds": 1.0, "second": 1.0, "sec": 1.0, "minutes": 60.0, "hours": 3600.0, "hour": 3600.0, "days": 86400.0, "day": 86400.0}[m.group(1).lower()]
+    ref = _parse_time(m.group(2).strip().replace("T", " ").split(".")[0])
+    return (ref - _dt.datetime(1970, 1, 1)).total_seconds() + np.asarray(var[:], dtype=np.float64) * scale
+
+
+def unit_factors(units: str):
+    """runoff [units] -> m/s: (time_conv, length_conv) as get_basin_runoff / init_model_data derive them."""
+    length, time = [u.strip().lower() for u in units.split("/")]
+    lc = {"mm": 1.0e-3, "m": 1.0}[length]
+    tc = {"s": 1.0, "sec": 1.0, "second": 1.0, "h": 1.0 / 3600.0, "hr": 1.0 / 3600.0, "hour": 1.0 / 3600.0, "d": 1.0 / 86400.0, "day": 1.0 / 86400.0}[time]
+    return tc, lc
+
+
+def build_network(ctl: dict, nml: dict):
+    """River network + parameters from the topology file, augmented as the reference does at start-up."""
+    name = lambda k: ctl.get(k, DEFAULT_NAMES[k])
+    f = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_ntopOld"]), "r", mmap=False)
+    v = f.variables
+    seg_id = np.asarray(v[name("varname_segId")][:], dtype=np.int64)
+    down_id = np.asarray(v[name("varname_downSegId")][:], dtype=np.int64)
+    length = np.asarray(v[name("varname_length")][:], dtype=np.float64)
+    slope = np.asarray(v[name("varname_slope")][:], dtype=np.float64)
+    hru_id = np.asarray(v[name("varname_HRUid")][:], dtype=np.int64)
+    hru_seg = np.asarray(v[name("varname_hruSegId")][:], dtype=np.int64)
+    hru_area = np.asarray(v[name("varname_area")][:], dtype=np.float64)
+    f.close()
+    N, H = seg_id.size, hru_id.size
+    ix = {int(s): i for i, s in enumerate(seg_id)}
+    downIndex = np.array([ix.get(int(dn), -1) + 1 for dn in down_id], dtype=np.int32)   # 0: outlet / not in the network
+    upOffset, upIndex = build_upstream_csr(downIndex)
+    # HRUs per segment in file order, weights = area fractions (network_topo.f90:188)
+    seg_of_hru = np.array([ix.get(int(s), -1) for s in hru_seg], dtype=np.int64)
+    order = np.argsort(seg_of_hru, kind="stable")
+    order = order[seg_of_hru[order] >= 0]
+    cnt = np.bincount(seg_of_hru[order], minlength=N)
+    hruOffset = np.zeros(N + 1, dtype=np.int32); hruOffset[1:] = np.cumsum(cnt)
+    hruIndex = (order + 1).astype(np.int32)
+    basarea = np.bincount(seg_of_hru[order], weights=hru_area[order], minlength=N)
+    w = np.where(basarea[seg_of_hru[order]] > 0, hru_area[order] / np.where(basarea[seg_of_hru[order]] > 0, basarea[seg_of_hru[order]], 1.0), 0.0)
+    totarea = basarea.copy()
+    down0 = downIndex.astype(np.int64) - 1
+    dist = hops_to_outlet(down0)
+    for dlev in range(int(dist.max()), 0, -1):
+        idx = np.nonzero(dist == dlev)[0]
+        np.add.at(totarea, down0[idx], totarea[idx])
+    width = nml["wscale"] * np.sqrt(totarea)
+    rdepth = np.full(N, HIGH_DEPTH)
+    side = np.zeros(N)
+    params = dict(R_SLOPE=np.maximum(slope, MIN_SLOPE), R_MAN_N=np.full(N, nml["mann_n"]), R_WIDTH=width, R_DEPTH=rdepth,
+                  RLENGTH=length, R_STORAGE=rdepth * (width + side * rdepth) * length, SIDE_SLOPE=side,
+                  FLDP_SLOPE=np.full(N, 1000.0), BASAREA=basarea, TOTAREA=totarea, MINFLOW=np.zeros(N))
+    good = (totarea > VERY_SMALL).astype(np.int32)
+    net = RiverNetwork(N=N, H=H, downIndex=downIndex, reachId=seg_id.astype(np.int32), upOffset=upOffset, upIndex=upIndex,
+                       upGood=np.repeat(good, np.diff(upOffset)).astype(np.int32), hruOffset=hruOffset, hruIndex=hruIndex,
+                       hruWeight=w, params=params)
+    return net, hru_id
+
+
+def _forcing_files(ctl: dict):
+    p = os.path.join(ctl.get("input_dir", ""), ctl["fname_qsim"])
+    if p.endswith(".nc"):
+        return [p]
+    return [os.path.join(ctl.get("input_dir", ""), ln.strip()) for ln in open(p) if ln.strip()]
+
+
+def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> dict:
+    ctl = read_control(control_path)
+    nml = read_param_nml(os.path.join(ctl.get("ancil_dir", ""), ctl["param_nml"]))
+    net, hru_id = build_network(ctl, nml)
+    dt = float(ctl.get("dt_qsim", 86400))
+    if float(ctl.get("dt_ro", dt)) != dt:
+        raise NotImplementedError("dt_ro /= dt_qsim: the time mapping of timeMap_sim_forc (get_basin_runoff.f90) is not implemented")
+    methods = [int(c) for c in ctl.get("route_opt", "0")]
+    t_beg, t_end = _parse_time(ctl["sim_start"]), _parse_time(ctl["sim_end"])
+    epoch = _dt.datetime(1970, 1, 1)
+    n_steps = int(round((t_end - t_beg).total_seconds() / dt)) + 1          # both ends included (init_model_data.f90)
+    tc, lc = unit_factors(ctl.get("units_qsim", "m/s"))
+    frac = uhmod.basin_uh(dt, nml["fshape"], nml["tscale"])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, nml["velo"], nml["diff"])
+    W = max(1, min(window, n_steps))
+    dom = api.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=W, device=device,
+                            does_basin_route=int(ctl.get("doesBasinRoute", 1)), hw_drain_point=int(ctl.get("hw_drain_point", 2)),
+                            time_conv=tc, length_conv=lc)
+    # ---- forcing: concatenate the files' time axes, find the record of every simulation step
+    files = _forcing_files(ctl)
+    handles = [netcdf_file(p, "r", mmap=False) for p in files]
+    taxis = np.concatenate([_time_axis(h.variables[ctl["vname_time"]]) for h in handles])
+    frec = np.concatenate([np.full(h.variables[ctl["vname_time"]].shape[0], i) for i, h in enumerate(handles)])
+    lrec = np.concatenate([np.arange(h.variables[ctl["vname_time"]].shape[0]) for h in handles])
+    t0 = (t_beg - epoch).total_seconds()
+    first = int(np.argmin(np.abs(taxis - t0)))
+    if abs(taxis[first] - t0) > 0.5 * dt or first + n_steps > taxis.size:
+        raise ValueError("forcing files do not cover the simulation period")
+    remap = _truth(ctl.get("is_remap", "F"))
+    if remap:
+        m = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_remap"]), "r", mmap=False)
+        mv = m.variables
+        src_id = np.asarray(handles[0].variables[ctl["vname_hruid"]][:], dtype=np.int64)
+        pos_rn = {int(x): i + 1 for i, x in enumerate(hru_id)}
+        pos_src = {int(x): i + 1 for i, x in enumerate(src_id)}
+        qid = np.asarray(mv[ctl["vname_qhruid"]][:], dtype=np.int64)
+        mp = dict(hru_ix=np.array([pos_rn.get(int(x), -9999) for x in mv[ctl["vname_hruid_in_remap"]][:]], dtype=np.int32),
+                  num_qhru=np.asarray(mv[ctl["vname_num_qhru"]][:], dtype=np.int32), weight=np.asarray(mv[ctl["vname_weight"]][:], dtype=np.float64),
+                  qhru_ix=np.array([pos_src.get(int(x), -9999) for x in qid], dtype=np.int32), qhru_id=qid, src_id=src_id,
+                  n1=src_id.size, n2=0, H=net.H)
+        m.close()
+        dom.set_remap(mp)
+    else:
+        src_id = np.asarray(handles[0].variables[ctl["vname_hruid"]][:], dtype=np.int64)
+        pos_rn = {int(x): i + 1 for i, x in enumerate(hru_id)}
+        dom.set_sort_map(np.array([pos_rn.get(int(x), -9999) for x in src_id], dtype=np.int32), True)
+    # ---- restart in
+    t_first = 0.0
+    state_in = ctl.get("fname_state_in", "coldstart")
+    if state_in and state_in.lower() != "coldstart" and not state_in.isupper():
+        tb = ncfiles.read_restart(os.path.join(ctl.get("output_dir", ""), state_in), dom)
+        t_first = float(tb[1])
+        log(f"restart from {state_in}: time_bound = {tb}")
+    # ---- history
+    of = ctl.get("outputFrequency", "1")
+    every = int(round(86400.0 / dt)) if of == "daily" else int(of)
+    os.makedirs(ctl.get("output_dir", "."), exist_ok=True)
+    hname = os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.h.{t_beg:%Y-%m-%d}-{t_beg.hour * 3600 + t_beg.minute * 60 + t_beg.second:05d}.nc")
+    hist = ncfiles.HistoryWriter(hname, net.reachId, methods, time_units=f"seconds since {t_beg:%Y-%m-%d %H:%M:%S}",
+                                 volumes=any(_truth(ctl.get(k, "F")) for k in ncfiles.HIST_VOL.values()))
+    import torch
+    dev = torch.device("cuda", device)
+    done = 0
+    qname = ctl["vname_qsim"]
+    while done < n_steps:
+        w = min(W, n_steps - done)
+        w = min(w, every - (done % every)) if every < W else w             # a window never straddles an output record
+        rows = [np.asarray(handles[frec[first + done + k]].variables[qname][lrec[first + done + k]], dtype=np.float64) for k in range(w)]
+        src = torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(dev)
+        dom.run_source_device(w, t_first + done * dt, src.data_ptr())
+        dom.sync()
+        done += w
+        if done % every == 0:
+            hist.append(done * dt, dom)
+    hist.close()
+    out = dict(history=hname, steps=n_steps, reaches=net.N)
+    if ctl.get("restart_write", "never").lower() == "last":
+        rname = os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.r.{t_end:%Y-%m-%d}-{t_end.hour * 3600:05d}.nc")
+        ncfiles.write_restart(rname, dom, net.reachId, (t_first + (n_steps - 1) * dt, t_first + n_steps * dt), restart_time=t_first + n_steps * dt)
+        out["restart"] = rname
+    for h in handles:
+        h.close()
+    dom.close()
+    log(f"routed {net.N} reaches x {n_steps} steps -> {hname}")
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("control")
+    ap.add_argument("--window", type=int, default=1024)
+    a = ap.parse_args()
+    run(a.control, a.window)

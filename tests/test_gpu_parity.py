@@ -434,6 +434,8 @@ def test_restart_continues_bit_exact(tmp_path, hip_lib):
     got = f.variables["KWTroutedRunoff"][:]
     assert got.shape == (3, net.N)
     assert np.allclose(got[2], want[0], rtol=1e-6)
+    for ix, meth in enumerate(methods):        # every method's mean is over its own 24 steps (one reset must not disturb the others)
+        assert np.allclose(f.variables[ncfiles.HIST_Q[meth]][:][2], want[ix], rtol=1e-6), meth
     f.close()
 
 

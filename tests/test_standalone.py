@@ -1,0 +1,131 @@
+"""Stand-alone driver (mizuroute_amd/standalone.py): control file, parameter namelist, network
+augmentation from a topology file, and -- on the GPU -- a whole run from files against the same run
+through the API."""
+import os
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+import mizuroute_amd as m
+from mizuroute_amd import standalone
+
+
+def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None):
+    """Topology, forcing (HM HRUs = RN HRUs in shuffled order), control file and namelist of a synthetic case."""
+    rng = np.random.default_rng(shuffle_seed)
+    N = net.N
+    hru_id = (np.arange(N) + 50001).astype(np.int32)
+    seg_of_hru = np.zeros(N, np.int32)
+    for r in range(N):
+        seg_of_hru[net.hruIndex[net.hruOffset[r]:net.hruOffset[r + 1]] - 1] = net.reachId[r]
+    f = netcdf_file(os.path.join(tmp, "ntopo.nc"), "w", version=2)
+    f.createDimension("seg", N); f.createDimension("hru", N)
+    def var(name, typ, dim, data):
+        v = f.createVariable(name, typ, (dim,)); v[:] = data
+    down_id = np.where(net.downIndex > 0, net.reachId[np.maximum(net.downIndex, 1) - 1], -1).astype(np.int32)
+    var("seg_id", "i", "seg", net.reachId.astype(np.int32)); var("tosegment", "i", "seg", down_id)
+    var("Length", "d", "seg", net.params["RLENGTH"]); var("Slope", "d", "seg", net.params["R_SLOPE"])
+    var("hruid", "i", "hru", hru_id); var("seg_hru_id", "i", "hru", seg_of_hru); var("Basin_Area", "d", "hru", net.params["BASAREA"])
+    f.close()
+    perm = rng.permutation(N)                       # forcing file lists the HRUs in another order
+    steps = runoff_mm_s.shape[0]
+    g = netcdf_file(os.path.join(tmp, "runoff.nc"), "w", version=2)
+    g.createDimension("time", None); g.createDimension("hru", N)
+    t = g.createVariable("time", "d", ("time",)); t.units = "hours since 2001-01-01 00:00:00"
+    h = g.createVariable("hru_id", "i", ("hru",)); h[:] = hru_id[perm]
+    q = g.createVariable("RUNOFF", "d", ("time", "hru"))
+    for k in range(steps):
+        t[k] = k * dt / 3600.0
+        q[k, :] = runoff_mm_s[k, perm]
+    g.close()
+    open(os.path.join(tmp, "param.nml"), "w").write("&HSLOPE\n fshape = 2.5\n tscale = 86400\n/\n&IRF_UH\n velo = 1.5\n diff = 5000.0\n/\n&KWT\n mann_n = 0.01\n wscale = 0.001\n/\n")
+    end = np.datetime64("2001-01-01T00:00:00") + np.timedelta64(int((steps - 1) * dt), "s")
+    ctl = f"""! synthetic case
+<case_name>      synth        ! name
+<sim_start>      2001-01-01 00:00:00  ! start
+<sim_end>        {str(end).replace('T', ' ')}  ! end
+<route_opt>      {route_opt}   ! methods
+<doesBasinRoute> 1
+<dt_qsim>        {int(dt)}
+<dt_ro>          {int(dt)}
+<ancil_dir>      {tmp}/
+<input_dir>      {tmp}/
+<output_dir>     {tmp}/out/
+<fname_ntopOld>  ntopo.nc
+<fname_qsim>     runoff.nc
+<vname_qsim>     RUNOFF
+<vname_time>     time
+<vname_hruid>    hru_id
+<units_qsim>     mm/s
+<is_remap>       F
+<param_nml>      param.nml
+<varname_area>      Basin_Area
+<varname_length>    Length
+<varname_slope>     Slope
+<varname_HRUid>     hruid
+<varname_hruSegId>  seg_hru_id
+<varname_segId>     seg_id
+<varname_downSegId> tosegment
+<restart_write>  last
+<outputFrequency> 6
+<newFileFrequency> single
+"""
+    path = os.path.join(tmp, "synth.control")
+    open(path, "w").write(ctl)
+    return path
+
+
+def test_control_namelist_and_units(tmp_path):
+    net = m.make_network(40, seed=4)
+    path = write_case(str(tmp_path), net, np.zeros((3, 40)), 3600.0)
+    ctl = standalone.read_control(path)
+    assert ctl["case_name"] == "synth" and ctl["route_opt"] == "2" and ctl["sim_start"] == "2001-01-01 00:00:00"
+    assert ctl["varname_downSegId"] == "tosegment" and ctl["outputFrequency"] == "6"
+    nml = standalone.read_param_nml(os.path.join(str(tmp_path), "param.nml"))
+    assert nml["fshape"] == 2.5 and nml["tscale"] == 86400.0 and nml["velo"] == 1.5 and nml["mann_n"] == 0.01 and nml["wscale"] == 0.001
+    assert standalone.unit_factors("mm/s") == (1.0, 1.0e-3) and standalone.unit_factors("m/s") == (1.0, 1.0)
+    tc, lc = standalone.unit_factors("mm/day")
+    assert lc == 1.0e-3 and tc == 1.0 / 86400.0
+
+
+def test_network_augmentation_matches_the_generator(tmp_path):
+    """Upstream lists, HRU weights, BASAREA/TOTAREA, goodBas and the hydraulic geometry recomputed from the
+    raw topology file equal what the synthetic generator (same formulas as process_ntopo.f90) holds."""
+    net = m.make_network(700, seed=12, p3=0.05, zero_area_frac=0.1)
+    path = write_case(str(tmp_path), net, np.zeros((2, 700)), 3600.0)
+    ctl = standalone.read_control(path)
+    got, hru_id = standalone.build_network(ctl, standalone.read_param_nml(os.path.join(str(tmp_path), "param.nml")))
+    assert np.array_equal(got.downIndex, net.downIndex) and np.array_equal(got.upOffset, net.upOffset)
+    assert np.array_equal(got.upIndex, net.upIndex) and np.array_equal(got.upGood, net.upGood)
+    assert np.array_equal(got.hruOffset, net.hruOffset) and np.array_equal(got.hruIndex, net.hruIndex)
+    pos = net.params["TOTAREA"] > 0      # (the generator gives zero-area reaches a 1 mm wide channel; the reference formula gives 0)
+    for k in net.PARAM_ORDER:
+        sel = pos if k in ("R_WIDTH", "R_STORAGE") else slice(None)
+        assert np.array_equal(got.params[k][sel], net.params[k][sel]), k
+    w = got.hruWeight[net.params["BASAREA"][np.repeat(np.arange(net.N), np.diff(net.hruOffset))] > 0]
+    assert np.array_equal(w, np.ones_like(w))
+
+
+@pytest.mark.gpu
+def test_run_from_files_equals_api_run(tmp_path, hip_lib):
+    from mizuroute_amd import uh as uhmod
+    net = m.make_network(1500, seed=13)
+    dt, steps = 3600.0, 48
+    ro = m.make_runoff(net.H, steps, seed=14, storm_prob=0.03, storm_amp=3e-6)       # m/s
+    path = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="21")            # file holds mm/s
+    out = standalone.run(path, window=16, log=lambda *_: None)
+    assert out["steps"] == steps
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    dom = m.RoutingDomain(net, dt, [m.KWT, m.IRF], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=16)
+    Q = dom.run((ro * 1000.0) * 1.0 * 1.0e-3)          # the driver converts with time_conv * length_conv on the device
+    f = netcdf_file(out["history"], "r", mmap=False)
+    got = f.variables["KWTroutedRunoff"][:]
+    irf = f.variables["IRFroutedRunoff"][:]
+    assert got.shape == (steps // 6, net.N)
+    want = Q.reshape(steps // 6, 6, 2, net.N).sum(axis=1) / 6.0
+    assert np.allclose(got, want[:, 0], rtol=2e-6, atol=1e-12) and np.allclose(irf, want[:, 1], rtol=2e-6, atol=1e-12)
+    f.close()
+    st = __import__("mizuroute_amd.ncfiles", fromlist=["x"]).read_restart_file(out["restart"])
+    assert np.array_equal(st["numWaves"], dom.kwt_state()[0])
