@@ -171,6 +171,8 @@ struct mzr_domain {
   // kwt
   DBuf<int> kwN, obN, kwtLight;
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtGeneric;
+  DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll;   // classes A / B over all stages, heaviest first: used by launches in which every stage is active
+  bool kwtAllValid = false;
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff;        // [nStages+1] stage offsets in h_kwtRouted / in the class-B list (kwtRoutedOff: class A)
   long long kwtWindows = 0, kwtStepsSince = 0; // KWT windows run since mzr_init_state, steps since the last regrouping
@@ -687,7 +689,7 @@ int mzr_init_state(mzr_handle h) {
           if (routed.empty()) routed.push_back(none);
           if (generic.empty()) generic.push_back(none);
           if (light.empty()) light.push_back(0);
-          h->kwtRouted.upload(routed); h->kwtRoutedB.upload(routed); h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
+          h->kwtRouted.upload(routed); h->kwtRoutedB.upload(routed); h->kwtRoutedAll.upload(routed); h->kwtRoutedBAll.upload(routed); h->kwtAllValid = false; h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
           h->h_kwtRouted = routed; h->kwtWindows = 0; h->kwtStepsSince = 0;
           h->kwtStageOff = h->kwtRoutedOff;                       // every routed reach starts in class A
           h->kwtBOff.assign(h->nStages + 1, 0);
@@ -744,7 +746,24 @@ static void kwt_regroup(mzr_handle h) {
   }
   h->kwtRoutedOff[h->nStages] = (int)A.size(); h->kwtBOff[h->nStages] = (int)B.size();
   if (!A.empty()) (void)hipMemcpy(h->kwtRouted.p, A.data(), A.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+  if (!A.empty()) {   // the same reaches, heaviest first regardless of stage
+    std::vector<std::pair<int, int>> k2; k2.reserve(A.size());
+    for (size_t i = 0; i < A.size(); ++i) k2.emplace_back(-need(A[i]), (int)i);
+    std::sort(k2.begin(), k2.end());
+    std::vector<MzrKwtRec> S; S.reserve(A.size());
+    for (const auto &k : k2) S.push_back(A[k.second]);
+    (void)hipMemcpy(h->kwtRoutedAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+    h->kwtAllValid = true;
+  }
   if (!B.empty()) (void)hipMemcpy(h->kwtRoutedB.p, B.data(), B.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+  if (!B.empty()) {
+    std::vector<std::pair<int, int>> k2; k2.reserve(B.size());
+    for (size_t i = 0; i < B.size(); ++i) k2.emplace_back(-need(B[i]), (int)i);
+    std::sort(k2.begin(), k2.end());
+    std::vector<MzrKwtRec> S; S.reserve(B.size());
+    for (const auto &k : k2) S.push_back(B[k.second]);
+    (void)hipMemcpy(h->kwtRoutedBAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+  }
 }
 
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
@@ -804,9 +823,15 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         }
         (void)hipEventRecord(rb.events[rb.evUsed].first, st);
       }
-      if (rb.method == MZR_KWT)
-        mzr_launch_stage_kwt(d, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1],
+      if (rb.method == MZR_KWT) {
+        MzrDev dk = d;
+        // every stage active: heaviest reaches first regardless of stage (shorter tail of the launch).  This gives up
+        // the stage-major locality of the rows, so only while the rows of all routed reaches (about 1 KB each) sit in
+        // the 256 MB Infinity Cache anyway; measured +12 % at 100 k reaches, -8 % at 400 k.
+        if (h->kwtAllValid && sLo == 0 && sHi == nS - 1 && h->h_kwtRouted.size() <= 150000) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; }
+        mzr_launch_stage_kwt(dk, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1],
                              h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
+      }
       else mzr_launch_stage(rb.method, d, s, rB, rE, st);
       if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, st); ++rb.evUsed; }
       ++rb.nLaunches;
