@@ -16,12 +16,14 @@
 // These solvers are FP64 transcendental-bound (Newton iterations with pow), not HBM-bound.
 #include "mzr_device.h"
 #include "lake_device.h"
+#include "mzr_math.h"
 
 namespace {
 
 constexpr double c13 = 1.0 / 3.0, c23 = 2.0 / 3.0, c53 = 5.0 / 3.0, c103 = 10.0 / 3.0;
 
-struct Chan { double b, zc, S, n, zf, D; };   // width, side slope, slope, Manning n, floodplain slope, bank depth
+struct Chan { double b, zc, S, n, zf, D; double Qbf, n06; };   // width, side slope, slope, Manning n, floodplain slope, bank depth;
+                                                                 // per reach, once: bankfull discharge (hydraulic.f90:345) and n**0.6 (:479)
 
 __device__ __forceinline__ double d_Btop(double y, const Chan &c) {
   if (y <= c.D) return c.b + 2 * y * c.zc;
@@ -53,13 +55,13 @@ __device__ double d_flow_depth(double Qin, const Chan &c) {
   if (!(Qin > 1.e-50)) return 0.0;
   const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c), Bbf = d_Btop(c.D, c);
   const double sqS = sqrt(c.S);
-  const double Qbf = Abf * pow(Abf / Pbf, c23) * sqS / c.n;
+  const double Qbf = c.Qbf;
   double err = 100.0, fd = 0.0;
   if (Qin < Qbf) {
     const double t = sqS / c.n / Qin;
     const double Coef1 = t * t * t;
     const double Coef2 = 2 * sqrt(c.zc * c.zc + 1.0);
-    double y0 = pow(1.0 / Coef1 / (c.b * c.b * c.b), 1.0 / 5.0);
+    double y0 = pow_0p2(1.0 / Coef1 / (c.b * c.b * c.b));
     int guard = 0;
     while (err > 0.005 && guard++ < 200) {
       const double A = d_area(y0, c), Bt = d_Btop(y0, c), P = d_Pwet(y0, c);
@@ -88,14 +90,14 @@ __device__ double d_flow_depth(double Qin, const Chan &c) {
 }
 __device__ double d_friction_slope(double Qin, double y, const Chan &c) {
   const double A = d_area(y, c), P = d_Pwet(y, c);
-  const double v = Qin * c.n / A / pow(A / P, c23);
+  const double v = Qin * c.n / A / pow_2_3(A / P);
   return v * v;
 }
 __device__ double d_celerity(double Qin, double y, const Chan &c) {
   if (!(y > 0.0)) return 0.0;
   const double Bt = d_Btop(y, c);
   const double Sf = d_friction_slope(Qin, y, c);
-  return c53 * pow(Sf, 0.3) * pow(Qin, 0.4) / pow(Bt, 0.4) / pow(c.n, 0.6);
+  return c53 * pow_0p3(Sf) * pow_0p4(Qin) / pow_0p4(Bt) / c.n06;
 }
 __device__ double d_diffusivity(double Qin, double y, const Chan &c) {
   if (!(y > 0.0)) return 0.0;
@@ -174,6 +176,9 @@ __device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, dou
 
 __device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
   Chan c; c.b = d.width[r]; c.zc = d.side[r]; c.S = d.slope[r]; c.n = d.mann[r]; c.zf = d.fldp[r]; c.D = d.depth[r];
+  const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c);
+  c.Qbf = Abf * pow_2_3(Abf / Pbf) * sqrt(c.S) / c.n;      // hydraulic.f90:345
+  c.n06 = pow_0p6(c.n);
   return c;
 }
 
