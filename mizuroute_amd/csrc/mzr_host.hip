@@ -138,6 +138,8 @@ struct mzr_domain {
   hipStream_t stream = nullptr;
   bool highPriority = false;
   hipStream_t basinStream = nullptr;          // hillslope pre-pass of the later parts of a window, behind the sweep
+  hipStream_t routeStream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // methods 2.. of a multi-method run
+  hipEvent_t routeEvent[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // [0] start of the sweeps, [ix] end of method ix
   std::vector<hipEvent_t> basinEvents;        // [0] window start, [c] chunk c ready, [last] state ready
   std::string msg;
   int N = 0, H = 0, nStages = 0, maxStageWidth = 0, wk = 64;
@@ -315,6 +317,7 @@ int mzr_destroy(mzr_handle h) {
   for (auto &rb : h->route) for (auto &e : rb.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
+  for (int ix = 0; ix < 6; ++ix) { if (h->routeStream[ix]) (void)hipStreamDestroy(h->routeStream[ix]); if (h->routeEvent[ix]) (void)hipEventDestroy(h->routeEvent[ix]); }
   for (auto &e : h->basinEvents) (void)hipEventDestroy(e);
   delete h;
   return 0;
@@ -790,7 +793,10 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // while the sweep runs and the sweep waits for chunk c right before launch s = c * chunk.
   const int CH = 1024;
   const int nChunks = (W + CH - 1) / CH;
-  const bool chunked = nChunks > 2;
+  // several routing methods are independent of each other once the hillslope series exist: each gets its own
+  // stream (their stage launches are small and latency-bound, so they fill each other's gaps)
+  const bool multi = h->cfg.nRoutes > 1;
+  const bool chunked = nChunks > 2 && !multi;
   if (!chunked) mzr_launch_basin(d, st);
   else {
     if (!h->basinStream) (void)hipStreamCreateWithFlags(&h->basinStream, hipStreamNonBlocking);
@@ -807,37 +813,57 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   }
   if (h->cfg.doesBasinRoute == 1) h->basCur ^= 1;
   const int nS = h->nStages;
-  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
-    RouteBufs &rb = h->route[ix];
-    setRoute(h, d, ix);
-    const bool prof = h->profiling;
-    if (prof) rb.evUsed = 0;
-    for (int s = 0; s < nS + W - 1; ++s) {
-      if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
-      const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
-      const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
-      if (rE <= rB) continue;
+  const int nR = h->cfg.nRoutes;
+  hipStream_t rst[6];
+  MzrDev dr[6];
+  for (int ix = 0; ix < nR; ++ix) {
+    rst[ix] = st;
+    if (multi && ix > 0) {
+      if (!h->routeStream[ix]) { (void)hipStreamCreateWithFlags(&h->routeStream[ix], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&h->routeEvent[ix], hipEventDisableTiming); }
+      rst[ix] = h->routeStream[ix];
+    }
+    dr[ix] = d;
+    setRoute(h, dr[ix], ix);
+    if (h->profiling) h->route[ix].evUsed = 0;
+  }
+  if (multi) {
+    if (!h->routeEvent[0]) (void)hipEventCreateWithFlags(&h->routeEvent[0], hipEventDisableTiming);
+    (void)hipEventRecord(h->routeEvent[0], st);                    // hillslope series of the window (and everything before) done
+    for (int ix = 1; ix < nR; ++ix) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
+  }
+  const bool prof = h->profiling;
+  for (int s = 0; s < nS + W - 1; ++s) {
+    if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
+    const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
+    const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
+    if (rE <= rB) continue;
+    for (int ix = 0; ix < nR; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      hipStream_t sx = rst[ix];
       if (prof) {
         if (rb.evUsed == rb.events.size()) {
           hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b);
         }
-        (void)hipEventRecord(rb.events[rb.evUsed].first, st);
+        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
       }
       if (rb.method == MZR_KWT) {
-        MzrDev dk = d;
+        MzrDev dk = dr[ix];
         // every stage active: heaviest reaches first regardless of stage (shorter tail of the launch).  This gives up
         // the stage-major locality of the rows, so only while the rows of all routed reaches (about 1 KB each) sit in
         // the 256 MB Infinity Cache anyway; measured +12 % at 100 k reaches, -8 % at 400 k.
         if (h->kwtAllValid && sLo == 0 && sHi == nS - 1 && h->h_kwtRouted.size() <= 150000) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; }
         mzr_launch_stage_kwt(dk, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1],
-                             h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
+                             h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], sx);
       }
-      else mzr_launch_stage(rb.method, d, s, rB, rE, st);
-      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, st); ++rb.evUsed; }
+      else mzr_launch_stage(rb.method, dr[ix], s, rB, rE, sx);
+      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
       ++rb.nLaunches;
     }
-    rb.reachSteps += (long long)N * W;
-    rb.meanSteps += W;
+  }
+  for (int ix = 0; ix < nR; ++ix) {
+    h->route[ix].reachSteps += (long long)N * W;
+    h->route[ix].meanSteps += W;
+    if (multi && ix > 0) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
   }
   if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
   h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0;
