@@ -69,7 +69,8 @@ int mzr_set_network(mzr_handle h, int nRch, int nHru, const int *downIndex, cons
                     const int *upIndex, const int *upGood, const int *hruOffset, const int *hruIndex,
                     const double *hruWeight, const int *reachId);
 /* RPARAM fields by name: R_SLOPE R_MAN_N R_WIDTH R_DEPTH RLENGTH R_STORAGE SIDE_SLOPE FLDP_SLOPE
-   BASAREA TOTAREA MINFLOW (dataTypes.f90:183-195) */
+   BASAREA TOTAREA MINFLOW (dataTypes.f90:183-195).  Set them before mzr_init_state: with KWT active a
+   later change invalidates the state (derived per-reach constants are packed at initialisation) */
 int mzr_set_param(mzr_handle h, const char *name, const double *values);
 /* NETOPO%UH per reach (process_param.f90:99-262 make_uh), CSR by reach */
 int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh);

@@ -432,6 +432,9 @@ int mzr_set_param(mzr_handle h, const char *name, const double *values) {
       (void)hipMemcpy(h->par[p].p, v.data(), h->N * sizeof(double), hipMemcpyHostToDevice);
       if (p == 0) h->h_slope = v;
       if (p == 1) h->h_mann = v;
+      // the KWT records hold derived copies (width ratios, K, celerity factor, length): a change after
+      // mzr_init_state must not go unnoticed -- the state has to be initialised (or restored) again
+      if (h->haveState && h->kwN.p) h->haveState = false;
       return 0;
     }
   }
