@@ -129,3 +129,51 @@ def test_run_from_files_equals_api_run(tmp_path, hip_lib):
     f.close()
     st = __import__("mizuroute_amd.ncfiles", fromlist=["x"]).read_restart_file(out["restart"])
     assert np.array_equal(st["numWaves"], dom.kwt_state()[0])
+
+
+@pytest.mark.gpu
+def test_run_from_files_with_a_mapping_file(tmp_path, hip_lib, oracle_lib):
+    """is_remap = T: the forcing is on 2000 hydrologic-model polygons and reaches the 1200 river-network HRUs
+    through a mapping file (remap_1D_runoff on the device); compared with the API run fed the oracle's remap."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_remap, make_source_runoff
+    tmp = str(tmp_path)
+    net = m.make_network(1200, seed=21)
+    dt, steps, n_src = 3600.0, 36, 2000
+    path = write_case(tmp, net, np.zeros((steps, net.N)), dt, route_opt="1")
+    mp = make_remap(net.H, n_src, 0, seed=22, missing_frac=0.0)
+    sim = np.abs(make_source_runoff(steps, n_src, 0, seed=23)) + 1e-9            # mm/s, no fill values: every HRU gets runoff
+    hru_id = (np.arange(net.N) + 50001).astype(np.int32)                          # ids written by write_case
+    src_id = mp["src_id"].astype(np.int32)
+    g = netcdf_file(os.path.join(tmp, "runoff_hm.nc"), "w", version=2)
+    g.createDimension("time", None); g.createDimension("hm", n_src)
+    t = g.createVariable("time", "d", ("time",)); t.units = "hours since 2001-01-01 00:00:00"
+    h = g.createVariable("hm_id", "i", ("hm",)); h[:] = src_id
+    q = g.createVariable("RUNOFF", "d", ("time", "hm"))
+    for k in range(steps):
+        t[k] = float(k); q[k, :] = sim[k]
+    g.close()
+    f = netcdf_file(os.path.join(tmp, "map.nc"), "w", version=2)
+    f.createDimension("hru", mp["hru_ix"].size); f.createDimension("data", mp["weight"].size)
+    rn = np.where(mp["hru_ix"] > 0, hru_id[np.maximum(mp["hru_ix"], 1) - 1], 999999999 % (2 ** 31 - 1)).astype(np.int32)
+    v = f.createVariable("RN_hruId", "i", ("hru",)); v[:] = rn
+    v = f.createVariable("nOverlaps", "i", ("hru",)); v[:] = np.where(mp["num_qhru"] < 0, 0, mp["num_qhru"]).astype(np.int32)
+    v = f.createVariable("weight", "d", ("data",)); v[:] = mp["weight"]
+    v = f.createVariable("overlapHruId", "i", ("data",)); v[:] = mp["qhru_id"].astype(np.int32)
+    f.close()
+    ctl = open(path).read().replace("<is_remap>       F", "<is_remap>       T").replace("<fname_qsim>     runoff.nc", "<fname_qsim>     runoff_hm.nc")
+    ctl = ctl.replace("<vname_hruid>    hru_id", "<vname_hruid>    hm_id")
+    ctl += "<fname_remap>          map.nc\n<vname_hruid_in_remap> RN_hruId\n<vname_weight>         weight\n<vname_qhruid>         overlapHruId\n<vname_num_qhru>       nOverlaps\n"
+    open(path, "w").write(ctl)
+    out = standalone.run(path, window=12, log=lambda *_: None)
+    # the same through the API: oracle remap (rows whose HRU is not in the network were written with a foreign id)
+    mp2 = dict(mp); mp2["num_qhru"] = np.where(mp["num_qhru"] < 0, 0, mp["num_qhru"]).astype(np.int32)
+    rc, basin = oracle_lib.remap_runoff(mp2, sim)
+    assert rc == 0
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    dom = m.RoutingDomain(net, dt, [m.IRF], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=12, length_conv=1.0e-3)
+    Q = dom.run(basin)
+    got = netcdf_file(out["history"], "r", mmap=False).variables["IRFroutedRunoff"][:]
+    want = Q[:, 0].reshape(steps // 6, 6, net.N).mean(axis=1)
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-12)
