@@ -15,7 +15,7 @@ Scope (what a run of the reference's SAMPLE.control needs, nothing more):
     R_WIDTH = wscale*sqrt(TOTAREA), R_DEPTH = high_depth without flood plain, R_MAN_N = mann_n,
     R_STORAGE (process_ntopo.f90:174-205), slope floor min_slope (:360), unit hydrographs (uh.py);
   * forcing from `<fname_qsim>` (one NetCDF file, or a text file listing them) on the simulation
-    step (dt_ro == dt_qsim; the general time mapping timeMap_sim_forc is not implemented), on the
+    step or on any other regular step `<dt_ro>` (timeMap_sim_forc: overlap-weighted records), on the
     river-network HRUs in file order (is_remap = F -> sort_flux) or remapped (is_remap = T, 1-D);
   * history file(s) `<case_name>.h.<start>.nc` at `<outputFrequency>` (a multiple of the step or
     `daily`), one file per run (`<newFileFrequency> single`), restart in / out (`<fname_state_in>`,
@@ -95,6 +95,30 @@ def unit_factors(units: str):
     return tc, lc
 
 
+def time_map(start_ro_sec: float, dt: float, dt_ro: float, n_ro: int, ix_time: int):
+    """timeMap_sim_forc (get_basin_runoff.f90): which forcing records overlap simulation step ix_time (1-based) and
+    with what weight.  start_ro_sec = simulation start minus forcing start [s].  Returns (records, fracs):
+    0-based record indices and their weights, fracs = None when one record covers the whole step (the reference
+    then uses that record as it is)."""
+    very_small = 1.0e-12
+    lo = start_ro_sec + dt * (ix_time - 1)
+    hi = lo + dt
+    edge = lambda i: dt_ro * i                     # frcLapse(i+1), i = 0..n_ro
+    front = next((i for i in range(1, n_ro + 1) if lo < edge(i)), None)
+    end = next((i for i in range(1, n_ro + 1) if hi < edge(i) or abs(hi - edge(i)) < very_small), None)
+    if front is None or end is None:
+        raise ValueError("forcing files do not cover the simulation period")
+    if front > end:
+        raise ValueError("timeMap_sim_forc/index of idxFront lower than idxEnd")
+    if front == end:
+        return [front - 1], None
+    recs, fracs = [], []
+    for i in range(front, end + 1):
+        recs.append(i - 1)
+        fracs.append((edge(i) - lo) / dt if i == front else (hi - edge(i - 1)) / dt if i == end else (edge(i) - edge(i - 1)) / dt)
+    return recs, fracs
+
+
 def build_network(ctl: dict, nml: dict):
     """River network + parameters from the topology file, augmented as the reference does at start-up."""
     name = lambda k: ctl.get(k, DEFAULT_NAMES[k])
@@ -152,8 +176,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     nml = read_param_nml(os.path.join(ctl.get("ancil_dir", ""), ctl["param_nml"]))
     net, hru_id = build_network(ctl, nml)
     dt = float(ctl.get("dt_qsim", 86400))
-    if float(ctl.get("dt_ro", dt)) != dt:
-        raise NotImplementedError("dt_ro /= dt_qsim: the time mapping of timeMap_sim_forc (get_basin_runoff.f90) is not implemented")
+    dt_ro = float(ctl.get("dt_ro", dt))
     methods = [int(c) for c in ctl.get("route_opt", "0")]
     t_beg, t_end = _parse_time(ctl["sim_start"]), _parse_time(ctl["sim_end"])
     epoch = _dt.datetime(1970, 1, 1)
@@ -172,9 +195,8 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     frec = np.concatenate([np.full(h.variables[ctl["vname_time"]].shape[0], i) for i, h in enumerate(handles)])
     lrec = np.concatenate([np.arange(h.variables[ctl["vname_time"]].shape[0]) for h in handles])
     t0 = (t_beg - epoch).total_seconds()
-    first = int(np.argmin(np.abs(taxis - t0)))
-    if abs(taxis[first] - t0) > 0.5 * dt or first + n_steps > taxis.size:
-        raise ValueError("forcing files do not cover the simulation period")
+    start_ro_sec = t0 - float(taxis[0])               # the first record covers [taxis[0], taxis[0] + dt_ro)
+    n_ro = taxis.size
     remap = _truth(ctl.get("is_remap", "F"))
     if remap:
         m = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_remap"]), "r", mmap=False)
@@ -214,7 +236,17 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     while done < n_steps:
         w = min(W, n_steps - done)
         w = min(w, every - (done % every)) if every < W else w             # a window never straddles an output record
-        rows = [np.asarray(handles[frec[first + done + k]].variables[qname][lrec[first + done + k]], dtype=np.float64) for k in range(w)]
+        rows = []
+        for k in range(w):                              # forcing of every simulation step: one record, or the weighted records it overlaps
+            recs, fracs = time_map(start_ro_sec, dt, dt_ro, n_ro, done + k + 1)
+            get = lambda i: np.asarray(handles[frec[i]].variables[qname][lrec[i]], dtype=np.float64)
+            if fracs is None:
+                rows.append(get(recs[0]))
+            else:
+                acc = np.zeros_like(get(recs[0]))
+                for i, fr in zip(recs, fracs):
+                    acc = acc + fr * get(i)
+                rows.append(acc)
         src = torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(dev)
         dom.run_source_device(w, t_first + done * dt, src.data_ptr())
         dom.sync()

@@ -177,3 +177,16 @@ def test_run_from_files_with_a_mapping_file(tmp_path, hip_lib, oracle_lib):
     got = netcdf_file(out["history"], "r", mmap=False).variables["IRFroutedRunoff"][:]
     want = Q[:, 0].reshape(steps // 6, 6, net.N).mean(axis=1)
     assert np.allclose(got, want, rtol=2e-6, atol=1e-12)
+
+
+def test_time_map_follows_the_reference_rule():
+    """timeMap_sim_forc: one record when the step lies inside a forcing interval, overlap fractions otherwise."""
+    tm = standalone.time_map
+    assert tm(0.0, 3600.0, 3600.0, 10, 1) == ([0], None) and tm(0.0, 3600.0, 3600.0, 10, 10) == ([9], None)
+    assert tm(0.0, 3600.0, 10800.0, 4, 2) == ([0], None) and tm(0.0, 3600.0, 10800.0, 4, 4) == ([1], None)     # 3-hourly forcing, hourly steps
+    r, f = tm(0.0, 10800.0, 3600.0, 12, 2)                                                                  # hourly forcing, 3-hourly steps
+    assert r == [3, 4, 5] and np.allclose(f, [1 / 3, 1 / 3, 1 / 3])
+    r, f = tm(1800.0, 3600.0, 3600.0, 10, 1)                                                                # half an hour out of phase
+    assert r == [0, 1] and np.allclose(f, [0.5, 0.5])
+    with pytest.raises(ValueError):
+        tm(0.0, 3600.0, 3600.0, 3, 4)
