@@ -89,7 +89,7 @@ def cpu_baseline(net, frac, sample_steps, spinup_steps=72, budget_s=40.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="timed batches (forcing windows)")
+    ap.add_argument("--steps", type=int, default=4, help="timed batches (forcing windows)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed batches")
     ap.add_argument("--window", type=int, default=0,
                     help="model time steps per batch; 0 = 8192, fewer when --steps is large (about 2M model steps in total)")
@@ -153,6 +153,17 @@ def main():
                     h = torch.empty(t.shape, dtype=t.dtype)
                     dist.recv(h, src)
                     t.copy_(h)
+                torch.cuda.current_stream().synchronize()
+
+            def recv_many(self, pairs):
+                """All boundary records of a window at once (one xGMI link per peer, transfers side by side)."""
+                if backend != "nccl":
+                    for t, src in pairs:
+                        self.recv(t, src)
+                    return
+                works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, t, src) for t, src in pairs])
+                for wk in works:
+                    wk.wait()
                 torch.cuda.current_stream().synchronize()
 
         def make(spec, **kw):

@@ -222,17 +222,26 @@ class PartitionedRouter:
             if rec is not None:
                 self.transport.send(rec, 0)
             return
+        # all records at once where the transport can (one link per peer: the transfers run side by side),
+        # one after the other otherwise
+        bufs = {}
+        for p in range(1, part.n_parts):
+            base, n = self.main_spec.halo_base[p]
+            if n:
+                bufs[p] = self.alloc(self.main.boundary_size(w, n))
+        recv_many = getattr(self.transport, "recv_many", None)
+        if recv_many is not None and len(bufs) > 1:
+            recv_many([(bufs[p], p) for p in sorted(bufs)])
+        else:
+            for p in sorted(bufs):
+                self.transport.recv(bufs[p], p)
         for p in range(part.n_parts):
             base, n = self.main_spec.halo_base[p]
             if n == 0:
                 continue
-            if p == 0:
-                buf = rec
-            else:
-                buf = self.alloc(self.main.boundary_size(w, n))
-                self.transport.recv(buf, p)
+            buf = rec if p == 0 else bufs[p]
             self.main.import_boundary(w, buf.data_ptr(), n, base)
-            self.main.sync()
+        self.main.sync()                                   # the imports have consumed the buffers
         self.main.run_device(w, t_start, runoff_main_ptr)
 
     def sync(self):
