@@ -171,6 +171,9 @@ int mzr_set_volume(mzr_handle h, int method, const double *vol /* [nRch] REACH_V
 
 /* schedule / measurement introspection */
 int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
+/* KWT persistent sweep: wavefronts the sweep kernel is launched with (0 = not in use), wavefronts the device
+   holds at once, items (blocks of reaches) dealt to them */
+int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems);
 /* measurement modes (bit mask, default 0):
    1  kernel-time accounting of the routing sweep: launches and summed device time [ms] per method
       (HIP events around every stage launch on the handle's stream), read with mzr_get_timing;

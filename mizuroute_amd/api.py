@@ -52,7 +52,8 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
-           "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume"]
+           "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
+           "mzr_get_sweep_info"]
 
 
 def load_library():
@@ -115,6 +116,7 @@ def load_library():
     L.mzr_get_mol_state.argtypes = [vp, ci, dp]
     L.mzr_get_basin_state.argtypes = [vp, dp]
     L.mzr_get_schedule.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.mzr_get_sweep_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.mzr_set_profiling.argtypes = [vp, ci]
     LL = C.POINTER(C.c_longlong)
     L.mzr_get_timing.argtypes = [vp, ci, LL, C.POINTER(cd), LL, ci]
@@ -320,6 +322,12 @@ class RoutingDomain:
         a, b = C.c_int(0), C.c_int(0)
         self._check(self.L.mzr_get_schedule(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def sweep_info(self):
+        """(wavefronts of the persistent KWT sweep, wavefronts the device holds at once, items dealt to them)"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self.L.mzr_get_sweep_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     # ---- forcing remap (process_remap.f90:32-316)
     def set_remap(self, mp):

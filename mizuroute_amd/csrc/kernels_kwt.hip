@@ -101,11 +101,59 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
+// Accesses to data that another wavefront of the SAME launch produces or consumes (persistent sweep):
+// relaxed agent-scope atomics = global_load / global_store ... sc1, which bypass the CU's L1 and are
+// coherent across the per-XCD L2s (MI355X_MICROARCH.md, inter-workgroup visibility).  P = false: plain.
+template <bool P> __device__ __forceinline__ double ldx(const double *p) {
+  if (P) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool P> __device__ __forceinline__ int ldx(const int *p) {
+  if (P) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool P> __device__ __forceinline__ void stx(double *p, double v) {
+  if (P) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool P> __device__ __forceinline__ void stx(int *p, int v) {
+  if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// Persistent sweep: wait until every lane's dependency counter (steps completed by an upstream or the
+// downstream reach in this window) has reached the value the lane needs.  Whole wavefront; true = give
+// up (another wavefront raised an error, or nothing moved for seconds: code 93 instead of a hung GPU).
+__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, int wneed) {
+  long long t0 = 0;
+  int spins = 0;
+  for (;;) {
+    int v = wneed;
+    if (wp) v = ldx<true>(wp);
+    if (__ballot(v < wneed) == 0ull) return false;
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 31) == 0) {
+      if (ldx<true>(&d.err->code) != 0) return true;
+      const long long now = wall_clock64();     // 100 MHz
+      if (!t0) t0 = now;
+      else if (now - t0 > 400000000LL) { mzr_raise(d, 93, -1, -1, 20); return true; }
+    }
+  }
+}
+
 }  // namespace
 
 
 // ---- group primitives: G adjacent lanes (G = 4, 8 or 16, aligned) cooperate on one reach ----------
 namespace {
+
+// Lane index through an opaque instruction pair: inside the persistent item loop everything derived
+// from threadIdx would otherwise count as loop-invariant, be computed once up front and spilled.
+__device__ __forceinline__ int mzr_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
@@ -148,13 +196,13 @@ template <int G> __device__ __forceinline__ double grp_min(double v) { return gr
 template <int G> __device__ __forceinline__ int grp_count(bool p) {
   const unsigned long long b = __ballot(p);
   if (G == 64) return __popcll(b);
-  const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+  const int gbase = mzr_lane() & ~(G - 1);
   return __popcll((b >> gbase) & ((1ull << (G & 63)) - 1ull));
 }
 template <int G> __device__ __forceinline__ bool grp_any(bool p) {
   const unsigned long long b = __ballot(p);
   if (G == 64) return b != 0ull;
-  const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+  const int gbase = mzr_lane() & ~(G - 1);
   return ((b >> gbase) & ((1ull << (G & 63)) - 1ull)) != 0ull;
 }
 template <int G, bool MAXI> __device__ __forceinline__ int grp_minmax_i(int v) {
@@ -179,13 +227,13 @@ template <int G, bool LAST> __device__ __forceinline__ void grp_argmin(double &v
 template <int G> __device__ __forceinline__ unsigned long long grp_bits(bool p) {
   const unsigned long long b = __ballot(p);
   if (G == 64) return b;
-  const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+  const int gbase = mzr_lane() & ~(G - 1);
   return (b >> gbase) & ((1ull << (G & 63)) - 1ull);
 }
 // value held by the first lane of the group
 template <int G> __device__ __forceinline__ int grp_first(int v) {
   if (G == 64) return __builtin_amdgcn_readfirstlane(v);
-  return __shfl(v, (int)(threadIdx.x & 63) & ~(G - 1), 64);
+  return __shfl(v, mzr_lane() & ~(G - 1), 64);
 }
 
 // LDS traffic of one group is ordered by the hardware (one wavefront, in-order LDS queue); this
@@ -271,14 +319,16 @@ __device__ __forceinline__ int kwt_merge_binary_serial(int nup, int ns, int nrA,
 }
 
 // Confluences of more than two reaches are rare: the reference's k-way merge runs on lane 0 of the
-// group, out of line, with the series cursors in private memory and every particle fetched from
-// the outbox on demand.
-__device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double RW, double T0, double T1,
-                                              const uint8_t *nGood, const double *width, const double *qlat_prev,
-                                              const double *qlat_cur, const int *obN, const double *obQ,
-                                              const double *obT, int N, double *QD, double *TD, int IMAX) {
-  int su[2 * MZR_MAXUP], slen[2 * MZR_MAXUP], snr[2 * MZR_MAXUP], ITIM[2 * MZR_MAXUP];
-  double sc[2 * MZR_MAXUP], CTIME[2 * MZR_MAXUP];
+// group, with the series cursors in the two work arrays the merge does not need (scrD: 32 doubles,
+// scrI: 64 ints of LDS) and every particle fetched from the outbox on demand.
+template <bool PERS>
+__device__ __forceinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double RW, double T0, double T1,
+                                                 const uint8_t *nGood, const double *width, const double *qlat_prev,
+                                                 const double *qlat_cur, const int *obN, const double *obQ,
+                                                 const double *obT, int N, double *QD, double *TD, int IMAX,
+                                                 double *scrD, int *scrI) {
+  int *su = scrI, *slen = scrI + 2 * MZR_MAXUP, *snr = scrI + 4 * MZR_MAXUP, *ITIM = scrI + 6 * MZR_MAXUP;
+  double *sc = scrD, *CTIME = scrD + 2 * MZR_MAXUP;
   int IUPR = 0;
 #pragma unroll 1
   for (int i = 0; i < nup; ++i) { su[i] = u0 + i; slen[i] = 2; snr[i] = 2; sc[i] = 1.0 / RW; ITIM[i] = 1; CTIME[i] = T1; }
@@ -287,12 +337,12 @@ __device__ __noinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double 
     const int u = u0 + i;
     if (nGood[u] > 0) {
       const int si = nup + IUPR; ++IUPR;
-      const int nr = obN[u];
-      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = obT[MZR_OBI(1, u)];
+      const int nr = ldx<PERS>(obN + u);
+      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = ldx<PERS>(obT + MZR_OBI(1, u));
     }
   }
-  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : obQ[MZR_OBI(k, su[i])]; };
-  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : obT[MZR_OBI(k, su[i])]; };
+  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : ldx<PERS>(obQ + MZR_OBI(k, su[i])); };
+  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : ldx<PERS>(obT + MZR_OBI(k, su[i])); };
   unsigned done = 0;
   const unsigned all = (1u << NUPS) - 1u;
   int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff;
@@ -397,11 +447,13 @@ __device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *
 }
 
 #ifdef MZR_KWT_TIMING
-#define KCOUNT(i, v) do { if (gl == 0) atomicAdd(&d.dbgCycles[i], (unsigned long long)(v)); } while (0)
-#define TSTAMP(i) do { const long long _n = clock64(); if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[i], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
+#define KCOUNT(i, v) do { if (gl == 0) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(v)); } while (0)
+#define TSTAMP(i) do { const long long _n = clock64(); if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
+#define TSTAMP_WAVE(i) do { if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], 1ull); } while (0)
 #else
 #define KCOUNT(i, v) do { } while (0)
 #define TSTAMP(i) do { } while (0)
+#define TSTAMP_WAVE(i) do { } while (0)
 #endif
 
 namespace {
@@ -426,14 +478,26 @@ __device__ __forceinline__ KwtStep kwt_step(const MzrDev &d, int t) {
 
 // Reaches that do not route particles: headwaters (kwt_route.f90:181-205), lake reaches
 // (lake_route replaces kwt_rch) and halo reaches of a partition (replay of the imported record).
-template <bool FULL>
-__device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int ltEnd) {
+template <bool FULL, bool PERS>
+__device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int ltEnd) {
   const int N = d.N;
   unsigned long long st_head = 0;
+  int r = -1, t = -1;
+  bool act = false;
   if (item < ltEnd) {
-    const int r = d.kwtLight[item];
-    const int t = s - d.sigma[r];
-    if (t >= 0 && t < d.W) {
+    r = d.kwtLight[item];
+    t = s - d.sigma[r];
+    act = t >= 0 && t < d.W;
+  }
+  if (PERS) {   // a lake needs the discharge of its upstream reaches, a halo reach overwrites the outbox its downstream reach read two steps ago
+    const bool halo = act && FULL && d.haloSlot && d.haloSlot[r] >= 0;
+    const int nu = (act && !halo) ? (int)d.nUp[r] : 0, u0 = act ? d.upStart[r] : 0;
+    const int dn = (halo && t >= 2) ? d.down[r] : -1;
+    for (int i = 0; __ballot(i < nu) != 0ull; ++i) if (kwt_wait_deps(d, i < nu ? d.kwDone + u0 + i : nullptr, t + 1)) return true;
+    if (kwt_wait_deps(d, dn >= 0 ? d.kwDone + dn : nullptr, t - 1)) return true;
+  }
+  if (act) {
+    {
       const KwtStep k = kwt_step(d, t);
       bool done = false;
       if (FULL && d.haloSlot) {   // tributary outlet computed in another partition
@@ -441,13 +505,13 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
         if (hs >= 0) {
           done = true;
           const size_t nH = d.nHalo;
-          k.Qrow[r] = d.imQ[(size_t)t * nH + hs];
+          stx<PERS>(k.Qrow + r, d.imQ[(size_t)t * nH + hs]);
           const int n = d.imN[(size_t)t * nH + hs];
-          d.obN[(size_t)k.par * N + r] = n;
+          stx<PERS>(d.obN + (size_t)k.par * N + r, n);
           double *oq = d.obQ + (size_t)k.par * MZR_OB_CAP * N, *ot = d.obT + (size_t)k.par * MZR_OB_CAP * N;
           for (int j = 0; j <= n && n > 0; ++j) {
-            oq[MZR_OBI(j, r)] = d.imOQ[((size_t)t * MZR_OB_CAP + j) * nH + hs];
-            ot[MZR_OBI(j, r)] = d.imOT[((size_t)t * MZR_OB_CAP + j) * nH + hs];
+            stx<PERS>(oq + MZR_OBI(j, r), d.imOQ[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
+            stx<PERS>(ot + MZR_OBI(j, r), d.imOT[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
           }
         }
       }
@@ -456,15 +520,14 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
         if (ls >= 0) {   // a lake keeps one sentinel particle (init_model_data.f90:431-439)
           done = true;
           double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
-          const double Q = mzr_lake::lake_route(d, r, t, ls, k.Qrow, k.qlat_cur[r], vol, vol0, ele, wb, wmAct);
-          k.Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
+          const double Q = mzr_lake::lake_route(d, r, t, ls, k.Qrow, k.qlat_cur[r], vol, vol0, ele, wb, wmAct, PERS);
+          stx<PERS>(k.Qrow + r, Q); d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb;
           if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
         }
       }
       if (!done) {   // headwater
         const double qlat_r = k.qlat_cur[r];
-        k.Qrow[r] = qlat_r;
-        d.qsum[r] += qlat_r;
+        stx<PERS>(k.Qrow + r, qlat_r);
         d.inflow[r] = 0.0;
         if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
         if (FULL && d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
@@ -472,10 +535,15 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
       }
     }
   }
+  if (PERS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (act) stx<true>(d.kwDone + r, t + 1);
+  }
   if (d.kwtStat) {
     const unsigned long long e = wave_sum(st_head);
     if ((threadIdx.x & 63) == 0 && e) atomicAdd(&d.kwtStat->n_head, e);
   }
+  return false;
 }
 
 }  // namespace
@@ -494,10 +562,13 @@ __device__ __forceinline__ void kwt_light(const MzrDev &d, int s, int item, int 
 // (an outbox row).  `off` = the group's slice of the LDS work arrays, `cap` = how many entries the
 // reach may need: a reach that needs more is left untouched and reported back (true), so that the
 // caller can give it a wider group.  CAN_THIN = false leaves remove_rch out (cap <= MAXQPAR).  ctx = 8 doubles of LDS for values needed again late.
-template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN>
-__device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
-                                          int off, int cap, double *sA, double *sB, double *sC, double *sD, double *ctx) {
-  const int lane = threadIdx.x & 63, gl = lane & (G - 1);
+// PERS: the persistent sweep -- wait for the reaches this step depends on, exchange outbox rows and
+// discharge with other wavefronts through sc1 accesses, publish the step in kwDone.  Returns bit 0: the
+// reach needs more than `cap` entries, bit 1: the sweep is abandoned (error raised somewhere).
+template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN, bool PERS>
+__device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
+                                         int off, int cap, double *sA, double *sB, double *sC, double *sD, double *ctx) {
+  const int lane = mzr_lane(), gl = lane & (G - 1);
   const int N = d.N;
   bool ovf = false;
   // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line)
@@ -526,6 +597,19 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
 #ifdef MZR_KWT_TIMING
   long long _tprev = clock64();
 #endif
+  if (PERS) {
+    // step t of this reach needs step t of every upstream reach (their outbox rows and discharge) and
+    // overwrites the outbox parity its downstream reach read in step t - 2
+    const int dn = uni<G>(rec.down);
+    const int *wp = nullptr;
+    int wneed = 0;
+    if (live) {
+      if (gl < nup) { wp = d.kwDone + u0 + gl; wneed = t + 1; }
+      else if (gl == nup && dn >= 0 && t >= 2) { wp = d.kwDone + dn; wneed = t - 1; }
+    }
+    if (kwt_wait_deps(d, wp, wneed)) return 2;
+    TSTAMP(21);
+  }
 
   // ---- round trip 2: everything that depends on the step, issued together -- particle counts,
   // hillslope inflow of the upstream basins, upstream discharge, own particle row (getusq_rch
@@ -543,13 +627,13 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
   for (int j = 0; j < OS; ++j) aq[j] = at[j] = bq[j] = bt[j] = 0.0;
   if (live) {
     int n_own_v = d.kwN[r], nrA_v = 0, nrB_v = 0;
-    if (!GEN && !upLake) { if (ns > 0) nrA_v = obN[uA]; if (ns > 1) nrB_v = obN[uB]; }
+    if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
     const double X0 = d.kwTR[MZR_KWI(0, r)];
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
     if (nup > 1) { bs.b1q0 = qlat_prev[u0 + 1]; b1q1 = qlat_cur[u0 + 1]; }
-    if (!GEN) { up0 = Qrow[u0]; if (nup > 1) up1 = Qrow[u0 + 1]; }
+    if (!GEN) { up0 = ldx<PERS>(Qrow + u0); if (nup > 1) up1 = ldx<PERS>(Qrow + u0 + 1); }
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
@@ -559,8 +643,8 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
 #pragma unroll
       for (int j = 0; j < OS; ++j) {
         const int k = gl + j * G, kk = k < MZR_OB_CAP ? k : 0;
-        if (ns > 0) { aq[j] = obQ[MZR_OBI(kk, uA)]; at[j] = obT[MZR_OBI(kk, uA)]; }
-        if (ns > 1) { bq[j] = obQ[MZR_OBI(kk, uB)]; bt[j] = obT[MZR_OBI(kk, uB)]; }
+        if (ns > 0) { aq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uA)); at[j] = ldx<PERS>(obT + MZR_OBI(kk, uA)); }
+        if (ns > 1) { bq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uB)); bt[j] = ldx<PERS>(obT + MZR_OBI(kk, uB)); }
       }
     }
     // ---- uniform: the work-array need
@@ -576,7 +660,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
       } else {
         for (int i = 0; i < nup; ++i) {
           if ((upGood >> i) & 1u) {
-            const int nr = uni<G>(obN[u0 + i]);
+            const int nr = uni<G>(ldx<PERS>(obN + u0 + i));
             if (nr < 2) empty = true;
             ++NUPR; IMAX += nr - 1; st_up += nr + 1;
           }
@@ -597,13 +681,13 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
       if (ng > 0 && (goodMask & 1u)) q_up = q_up + up0;
       if (ng > 1 && (goodMask & 2u)) q_up = q_up + up1;
     } else {
-      for (int i = 0; i < ng; ++i) { if (!((goodMask >> i) & 1u)) continue; q_up = q_up + Qrow[u0 + i]; }
+      for (int i = 0; i < ng; ++i) { if (!((goodMask >> i) & 1u)) continue; q_up = q_up + ldx<PERS>(Qrow + u0 + i); }
     }
     if (gl == 0) {
       double *c = ctx;
       c[6] = q_up;                     // REACH_INFLOW, stored with the other results at the end
       c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
-      c[1] = qlat_r; c[2] = rec.K; c[3] = rec.CW; c[4] = rec.length; c[5] = RW;
+      c[1] = qlat_r; c[3] = rec.CW; c[4] = rec.length; c[5] = RW;
       if (d.kwtStat && !ovf) {
         atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own); atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
         atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
@@ -637,7 +721,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
         int ND;
         double *QD = Qw + NJ + 1, *TD = Tw + NJ + 1;
         if (upLake) {      // lake outflow enters the river as one particle, getusq_rch :554-559
-          if (gl == 0) { QD[0] = Qrow[u0] / RW; TD[0] = T1; }
+          if (gl == 0) { QD[0] = ldx<PERS>(Qrow + u0) / RW; TD[0] = T1; }
           ND = 1;
         } else if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
           if (gl == 0) { QD[0] = bs.b0q1 / RW; TD[0] = T1; }
@@ -707,7 +791,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
           }
         } else {
           int nd = -60;
-          if (GEN && gl == 0) nd = kwt_merge_generic(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, QD, TD, IMAX);
+          if (GEN && gl == 0) nd = kwt_merge_generic<PERS>(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, QD, TD, IMAX, Xw, (int *)Yw);
           ND = grp_first<G>(nd);
         }
         TSTAMP(1);
@@ -821,8 +905,8 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
         const int NI = size - 1;
         int NQ2 = 0;
         {
-          // K = sqrt(R_SLOPE)/R_MAN_N, cw = ALFA*K**(1/ALFA) with ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
-          const double K = ctx[2], cw = ctx[3], XMX = ctx[4];
+          // cw = ALFA*K**(1/ALFA) with K = sqrt(R_SLOPE)/R_MAN_N and ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
+          const double cw = ctx[3], XMX = ctx[4];
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
@@ -870,6 +954,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
               const int endI = nextHead(IXB);
               double q2 = Qw[JXB], q1 = Qw[JXB];
               for (int j = JXB + 1; j < endI; ++j) { const double q = Qw[j]; q2 = fmax(q2, q); q1 = fmin(q1, q); }
+              const double K = d.kwK[r];                            // shock merges are rare: fetched on demand
               const double a = pow_0p6(((gl & 1) ? q1 : q2) / K);   // A2 on even, A1 on odd lanes
               const double b = dpp_d<MZR_DPP_XOR1>(a);
               const double A2 = (gl & 1) ? b : a, A1 = (gl & 1) ? a : b;
@@ -975,8 +1060,10 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
 #pragma unroll
         for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
+        TSTAMP(16);
         double QNEW;
         if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
+        TSTAMP(17);
         const double Qout = QNEW * ctx[5] + ctx[1];
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
@@ -987,11 +1074,9 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
         // registers since the loads at the top
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
-#ifdef X_NOQSUM
-        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] = Qout; d.kwN[r] = NN2 + 1; }
-#else
-        if (gl == 0) { d.Q[(size_t)tq * N + r] = Qout; d.qsum[r] += Qout; d.kwN[r] = NN2 + 1; d.inflow[r] = ctx[6]; }
-#endif
+        // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
+        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); d.kwN[r] = NN2 + 1; d.inflow[r] = ctx[6]; }
+        TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         const bool outbox = !isOut;
@@ -999,7 +1084,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
           const int pq = tq & 1;
           int *obNw = d.obN + (size_t)pq * N;
           double *obQw = d.obQ + (size_t)pq * MZR_OB_CAP * N, *obTw = d.obT + (size_t)pq * MZR_OB_CAP * N;
-          if (gl == 0 && outbox) obNw[r] = NR + 2;
+          if (gl == 0 && outbox) stx<PERS>(obNw + r, NR + 2);
           if (gl == 0 && es >= 0) d.exN[(size_t)tq * d.nExp + es] = NR + 2;
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
@@ -1007,7 +1092,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
             if (k2 <= NR + 2) {
               const double q = k2 <= NR ? Qw[k2] : k2 == NR + 1 ? Q_END : qN1;
               const double x = k2 <= NR ? Xw[k2] : k2 == NR + 1 ? T_END : xN1;
-              if (outbox) { obQw[MZR_OBI(k2, r)] = q; obTw[MZR_OBI(k2, r)] = x; }
+              if (outbox) { stx<PERS>(obQw + MZR_OBI(k2, r), q); stx<PERS>(obTw + MZR_OBI(k2, r), x); }
               if (es >= 0) {   // tributary outlet of a partition: the same record goes to the time-indexed export buffer
                 const size_t nE = d.nExp;
                 d.exOQ[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = q; d.exOT[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = x;
@@ -1015,6 +1100,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
             }
           }
         }
+        TSTAMP(19);
         // at-rest state: KWAVE(NR+1:NQ2+1)
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
@@ -1023,19 +1109,20 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
             const bool first = k2 == 0;
             d.kwQ[MZR_KWI(k2, r)] = first ? Q_END : Qw[NR + k2];
             d.kwTI[MZR_KWI(k2, r)] = first ? TIMEI : Tw[NR + k2];
-#ifndef X_NOTR
             d.kwTR[MZR_KWI(k2, r)] = first ? T_END : Xw[NR + k2];
-#else
-            if (first) d.kwTR[MZR_KWI(k2, r)] = T_END;
-#endif
           }
         }
         if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
-        TSTAMP(7);
+        TSTAMP(7); TSTAMP_WAVE(20);
+        if (PERS) {   // results written through (sc1) and drained, then the step is published
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (gl == 0) stx<true>(d.kwDone + r, tq + 1);
+          TSTAMP(22);
+        }
       } while (0);
     }
   }
-  return ovf;
+  return ovf ? 1 : 0;
 }
 
 // One launch = every routed, headwater, lake and halo reach of the stages that are active in this
@@ -1044,6 +1131,7 @@ __device__ __forceinline__ bool kwt_reach(const MzrDev &d, int s, const MzrKwtRe
 // reach (8 per wavefront, no thinning code, capacity MAXQPAR entries).  A class-B reach that has grown
 // beyond that is picked up by 16-lane groups of the same wavefront right away, four at a time, so
 // the classification only has to be usually right.  GEN: confluences of more than two reaches.
+// Used for short windows (mzr_step: one step per call); long windows take k_sweep_kwt below.
 template <bool FULL, bool GEN, int POOL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : MZR_KWT_OCC, GEN ? 2 : MZR_KWT_OCC)))
 k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, int hbEnd, int nBBlocks, int ltBegin, int ltEnd) {
@@ -1053,10 +1141,10 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
   constexpr int GPA = POOL / RA, GPB = POOL / RB;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
-  __shared__ double sCtx[RB][8];   // per reach: values needed again late (X0, BASIN_QR(1), K, cw, RLENGTH, R_WIDTH, inflow)
+  __shared__ double sCtx[RB][8];   // per reach: values needed again late (X0, BASIN_QR(1), cw, RLENGTH, R_WIDTH, inflow)
   const int b = blockIdx.x, lane = threadIdx.x & 63;
   if (!GEN && b >= nABlocks + nBBlocks) {
-    kwt_light<FULL>(d, s, ltBegin + (b - nABlocks - nBBlocks) * 64 + lane, ltEnd);
+    kwt_light<FULL, false>(d, s, ltBegin + (b - nABlocks - nBBlocks) * 64 + lane, ltEnd);
     return;
   }
   const bool isB = !GEN && b >= nABlocks;
@@ -1070,7 +1158,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   if (isB) {
     const int g8 = lane / GB;
     const int item = hbBegin + (b - nABlocks) * RB + g8;
-    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, false>(d, s, d.kwtRoutedB, item, item < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, false, false>(d, s, d.kwtRoutedB, item, item < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
     const unsigned long long bal = __ballot(ovf);
 #ifdef MZR_KWT_HIST
     if ((lane & 7) == 0 && item < hbEnd) { atomicAdd(&d.dbgCycles[0], 1ull); if (ovf) atomicAdd(&d.dbgCycles[1], 1ull); }
@@ -1082,7 +1170,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   const int g16 = lane / GA;
   if (!isB) {
     const int item = haBegin + b * RA + g16;
-    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]) & 1;
     if (ovf) mzr_raise(d, 60, d.kwtRouted[item < haEnd ? item : haEnd - 1].r, s, 10);      // work array bounds exceeded
     WAVE_DONE(0);
     return;
@@ -1098,9 +1186,147 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
     const bool have = sel >= 0;
     const int item = hbBegin + (b - nABlocks) * RB + (have ? sel : 0);
     for (int k = 0; k < RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
-    const bool ovf = kwt_reach<FULL, false, GA, KA, OA, true>(d, s, d.kwtRoutedB, item, have, hbEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+    const bool ovf = kwt_reach<FULL, false, GA, KA, OA, true, false>(d, s, d.kwtRoutedB, item, have, hbEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]) & 1;
     if (ovf) mzr_raise(d, 60, d.kwtRoutedB[have ? item : hbEnd - 1].r, s, 10);
   }
+}
+
+// The rare item kinds of the persistent sweep are real calls, so that their registers are not part of the loop body's.
+template <bool FULL, int POOL>
+__device__ __noinline__ int kwt_item_generic(const MzrDev &d, int s, int bi, double *sA, double *sB, double *sC, double *sD, double *ctx) {
+  constexpr int GA = 16, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
+  const int g16 = mzr_lane() / GA;
+  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + 8 * g16);
+}
+template <bool FULL>
+__device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
+  return kwt_light<FULL, true>(d, s, bi * 64 + mzr_lane(), d.nDepLight);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent sweep.  ONE launch advances the skewed schedule through launches s = sBegin .. sEnd-1
+// of k_stage_kwt: every wavefront owns a fixed set of items (blocks of 4 class-A reaches, 8 class-B
+// reaches, one confluence of more than two reaches, or 64 lake / halo reaches; dealt by the host,
+// heaviest first onto the least loaded wavefront) and takes them through the steps in order.  What
+// a kernel boundary used to guarantee is now per reach: step t of reach r starts when kwDone of
+// its upstream reaches has reached t+1 and kwDone of its downstream reach t-1 (kwt_reach).  The
+// earliest unfinished item of the whole sweep never waits, every wavefront takes its items in
+// launch order, and the grid is sized to be co-resident, so the sweep always moves; wavefronts
+// that wait sleep, and give up when an error was raised or nothing has moved for seconds.
+// Own state (at-rest rows) stays with the owning wavefront, hence on one CU: plain accesses.
+// Headwater reaches need nothing from anybody and are filled in for the whole window by
+// k_kwt_window_init before the sweep starts.
+template <bool FULL, int POOL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC)))
+k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
+  // The domain description has ~90 fields; kept live around the item loop they spill.  They are read
+  // through the kernel-argument segment instead (scalar loads, constant address space) and the
+  // pointer is made opaque once per item, so that nothing is hoisted out of the loop.
+  typedef const MzrDev __attribute__((address_space(4))) *MzrDevK;
+  MzrDevK dk0 = (MzrDevK)__builtin_amdgcn_kernarg_segment_ptr();
+  const MzrDev &d0 = *(const MzrDev *)dk0;
+  constexpr int GA = 16, RA = 64 / GA, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
+  constexpr int GB = 8, RB = 64 / GB, KB = MZR_KWT_KB;
+  constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
+  constexpr int GPA = POOL / RA, GPB = POOL / RB;
+  __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
+  __shared__ double sCtx[RB][8];
+  const int i0 = d0.swOff[blockIdx.x], i1 = d0.swOff[blockIdx.x + 1];
+  const int Wm1 = d0.W - 1;
+#pragma unroll 1
+  for (int s = sBegin; s < sEnd; ++s) {
+#pragma unroll 1
+    for (int i = i0; i < i1; ++i) {
+      MzrDevK dk = dk0;
+      asm volatile("" : "+s"(dk));
+      const MzrDev &d = *(const MzrDev *)dk;
+      const int lane = mzr_lane(), g16 = lane / GA, g8 = lane / GB;
+      if (s < d.swLo[i] || s > d.swHi[i] + Wm1) continue;        // none of the item's reaches has a step in this launch
+      const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
+      const int cls = it >> 28, bi = it & 0x0fffffff;
+      if (cls == 3) {
+        if (kwt_item_light<FULL>(d, s, bi)) return;
+        continue;
+      }
+      if (cls == 2) {   // one confluence of more than two reaches, first lane group, the whole pool
+        const int st = kwt_item_generic<FULL, POOL>(d, s, bi, sA, sB, sC, sD, &sCtx[0][0]);
+        if (__ballot(st & 2) != 0ull) return;
+        if (st & 1) mzr_raise(d, 60, d.kwtGeneric[bi].r, s, 10);
+        continue;
+      }
+      unsigned ovfMask = 0;
+      if (cls == 1) {
+        const int item = bi * RB + g8;
+        const int st = kwt_reach<FULL, false, GB, KB, KB, false, true>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+        if (__ballot(st & 2) != 0ull) return;
+        const unsigned long long bal = __ballot(st & 1);
+#pragma unroll
+        for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
+        if (!ovfMask) continue;
+      }
+      // class A, or the class-B reaches of this item that have outgrown 8 lanes, four at a time
+#pragma unroll 1
+      do {
+        const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : d.kwtRoutedB;
+        const int last = (cls == 0 ? d.nA : d.nB) - 1;
+        int item = bi * RA + g16;
+        bool have = item <= last;
+        if (cls == 1) {
+          unsigned m = ovfMask;
+          int sel = -1;
+          for (int k = 0; k <= g16 && m; ++k) { sel = (k == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
+          have = sel >= 0;
+          item = bi * RB + (have ? sel : 0);
+          for (int k = 0; k < RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
+        }
+        const int st = kwt_reach<FULL, false, GA, KA, OA, true, true>(d, s, recs, item, have, last, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+        if (__ballot(st & 2) != 0ull) return;
+        if (st & 1) mzr_raise(d, 60, recs[have ? item : last].r, s, 10);
+      } while (ovfMask);
+    }
+  }
+}
+
+// Start of a KWT window in persistent mode: progress counters back to zero, and the headwater reaches
+// (kwt_route.f90:181-205: REACH_Q = BASIN_QR(1), one sentinel particle) for every step of the window.
+template <bool FULL>
+__global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, int tEnd, int first) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (first && blockIdx.y == 0) {   // first slab of the first chunk of steps: also the per-reach bookkeeping
+    for (int r = i; r < d.N; r += gridDim.x * blockDim.x) d.kwDone[r] = 0;
+  }
+  if (i >= d.nHead) return;
+  const int r = d.kwtHead[i];
+  const int N = d.N;
+  const int per = (tEnd - tBegin + gridDim.y - 1) / gridDim.y;
+  const int tB = tBegin + blockIdx.y * per, tE = min(tEnd, tB + per);
+  const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
+  for (int t = tB; t < tE; ++t) {
+    d.Q[(size_t)t * N + r] = d.qlat[(size_t)(t + 1) * N + r];
+    if (es >= 0) d.exN[(size_t)t * d.nExp + es] = 0;
+  }
+  if (first && blockIdx.y == 0) {
+    d.inflow[r] = 0.0;
+    if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
+  }
+}
+// second, tiny kernel (after the zeroing above has finished): headwaters are complete for the whole window
+__global__ void __launch_bounds__(256) k_kwt_head_done(MzrDev d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.nHead) d.kwDone[d.kwtHead[i]] = d.W;
+}
+
+// History sum of REACH_Q (histVars_data.f90:229-231 accumulates step by step): the window's rows added in step order.
+__global__ void __launch_bounds__(256) k_accum_qsum(const double *Q, double *qsum, int N, int W) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  double a = qsum[r];
+  for (int t = 0; t < W; ++t) a = a + Q[(size_t)t * N + r];
+  qsum[r] = a;
+}
+
+void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream) {
+  hipLaunchKernelGGL(k_accum_qsum, dim3((N + 255) / 256), dim3(256), 0, stream, Q, qsum, N, W);
 }
 
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int gnBegin, int gnEnd,
@@ -1122,4 +1348,36 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
     if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0);
     else hipLaunchKernelGGL((k_stage_kwt<false, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0);
   }
+}
+
+// ---- persistent sweep, host side
+static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm); }
+
+// wavefronts of k_sweep_kwt that are resident at once on this device (the sweep needs all of its wavefronts running)
+int mzr_sweep_kwt_capacity(bool full) {
+  int dev = 0, cus = 0, perCu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<true, 240>, 64, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<false, 240>, 64, 0);
+  if (e != hipSuccess) return 0;
+  return cus * perCu;
+}
+
+// headwater reaches for steps [tBegin, tEnd) of the window; tBegin == 0 also resets the progress counters
+void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream) {
+  const int first = tBegin == 0;
+  const int n = first ? (d.nHead > d.N / 8 ? d.nHead : d.N / 8) : d.nHead;
+  if (n < 1 && !first) return;
+  const int slabs = tEnd - tBegin >= 64 ? 8 : 1;
+  dim3 grid((n + 255) / 256 > 0 ? (n + 255) / 256 : 1, slabs), block(256);
+  if (kwt_full(d)) hipLaunchKernelGGL(k_kwt_window_init<true>, grid, block, 0, stream, d, tBegin, tEnd, first);
+  else hipLaunchKernelGGL(k_kwt_window_init<false>, grid, block, 0, stream, d, tBegin, tEnd, first);
+  if (first && d.nHead > 0) hipLaunchKernelGGL(k_kwt_head_done, dim3((d.nHead + 255) / 256), block, 0, stream, d);
+}
+
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {
+  if (nWaves < 1 || sEnd <= sBegin) return;
+  if (kwt_full(d)) hipLaunchKernelGGL((k_sweep_kwt<true, 240>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
+  else hipLaunchKernelGGL((k_sweep_kwt<false, 240>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
 }

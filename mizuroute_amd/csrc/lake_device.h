@@ -24,7 +24,7 @@ __device__ inline double ring_mean(const double *ring, int L, int head, int n) {
 
 // returns REACH_Q; updates vol (REACH_VOL(1)), vol0, ele, wb
 __device__ inline double lake_route(const MzrDev &d, int r, int t, int ls, const double *Qrow, double qlat,
-                                    double &vol, double &vol0, double &ele, double &wb, double &wmAct) {
+                                    double &vol, double &vol0, double &ele, double &wb, double &wmAct, bool coherent = false) {
   const int nL = d.nLake;
   auto P = [&](int p) -> double { return d.lakePar[(size_t)p * nL + ls]; };
   double *mut = d.lakeMut;                       // [25][nLake]
@@ -34,7 +34,10 @@ __device__ inline double lake_route(const MzrDev &d, int r, int t, int ls, const
   double q_up = 0.0;
   {
     const int nu = d.nUp[r], u0 = d.upStart[r];
-    for (int i = 0; i < nu; ++i) q_up = q_up + Qrow[u0 + i];
+    // coherent: the upstream discharge was written by another wavefront of the same launch (persistent KWT sweep)
+    for (int i = 0; i < nu; ++i)
+      q_up = q_up + (coherent ? __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(Qrow + u0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                              : Qrow[u0 + i]);
   }
   if (d.iTime0 + t + 1 == 1) {   // cold start, lake_route.f90:121-144
     vol = type == 0 ? P(P_D03_S0) : type == 1 ? P(P_D03_MaxStorage) : type == 2 ? P(P_H06_Smax)

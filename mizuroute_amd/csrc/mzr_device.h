@@ -37,8 +37,9 @@ struct MzrKwtRec {
   uint8_t flags;              // bits 0-3 count(goodBas), bit 6 an upstream reach is a lake, bit 7 outlet (DREACHK <= 0)
   uint8_t upGood;             // bit i: upstream i has upstream reaches of its own (publishes an outbox)
   uint8_t goodMask;           // bit i: goodBas(i+1)
-  double width, K, CW, length;   // R_WIDTH, sqrt(R_SLOPE)/R_MAN_N, ALFA*K**(1/ALFA), RLENGTH
+  double width, CW, length;   // R_WIDTH, ALFA*K**(1/ALFA) with K = sqrt(R_SLOPE)/R_MAN_N (K itself: kwK[r], shock merges only), RLENGTH
   double scA, scB;            // R_WIDTH of the first / second non-headwater upstream over R_WIDTH (:929)
+  int down, pad;              // downstream reach (internal index, -1 = outlet): whose progress the persistent sweep polls
 };
 
 static_assert(sizeof(MzrKwtRec) == 64, "MzrKwtRec is one 64-byte line");
@@ -98,6 +99,15 @@ struct MzrDev {
   const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 16 work-array entries, 8 lanes each (host regroups)
   const MzrKwtRec *kwtGeneric;   // ... with more than two upstream reaches
   const int *kwtLight;        // headwater, lake and halo reaches, stage-major (one lane each)
+  // ---- KWT persistent sweep (k_sweep_kwt): waves own items for a whole window and hand results on through kwDone
+  int *kwDone;                // [N] steps of the current window a reach has completed (headwaters: W from the start)
+  const int *down;            // [N] downstream reach (internal index), -1 = outlet
+  const int *swOff;           // [nWaves+1] items of persistent wave w: swItem[swOff[w] .. swOff[w+1])
+  const int *swItem;          // item = class << 28 | block index in the class list (0 A, 1 B, 2 generic, 3 lake / halo)
+  const int *swLo, *swHi;     // per item: smallest / largest stage among its reaches
+  const int *kwtHead;         // headwater reaches (bulk kernel before the sweep)
+  int nHead, nDepLight;       // entries of kwtHead / of kwtLight in persistent mode (lake and halo reaches only)
+  int nA, nB, nG;             // routed records per class in persistent mode
   // ---- lakes (null / 0 without lakes)
   const int *lakeSlot;        // [N] lake index of a lake reach, -1 otherwise
   const int *lakeModel;       // [nLake]
@@ -119,7 +129,7 @@ struct MzrDev {
   int    *exN;                // [Wmax][nExp]
   double *exOQ, *exOT;        // [Wmax][MZR_OB_CAP][nExp]
   MzrKwtStat *kwtStat;
-  unsigned long long *dbgCycles;   // [16] per-section wave cycles (only with -DMZR_KWT_TIMING)
+  unsigned long long *dbgCycles;   // [32] per-section wave cycles (only with -DMZR_KWT_TIMING)
   MzrErr *err;
 };
 

@@ -14,6 +14,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -33,6 +37,11 @@ void mzr_launch_sort_flux(int H, int nSteps, int nSrc, const int *srcOf, int rem
                           hipStream_t stream);
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int gnBegin, int gnEnd,
                           int ltBegin, int ltEnd, hipStream_t stream);
+
+void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream);
+int mzr_sweep_kwt_capacity(bool full);
+void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream);
 
 namespace {
 
@@ -175,6 +184,12 @@ struct mzr_domain {
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtGeneric;
   DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll;   // classes A / B over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
+  // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
+  DBuf<int> kwDone, down, swOff, swItem, swLo, swHi, kwtHead, kwtDepLight;
+  std::vector<int> h_down, h_kwtHead, h_kwtDepLight;
+  std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB;   // class lists of the sweep, host copies (h_swA/B: heaviest first)
+  int swWaves = 0, swCap = 0;
+  long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff;        // [nStages+1] stage offsets in h_kwtRouted / in the class-B list (kwtRoutedOff: class A)
   long long kwtWindows = 0, kwtStepsSince = 0; // KWT windows run since mzr_init_state, steps since the last regrouping
@@ -234,6 +249,9 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
   d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
+  d.kwDone = h->kwDone.p; d.down = h->down.p; d.swOff = h->swOff.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
+  d.kwtHead = h->kwtHead.p; d.nHead = (int)h->h_kwtHead.size(); d.nDepLight = (int)h->h_kwtDepLight.size();
+  d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nG = (int)h->h_kwtGeneric.size();
   d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
   d.lakeSlot = h->nLake ? h->lakeSlot.p : nullptr; d.lakeModel = h->lakeModel.p; d.lakePar = h->lakePar.p;
   d.lakeEvap = h->lakeEvap.p; d.lakePrecip = h->lakePrecip.p; d.calMonth = h->calMonth.p; d.calDay = h->calDay.p; d.calDoy = h->calDoy.p;
@@ -278,6 +296,98 @@ int checkDeviceError(mzr_handle h) {
   char buf[512];
   snprintf(buf, sizeof buf, "main_routing/route_network/%s [reach index %d id %d, window step %d]", what, ext + 1, id, e.step);
   return fail(h, e.code, buf);
+}
+
+// ---- persistent KWT sweep: host side ------------------------------------------------------------
+// Items of the sweep (blocks of 4 class-A reaches, 8 class-B reaches, single confluences of more than two
+// reaches, 64 lake / halo reaches) are dealt to the wavefronts of k_sweep_kwt heaviest first onto the
+// least loaded wavefront.  `need` (null before the first regrouping) = work-array entries of a reach in
+// the last step, the proxy for what an item costs.
+void kwt_build_sweep(mzr_handle h, const std::function<int(const MzrKwtRec &)> *need) {
+  const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
+  int cap = mzr_sweep_kwt_capacity(full);
+  if (cap < 1) cap = 1024;
+  h->swCap = cap;
+  // a mainstem domain (halo reaches) shares its GPU with the tributary domain of the same rank: both sweeps
+  // must be resident at once, so neither may take the whole device
+  if (h->nHalo) cap = std::max(1, cap / 4); else if (h->nExp) cap = std::max(1, cap - cap / 4);
+  if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = std::min(cap, v); }
+  double cA0 = 1.0, cA1 = 0.02, cB0 = 0.8, cB1 = 0.02;
+  if (const char *e = getenv("MZR_KWT_SWEEP_COST")) sscanf(e, "%lf,%lf,%lf,%lf", &cA0, &cA1, &cB0, &cB1);
+  struct It { int code, lo, hi; double cost; };
+  std::vector<It> items;
+  auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, int per, double c0, double c1) {
+    for (size_t b = 0; b * per < v.size(); ++b) {
+      It it{(cls << 28) | (int)b, 1 << 30, -1, 0.0};
+      int mx = 0;
+      for (size_t k = b * per; k < std::min(v.size(), (b + 1) * per); ++k) {
+        it.lo = std::min(it.lo, v[k].sigma); it.hi = std::max(it.hi, v[k].sigma);
+        mx = std::max(mx, need ? (*need)(v[k]) : 20);
+      }
+      it.cost = c0 + c1 * mx;
+      items.push_back(it);
+    }
+  };
+  addRouted(h->h_swA, 0, 4, cA0, cA1);
+  addRouted(h->h_swB, 1, 8, cB0, cB1);
+  addRouted(h->h_kwtGeneric, 2, 1, 1.5, 0.02);
+  {
+    std::vector<int> sg(h->N);
+    if (!h->h_kwtDepLight.empty()) (void)hipMemcpy(sg.data(), h->sigma.p, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost);
+    for (size_t b = 0; b * 64 < h->h_kwtDepLight.size(); ++b) {
+      It it{(3 << 28) | (int)b, 1 << 30, -1, 0.5};
+      for (size_t k = b * 64; k < std::min(h->h_kwtDepLight.size(), (b + 1) * 64); ++k) {
+        const int sgm = sg[h->h_kwtDepLight[k]];
+        it.lo = std::min(it.lo, sgm); it.hi = std::max(it.hi, sgm);
+      }
+      items.push_back(it);
+    }
+  }
+  const int nW = std::max(1, std::min(cap, (int)items.size()));
+  std::vector<int> order(items.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].cost > items[b].cost; });
+  typedef std::pair<double, int> LW;
+  std::priority_queue<LW, std::vector<LW>, std::greater<LW>> pq;
+  for (int w = 0; w < nW; ++w) pq.push(LW(0.0, w));
+  std::vector<std::vector<int>> own(nW);
+  for (int i : order) { LW t = pq.top(); pq.pop(); own[t.second].push_back(i); t.first += items[i].cost; pq.push(t); }
+  std::vector<int> off(nW + 1, 0), code, lo, hi;
+  for (int w = 0; w < nW; ++w) {
+    std::sort(own[w].begin(), own[w].end());
+    for (int i : own[w]) { code.push_back(items[i].code); lo.push_back(items[i].lo); hi.push_back(items[i].hi); }
+    off[w + 1] = (int)code.size();
+  }
+  if (code.empty()) { code.push_back(0); lo.push_back(1 << 30); hi.push_back(-1); }
+  (void)hipStreamSynchronize(h->stream);
+  h->swOff.upload(off); h->swItem.upload(code); h->swLo.upload(lo); h->swHi.upload(hi);
+  h->swWaves = items.empty() ? 0 : nW;
+}
+
+// Sweeps of several domains (or streams) on one device: every wavefront of a sweep has to be resident, so two
+// sweeps may overlap only while their grids fit the device together; otherwise the later one waits for the earlier.
+struct SweepInflight { hipEvent_t ev; int grid; };
+std::mutex g_sweepMutex;
+std::map<int, std::vector<SweepInflight>> g_sweepInflight;
+std::vector<hipEvent_t> g_sweepEventPool;
+
+void sweep_admit(int device, hipStream_t st, int grid, int cap) {
+  std::lock_guard<std::mutex> lk(g_sweepMutex);
+  auto &v = g_sweepInflight[device];
+  int sum = 0;
+  for (size_t i = 0; i < v.size();) {
+    if (hipEventQuery(v[i].ev) == hipSuccess) { g_sweepEventPool.push_back(v[i].ev); v[i] = v.back(); v.pop_back(); }
+    else { sum += v[i].grid; ++i; }
+  }
+  if (sum + grid > cap) for (auto &f : v) (void)hipStreamWaitEvent(st, f.ev, 0);
+}
+void sweep_record(int device, hipStream_t st, int grid) {
+  std::lock_guard<std::mutex> lk(g_sweepMutex);
+  hipEvent_t ev;
+  if (!g_sweepEventPool.empty()) { ev = g_sweepEventPool.back(); g_sweepEventPool.pop_back(); }
+  else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+  (void)hipEventRecord(ev, st);
+  g_sweepInflight[device].push_back(SweepInflight{ev, grid});
 }
 
 }  // namespace
@@ -401,6 +511,9 @@ int mzr_set_network(mzr_handle h, int N, int H, const int *downIndex, const int 
     }
     h->wk = wkNeed <= 64 ? 64 : wkNeed <= 128 ? 128 : 192;
     h->h_nGood = nGood; h->h_nUp = nUp;
+    h->h_down.assign(N, -1);
+    for (int i = 0; i < N; ++i) { const int dn = downIndex[h->int2ext[i]]; if (dn >= 1 && dn <= N) h->h_down[i] = h->ext2int[dn - 1]; }
+    h->down.upload(h->h_down);
     std::vector<int> hOff(N + 1, 0), hIdx; std::vector<double> hW;
     for (int i = 0; i < N; ++i) {
       const int e = h->int2ext[i];
@@ -664,16 +777,16 @@ int mzr_init_state(mzr_handle h) {
           (void)hipMemcpy(upStart.data(), h->upStart.p, N * sizeof(int), hipMemcpyDeviceToHost);
           (void)hipMemcpy(gmask.data(), h->goodMask.p, N * sizeof(uint32_t), hipMemcpyDeviceToHost);
           (void)hipMemcpy(isOut.data(), h->isOutlet.p, N * sizeof(uint8_t), hipMemcpyDeviceToHost);
-          std::vector<MzrKwtRec> routed, generic; std::vector<int> light;
+          std::vector<MzrKwtRec> routed, generic; std::vector<int> light, head, depLight;
           h->kwtRoutedOff.assign(h->nStages + 1, 0); h->kwtGenericOff.assign(h->nStages + 1, 0); h->kwtLightOff.assign(h->nStages + 1, 0);
           for (int sg = 0; sg < h->nStages; ++sg) {
             h->kwtRoutedOff[sg] = (int)routed.size(); h->kwtGenericOff[sg] = (int)generic.size(); h->kwtLightOff[sg] = (int)light.size();
             for (int i = h->stageStart[sg]; i < h->stageStart[sg + 1]; ++i) {
               const bool halo = h->nHalo && !h->h_haloSlot.empty() && h->h_haloSlot[i] >= 0;
               const bool lake = !h->h_lakeSlot.empty() && h->h_lakeSlot[i] >= 0;
-              if (halo || lake || h->h_nGood[i] == 0) { light.push_back(i); continue; }
+              if (halo || lake || h->h_nGood[i] == 0) { light.push_back(i); (halo || lake ? depLight : head).push_back(i); continue; }
               MzrKwtRec rc; memset(&rc, 0, sizeof rc);
-              rc.r = i; rc.sigma = sg; rc.u0 = upStart[i]; rc.nup = h->h_nUp[i];
+              rc.r = i; rc.sigma = sg; rc.u0 = upStart[i]; rc.nup = h->h_nUp[i]; rc.down = h->h_down[i];
               rc.flags = (uint8_t)(h->h_nGood[i] & 15) | (isOut[i] ? 0x80 : 0);
               rc.goodMask = (uint8_t)(gmask[i] & 0xff);
               int nsr = 0;
@@ -686,7 +799,7 @@ int mzr_init_state(mzr_handle h) {
                   ++nsr;
                 }
               }
-              rc.width = width[i]; rc.K = K[i]; rc.CW = CW[i]; rc.length = length[i];
+              rc.width = width[i]; rc.CW = CW[i]; rc.length = length[i];
               if (rc.nup > 2) generic.push_back(rc); else routed.push_back(rc);
             }
           }
@@ -699,6 +812,17 @@ int mzr_init_state(mzr_handle h) {
           h->h_kwtRouted = routed; h->kwtWindows = 0; h->kwtStepsSince = 0;
           h->kwtStageOff = h->kwtRoutedOff;                       // every routed reach starts in class A
           h->kwtBOff.assign(h->nStages + 1, 0);
+          // persistent sweep: every routed reach starts in class A, in stage order
+          h->h_swA = h->kwtRoutedOff[h->nStages] > 0 ? routed : std::vector<MzrKwtRec>();
+          h->h_swB.clear();
+          h->h_kwtGeneric = h->kwtGenericOff[h->nStages] > 0 ? generic : std::vector<MzrKwtRec>();
+          h->h_kwtHead = head; h->h_kwtDepLight = depLight;
+          if (head.empty()) head.push_back(0);
+          if (depLight.empty()) depLight.push_back(0);
+          h->kwtHead.upload(head); h->kwtDepLight.upload(depLight);
+          h->kwDone.alloc(N); h->kwDone.zero();
+          h->kwtHeadSteps = 0;
+          kwt_build_sweep(h, nullptr);
         }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
@@ -707,7 +831,7 @@ int mzr_init_state(mzr_handle h) {
         h->obQ.alloc((size_t)2 * MZR_OB_CAP * N); h->obT.alloc((size_t)2 * MZR_OB_CAP * N);
         h->obQ.zero(); h->obT.zero();
         h->kwtStat.alloc(1); h->kwtStat.zero();
-        h->dbgCycles.alloc(16); h->dbgCycles.zero();
+        h->dbgCycles.alloc(32 * 1024); h->dbgCycles.zero();
       }
       rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0; rb.meanSteps = 0;
     }
@@ -760,7 +884,8 @@ static void kwt_regroup(mzr_handle h) {
     for (const auto &k : k2) S.push_back(A[k.second]);
     (void)hipMemcpy(h->kwtRoutedAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
     h->kwtAllValid = true;
-  }
+    h->h_swA = S;
+  } else h->h_swA.clear();
   if (!B.empty()) (void)hipMemcpy(h->kwtRoutedB.p, B.data(), B.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
   if (!B.empty()) {
     std::vector<std::pair<int, int>> k2; k2.reserve(B.size());
@@ -769,7 +894,10 @@ static void kwt_regroup(mzr_handle h) {
     std::vector<MzrKwtRec> S; S.reserve(B.size());
     for (const auto &k : k2) S.push_back(B[k.second]);
     (void)hipMemcpy(h->kwtRoutedBAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
-  }
+    h->h_swB = S;
+  } else h->h_swB.clear();
+  std::function<int(const MzrKwtRec &)> nf = need;
+  kwt_build_sweep(h, &nf);
 }
 
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
@@ -799,7 +927,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // several routing methods are independent of each other once the hillslope series exist: each gets its own
   // stream (their stage launches are small and latency-bound, so they fill each other's gaps)
   const bool multi = h->cfg.nRoutes > 1;
-  const bool chunked = nChunks > 2 && !multi;
+  bool chunked = nChunks > 2 && !multi;
+  if (const char *e = getenv("MZR_BASIN_CHUNKED")) chunked = chunked && atoi(e) != 0;   // debugging aid
   if (!chunked) mzr_launch_basin(d, st);
   else {
     if (!h->basinStream) (void)hipStreamCreateWithFlags(&h->basinStream, hipStreamNonBlocking);
@@ -835,7 +964,38 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 1; ix < nR; ++ix) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
   }
   const bool prof = h->profiling;
+  // KWT: windows of more than a few steps go through the persistent sweep (one launch per chunk of the skewed
+  // schedule, progress counters instead of kernel boundaries); single steps keep one launch per stage.
+  // MZR_KWT_SWEEP=0 / 1 forces one or the other.
+  bool sweep = W >= 8;
+  if (const char *e = getenv("MZR_KWT_SWEEP")) sweep = atoi(e) != 0;
+  const int kwtIx = idxOf(h, MZR_KWT);
+  if (kwtIx < 0 || h->swWaves < 1) sweep = false;
+  if (sweep) {
+    RouteBufs &rb = h->route[kwtIx];
+    hipStream_t sx = rst[kwtIx];
+    MzrDev dk = dr[kwtIx];
+    dk.kwtRouted = h->kwtAllValid ? h->kwtRoutedAll.p : h->kwtRouted.p;   // before the first regrouping: every routed reach in class A, stage order
+    dk.kwtRoutedB = h->kwtRoutedBAll.p;
+    dk.kwtLight = h->kwtDepLight.p;
+    const int nLaunch = nS + W - 1;
+    for (int c = 0; c * CH < nLaunch; ++c) {
+      if (chunked && c > 0 && c < nChunks) (void)hipStreamWaitEvent(sx, h->basinEvents[c], 0);
+      if (c * CH < W) mzr_launch_kwt_window_init(dk, c * CH, std::min(W, (c + 1) * CH), sx);
+      sweep_admit(h->cfg.device, sx, h->swWaves, h->swCap);
+      if (prof) {
+        if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
+      }
+      mzr_launch_sweep_kwt(dk, h->swWaves, c * CH, std::min(nLaunch, (c + 1) * CH), sx);
+      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+      sweep_record(h->cfg.device, sx, h->swWaves);
+      ++rb.nLaunches;
+    }
+    if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
+  }
   for (int s = 0; s < nS + W - 1; ++s) {
+    if (sweep && nR == 1) break;
     if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
     const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
     const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
@@ -843,6 +1003,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 0; ix < nR; ++ix) {
       RouteBufs &rb = h->route[ix];
       hipStream_t sx = rst[ix];
+      if (sweep && ix == kwtIx) continue;
       if (prof) {
         if (rb.evUsed == rb.events.size()) {
           hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b);
@@ -864,6 +1025,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
   }
   for (int ix = 0; ix < nR; ++ix) {
+    if (h->route[ix].method == MZR_KWT) mzr_launch_accum_qsum(h->route[ix].Q.p, h->route[ix].qsum.p, N, W, rst[ix]);
     h->route[ix].reachSteps += (long long)N * W;
     h->route[ix].meanSteps += W;
     if (multi && ix > 0) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
@@ -1214,17 +1376,25 @@ int mzr_set_volume(mzr_handle h, int method, const double *vol) {
 }
 
 // debug: per-section wave cycles of the KWT kernel (library built with -DMZR_KWT_TIMING)
-int mzr_debug_cycles(mzr_handle h, unsigned long long *out16, int reset) {
+int mzr_debug_cycles(mzr_handle h, unsigned long long *out32, int reset) {
   if (!h || !h->dbgCycles.p) return 1;
   (void)hipStreamSynchronize(h->stream);
-  (void)hipMemcpy(out16, h->dbgCycles.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  if (reset) (void)hipMemset(h->dbgCycles.p, 0, 16 * sizeof(unsigned long long));
+  std::vector<unsigned long long> all((size_t)32 * 1024);   // 1024 slots of 32 counters (uncontended atomics), summed here
+  (void)hipMemcpy(all.data(), h->dbgCycles.p, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  for (int i = 0; i < 32; ++i) { out32[i] = 0; for (int k = 0; k < 1024; ++k) out32[i] += all[(size_t)k * 32 + i]; }
+  if (reset) (void)hipMemset(h->dbgCycles.p, 0, all.size() * sizeof(unsigned long long));
   return 0;
 }
 
 int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {
   if (!h || !h->haveNet) return 1;
   *nStages = h->nStages; *maxStageWidth = h->maxStageWidth;
+  return 0;
+}
+
+int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems) {
+  if (!h || !h->haveState) return 1;
+  *nWaves = h->swWaves; *capacity = h->swCap; *nItems = (int)(h->swItem.n);
   return 0;
 }
 
@@ -1247,8 +1417,8 @@ int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long lon
   MzrKwtStat s;
   (void)hipMemcpy(&s, h->kwtStat.p, sizeof s, hipMemcpyDeviceToHost);
   *w_in = (long long)s.w_in; *w_up = (long long)s.w_up; *w_out = (long long)s.w_out;
-  *n_head = (long long)s.n_head; *n_route = (long long)s.n_route; *n_edges = (long long)s.n_edges;
-  if (reset) (void)hipMemset(h->kwtStat.p, 0, sizeof s);
+  *n_head = (long long)s.n_head + h->kwtHeadSteps; *n_route = (long long)s.n_route; *n_edges = (long long)s.n_edges;
+  if (reset) { (void)hipMemset(h->kwtStat.p, 0, sizeof s); h->kwtHeadSteps = 0; }
   return 0;
 }
 

@@ -37,7 +37,7 @@ MODULE mzr_c
             mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
-            mzr_set_lakes, mzr_set_lake_forcing
+            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info
   public :: mzr_message
 
   INTERFACE
@@ -157,6 +157,11 @@ MODULE mzr_c
       import :: c_ptr, c_int
       type(c_ptr), value :: h
       integer(c_int), intent(out) :: nStages, maxStageWidth
+    end function
+    integer(c_int) function mzr_get_sweep_info(h, nWaves, capacity, nItems) bind(C, name='mzr_get_sweep_info')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), intent(out) :: nWaves, capacity, nItems
     end function
     integer(c_int) function mzr_set_boundary(h, nExport, exportReach, nHalo, haloReach, haloGood) bind(C, name='mzr_set_boundary')
       import :: c_ptr, c_int
