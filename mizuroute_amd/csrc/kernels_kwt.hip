@@ -130,7 +130,12 @@ __device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, in
   for (;;) {
     int v = wneed;
     if (wp) v = ldx<true>(wp);
-    if (__ballot(v < wneed) == 0ull) return false;
+    if (__ballot(v < wneed) == 0ull) {
+#ifdef MZR_KWT_TIMING
+      if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + 23], spins ? 1ull : 0ull); atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + 24], (unsigned long long)spins); }
+#endif
+      return false;
+    }
     __builtin_amdgcn_s_sleep(4);
     if ((++spins & 31) == 0) {
       if (ldx<true>(&d.err->code) != 0) return true;
@@ -448,12 +453,18 @@ __device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *
 
 #ifdef MZR_KWT_TIMING
 #define KCOUNT(i, v) do { if (gl == 0) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(v)); } while (0)
-#define TSTAMP(i) do { const long long _n = clock64(); if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
+#define TSTAMP(i) do { const long long _n = clock64(); _sec[i] += (unsigned)(_n - _tprev); if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
+// one record per sampled pass behind the counters: lane group size, largest list and most removals among the pass's reaches, cycles per section
+#define MZR_REC_N 65536
+#define TRECORD(G_, size_, nrem_) do { int _sz = (size_), _nr = (nrem_); for (int _o = 32; _o > 0; _o >>= 1) { _sz = max(_sz, __shfl_xor(_sz, _o, 64)); _nr = max(_nr, __shfl_xor(_nr, _o, 64)); } \
+  if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { unsigned *_rb = (unsigned *)(d.dbgCycles + 32 * 1024); const unsigned _k = atomicAdd(_rb, 1u) % MZR_REC_N; unsigned *_r = _rb + 16 + (size_t)_k * 16; \
+    _r[0] = (G_); _r[1] = _sz; _r[2] = _nr; _r[3] = _sec[21]; _r[4] = _sec[0]; _r[5] = _sec[1]; _r[6] = _sec[2] + _sec[3]; _r[7] = _sec[4] + _sec[5]; _r[8] = _sec[6]; _r[9] = _sec[16] + _sec[17]; _r[10] = _sec[18] + _sec[19] + _sec[7]; _r[11] = _sec[22]; } } while (0)
 #define TSTAMP_WAVE(i) do { if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], 1ull); } while (0)
 #else
 #define KCOUNT(i, v) do { } while (0)
 #define TSTAMP(i) do { } while (0)
 #define TSTAMP_WAVE(i) do { } while (0)
+#define TRECORD(G_, size_, nrem_) do { } while (0)
 #endif
 
 namespace {
@@ -495,6 +506,9 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
     const int dn = (halo && t >= 2) ? d.down[r] : -1;
     for (int i = 0; __ballot(i < nu) != 0ull; ++i) if (kwt_wait_deps(d, i < nu ? d.kwDone + u0 + i : nullptr, t + 1)) return true;
     if (kwt_wait_deps(d, dn >= 0 ? d.kwDone + dn : nullptr, t - 1)) return true;
+    if (kwt_wait_deps(d, (act && t >= 1) ? d.kwDone + r : nullptr, t)) return true;      // its own previous step
+    // a lake's own state (volume, Hanasaki memory) was written by whichever wavefront took its last step
+    if (__ballot(act && !halo) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   if (act) {
     {
@@ -536,6 +550,7 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
     }
   }
   if (PERS) {
+    if (__ballot(act && FULL && d.lakeSlot && d.lakeSlot[r] >= 0) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plain lake state stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (act) stx<true>(d.kwDone + r, t + 1);
   }
@@ -556,7 +571,7 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #define MZR_KWT_KB 3   // particle slots per lane of the 8-lane class
 #endif
 #ifndef MZR_KWT_OCC
-#define MZR_KWT_OCC 4
+#define MZR_KWT_OCC 5
 #endif
 // One reach by a group of G adjacent lanes with KS (OS) particle slots per lane for the own row
 // (an outbox row).  `off` = the group's slice of the LDS work arrays, `cap` = how many entries the
@@ -571,10 +586,15 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const int lane = mzr_lane(), gl = lane & (G - 1);
   const int N = d.N;
   bool ovf = false;
-  // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line)
-  const MzrKwtRec rec = recs[have ? item : lastItem];
-  const int r = uni<G>(rec.r);
-  const int t = uni<G>(have ? s - rec.sigma : -1);
+  // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line), fetched by eight lanes of
+  // the group into LDS (ctx[8..15]) and read from there when a field is needed, not held in registers
+  double *rc = ctx + 8;
+  if (gl < 8) rc[gl] = ((const double *)(recs + (have ? item : lastItem)))[gl];
+  grp_sync();
+  const int *rci = (const int *)rc;      // r, sigma | u0, nup flags upGood goodMask | width | CW | length | scA | scB | down, -
+  const int r = uni<G>(rci[0]);
+  const int t = uni<G>(have ? s - rci[1] : -1);
+  const unsigned rcb = (unsigned)rci[3];
   const bool live = t >= 0 && t < d.W;
   const KwtStep ks = kwt_step(d, t);
   const double T0 = ks.T0, T1 = ks.T1;
@@ -585,27 +605,30 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const int *obN = d.obN + (size_t)par * N;
   const double *obQ = d.obQ + (size_t)par * MZR_OB_CAP * N;
   const double *obT = d.obT + (size_t)par * MZR_OB_CAP * N;
-  const int nup = uni<G>((int)rec.nup), ng = uni<G>((int)(rec.flags & 15)), u0 = uni<G>(rec.u0);
-  const unsigned upGood = uni<G>((int)rec.upGood), goodMask = uni<G>((int)rec.goodMask);
-  const bool isOut = (uni<G>((int)rec.flags) & 0x80) != 0;
-  const bool upLake = FULL && (uni<G>((int)rec.flags) & 0x40) != 0;   // an upstream reach is a lake
-  const double RW = rec.width, scA = rec.scA, scB = rec.scB;
+  const int nup = (int)(rcb & 0xff), ng = (int)((rcb >> 8) & 15), u0 = rci[2];
+  const unsigned upGood = (rcb >> 16) & 0xff, goodMask = rcb >> 24;
+  const bool isOut = (rcb & 0x8000u) != 0;
+  const bool upLake = FULL && (rcb & 0x4000u) != 0;   // an upstream reach is a lake
+  const double RW = rc[2];
   // reach series A / B: first and second non-headwater upstream in UREACHI order
   const int ns = __popc(upGood);
   const int uA = u0 + (upGood ? __ffs(upGood) - 1 : 0);
   const int uB = u0 + ((upGood & (upGood - 1u)) ? __ffs(upGood & (upGood - 1u)) - 1 : 0);
 #ifdef MZR_KWT_TIMING
   long long _tprev = clock64();
+  unsigned _sec[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int _recSize = 0, _recRem = 0;
 #endif
   if (PERS) {
-    // step t of this reach needs step t of every upstream reach (their outbox rows and discharge) and
-    // overwrites the outbox parity its downstream reach read in step t - 2
-    const int dn = uni<G>(rec.down);
+    // step t of this reach needs step t of every upstream reach (their outbox rows and discharge), its own
+    // step t - 1, and overwrites the outbox parity its downstream reach read in step t - 2
+    const int dn = rci[14];
     const int *wp = nullptr;
     int wneed = 0;
     if (live) {
       if (gl < nup) { wp = d.kwDone + u0 + gl; wneed = t + 1; }
       else if (gl == nup && dn >= 0 && t >= 2) { wp = d.kwDone + dn; wneed = t - 1; }
+      else if (gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
     if (kwt_wait_deps(d, wp, wneed)) return 2;
     TSTAMP(21);
@@ -626,9 +649,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
   for (int j = 0; j < OS; ++j) aq[j] = at[j] = bq[j] = bt[j] = 0.0;
   if (live) {
-    int n_own_v = d.kwN[r], nrA_v = 0, nrB_v = 0;
+    int n_own_v = ldx<PERS>(d.kwN + r), nrA_v = 0, nrB_v = 0;
     if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
-    const double X0 = d.kwTR[MZR_KWI(0, r)];
+    const double X0 = ldx<PERS>(d.kwTR + MZR_KWI(0, r));
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
@@ -637,7 +660,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
-      q[j] = d.kwQ[MZR_KWI(kk, r)]; ti[j] = d.kwTI[MZR_KWI(kk, r)];
+      q[j] = ldx<PERS>(d.kwQ + MZR_KWI(kk, r)); ti[j] = ldx<PERS>(d.kwTI + MZR_KWI(kk, r));
     }
     if (!GEN && !upLake) {
 #pragma unroll
@@ -687,7 +710,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       double *c = ctx;
       c[6] = q_up;                     // REACH_INFLOW, stored with the other results at the end
       c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
-      c[1] = qlat_r; c[3] = rec.CW; c[4] = rec.length; c[5] = RW;
+      c[1] = qlat_r;
       if (d.kwtStat && !ovf) {
         atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own); atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
         atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
@@ -732,6 +755,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           // particle = its index in its own series + the number of particles of the other series
           // that the cursor walk consumes before it (ties: series A first).
           const double *SAq = Xw, *SAt = Yw, *SBq = Xw + nrA, *SBt = Yw + nrA;
+          const double scA = rc[5], scB = rc[6];
           const int nA = ns > 0 ? nrA - 2 : 0, nB = ns > 1 ? nrB - 2 : 0;
           ND = nA + nB + 1;
           bool slow = false;
@@ -803,6 +827,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           grp_sync();
         }
         int size = NJ + 1 + ND;
+#ifdef MZR_KWT_TIMING
+        _recSize = size;
+#endif
 #ifdef MZR_KWT_HIST
         if (gl == 0 && (blockIdx.x & 15) == 0) { const int b = size <= 4 ? 0 : size <= 8 ? 1 : size <= 12 ? 2 : size <= 16 ? 3 : size <= 20 ? 4 : size <= 32 ? 5 : size <= 48 ? 6 : 7; atomicAdd(&d.dbgCycles[8 + b], 1ull); }
 #endif
@@ -818,31 +845,69 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         // ---- remove_rch :999-1123: drop the particle with the least interpolation error until < MAXQPAR
         if (CAN_THIN && size > MZR_MAXQPAR_DEV) {
           KCOUNT(13, 1); KCOUNT(14, size - MZR_MAXQPAR_DEV);
+#ifdef MZR_KWT_TIMING
+          _recRem = size - MZR_MAXQPAR_DEV;
+#endif
           const int NPRT = size - 1;
           const bool big = GEN && NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
+          unsigned long long mask = NPRT >= 63 ? ~0ull : ((2ull << NPRT) - 1ull);   // bits 0..NPRT
+          int MPRT = NPRT;
+          if (!big) {
+            // The interpolation errors stay in registers (lane gl holds particles gl, gl+G, ...): one removal = local
+            // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
+            // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
+            constexpr int KT = 64 / G;
+            double e[KT];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+              const int i = gl + j * G;
+              e[j] = DBL_MAX;
+              if (i >= 1 && i < NPRT) e[j] = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
+            }
+            while (MPRT >= MZR_MAXQPAR_DEV) {
+              double emin = DBL_MAX; int ISEL = 0;
+#pragma unroll
+              for (int j = 0; j < KT; ++j) if (e[j] < emin) { emin = e[j]; ISEL = gl + j * G; }
+              grp_argmin<G, false>(emin, ISEL);           // first minimum of ABSERR (removed entries hold +Inf)
+              if (ISEL == 0) break;                         // no finite interpolation error left (NaN/Inf input)
+              mask &= ~(1ull << (ISEL & 63));
+              const int pm = 63 - __clzll((long long)(mask & ((1ull << ISEL) - 1ull)));       // INDEX1(ISEL-1)
+              const int pn = __ffsll((long long)(mask & ~((2ull << ISEL) - 1ull))) - 1;        // INDEX1(ISEL+1)
+              const bool side = gl & 1;
+              const int c = side ? pn : pm;
+              const bool valid = side ? pn < NPRT : pm > 0;
+              double en = 0.0;
+              if (valid) {   // pm: between INDEX1(pm-1) and pn; pn: between pm and INDEX1(pn+1)
+                const int a = side ? pm : 63 - __clzll((long long)(mask & ((1ull << pm) - 1ull)));
+                const int b = side ? __ffsll((long long)(mask & ~((2ull << pn) - 1ull))) - 1 : pn;
+                en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
+              }
+              const double eo = dpp_d<MZR_DPP_XOR1>(en);   // the other side's result
+              const double e_pm = side ? eo : en, e_pn = side ? en : eo;
+#pragma unroll
+              for (int j = 0; j < KT; ++j) {
+                const int i = gl + j * G;
+                if (i == pm && pm > 0) e[j] = e_pm;
+                if (i == pn && pn < NPRT) e[j] = e_pn;
+                if (i == ISEL) e[j] = INFINITY;           // removed: never the minimum again
+              }
+              --MPRT;
+            }
+          } else {
           for (int i = gl; i <= NPRT; i += G) {
             double e = DBL_MAX;
             if (i >= 1 && i < NPRT) e = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
             Xw[i] = e;
           }
           grp_sync();
-          unsigned long long mask = NPRT >= 63 ? ~0ull : ((2ull << NPRT) - 1ull);   // bits 0..NPRT
-          int MPRT = NPRT;
           while (MPRT >= MZR_MAXQPAR_DEV) {
             double emin = DBL_MAX; int ISEL = 0;
             for (int i = gl; i <= NPRT; i += G) { const double e = Xw[i]; if (e < emin) { emin = e; ISEL = i; } }
             grp_argmin<G, false>(emin, ISEL);           // first minimum of ABSERR (removed entries hold +Inf)
             ISEL = uni<G>(ISEL);
             if (ISEL == 0) break;                         // no finite interpolation error left (NaN/Inf input)
-            auto prevA = [&](int c) -> int {
-              if (!big) return 63 - __clzll((long long)(mask & ((1ull << c) - 1ull)));
-              int i = c - 1; while (i > 0 && (i == ISEL || Xw[i] == INFINITY)) --i; return i;
-            };
-            auto nextA = [&](int c) -> int {
-              if (!big) return __ffsll((long long)(mask & ~((2ull << c) - 1ull))) - 1;
-              int i = c + 1; while (i < NPRT && (i == ISEL || Xw[i] == INFINITY)) ++i; return i;
-            };
-            mask &= ~(1ull << (ISEL & 63));
+            auto prevA = [&](int c) -> int { int i = c - 1; while (i > 0 && (i == ISEL || Xw[i] == INFINITY)) --i; return i; };
+            auto nextA = [&](int c) -> int { int i = c + 1; while (i < NPRT && (i == ISEL || Xw[i] == INFINITY)) ++i; return i; };
             const int pm = prevA(ISEL), pn = nextA(ISEL);   // INDEX1(ISEL-1), INDEX1(ISEL+1)
             // the two neighbours are re-evaluated against their new neighbours, one on even and one on odd lanes
             const bool side = gl & 1;
@@ -858,6 +923,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             if (gl == 0) Xw[ISEL] = INFINITY;              // removed: never the minimum again
             --MPRT;
             grp_sync();
+          }
           }
           if (MPRT >= MZR_MAXQPAR_DEV) { mzr_raise(d, 62, r, t, 16); break; }
           if (!big) {   // compact into the two free arrays, then swap roles
@@ -880,7 +946,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             double Qavg;
             if (d_interp_rch(Tw, Qw, size, T_START, T_END, &Qavg)) { mzr_raise(d, 1, r, t, 17); break; }
             grp_sync();
-            const double totQ = Qavg * RW;
+            const double totQ = Qavg * rc[2];
             if (Qtake > 0.0) {
               const double Qfrac = Qtake / totQ;
               for (int i = 1 + gl; i < size; i += G) Qw[i] = Qw[i] * (1.0 + Qfrac);
@@ -906,7 +972,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         int NQ2 = 0;
         {
           // cw = ALFA*K**(1/ALFA) with K = sqrt(R_SLOPE)/R_MAN_N and ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
-          const double cw = ctx[3], XMX = ctx[4];
+          const double cw = rc[3], XMX = rc[4];
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
@@ -1064,7 +1130,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         double QNEW;
         if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
         TSTAMP(17);
-        const double Qout = QNEW * ctx[5] + ctx[1];
+        const double Qout = QNEW * rc[2] + ctx[1];
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
         const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
@@ -1075,7 +1141,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
         // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
-        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); d.kwN[r] = NN2 + 1; d.inflow[r] = ctx[6]; }
+        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); stx<PERS>(d.kwN + r, NN2 + 1); d.inflow[r] = ctx[6]; }
         TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
@@ -1107,9 +1173,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           const int k2 = gl + j * G;
           if (k2 <= NN2) {
             const bool first = k2 == 0;
-            d.kwQ[MZR_KWI(k2, r)] = first ? Q_END : Qw[NR + k2];
-            d.kwTI[MZR_KWI(k2, r)] = first ? TIMEI : Tw[NR + k2];
-            d.kwTR[MZR_KWI(k2, r)] = first ? T_END : Xw[NR + k2];
+            stx<PERS>(d.kwQ + MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2]);
+            stx<PERS>(d.kwTI + MZR_KWI(k2, r), first ? TIMEI : Tw[NR + k2]);
+            // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
+            if (first || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
           }
         }
         if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
@@ -1122,6 +1189,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       } while (0);
     }
   }
+#ifdef MZR_KWT_TIMING
+  if (PERS) TRECORD(G, _recSize, _recRem);
+#endif
   return ovf ? 1 : 0;
 }
 
@@ -1141,7 +1211,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
   constexpr int GPA = POOL / RA, GPB = POOL / RB;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
-  __shared__ double sCtx[RB][8];   // per reach: values needed again late (X0, BASIN_QR(1), cw, RLENGTH, R_WIDTH, inflow)
+  __shared__ double sCtx[RB][16];   // per reach: [0..7] values needed again late (X0, BASIN_QR(1), inflow), [8..15] the reach's record
   const int b = blockIdx.x, lane = threadIdx.x & 63;
   if (!GEN && b >= nABlocks + nBBlocks) {
     kwt_light<FULL, false>(d, s, ltBegin + (b - nABlocks - nBBlocks) * 64 + lane, ltEnd);
@@ -1196,7 +1266,7 @@ template <bool FULL, int POOL>
 __device__ __noinline__ int kwt_item_generic(const MzrDev &d, int s, int bi, double *sA, double *sB, double *sC, double *sD, double *ctx) {
   constexpr int GA = 16, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
   const int g16 = mzr_lane() / GA;
-  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + 8 * g16);
+  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + 16 * g16);
 }
 template <bool FULL>
 __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
@@ -1205,24 +1275,27 @@ __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
 
 // ------------------------------------------------------------------------------------------------
 // Persistent sweep.  ONE launch advances the skewed schedule through launches s = sBegin .. sEnd-1
-// of k_stage_kwt: every wavefront owns a fixed set of items (blocks of 4 class-A reaches, 8 class-B
-// reaches, one confluence of more than two reaches, or 64 lake / halo reaches; dealt by the host,
-// heaviest first onto the least loaded wavefront) and takes them through the steps in order.  What
-// a kernel boundary used to guarantee is now per reach: step t of reach r starts when kwDone of
-// its upstream reaches has reached t+1 and kwDone of its downstream reach t-1 (kwt_reach).  The
-// earliest unfinished item of the whole sweep never waits, every wavefront takes its items in
-// launch order, and the grid is sized to be co-resident, so the sweep always moves; wavefronts
+// of k_stage_kwt.  The items of a launch (blocks of 4 class-A reaches, 8 class-B reaches, one
+// confluence of more than two reaches, or 64 lake / halo reaches; stage-ordered list made by the
+// host) are numbered in launch order and drawn by the wavefronts from ticket counters -- eight of
+// them, one per XCD (queue q = items i with i % 8 == q), because one address takes < 100 atomics
+// per microsecond; a wavefront serves the queue of the XCD it runs on and, once that is empty,
+// what is left in the others.  What a kernel boundary used to guarantee is now per reach: step t
+// of reach r starts when kwDone of its upstream reaches has reached t+1, its own t, and that of
+// its downstream reach t-1 (kwt_reach).  Every ticket depends only on tickets of the launch before,
+// each queue is served in order and nothing is owned by a particular wavefront, so the sweep moves
+// whichever wavefronts of the grid happen to be resident -- no co-residency assumption; wavefronts
 // that wait sleep, and give up when an error was raised or nothing has moved for seconds.
-// Own state (at-rest rows) stays with the owning wavefront, hence on one CU: plain accesses.
-// Headwater reaches need nothing from anybody and are filled in for the whole window by
-// k_kwt_window_init before the sweep starts.
+// Results cross CUs, so state, outbox rows and discharge go through sc1 accesses (ldx / stx).
+// Headwater reaches need nothing from anybody and are filled in by k_kwt_window_init.
 template <bool FULL, int POOL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC)))
 k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
-  // The domain description has ~90 fields; kept live around the item loop they spill.  They are read
+  // The domain description has ~100 fields; kept live around the item loop they spill.  They are read
   // through the kernel-argument segment instead (scalar loads, constant address space) and the
   // pointer is made opaque once per item, so that nothing is hoisted out of the loop.
   typedef const MzrDev __attribute__((address_space(4))) *MzrDevK;
+  typedef const int __attribute__((address_space(4))) *IntK;
   MzrDevK dk0 = (MzrDevK)__builtin_amdgcn_kernarg_segment_ptr();
   const MzrDev &d0 = *(const MzrDev *)dk0;
   constexpr int GA = 16, RA = 64 / GA, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
@@ -1230,18 +1303,37 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
   constexpr int GPA = POOL / RA, GPB = POOL / RB;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
-  __shared__ double sCtx[RB][8];
-  const int i0 = d0.swOff[blockIdx.x], i1 = d0.swOff[blockIdx.x + 1];
+  __shared__ double sCtx[RB][16];
   const int Wm1 = d0.W - 1;
+  const int q0 = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;     // HW_REG_XCC_ID: a speed hint only
+  IntK P = (IntK)d0.swP, RAs = (IntK)d0.swRA;
 #pragma unroll 1
-  for (int s = sBegin; s < sEnd; ++s) {
+  for (int dq = 0; dq < 8; ++dq) {
+    const int q = (q0 + dq) & 7;
+    const int pEnd = P[sEnd * 8 + q];
+    int sCur = sBegin, pLo = P[sBegin * 8 + q], pHi = P[(sBegin + 1) * 8 + q];   // tickets [pLo, pHi) of queue q belong to launch sCur
 #pragma unroll 1
-    for (int i = i0; i < i1; ++i) {
+    for (;;) {
       MzrDevK dk = dk0;
       asm volatile("" : "+s"(dk));
       const MzrDev &d = *(const MzrDev *)dk;
-      const int lane = mzr_lane(), g16 = lane / GA, g8 = lane / GB;
+      int k = 0;
+      if (mzr_lane() == 0) k = atomicAdd(d.swHead + q * 16, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= pEnd) break;
+      if (k >= pHi) {   // the next launch, or (after a pause, or in a queue taken over from another XCD) a later one
+        ++sCur; pLo = pHi; pHi = P[(sCur + 1) * 8 + q];
+        if (k >= pHi) {
+          int lo = sCur + 1, hi = sEnd - 1;          // largest s with P[s] <= k
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P[mid * 8 + q] <= k) lo = mid; else hi = mid - 1; }
+          sCur = lo; pLo = P[sCur * 8 + q]; pHi = P[(sCur + 1) * 8 + q];
+        }
+      }
+      const int s = sCur;
+      const int a = RAs[s];
+      const int i = a + ((q - a) & 7) + 8 * (k - pLo);
       if (s < d.swLo[i] || s > d.swHi[i] + Wm1) continue;        // none of the item's reaches has a step in this launch
+      const int lane = mzr_lane(), g16 = lane / GA, g8 = lane / GB;
       const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
       const int cls = it >> 28, bi = it & 0x0fffffff;
       if (cls == 3) {
@@ -1274,10 +1366,10 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
         if (cls == 1) {
           unsigned m = ovfMask;
           int sel = -1;
-          for (int k = 0; k <= g16 && m; ++k) { sel = (k == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
+          for (int kk = 0; kk <= g16 && m; ++kk) { sel = (kk == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
           have = sel >= 0;
           item = bi * RB + (have ? sel : 0);
-          for (int k = 0; k < RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
+          for (int kk = 0; kk < RA && ovfMask; ++kk) ovfMask &= ovfMask - 1u;
         }
         const int st = kwt_reach<FULL, false, GA, KA, OA, true, true>(d, s, recs, item, have, last, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
         if (__ballot(st & 2) != 0ull) return;
@@ -1376,8 +1468,13 @@ void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream
   if (first && d.nHead > 0) hipLaunchKernelGGL(k_kwt_head_done, dim3((d.nHead + 255) / 256), block, 0, stream, d);
 }
 
+__global__ void k_sweep_heads(MzrDev d, int sBegin) {
+  if (threadIdx.x < 8) d.swHead[threadIdx.x * 16] = d.swP[sBegin * 8 + threadIdx.x];
+}
+
 void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {
   if (nWaves < 1 || sEnd <= sBegin) return;
+  hipLaunchKernelGGL(k_sweep_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
   if (kwt_full(d)) hipLaunchKernelGGL((k_sweep_kwt<true, 240>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
   else hipLaunchKernelGGL((k_sweep_kwt<false, 240>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
 }

@@ -99,15 +99,18 @@ struct MzrDev {
   const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 16 work-array entries, 8 lanes each (host regroups)
   const MzrKwtRec *kwtGeneric;   // ... with more than two upstream reaches
   const int *kwtLight;        // headwater, lake and halo reaches, stage-major (one lane each)
-  // ---- KWT persistent sweep (k_sweep_kwt): waves own items for a whole window and hand results on through kwDone
+  // ---- KWT persistent sweep (k_sweep_kwt): wavefronts draw items (blocks of reaches) of the skewed schedule in
+  // launch order from per-XCD ticket counters and hand results on through kwDone
   int *kwDone;                // [N] steps of the current window a reach has completed (headwaters: W from the start)
   const int *down;            // [N] downstream reach (internal index), -1 = outlet
-  const int *swOff;           // [nWaves+1] items of persistent wave w: swItem[swOff[w] .. swOff[w+1])
-  const int *swItem;          // item = class << 28 | block index in the class list (0 A, 1 B, 2 generic, 3 lake / halo)
-  const int *swLo, *swHi;     // per item: smallest / largest stage among its reaches
+  const int *swItem;          // [nItems] stage-ordered; item = class << 28 | block index in the class list (0 A, 1 B, 2 generic, 3 lake / halo)
+  const int *swLo, *swHi;     // [nItems] smallest / largest stage among the item's reaches
+  const int *swRA;            // [nLaunch] first item that can be active in launch s (the last one follows from the tickets)
+  const int *swP;             // [nLaunch+1][8] tickets of queue q before launch s (queue q = items i with i % 8 == q)
+  int *swHead;                // [8][16] next ticket of each queue (one cache line each)
   const int *kwtHead;         // headwater reaches (bulk kernel before the sweep)
   int nHead, nDepLight;       // entries of kwtHead / of kwtLight in persistent mode (lake and halo reaches only)
-  int nA, nB, nG;             // routed records per class in persistent mode
+  int nA, nB, nG;             // routed records per class
   // ---- lakes (null / 0 without lakes)
   const int *lakeSlot;        // [N] lake index of a lake reach, -1 otherwise
   const int *lakeModel;       // [nLake]

@@ -15,8 +15,6 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
-#include <map>
-#include <mutex>
 #include <queue>
 #include <string>
 #include <vector>
@@ -185,10 +183,10 @@ struct mzr_domain {
   DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll;   // classes A / B over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
-  DBuf<int> kwDone, down, swOff, swItem, swLo, swHi, kwtHead, kwtDepLight;
-  std::vector<int> h_down, h_kwtHead, h_kwtDepLight;
-  std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB;   // class lists of the sweep, host copies (h_swA/B: heaviest first)
-  int swWaves = 0, swCap = 0;
+  DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
+  std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
+  std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB;   // class lists of the sweep, host copies (stage order)
+  int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1;
   long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff;        // [nStages+1] stage offsets in h_kwtRouted / in the class-B list (kwtRoutedOff: class A)
@@ -249,7 +247,8 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
   d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
-  d.kwDone = h->kwDone.p; d.down = h->down.p; d.swOff = h->swOff.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
+  d.kwDone = h->kwDone.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
+  d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p;
   d.kwtHead = h->kwtHead.p; d.nHead = (int)h->h_kwtHead.size(); d.nDepLight = (int)h->h_kwtDepLight.size();
   d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nG = (int)h->h_kwtGeneric.size();
   d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
@@ -299,95 +298,67 @@ int checkDeviceError(mzr_handle h) {
 }
 
 // ---- persistent KWT sweep: host side ------------------------------------------------------------
-// Items of the sweep (blocks of 4 class-A reaches, 8 class-B reaches, single confluences of more than two
-// reaches, 64 lake / halo reaches) are dealt to the wavefronts of k_sweep_kwt heaviest first onto the
-// least loaded wavefront.  `need` (null before the first regrouping) = work-array entries of a reach in
-// the last step, the proxy for what an item costs.
-void kwt_build_sweep(mzr_handle h, const std::function<int(const MzrKwtRec &)> *need) {
+// Items of the sweep = consecutive blocks of the stage-ordered class lists (4 class-A reaches, 8 class-B reaches,
+// single confluences of more than two reaches, 64 lake / halo reaches), merged into one list ordered by stage.
+// The items of launch s are a contiguous range of that list, and the tickets of the kernel number them launch
+// after launch in eight queues (item i belongs to queue i % 8): kwt_sweep_tables makes the per-launch ranges
+// and ticket prefix sums for a window length.
+void kwt_build_sweep(mzr_handle h) {
   const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
   int cap = mzr_sweep_kwt_capacity(full);
   if (cap < 1) cap = 1024;
-  h->swCap = cap;
-  // a mainstem domain (halo reaches) shares its GPU with the tributary domain of the same rank: both sweeps
-  // must be resident at once, so neither may take the whole device
-  if (h->nHalo) cap = std::max(1, cap / 4); else if (h->nExp) cap = std::max(1, cap - cap / 4);
   if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = std::min(cap, v); }
-  double cA0 = 1.0, cA1 = 0.02, cB0 = 0.8, cB1 = 0.02;
-  if (const char *e = getenv("MZR_KWT_SWEEP_COST")) sscanf(e, "%lf,%lf,%lf,%lf", &cA0, &cA1, &cB0, &cB1);
-  struct It { int code, lo, hi; double cost; };
+  h->swCap = cap;
+  struct It { int code, lo, hi; };
   std::vector<It> items;
-  auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, int per, double c0, double c1) {
-    for (size_t b = 0; b * per < v.size(); ++b) {
-      It it{(cls << 28) | (int)b, 1 << 30, -1, 0.0};
-      int mx = 0;
-      for (size_t k = b * per; k < std::min(v.size(), (b + 1) * per); ++k) {
-        it.lo = std::min(it.lo, v[k].sigma); it.hi = std::max(it.hi, v[k].sigma);
-        mx = std::max(mx, need ? (*need)(v[k]) : 20);
-      }
-      it.cost = c0 + c1 * mx;
-      items.push_back(it);
-    }
+  auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, size_t per) {
+    for (size_t b = 0; b * per < v.size(); ++b)
+      items.push_back(It{(cls << 28) | (int)b, v[b * per].sigma, v[std::min(v.size(), (b + 1) * per) - 1].sigma});
   };
-  addRouted(h->h_swA, 0, 4, cA0, cA1);
-  addRouted(h->h_swB, 1, 8, cB0, cB1);
-  addRouted(h->h_kwtGeneric, 2, 1, 1.5, 0.02);
-  {
+  addRouted(h->h_swA, 0, 4);
+  addRouted(h->h_swB, 1, 8);
+  addRouted(h->h_kwtGeneric, 2, 1);
+  if (!h->h_kwtDepLight.empty()) {
     std::vector<int> sg(h->N);
-    if (!h->h_kwtDepLight.empty()) (void)hipMemcpy(sg.data(), h->sigma.p, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost);
-    for (size_t b = 0; b * 64 < h->h_kwtDepLight.size(); ++b) {
-      It it{(3 << 28) | (int)b, 1 << 30, -1, 0.5};
-      for (size_t k = b * 64; k < std::min(h->h_kwtDepLight.size(), (b + 1) * 64); ++k) {
-        const int sgm = sg[h->h_kwtDepLight[k]];
-        it.lo = std::min(it.lo, sgm); it.hi = std::max(it.hi, sgm);
-      }
-      items.push_back(it);
+    (void)hipMemcpy(sg.data(), h->sigma.p, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost);
+    for (size_t b = 0; b * 64 < h->h_kwtDepLight.size(); ++b)
+      items.push_back(It{(3 << 28) | (int)b, sg[h->h_kwtDepLight[b * 64]], sg[h->h_kwtDepLight[std::min(h->h_kwtDepLight.size(), (b + 1) * 64) - 1]]});
+  }
+  std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.lo < b.lo; });
+  h->h_swLo.clear(); h->h_swHiMax.clear();
+  std::vector<int> code, hi;
+  int run = -1;
+  for (const It &it : items) { code.push_back(it.code); h->h_swLo.push_back(it.lo); hi.push_back(it.hi); run = std::max(run, it.hi); h->h_swHiMax.push_back(run); }
+  const std::vector<int> lo = h->h_swLo;
+  if (code.empty()) { code.push_back(0); hi.push_back(-1); }
+  (void)hipStreamSynchronize(h->stream);
+  h->swItem.upload(code); h->swLo.upload(lo.empty() ? std::vector<int>(1, 1 << 30) : lo); h->swHi.upload(hi);
+  if (!h->swHead.p) { h->swHead.alloc(8 * 16); h->swHead.zero(); }
+  h->swItems = (int)items.size();
+  h->swTablesW = -1;          // ticket tables have to be made again
+}
+
+// launch ranges and ticket prefix sums of a window of W steps
+void kwt_sweep_tables(mzr_handle h, int W) {
+  if (h->swTablesW == W) return;
+  const int nS = h->nStages, nL = nS + W - 1, nI = h->swItems;
+  std::vector<int> ra(nL, 0), P((size_t)(nL + 1) * 8, 0);
+  int maxAct = 0;
+  for (int s = 0; s < nL; ++s) {
+    const int b = (int)(std::upper_bound(h->h_swLo.begin(), h->h_swLo.end(), s) - h->h_swLo.begin());                 // items with lo <= s
+    const int a = std::min(b, (int)(std::lower_bound(h->h_swHiMax.begin(), h->h_swHiMax.end(), s - W + 1) - h->h_swHiMax.begin()));   // first with hi >= s-W+1
+    ra[s] = a;
+    maxAct = std::max(maxAct, b - a);
+    for (int q = 0; q < 8; ++q) {
+      const int first = a + (((q - a) % 8 + 8) % 8);
+      P[(size_t)(s + 1) * 8 + q] = P[(size_t)s * 8 + q] + (first < b ? (b - first + 7) / 8 : 0);
     }
   }
-  const int nW = std::max(1, std::min(cap, (int)items.size()));
-  std::vector<int> order(items.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].cost > items[b].cost; });
-  typedef std::pair<double, int> LW;
-  std::priority_queue<LW, std::vector<LW>, std::greater<LW>> pq;
-  for (int w = 0; w < nW; ++w) pq.push(LW(0.0, w));
-  std::vector<std::vector<int>> own(nW);
-  for (int i : order) { LW t = pq.top(); pq.pop(); own[t.second].push_back(i); t.first += items[i].cost; pq.push(t); }
-  std::vector<int> off(nW + 1, 0), code, lo, hi;
-  for (int w = 0; w < nW; ++w) {
-    std::sort(own[w].begin(), own[w].end());
-    for (int i : own[w]) { code.push_back(items[i].code); lo.push_back(items[i].lo); hi.push_back(items[i].hi); }
-    off[w + 1] = (int)code.size();
-  }
-  if (code.empty()) { code.push_back(0); lo.push_back(1 << 30); hi.push_back(-1); }
-  (void)hipStreamSynchronize(h->stream);
-  h->swOff.upload(off); h->swItem.upload(code); h->swLo.upload(lo); h->swHi.upload(hi);
-  h->swWaves = items.empty() ? 0 : nW;
-}
-
-// Sweeps of several domains (or streams) on one device: every wavefront of a sweep has to be resident, so two
-// sweeps may overlap only while their grids fit the device together; otherwise the later one waits for the earlier.
-struct SweepInflight { hipEvent_t ev; int grid; };
-std::mutex g_sweepMutex;
-std::map<int, std::vector<SweepInflight>> g_sweepInflight;
-std::vector<hipEvent_t> g_sweepEventPool;
-
-void sweep_admit(int device, hipStream_t st, int grid, int cap) {
-  std::lock_guard<std::mutex> lk(g_sweepMutex);
-  auto &v = g_sweepInflight[device];
-  int sum = 0;
-  for (size_t i = 0; i < v.size();) {
-    if (hipEventQuery(v[i].ev) == hipSuccess) { g_sweepEventPool.push_back(v[i].ev); v[i] = v.back(); v.pop_back(); }
-    else { sum += v[i].grid; ++i; }
-  }
-  if (sum + grid > cap) for (auto &f : v) (void)hipStreamWaitEvent(st, f.ev, 0);
-}
-void sweep_record(int device, hipStream_t st, int grid) {
-  std::lock_guard<std::mutex> lk(g_sweepMutex);
-  hipEvent_t ev;
-  if (!g_sweepEventPool.empty()) { ev = g_sweepEventPool.back(); g_sweepEventPool.pop_back(); }
-  else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
-  (void)hipEventRecord(ev, st);
-  g_sweepInflight[device].push_back(SweepInflight{ev, grid});
+  (void)nI;
+  (void)hipStreamSynchronize(h->stream);     // a sweep still in flight reads the old tables
+  h->swRA.upload(ra); h->swP.upload(P);
+  h->swWaves = h->swItems > 0 ? std::max(8, std::min(h->swCap, maxAct)) : 0;
+  h->swTablesW = W;
 }
 
 }  // namespace
@@ -822,7 +793,7 @@ int mzr_init_state(mzr_handle h) {
           h->kwtHead.upload(head); h->kwtDepLight.upload(depLight);
           h->kwDone.alloc(N); h->kwDone.zero();
           h->kwtHeadSteps = 0;
-          kwt_build_sweep(h, nullptr);
+          kwt_build_sweep(h);
         }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
@@ -831,7 +802,7 @@ int mzr_init_state(mzr_handle h) {
         h->obQ.alloc((size_t)2 * MZR_OB_CAP * N); h->obT.alloc((size_t)2 * MZR_OB_CAP * N);
         h->obQ.zero(); h->obT.zero();
         h->kwtStat.alloc(1); h->kwtStat.zero();
-        h->dbgCycles.alloc(32 * 1024); h->dbgCycles.zero();
+        h->dbgCycles.alloc(32 * 1024 + 8 + 65536 * 8); h->dbgCycles.zero();   // counters, then (timing builds) one record per sampled pass
       }
       rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0; rb.meanSteps = 0;
     }
@@ -884,8 +855,8 @@ static void kwt_regroup(mzr_handle h) {
     for (const auto &k : k2) S.push_back(A[k.second]);
     (void)hipMemcpy(h->kwtRoutedAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
     h->kwtAllValid = true;
-    h->h_swA = S;
-  } else h->h_swA.clear();
+  }
+  h->h_swA = A;
   if (!B.empty()) (void)hipMemcpy(h->kwtRoutedB.p, B.data(), B.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
   if (!B.empty()) {
     std::vector<std::pair<int, int>> k2; k2.reserve(B.size());
@@ -894,10 +865,9 @@ static void kwt_regroup(mzr_handle h) {
     std::vector<MzrKwtRec> S; S.reserve(B.size());
     for (const auto &k : k2) S.push_back(B[k.second]);
     (void)hipMemcpy(h->kwtRoutedBAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
-    h->h_swB = S;
-  } else h->h_swB.clear();
-  std::function<int(const MzrKwtRec &)> nf = need;
-  kwt_build_sweep(h, &nf);
+  }
+  h->h_swB = B;
+  kwt_build_sweep(h);
 }
 
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
@@ -970,26 +940,24 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   bool sweep = W >= 8;
   if (const char *e = getenv("MZR_KWT_SWEEP")) sweep = atoi(e) != 0;
   const int kwtIx = idxOf(h, MZR_KWT);
-  if (kwtIx < 0 || h->swWaves < 1) sweep = false;
+  if (kwtIx < 0 || h->swItems < 1) sweep = false;
   if (sweep) {
+    kwt_sweep_tables(h, W);
     RouteBufs &rb = h->route[kwtIx];
     hipStream_t sx = rst[kwtIx];
     MzrDev dk = dr[kwtIx];
-    dk.kwtRouted = h->kwtAllValid ? h->kwtRoutedAll.p : h->kwtRouted.p;   // before the first regrouping: every routed reach in class A, stage order
-    dk.kwtRoutedB = h->kwtRoutedBAll.p;
+    dk.swRA = h->swRA.p; dk.swP = h->swP.p;
     dk.kwtLight = h->kwtDepLight.p;
     const int nLaunch = nS + W - 1;
     for (int c = 0; c * CH < nLaunch; ++c) {
       if (chunked && c > 0 && c < nChunks) (void)hipStreamWaitEvent(sx, h->basinEvents[c], 0);
       if (c * CH < W) mzr_launch_kwt_window_init(dk, c * CH, std::min(W, (c + 1) * CH), sx);
-      sweep_admit(h->cfg.device, sx, h->swWaves, h->swCap);
       if (prof) {
         if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
         (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
       }
       mzr_launch_sweep_kwt(dk, h->swWaves, c * CH, std::min(nLaunch, (c + 1) * CH), sx);
       if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
-      sweep_record(h->cfg.device, sx, h->swWaves);
       ++rb.nLaunches;
     }
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
@@ -1386,6 +1354,17 @@ int mzr_debug_cycles(mzr_handle h, unsigned long long *out32, int reset) {
   return 0;
 }
 
+// debug: per-pass records of a timing build (16 unsigned each), newest `n` at most
+int mzr_debug_records(mzr_handle h, unsigned *out, int n) {
+  if (!h || !h->dbgCycles.p) return -1;
+  (void)hipStreamSynchronize(h->stream);
+  std::vector<unsigned> all((size_t)16 + (size_t)65536 * 16);
+  (void)hipMemcpy(all.data(), h->dbgCycles.p + 32 * 1024, all.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+  const int have = (int)std::min<unsigned>(all[0], 65536u), m = std::min(n, have);
+  memcpy(out, all.data() + 16, (size_t)m * 16 * sizeof(unsigned));
+  return m;
+}
+
 int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {
   if (!h || !h->haveNet) return 1;
   *nStages = h->nStages; *maxStageWidth = h->maxStageWidth;
@@ -1394,7 +1373,7 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {
 
 int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems) {
   if (!h || !h->haveState) return 1;
-  *nWaves = h->swWaves; *capacity = h->swCap; *nItems = (int)(h->swItem.n);
+  *nWaves = h->swWaves; *capacity = h->swCap; *nItems = h->swItems;
   return 0;
 }
 

@@ -27,6 +27,7 @@ for i, n in enumerate(names):
 for i, n in zip(list(range(16, 20)) + [21, 22], ["7a count routed", "7b interp", "7c Q_END + scalar stores", "7d outbox stores", "P1 wait for dependencies", "P2 drain + publish"]):
     print(f"{n:22s} {buf[i]:16d}  {100.0*buf[i]/tot:5.1f}%")
 print("(7 = at-rest stores only when the 7a-7d stamps are present)")
+print("dependency polls that had to wait", buf[23], "spin iterations", buf[24])
 print("stamped wave passes", buf[20], "cycles per pass", tot / max(1, buf[20]))
 print("slow merges", buf[8], "exit-time fixes", buf[9], "deferred to next round", buf[10], "sampled routed reach-steps (1/16 of blocks)", buf[11],
       "mean LDS need", buf[12] / max(1, buf[11]), "thinned", buf[13], "particles removed", buf[14], "shock merges", buf[15])
