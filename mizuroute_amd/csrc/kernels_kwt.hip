@@ -586,10 +586,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const int lane = mzr_lane(), gl = lane & (G - 1);
   const int N = d.N;
   bool ovf = false;
+  // The sweep is as fast as its slowest chain of passes, and those are the wide ones (long particle lists, thinning):
+  // they go first whenever the SIMD has a choice.
+  if (G >= 16) __builtin_amdgcn_s_setprio(2);
   // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line), fetched by eight lanes of
-  // the group into LDS (ctx[8..15]) and read from there when a field is needed, not held in registers
-  double *rc = ctx + 8;
-  if (gl < 8) rc[gl] = ((const double *)(recs + (have ? item : lastItem)))[gl];
+  // the group into LDS (ctx[4..11]) and read from there when a field is needed, not held in registers
+  double *rc = ctx + 4;
+  for (int k = gl; k < 8; k += G) rc[k] = ((const double *)(recs + (have ? item : lastItem)))[k];
   grp_sync();
   const int *rci = (const int *)rc;      // r, sigma | u0, nup flags upGood goodMask | width | CW | length | scA | scB | down, -
   const int r = uni<G>(rci[0]);
@@ -708,7 +711,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     }
     if (gl == 0) {
       double *c = ctx;
-      c[6] = q_up;                     // REACH_INFLOW, stored with the other results at the end
+      c[2] = q_up;                     // REACH_INFLOW, stored with the other results at the end
       c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
       c[1] = qlat_r;
       if (d.kwtStat && !ovf) {
@@ -848,6 +851,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #ifdef MZR_KWT_TIMING
           _recRem = size - MZR_MAXQPAR_DEV;
 #endif
+          // a pass that has to thin is the slowest kind, and the sweep is as fast as its slowest chain of passes:
+          // it goes first whenever the SIMD has a choice
+          __builtin_amdgcn_s_setprio(3);
           const int NPRT = size - 1;
           const bool big = GEN && NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
           unsigned long long mask = NPRT >= 63 ? ~0ull : ((2ull << NPRT) - 1ull);   // bits 0..NPRT
@@ -856,7 +862,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // The interpolation errors stay in registers (lane gl holds particles gl, gl+G, ...): one removal = local
             // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
             // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
-            constexpr int KT = 64 / G;
+            constexpr int KT = G >= 16 ? 64 / G : 32 / G;      // entries before thinning: at most 60 (16 lanes), 30 (8 lanes)
             double e[KT];
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
@@ -1141,7 +1147,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
         // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
-        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); stx<PERS>(d.kwN + r, NN2 + 1); d.inflow[r] = ctx[6]; }
+        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); stx<PERS>(d.kwN + r, NN2 + 1); d.inflow[r] = ctx[2]; }
         TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
@@ -1192,81 +1198,90 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #ifdef MZR_KWT_TIMING
   if (PERS) TRECORD(G, _recSize, _recRem);
 #endif
+  if (CAN_THIN || G >= 16) __builtin_amdgcn_s_setprio(0);
   return ovf ? 1 : 0;
 }
 
+// Lane classes.  A routed reach is worked on by a group of adjacent lanes; how many is the host's choice
+// (kwt_regroup, by the work-array entries the reach needed in the last step):
+//   class C   4 lanes, 16 reaches per wavefront, at most 11 entries, no thinning code
+//   class B   8 lanes,  8 reaches per wavefront, at most 30 entries
+//   class A  16 lanes,  4 reaches per wavefront, at most 60 entries (a full binary confluence)
+// A reach that has outgrown its class is left untouched by its group and routed right away by 16-lane groups
+// of the same wavefront, four at a time, so the classification only has to be usually right.
+#define MZR_CTX 12     // doubles of LDS per reach slot: X0, BASIN_QR(1), inflow, -, then the 64-byte record
+struct KwtCls {
+  static constexpr int GA = 16, RA = 4, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
+  static constexpr int GB = 8, RB = 8, KB = MZR_KWT_KB;
+  static constexpr int GC = 4, RC = 16, KC = 3;
+};
+// class-B / class-C reaches of one item that overflowed (bit g = group g of the narrow pass): the k-th of them for wide group g16
+__device__ __forceinline__ int kwt_pick(unsigned &ovfMask, int g16) {
+  unsigned m = ovfMask;
+  int sel = -1;
+  for (int k = 0; k <= g16 && m; ++k) { sel = (k == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
+  for (int k = 0; k < KwtCls::RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
+  return sel;
+}
+
 // One launch = every routed, headwater, lake and halo reach of the stages that are active in this
-// launch.  Routed reaches come in two host-made classes (kwt_regroup): class A, 16 lanes per reach
-// (4 per wavefront), and class B, reaches that needed at most 16 work-array entries lately, 8 lanes per
-// reach (8 per wavefront, no thinning code, capacity MAXQPAR entries).  A class-B reach that has grown
-// beyond that is picked up by 16-lane groups of the same wavefront right away, four at a time, so
-// the classification only has to be usually right.  GEN: confluences of more than two reaches.
-// Used for short windows (mzr_step: one step per call); long windows take k_sweep_kwt below.
+// launch: blocks of class-A, class-B and class-C reaches, then one lane per light reach.  GEN: confluences of
+// more than two reaches.  Used for short windows (mzr_step: one step per call); long windows take k_sweep_kwt.
 template <bool FULL, bool GEN, int POOL>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GEN ? 1 : MZR_KWT_OCC, GEN ? 2 : MZR_KWT_OCC)))
-k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, int hbEnd, int nBBlocks, int ltBegin, int ltEnd) {
-  constexpr int GA = 16, RA = 64 / GA, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
-  constexpr int GB = 8, RB = 64 / GB, KB = MZR_KWT_KB;
-  // entries 0..GB*KB-1 (the outbox write reaches index NR+2 <= size), and never enough particles to thin
-  constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
-  constexpr int GPA = POOL / RA, GPB = POOL / RB;
+k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, int hbEnd, int nBBlocks, int hcBegin, int hcEnd, int nCBlocks,
+            int ltBegin, int ltEnd) {
+  constexpr int GA = KwtCls::GA, RA = KwtCls::RA, KA = KwtCls::KA, OA = KwtCls::OA;
+  constexpr int GB = KwtCls::GB, RB = KwtCls::RB, KB = KwtCls::KB, GC = KwtCls::GC, RC = KwtCls::RC, KC = KwtCls::KC;
+  constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
+  // entries 0..G*K-1 (the outbox write reaches index NR+2 <= size) within the group's slice of the pool
+  constexpr int CAPB = GB * 4 - 1 < GPB ? GB * 4 - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
-  __shared__ double sCtx[RB][16];   // per reach: [0..7] values needed again late (X0, BASIN_QR(1), inflow), [8..15] the reach's record
+  __shared__ double sCtx[RC][MZR_CTX];
   const int b = blockIdx.x, lane = threadIdx.x & 63;
-  if (!GEN && b >= nABlocks + nBBlocks) {
-    kwt_light<FULL, false>(d, s, ltBegin + (b - nABlocks - nBBlocks) * 64 + lane, ltEnd);
+  if (!GEN && b >= nABlocks + nBBlocks + nCBlocks) {
+    kwt_light<FULL, false>(d, s, ltBegin + (b - nABlocks - nBBlocks - nCBlocks) * 64 + lane, ltEnd);
     return;
   }
-  const bool isB = !GEN && b >= nABlocks;
-#ifdef MZR_KWT_HIST
-  const long long _w0 = clock64();
-#define WAVE_DONE(k) do { if (lane == 0 && (b & 7) == 0) { const unsigned long long dt_ = (unsigned long long)(clock64() - _w0); atomicAdd(&d.dbgCycles[3 * (k) + 2], dt_); atomicAdd(&d.dbgCycles[3 * (k) + 3], 1ull); atomicMax(&d.dbgCycles[3 * (k) + 4], dt_); } } while (0)
-#else
-#define WAVE_DONE(k) do { } while (0)
-#endif
-  unsigned ovfMask = 0;      // class B: groups whose reach needs the wide path (wave-uniform)
-  if (isB) {
+  const int cls = (GEN || b < nABlocks) ? 0 : b < nABlocks + nBBlocks ? 1 : 2;
+  unsigned ovfMask = 0;      // groups of the narrow pass whose reach needs the wide path (wave-uniform)
+  int base = 0;
+  if (cls == 1) {
     const int g8 = lane / GB;
-    const int item = hbBegin + (b - nABlocks) * RB + g8;
-    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, false, false>(d, s, d.kwtRoutedB, item, item < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
+    base = hbBegin + (b - nABlocks) * RB;
+    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, true, false>(d, s, d.kwtRoutedB, base + g8, base + g8 < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
     const unsigned long long bal = __ballot(ovf);
-#ifdef MZR_KWT_HIST
-    if ((lane & 7) == 0 && item < hbEnd) { atomicAdd(&d.dbgCycles[0], 1ull); if (ovf) atomicAdd(&d.dbgCycles[1], 1ull); }
-#endif
 #pragma unroll
     for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
-    if (!ovfMask) { WAVE_DONE(1); return; }
+    if (!ovfMask) return;
+  } else if (cls == 2) {
+    const int g4 = lane / GC;
+    base = hcBegin + (b - nABlocks - nBBlocks) * RC;
+    const bool ovf = kwt_reach<FULL, false, GC, KC, KC, false, false>(d, s, d.kwtRoutedC, base + g4, base + g4 < hcEnd, hcEnd - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]) & 1;
+    const unsigned long long bal = __ballot(ovf);
+#pragma unroll
+    for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
+    if (!ovfMask) return;
   }
   const int g16 = lane / GA;
-  if (!isB) {
-    const int item = haBegin + b * RA + g16;
-    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false>(d, s, d.kwtRouted, item, item < haEnd, haEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]) & 1;
-    if (ovf) mzr_raise(d, 60, d.kwtRouted[item < haEnd ? item : haEnd - 1].r, s, 10);      // work array bounds exceeded
-    WAVE_DONE(0);
-    return;
-  }
-  // class-B reaches that have outgrown 8 lanes: four at a time; eight groups = at most two rounds (rare),
-  // written out instead of looped so that nothing of the wide path is carried around a loop
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    if (round == 1 && !ovfMask) break;
-    unsigned m = ovfMask;
-    int sel = -1;
-    for (int k = 0; k <= g16 && m; ++k) { sel = (k == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
-    const bool have = sel >= 0;
-    const int item = hbBegin + (b - nABlocks) * RB + (have ? sel : 0);
-    for (int k = 0; k < RA && ovfMask; ++k) ovfMask &= ovfMask - 1u;
-    const bool ovf = kwt_reach<FULL, false, GA, KA, OA, true, false>(d, s, d.kwtRoutedB, item, have, hbEnd - 1, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]) & 1;
-    if (ovf) mzr_raise(d, 60, d.kwtRoutedB[have ? item : hbEnd - 1].r, s, 10);
-  }
+#pragma unroll 1
+  do {
+    const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : cls == 1 ? d.kwtRoutedB : d.kwtRoutedC;
+    const int last = (cls == 0 ? haEnd : cls == 1 ? hbEnd : hcEnd) - 1;
+    int item = haBegin + b * RA + g16;
+    bool have = item <= last;
+    if (cls != 0) { const int sel = kwt_pick(ovfMask, g16); have = sel >= 0; item = base + (have ? sel : 0); }
+    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false>(d, s, recs, item, have, last, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]) & 1;
+    if (ovf) mzr_raise(d, 60, recs[have ? item : last].r, s, 10);      // work array bounds exceeded
+  } while (ovfMask);
 }
 
 // The rare item kinds of the persistent sweep are real calls, so that their registers are not part of the loop body's.
 template <bool FULL, int POOL>
 __device__ __noinline__ int kwt_item_generic(const MzrDev &d, int s, int bi, double *sA, double *sB, double *sC, double *sD, double *ctx) {
-  constexpr int GA = 16, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
+  constexpr int GA = KwtCls::GA, KA = KwtCls::KA, OA = KwtCls::OA;
   const int g16 = mzr_lane() / GA;
-  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + 16 * g16);
+  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + MZR_CTX * g16);
 }
 template <bool FULL>
 __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
@@ -1298,12 +1313,12 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   typedef const int __attribute__((address_space(4))) *IntK;
   MzrDevK dk0 = (MzrDevK)__builtin_amdgcn_kernarg_segment_ptr();
   const MzrDev &d0 = *(const MzrDev *)dk0;
-  constexpr int GA = 16, RA = 64 / GA, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
-  constexpr int GB = 8, RB = 64 / GB, KB = MZR_KWT_KB;
-  constexpr int CAPB = GB * KB - 1 < MZR_MAXQPAR_DEV ? GB * KB - 1 : MZR_MAXQPAR_DEV;
-  constexpr int GPA = POOL / RA, GPB = POOL / RB;
+  constexpr int GA = KwtCls::GA, RA = KwtCls::RA, KA = KwtCls::KA, OA = KwtCls::OA;
+  constexpr int GB = KwtCls::GB, RB = KwtCls::RB, KB = KwtCls::KB, GC = KwtCls::GC, RC = KwtCls::RC, KC = KwtCls::KC;
+  constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
+  constexpr int CAPB = GB * 4 - 1 < GPB ? GB * 4 - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
-  __shared__ double sCtx[RB][16];
+  __shared__ double sCtx[RC][MZR_CTX];
   const int Wm1 = d0.W - 1;
   const int q0 = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;     // HW_REG_XCC_ID: a speed hint only
   IntK P = (IntK)d0.swP, RAs = (IntK)d0.swRA;
@@ -1333,9 +1348,9 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       const int a = RAs[s];
       const int i = a + ((q - a) & 7) + 8 * (k - pLo);
       if (s < d.swLo[i] || s > d.swHi[i] + Wm1) continue;        // none of the item's reaches has a step in this launch
-      const int lane = mzr_lane(), g16 = lane / GA, g8 = lane / GB;
+      const int lane = mzr_lane(), g16 = lane / GA;
       const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
-      const int cls = it >> 28, bi = it & 0x0fffffff;
+      const int cls = it >> 28, bi = it & 0x0fffffff;      // 0 A, 1 B, 2 generic, 3 lake / halo, 4 C
       if (cls == 3) {
         if (kwt_item_light<FULL>(d, s, bi)) return;
         continue;
@@ -1348,29 +1363,30 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       }
       unsigned ovfMask = 0;
       if (cls == 1) {
-        const int item = bi * RB + g8;
-        const int st = kwt_reach<FULL, false, GB, KB, KB, false, true>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+        const int g8 = lane / GB, item = bi * RB + g8;
+        const int st = kwt_reach<FULL, false, GB, KB, KB, true, true>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
         if (__ballot(st & 2) != 0ull) return;
         const unsigned long long bal = __ballot(st & 1);
 #pragma unroll
         for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
         if (!ovfMask) continue;
+      } else if (cls == 4) {
+        const int g4 = lane / GC, item = bi * RC + g4;
+        const int st = kwt_reach<FULL, false, GC, KC, KC, false, true>(d, s, d.kwtRoutedC, item, item < d.nC, d.nC - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]);
+        if (__ballot(st & 2) != 0ull) return;
+        const unsigned long long bal = __ballot(st & 1);
+#pragma unroll
+        for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
+        if (!ovfMask) continue;
       }
-      // class A, or the class-B reaches of this item that have outgrown 8 lanes, four at a time
+      // class A, or the reaches of this item that have outgrown their narrow group, four at a time
 #pragma unroll 1
       do {
-        const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : d.kwtRoutedB;
-        const int last = (cls == 0 ? d.nA : d.nB) - 1;
+        const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : cls == 1 ? d.kwtRoutedB : d.kwtRoutedC;
+        const int last = (cls == 0 ? d.nA : cls == 1 ? d.nB : d.nC) - 1;
         int item = bi * RA + g16;
         bool have = item <= last;
-        if (cls == 1) {
-          unsigned m = ovfMask;
-          int sel = -1;
-          for (int kk = 0; kk <= g16 && m; ++kk) { sel = (kk == g16) ? __ffs(m) - 1 : -1; m &= m - 1u; }
-          have = sel >= 0;
-          item = bi * RB + (have ? sel : 0);
-          for (int kk = 0; kk < RA && ovfMask; ++kk) ovfMask &= ovfMask - 1u;
-        }
+        if (cls != 0) { const int sel = kwt_pick(ovfMask, g16); have = sel >= 0; item = bi * (cls == 1 ? RB : RC) + (have ? sel : 0); }
         const int st = kwt_reach<FULL, false, GA, KA, OA, true, true>(d, s, recs, item, have, last, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
         if (__ballot(st & 2) != 0ull) return;
         if (st & 1) mzr_raise(d, 60, recs[have ? item : last].r, s, 10);
@@ -1421,24 +1437,24 @@ void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStrea
   hipLaunchKernelGGL(k_accum_qsum, dim3((N + 255) / 256), dim3(256), 0, stream, Q, qsum, N, W);
 }
 
-void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int gnBegin, int gnEnd,
+void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int hcBegin, int hcEnd, int gnBegin, int gnEnd,
                           int ltBegin, int ltEnd, hipStream_t stream) {
   constexpr int POOL = 240, POOLG = 1024;   // binary confluence: 20 + 2 + 2 * 19 = 60 entries per reach at most, 4 reaches
-  const int nA = haEnd - haBegin, nB = hbEnd - hbBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
+  const int nA = haEnd - haBegin, nB = hbEnd - hbBegin, nC = hcEnd - hcBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
   dim3 block(64);
-  if (nA > 0 || nB > 0 || nLt > 0) {
-    const int nABlocks = (nA + 3) / 4, nBBlocks = (nB + 7) / 8;
-    dim3 grid(nABlocks + nBBlocks + (nLt + 63) / 64);
-    if (full) hipLaunchKernelGGL((k_stage_kwt<true, false, POOL>), grid, block, 0, stream, d, s, haBegin, haEnd, nABlocks, hbBegin, hbEnd, nBBlocks, ltBegin, ltEnd);
-    else hipLaunchKernelGGL((k_stage_kwt<false, false, POOL>), grid, block, 0, stream, d, s, haBegin, haEnd, nABlocks, hbBegin, hbEnd, nBBlocks, ltBegin, ltEnd);
+  if (nA > 0 || nB > 0 || nC > 0 || nLt > 0) {
+    const int nABlocks = (nA + 3) / 4, nBBlocks = (nB + 7) / 8, nCBlocks = (nC + 15) / 16;
+    dim3 grid(nABlocks + nBBlocks + nCBlocks + (nLt + 63) / 64);
+    if (full) hipLaunchKernelGGL((k_stage_kwt<true, false, POOL>), grid, block, 0, stream, d, s, haBegin, haEnd, nABlocks, hbBegin, hbEnd, nBBlocks, hcBegin, hcEnd, nCBlocks, ltBegin, ltEnd);
+    else hipLaunchKernelGGL((k_stage_kwt<false, false, POOL>), grid, block, 0, stream, d, s, haBegin, haEnd, nABlocks, hbBegin, hbEnd, nBBlocks, hcBegin, hcEnd, nCBlocks, ltBegin, ltEnd);
   }
   if (nGn > 0) {   // confluences of more than two reaches: the reference's k-way merge on one lane of the group
     MzrDev dg = d; dg.kwtRouted = d.kwtGeneric;
     const int nBlocks = (nGn + 3) / 4;
     dim3 grid(nBlocks);
-    if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0);
-    else hipLaunchKernelGGL((k_stage_kwt<false, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0);
+    if (full) hipLaunchKernelGGL((k_stage_kwt<true, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0, 0, 0, 0);
+    else hipLaunchKernelGGL((k_stage_kwt<false, true, POOLG>), grid, block, 0, stream, dg, s, gnBegin, gnEnd, nBlocks, 0, 0, 0, 0, 0, 0, 0, 0);
   }
 }
 

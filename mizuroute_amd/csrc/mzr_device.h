@@ -96,7 +96,8 @@ struct MzrDev {
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
   double *obQ, *obT;          // [2][N][MZR_OB_CAP]
   const MzrKwtRec *kwtRouted;    // reaches that route particles (at most two upstream reaches), stage-major, class A: 16 lanes each
-  const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 16 work-array entries, 8 lanes each (host regroups)
+  const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 20 work-array entries, 8 lanes each (host regroups)
+  const MzrKwtRec *kwtRoutedC;   // ... class C: at most 9 entries, 4 lanes each
   const MzrKwtRec *kwtGeneric;   // ... with more than two upstream reaches
   const int *kwtLight;        // headwater, lake and halo reaches, stage-major (one lane each)
   // ---- KWT persistent sweep (k_sweep_kwt): wavefronts draw items (blocks of reaches) of the skewed schedule in
@@ -110,7 +111,7 @@ struct MzrDev {
   int *swHead;                // [8][16] next ticket of each queue (one cache line each)
   const int *kwtHead;         // headwater reaches (bulk kernel before the sweep)
   int nHead, nDepLight;       // entries of kwtHead / of kwtLight in persistent mode (lake and halo reaches only)
-  int nA, nB, nG;             // routed records per class
+  int nA, nB, nC, nG;         // routed records per class
   // ---- lakes (null / 0 without lakes)
   const int *lakeSlot;        // [N] lake index of a lake reach, -1 otherwise
   const int *lakeModel;       // [nLake]

@@ -33,7 +33,7 @@ void mzr_launch_remap(int H, int nSteps, int nSrc, const int *rowStart, const in
                       const double *weight, const double *src, double *srcT, double *dst, hipStream_t stream);
 void mzr_launch_sort_flux(int H, int nSteps, int nSrc, const int *srcOf, int removeNegatives, const double *src, double *dst,
                           hipStream_t stream);
-void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int gnBegin, int gnEnd,
+void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int hcBegin, int hcEnd, int gnBegin, int gnEnd,
                           int ltBegin, int ltEnd, hipStream_t stream);
 
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream);
@@ -179,17 +179,17 @@ struct mzr_domain {
   bool havePrevQlat = false;
   // kwt
   DBuf<int> kwN, obN, kwtLight;
-  DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtGeneric;
-  DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll;   // classes A / B over all stages, heaviest first: used by launches in which every stage is active
+  DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
+  DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll, kwtRoutedCAll;   // classes A / B / C over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
   std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
-  std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB;   // class lists of the sweep, host copies (stage order)
+  std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
   int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1;
   long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
-  std::vector<int> kwtStageOff, kwtBOff;        // [nStages+1] stage offsets in h_kwtRouted / in the class-B list (kwtRoutedOff: class A)
+  std::vector<int> kwtStageOff, kwtBOff, kwtCOff;   // [nStages+1] stage offsets in h_kwtRouted / in the class-B and class-C lists (kwtRoutedOff: class A)
   long long kwtWindows = 0, kwtStepsSince = 0; // KWT windows run since mzr_init_state, steps since the last regrouping
   std::vector<int> kwtRoutedOff, kwtGenericOff, kwtLightOff;   // [nStages+1] offsets of each stage in the two lists
   DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
@@ -246,11 +246,11 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
   d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
-  d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
+  d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtRoutedC = h->kwtRoutedC.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
   d.kwDone = h->kwDone.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
   d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p;
   d.kwtHead = h->kwtHead.p; d.nHead = (int)h->h_kwtHead.size(); d.nDepLight = (int)h->h_kwtDepLight.size();
-  d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nG = (int)h->h_kwtGeneric.size();
+  d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nC = (int)h->h_swC.size(); d.nG = (int)h->h_kwtGeneric.size();
   d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
   d.lakeSlot = h->nLake ? h->lakeSlot.p : nullptr; d.lakeModel = h->lakeModel.p; d.lakePar = h->lakePar.p;
   d.lakeEvap = h->lakeEvap.p; d.lakePrecip = h->lakePrecip.p; d.calMonth = h->calMonth.p; d.calDay = h->calDay.p; d.calDoy = h->calDoy.p;
@@ -317,6 +317,7 @@ void kwt_build_sweep(mzr_handle h) {
   };
   addRouted(h->h_swA, 0, 4);
   addRouted(h->h_swB, 1, 8);
+  addRouted(h->h_swC, 4, 16);
   addRouted(h->h_kwtGeneric, 2, 1);
   if (!h->h_kwtDepLight.empty()) {
     std::vector<int> sg(h->N);
@@ -779,13 +780,13 @@ int mzr_init_state(mzr_handle h) {
           if (routed.empty()) routed.push_back(none);
           if (generic.empty()) generic.push_back(none);
           if (light.empty()) light.push_back(0);
-          h->kwtRouted.upload(routed); h->kwtRoutedB.upload(routed); h->kwtRoutedAll.upload(routed); h->kwtRoutedBAll.upload(routed); h->kwtAllValid = false; h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
+          h->kwtRouted.upload(routed); h->kwtRoutedB.upload(routed); h->kwtRoutedC.upload(routed); h->kwtRoutedAll.upload(routed); h->kwtRoutedBAll.upload(routed); h->kwtRoutedCAll.upload(routed); h->kwtAllValid = false; h->kwtGeneric.upload(generic); h->kwtLight.upload(light);
           h->h_kwtRouted = routed; h->kwtWindows = 0; h->kwtStepsSince = 0;
           h->kwtStageOff = h->kwtRoutedOff;                       // every routed reach starts in class A
-          h->kwtBOff.assign(h->nStages + 1, 0);
+          h->kwtBOff.assign(h->nStages + 1, 0); h->kwtCOff.assign(h->nStages + 1, 0);
           // persistent sweep: every routed reach starts in class A, in stage order
           h->h_swA = h->kwtRoutedOff[h->nStages] > 0 ? routed : std::vector<MzrKwtRec>();
-          h->h_swB.clear();
+          h->h_swB.clear(); h->h_swC.clear();
           h->h_kwtGeneric = h->kwtGenericOff[h->nStages] > 0 ? generic : std::vector<MzrKwtRec>();
           h->h_kwtHead = head; h->h_kwtDepLight = depLight;
           if (head.empty()) head.push_back(0);
@@ -830,43 +831,39 @@ static void kwt_regroup(mzr_handle h) {
     for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) l += std::max(std::max(ob[rc.u0 + k], ob[(size_t)N + rc.u0 + k]) - 1, 0);
     return l;
   };
-  // class B (8 lanes, capacity MAXQPAR entries, no thinning): reaches that needed at most 16 entries in the last step.
-  // MZR_KWT_CLASSB_MAX overrides the threshold (tests: 0 = nobody, 64 = everybody, through the fall-back).
-  int classBMax = 16;
+  // class C (4 lanes, capacity 11 entries): reaches that needed at most 9 entries in the last step; class B (8 lanes,
+  // capacity 30): at most 20 (wider lists thin, and a pass is as slow as its busiest reach: measured best); class A
+  // (16 lanes): the others.  MZR_KWT_CLASSB_MAX / MZR_KWT_CLASSC_MAX override the
+  // thresholds (tests: 0 = nobody, 64 = everybody, through the fall-back).
+  int classBMax = 20, classCMax = 9;
   if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
+  if (const char *e = getenv("MZR_KWT_CLASSC_MAX")) classCMax = atoi(e);
   const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
-  std::vector<MzrKwtRec> A, B;
-  A.reserve(v.size()); B.reserve(v.size());
+  std::vector<MzrKwtRec> L[3];    // A, B, C
+  for (auto &l : L) l.reserve(v.size());
   std::vector<std::pair<int, int>> key;
   for (int sg = 0; sg < h->nStages; ++sg) {
-    h->kwtRoutedOff[sg] = (int)A.size(); h->kwtBOff[sg] = (int)B.size();
+    h->kwtRoutedOff[sg] = (int)L[0].size(); h->kwtBOff[sg] = (int)L[1].size(); h->kwtCOff[sg] = (int)L[2].size();
     key.clear();
     for (int i = h->kwtStageOff[sg]; i < h->kwtStageOff[sg + 1]; ++i) key.emplace_back(-need(v[i]), i);
     std::sort(key.begin(), key.end());
-    for (const auto &k : key) (-k.first <= classBMax ? B : A).push_back(v[k.second]);
+    for (const auto &k : key) L[-k.first <= classCMax ? 2 : -k.first <= classBMax ? 1 : 0].push_back(v[k.second]);
   }
-  h->kwtRoutedOff[h->nStages] = (int)A.size(); h->kwtBOff[h->nStages] = (int)B.size();
-  if (!A.empty()) (void)hipMemcpy(h->kwtRouted.p, A.data(), A.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
-  if (!A.empty()) {   // the same reaches, heaviest first regardless of stage
-    std::vector<std::pair<int, int>> k2; k2.reserve(A.size());
-    for (size_t i = 0; i < A.size(); ++i) k2.emplace_back(-need(A[i]), (int)i);
+  h->kwtRoutedOff[h->nStages] = (int)L[0].size(); h->kwtBOff[h->nStages] = (int)L[1].size(); h->kwtCOff[h->nStages] = (int)L[2].size();
+  DBuf<MzrKwtRec> *devStage[3] = {&h->kwtRouted, &h->kwtRoutedB, &h->kwtRoutedC}, *devAll[3] = {&h->kwtRoutedAll, &h->kwtRoutedBAll, &h->kwtRoutedCAll};
+  for (int c = 0; c < 3; ++c) {
+    if (L[c].empty()) continue;
+    (void)hipMemcpy(devStage[c]->p, L[c].data(), L[c].size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
+    // the same reaches, heaviest first regardless of stage
+    std::vector<std::pair<int, int>> k2; k2.reserve(L[c].size());
+    for (size_t i = 0; i < L[c].size(); ++i) k2.emplace_back(-need(L[c][i]), (int)i);
     std::sort(k2.begin(), k2.end());
-    std::vector<MzrKwtRec> S; S.reserve(A.size());
-    for (const auto &k : k2) S.push_back(A[k.second]);
-    (void)hipMemcpy(h->kwtRoutedAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
-    h->kwtAllValid = true;
+    std::vector<MzrKwtRec> S; S.reserve(L[c].size());
+    for (const auto &k : k2) S.push_back(L[c][k.second]);
+    (void)hipMemcpy(devAll[c]->p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
   }
-  h->h_swA = A;
-  if (!B.empty()) (void)hipMemcpy(h->kwtRoutedB.p, B.data(), B.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
-  if (!B.empty()) {
-    std::vector<std::pair<int, int>> k2; k2.reserve(B.size());
-    for (size_t i = 0; i < B.size(); ++i) k2.emplace_back(-need(B[i]), (int)i);
-    std::sort(k2.begin(), k2.end());
-    std::vector<MzrKwtRec> S; S.reserve(B.size());
-    for (const auto &k : k2) S.push_back(B[k.second]);
-    (void)hipMemcpy(h->kwtRoutedBAll.p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
-  }
-  h->h_swB = B;
+  h->kwtAllValid = true;
+  h->h_swA = L[0]; h->h_swB = L[1]; h->h_swC = L[2];
   kwt_build_sweep(h);
 }
 
@@ -983,8 +980,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         // every stage active: heaviest reaches first regardless of stage (shorter tail of the launch).  This gives up
         // the stage-major locality of the rows, so only while the rows of all routed reaches (about 1 KB each) sit in
         // the 256 MB Infinity Cache anyway; measured +12 % at 100 k reaches, -8 % at 400 k.
-        if (h->kwtAllValid && sLo == 0 && sHi == nS - 1 && h->h_kwtRouted.size() <= 150000) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; }
-        mzr_launch_stage_kwt(dk, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1],
+        if (h->kwtAllValid && sLo == 0 && sHi == nS - 1 && h->h_kwtRouted.size() <= 150000) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; dk.kwtRoutedC = h->kwtRoutedCAll.p; }
+        mzr_launch_stage_kwt(dk, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1], h->kwtCOff[sLo], h->kwtCOff[sHi + 1],
                              h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], sx);
       }
       else mzr_launch_stage(rb.method, dr[ix], s, rB, rE, sx);

@@ -439,10 +439,10 @@ def test_restart_continues_bit_exact(tmp_path, hip_lib):
     f.close()
 
 
-@pytest.mark.parametrize("class_b_max", ["0", "64"])
-def test_kwt_lane_classes_give_the_same_answer(class_b_max, hip_lib, monkeypatch):
-    """Routed reaches are served by 16 or by 8 lanes depending on a host-side guess of their particle
-    count; a wrong guess is caught in the wavefront (wide fall-back).  Forcing every reach into either
+@pytest.mark.parametrize("class_b_max,class_c_max", [("0", "0"), ("64", "0"), ("64", "64"), ("0", "64")])
+def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, hip_lib, monkeypatch):
+    """Routed reaches are served by 16, 8 or 4 lanes depending on a host-side guess of their particle
+    count; a wrong guess is caught in the wavefront (wide fall-back).  Forcing every reach into any one
     class must not change a bit."""
     net = m.make_network(4000, seed=51)
     ro = m.make_runoff(net.H, 120, seed=52, storm_prob=0.03, storm_amp=3e-6)
@@ -450,6 +450,7 @@ def test_kwt_lane_classes_give_the_same_answer(class_b_max, hip_lib, monkeypatch
     ref = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=30)
     Qr = ref.run(ro)
     monkeypatch.setenv("MZR_KWT_CLASSB_MAX", class_b_max)
+    monkeypatch.setenv("MZR_KWT_CLASSC_MAX", class_c_max)
     dom = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=30)
     Qd = dom.run(ro)
     assert np.array_equal(Qd, Qr)

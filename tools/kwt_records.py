@@ -21,7 +21,7 @@ r = buf[:n].astype(np.int64)
 names = ["wait deps", "setup/loads", "merge", "min+remove", "pow+shock", "routing", "count+interp", "stores", "drain"]
 tot = r[:, 3:12].sum(axis=1)
 print("records", n)
-for G in (8, 16):
+for G in (4, 8, 16):
     sel = r[:, 0] == G
     if not sel.any(): continue
     t = tot[sel]; c = t - r[sel, 3]
