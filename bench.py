@@ -11,7 +11,10 @@ one forcing window of `window_steps` model time steps (8192 by default; one main
 model time step in the reference; the device sweeps a window time-skewed over the stages,
 DESIGN.md 2): cold start, W untimed batches, then exactly K timed batches.  `value` counts MODEL
 time steps: reaches x K x window_steps / elapsed.  Forcing windows are generated on the device
-before the timed region (two of them, used alternately), so `value` is the HBM-resident rate.
+before the timed region (two of them, used alternately), so `value` is the HBM-resident rate;
+`value_with_h2d` (N = 1) repeats the timed region with every window handed over in page-locked host
+memory (mzr_run_async: copy on its own stream behind the sweep of the window before), and
+`single_step` times mzr_step, one main_route-equivalent call per model time step (the coupled-model use).
 
 One JSON line on rank 0 with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel (KWT stage sweep): algorithmic bytes from the
@@ -55,35 +58,39 @@ def device_runoff(torch, H, n_steps, t0, seed, device):
     return ro.contiguous()
 
 
-def cpu_baseline(net, frac, sample_steps, spinup_steps=72, budget_s=40.0):
-    """Reference Fortran solvers (oracle/_ref/ref_route) on the host cores, bounded sample: the last
-    `sample_steps` of a run that first spins the particle lists up for `spinup_steps` (untimed)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240):
+    """Reference Fortran solvers (oracle/_ref/ref_route) on the host cores, bounded sample of the SAME
+    forcing the GPU leg routes: `sample_steps` steps timed after `spinup_steps` untimed ones (particle lists at
+    steady state), OpenMP over the reference's own stream-order branches at 16 threads (the best count of the
+    round-1 sweep 1/8/16/32/64; fewer if the host has fewer cores), plus a short 1-thread run."""
     from oracle import refrun
-    import mizuroute_amd as m
     if not refrun.available():
         return None
     cores = os.cpu_count() or 1
-    ro = m.make_runoff(net.H, spinup_steps + sample_steps, seed=7, storm_prob=0.01, storm_amp=1e-6)
     uh_off = np.arange(net.N + 1, dtype=np.int32)
     uh = np.ones(net.N)
-    common = dict(uh=(frac, uh_off, uh), dump_every=0, time_from=spinup_steps)
-    t0 = time.time()
-    one = refrun.run_case(net, ro, DT, [2], nthreads=1, **common)
-    best, used, note = one["reach_steps_per_s"], 1, f"1 thread {one['reach_steps_per_s']:.3e}"
+    nt = max(1, min(16, cores))
     sched = refrun.streamorder_schedule(net)
-    for nt in (8, 16, 32, 64, cores):   # the reference's OpenMP path (stream-order schedule); keep the best
-        if nt > cores or time.time() - t0 > budget_s:
-            continue
-        r = refrun.run_case(net, ro, DT, [2], nthreads=nt, schedule=sched, **common)
-        note += f"; {nt} thr {r['reach_steps_per_s']:.3e}"
-        if r["reach_steps_per_s"] > best:
-            best, used = r["reach_steps_per_s"], nt
-        elif r["reach_steps_per_s"] < 0.6 * best:      # past the peak: more threads only add scheduling cost
-            break
-    note += " (OpenMP over the reference's stream-order branches, main_route.f90:356-405)"
-    return {"value": best, "unit": "reaches*timesteps/s", "cores": used, "kind": "reference",
-            "sample": f"same {net.N}-reach network, KWT, {sample_steps} steps timed after {spinup_steps} spin-up steps; "
-                      f"unmodified reference kwt_route.f90/main_route.f90 built with flang -O2; {note}"}
+    r = refrun.run_case(net, runoff[:spinup_steps + sample_steps], DT, [2], nthreads=nt, schedule=sched,
+                        uh=(frac, uh_off, uh), dump_every=0, time_from=spinup_steps)
+    one = refrun.run_case(net, runoff[:36], DT, [2], nthreads=1, uh=(frac, uh_off, uh), dump_every=0, time_from=24)
+    return {"value": r["reach_steps_per_s"], "unit": "reaches*timesteps/s", "cores": nt, "kind": "reference",
+            "host_cores": cores, "cpu_model": cpu_model(),
+            "one_thread": one["reach_steps_per_s"],
+            "sample": f"same {net.N}-reach network and forcing, KWT, {sample_steps} steps timed after {spinup_steps} spin-up "
+                      f"steps at {nt} OpenMP threads over the reference's stream-order branches (main_route.f90:356-405); "
+                      f"unmodified reference kwt_route.f90/main_route.f90 built with flang -O2; one_thread = 12 steps "
+                      f"timed after 24 (lists not yet at steady state: an upper bound for one core)"}
 
 
 def main():
@@ -95,6 +102,8 @@ def main():
                     help="model time steps per batch; 0 = 8192, fewer when --steps is large (about 2M model steps in total)")
     ap.add_argument("--reaches", type=int, default=N_REACH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-forcing leg (value_with_h2d)")
+    ap.add_argument("--no-single-step", action="store_true", help="skip the mzr_step leg (single_step)")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
@@ -179,13 +188,13 @@ def main():
         return [device_runoff(torch, H, n_steps, t0, 7 + rank + 101 * i, dev) for i, (_, H) in enumerate(doms)]
 
     pool = [gen(W, 0), gen(W, W)]          # two forcing windows, used alternately
-    state = {"batch": 0}                    # batches routed so far (the simulation clock)
+    state = {"batch": 0, "t": 0.0}          # batches routed so far, simulation clock [s]
 
     def run_batches(nb):
         for _ in range(nb):
             k = state["batch"]
             ros = pool[k % 2]
-            t_start = k * W * DT
+            t_start = state["t"]
             if router is None:
                 dom.run_device(W, t_start, ros[0].data_ptr())
             else:
@@ -193,6 +202,7 @@ def main():
                 pm = ros[-1].data_ptr() if router.main is not None else 0
                 router.run_window(W, t_start, pt, pm, keep=ros)
             state["batch"] = k + 1
+            state["t"] = t_start + W * DT
 
     def sync_all():
         if router is not None:
@@ -224,9 +234,48 @@ def main():
     total_reach_steps = float(net.N) * K * W
     value = total_reach_steps / elapsed
 
+    # ---- the same timed region with the forcing handed over in page-locked host memory (N = 1): two host
+    # windows, copied by the library on its own stream while the window before is routed
+    value_h2d = None
+    if world == 1 and not args.no_h2d:
+        try:
+            hosts = [torch.empty((W, net.H), dtype=torch.float64).pin_memory() for _ in range(2)]
+            for hb, ro in zip(hosts, pool):
+                hb.copy_(ro[0])
+            torch.cuda.synchronize()
+            k0 = state["batch"]
+            dom.run_async(W, state["t"], hosts[k0 % 2].data_ptr())      # one untimed window fills the pipeline
+            dom.sync()
+            state["t"] += W * DT
+            t1 = time.perf_counter()
+            for k in range(k0 + 1, k0 + 1 + K):
+                dom.run_async(W, state["t"], hosts[k % 2].data_ptr())
+                state["t"] += W * DT
+            dom.sync()
+            value_h2d = float(net.N) * K * W / (time.perf_counter() - t1)
+            state["batch"] = k0 + 1 + K
+            del hosts
+        except Exception as e:   # reported, never required
+            value_h2d = f"failed: {e}"
+
+    # ---- one main_route-equivalent call per model time step (mzr_step: forcing row in, sweep, sync)
+    single = None
+    if world == 1 and not args.no_single_step:
+        n1 = 40
+        rows = pool[0][0][:n1].cpu().numpy()
+        tb = state["t"]
+        dom.step(tb, tb + DT, rows[0])
+        t1 = time.perf_counter()
+        for k in range(1, n1):
+            dom.step(tb + k * DT, tb + (k + 1) * DT, rows[k])
+        el1 = time.perf_counter() - t1
+        state["t"] = tb + n1 * DT
+        single = {"value": float(net.N) * (n1 - 1) / el1, "unit": "reaches*timesteps/s", "ms_per_model_timestep": el1 / (n1 - 1) * 1e3,
+                  "steps": n1 - 1, "what": "mzr_step: host forcing row -> device, one sweep over the stages, results synchronised every step"}
+
     # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
     # every stage launch on the library's stream, on the window that follows the timed region
-    roof = None
+    roof, ktf = None, None
     if args.no_roofline:
         pass
     elif world > 1:      # every rank takes part in the profiled window (the exchange is collective)
@@ -240,10 +289,13 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        t_prof = time.perf_counter()
         run_batches(1)
         sync_all()
+        t_prof = time.perf_counter() - t_prof
         dom.set_profiling(0)
         pt = dom.timing(m.KWT, reset=True)
+        ktf = pt["kernel_ms"] * 1e-3 / t_prof if t_prof > 0 else None
     # particle-traffic counters (device atomics) are collected on one more window so that they do
     # not disturb the event-timed launches; bytes per reach-step of that window x the reach-steps
     # of the timed window = algorithmic bytes of the timed window
@@ -275,7 +327,9 @@ def main():
                     traffic = tj["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "k_stage_kwt", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        sw = dom.sweep_info()
+        roof = {"bound": "hbm", "kernel": "k_sweep_kwt" if sw[0] > 0 and os.environ.get("MZR_KWT_SWEEP", "1") != "0" else "k_stage_kwt",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_total / launches,
                 "bytes_per_reach_step": per_rs,
@@ -285,7 +339,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         try:
-            cpu = cpu_baseline(net if world == 1 else m.make_network(args.reaches, seed=20240529), frac, sample_steps=24)
+            ro_cpu = device_runoff(torch, net.H, 480, 0, 7, dev).cpu().numpy()      # the first 480 steps of the GPU leg's forcing
+            cpu = cpu_baseline(net, frac, ro_cpu)
         except Exception as e:   # the baseline is reported, never required
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
 
@@ -301,10 +356,12 @@ def main():
                        "step": "one forcing window (batch) of window_steps model time steps",
                        "window_steps": W, "model_timesteps_timed": K * W, "ms_per_model_timestep": elapsed / (K * W) * 1e3,
                        "simulated_years_per_wallclock_day": (K * W * DT / 31536000.0) / (elapsed / 86400.0),
-                       "kernel_time_fraction": tm["kernel_ms"] * 1e-3 / elapsed if tm["kernel_ms"] else None,
+                       "kernel_time_fraction": ktf,
+                       "kwt_sweep": dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 else None,
                        "parallelism": ("1 domain" if world == 1 else
                                        f"{world} sub-basin partitions (reference mainstem rule), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
+            "value_with_h2d": value_h2d, "single_step": single,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -123,6 +123,11 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff);
 /* same, runoff already resident in device memory (zero copy); launches are asynchronous on the
    handle's stream, errors surface at the next mzr_sync / mzr_get_* call */
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev);
+/* same, runoff in HOST memory (page-locked for the copy to overlap), returns at once: the window is copied on a
+   stream of its own into one of two device buffers while the window before is still being routed -- the loop of
+   standalone/route_runoff.f90:80-108 (read forcing, route) with the read hidden.  The host buffer must stay
+   unchanged until the next-but-one mzr_run_async returns, or until mzr_sync. */
+int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff);
 int mzr_sync(mzr_handle h);
 
 /* Forcing remap in front of basin2reach (get_basin_runoff.f90:86-98 -> process_remap.f90:32-316),

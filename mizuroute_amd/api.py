@@ -53,7 +53,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
-           "mzr_get_sweep_info"]
+           "mzr_get_sweep_info", "mzr_run_async"]
 
 
 def load_library():
@@ -95,6 +95,7 @@ def load_library():
     L.mzr_step.argtypes = [vp, cd, cd, dp]
     L.mzr_run.argtypes = [vp, ci, cd, dp]
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
+    L.mzr_run_async.argtypes = [vp, ci, cd, vp]
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
     L.mzr_set_irf_state.argtypes = [vp, dp]
@@ -244,6 +245,11 @@ class RoutingDomain:
     def run_device(self, n_steps, t_start, runoff_dev_ptr):
         """Asynchronous window on device-resident runoff [n_steps, nHru] (e.g. a torch tensor's data_ptr())."""
         self._check(self.L.mzr_run_dev(self.h, int(n_steps), float(t_start), C.c_void_p(int(runoff_dev_ptr))))
+
+    def run_async(self, n_steps, t_start, runoff_host_ptr):
+        """Asynchronous window on host-resident (page-locked) runoff [n_steps, nHru]: copy and routing overlap
+        with the window before."""
+        self._check(self.L.mzr_run_async(self.h, int(n_steps), float(t_start), C.c_void_p(int(runoff_host_ptr))))
 
     def sync(self):
         self._check(self.L.mzr_sync(self.h))

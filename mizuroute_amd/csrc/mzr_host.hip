@@ -172,7 +172,11 @@ struct mzr_domain {
   DBuf<uint16_t> ntdh;
   std::vector<int> uhOff;
   // window buffers
-  DBuf<double> runoffW, qi, qlat, qr0Last, basS[2], scratchOut, wm;
+  DBuf<double> runoffW, runoffW2, qi, qlat, qr0Last, basS[2], scratchOut, wm;
+  hipStream_t copyStream = nullptr;             // host -> device forcing windows of mzr_run_async, behind the sweep of the window before
+  hipEvent_t rwCopied[2] = {nullptr, nullptr}, rwRead[2] = {nullptr, nullptr};
+  bool rwUsed[2] = {false, false};
+  int rwCur = 0;
   int wmSteps = 0;
   int basCur = 0;
   int lastW = 0;
@@ -399,6 +403,8 @@ int mzr_destroy(mzr_handle h) {
   for (auto &rb : h->route) for (auto &e : rb.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
+  if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
+  for (int i = 0; i < 2; ++i) { if (h->rwCopied[i]) (void)hipEventDestroy(h->rwCopied[i]); if (h->rwRead[i]) (void)hipEventDestroy(h->rwRead[i]); }
   for (int ix = 0; ix < 6; ++ix) { if (h->routeStream[ix]) (void)hipStreamDestroy(h->routeStream[ix]); if (h->routeEvent[ix]) (void)hipEventDestroy(h->routeEvent[ix]); }
   for (auto &e : h->basinEvents) (void)hipEventDestroy(e);
   delete h;
@@ -931,10 +937,10 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 1; ix < nR; ++ix) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
   }
   const bool prof = h->profiling;
-  // KWT: windows of more than a few steps go through the persistent sweep (one launch per chunk of the skewed
-  // schedule, progress counters instead of kernel boundaries); single steps keep one launch per stage.
-  // MZR_KWT_SWEEP=0 / 1 forces one or the other.
-  bool sweep = W >= 8;
+  // KWT goes through the persistent sweep (one launch per chunk of the skewed schedule, progress counters instead
+  // of kernel boundaries), single steps too: 842 dependent stages cost 15 ms per step as hand-offs, 18 ms as
+  // launches.  MZR_KWT_SWEEP=0 keeps one launch per stage (k_stage_kwt), the form the sweep is tested against.
+  bool sweep = true;
   if (const char *e = getenv("MZR_KWT_SWEEP")) sweep = atoi(e) != 0;
   const int kwtIx = idxOf(h, MZR_KWT);
   if (kwtIx < 0 || h->swItems < 1) sweep = false;
@@ -1044,6 +1050,35 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
   const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
   if (rc) return rc;
   return mzr_sync(h);
+}
+
+// The stand-alone driver's loop (standalone/route_runoff.f90:80-108) reads forcing and routes, step after step;
+// here a whole window of forcing is handed over in host memory and the call returns at once: the copy runs on its
+// own stream into one of two device buffers while the window before is still being routed.
+int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff) {
+  if (!h) return 1;
+  if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  try {
+    if (!h->runoffW2.p) h->runoffW2.alloc((size_t)h->cfg.maxWindow * h->H);
+  } catch (const std::string &e) { return fail(h, 91, "mzr_run_async/" + e); }
+  if (!h->copyStream) {
+    if (hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) != hipSuccess) return fail(h, 90, "mzr_run_async/hipStreamCreate failed");
+    for (int i = 0; i < 2; ++i) { (void)hipEventCreateWithFlags(&h->rwCopied[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->rwRead[i], hipEventDisableTiming); }
+  }
+  const int k = h->rwCur;
+  double *buf = k == 0 ? h->runoffW.p : h->runoffW2.p;
+  if (h->rwUsed[k]) (void)hipStreamWaitEvent(h->copyStream, h->rwRead[k], 0);     // the window that last read this buffer
+  if (hipMemcpyAsync(buf, runoff, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, h->copyStream) != hipSuccess)
+    return fail(h, 92, "mzr_run_async/hipMemcpyAsync failed");
+  (void)hipEventRecord(h->rwCopied[k], h->copyStream);
+  (void)hipStreamWaitEvent(h->stream, h->rwCopied[k], 0);
+  const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, buf);
+  if (rc) return rc;
+  (void)hipEventRecord(h->rwRead[k], h->stream);
+  h->rwUsed[k] = true; h->rwCur = k ^ 1;
+  return 0;
 }
 
 int mzr_set_remap(mzr_handle h, int kind, int nMap, const int *hru_ix, const int *num_qhru, int nOverlap, const int *qhru_ix,

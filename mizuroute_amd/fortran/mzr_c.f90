@@ -37,7 +37,7 @@ MODULE mzr_c
             mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
-            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info
+            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async
   public :: mzr_message
 
   INTERFACE
@@ -208,6 +208,13 @@ MODULE mzr_c
       type(c_ptr), value :: h, runoff_dev
       integer(c_int), value :: nSteps
       real(c_double), value :: t_start
+    end function
+    integer(c_int) function mzr_run_async(h, nSteps, t_start, runoff) bind(C, name='mzr_run_async')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), value :: t_start
+      real(c_double), intent(in) :: runoff(*)
     end function
     ! restart (read_restart.f90:152-742): state back in, the layouts of the getters
     integer(c_int) function mzr_set_irf_state(h, qfuture) bind(C, name='mzr_set_irf_state')

@@ -23,8 +23,11 @@ def domain_from_golden(net, z, **kw):
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-@pytest.mark.parametrize("window", [1000, 7])
-def test_matches_reference_golden(name, window, hip_lib):
+@pytest.mark.parametrize("window,sweep", [(1000, "1"), (7, "1"), (1, "1"), (1000, "0"), (7, "0")])
+def test_matches_reference_golden(name, window, sweep, hip_lib, monkeypatch):
+    """window: steps per call (1 = mzr_step-like); sweep: "1" the persistent KWT sweep (k_sweep_kwt, progress counters),
+    "0" one launch per stage (k_stage_kwt)."""
+    monkeypatch.setenv("MZR_KWT_SWEEP", sweep)
     net, z = load_golden(name)
     dom = domain_from_golden(net, z, max_window=window)
     Q = dom.run(z["runoff"])
