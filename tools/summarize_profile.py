@@ -1,85 +1,119 @@
 #!/usr/bin/env python
-"""Turn a gpurun_out/<tag>/ profile bundle (tools/profile_bundle.sh) into the tracked summary under
-profiles/: kernel stats CSV, HBM PMC totals per kernel, the bench line, and
-profiles/kwt_hbm_traffic.json (read by bench.py for roofline.traffic).
-
-HBM bytes per launch follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are
-collected in separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes
-of a wide coalesced read, so reads are doubled:  traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
-"""
-import collections
+"""Turn a gpurun_out/<tag>/ profile bundle (tools/profile_bundle.sh) into the tracked summaries under profiles/:
+  <tag>_kernel_stats.csv, <tag>_kernel_stats_400k.csv   rocprofv3 --kernel-trace --stats
+  <tag>_bench.json, <tag>_bench_400k.json               the un-profiled bench lines of the same build
+  <tag>_pmc.md / <tag>_pmc.json                         SQ counters per kernel (separate --pmc passes) + derived utilisation
+  <tag>_calib.json                                      FETCH_SIZE / WRITE_SIZE against known byte counts (tools/calib_hbm.hip)
+  <tag>_summary.md                                      the table the roofline numbers come from
+  kwt_hbm_traffic.json                                  HBM bytes per sweep launch, read by bench.py (roofline.traffic)
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE in separate passes, KiB; the read and
+write factors are the ones measured by the calibration kernels of the same bundle (8 bytes per lane, contiguous and
+160-byte row gathers), not assumed."""
 import csv
 import json
 import os
-import shutil
 import re
+import shutil
 import sys
+
+tag = sys.argv[1]
+src, dst = os.path.join("gpurun_out", tag), "profiles"
+os.makedirs(dst, exist_ok=True)
 
 
 def kname(full):
-    """'void k_stage_kwt<false, 1024>(MzrDev, ...)' -> 'k_stage_kwt' (template instances pooled)."""
     return re.sub(r"<.*", "", full.split("(")[0].replace("void ", "")).strip()
 
-tag = sys.argv[1]
-src = os.path.join("gpurun_out", tag)
-dst = "profiles"
-os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, "stats", "k_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
-bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
+
+def last_json(path):
+    try:
+        return json.loads([l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        return None
 
 
-def pmc(name, counter):
-    agg, cnt = collections.defaultdict(float), collections.Counter()
-    path = os.path.join(src, name, "k_counter_collection.csv")
-    if not os.path.exists(path):
-        path += ".part"
-    for row in csv.DictReader(open(path)):
-        if row.get("Counter_Name") != counter:
-            continue
-        k = kname(row["Kernel_Name"])
-        agg[k] += float(row["Counter_Value"]); cnt[k] += 1
-    return agg, cnt
+calib = json.load(open(os.path.join(src, "calib.json")))
+KNOWN = {"k_copy8": (2 ** 31, 2 ** 31), "k_copy16": (2 ** 31, 2 ** 31), "k_rows8": ((2 ** 28 // 20) * 164, (2 ** 28 // 20) * 8)}
+cal = {}
+for k, (rd, wr) in KNOWN.items():
+    c = calib.get(k, {})
+    if "FETCH_SIZE_KiB_per_launch" in c:
+        cal[k] = dict(known_read_bytes=rd, known_write_bytes=wr, FETCH_SIZE_KiB=c["FETCH_SIZE_KiB_per_launch"], WRITE_SIZE_KiB=c["WRITE_SIZE_KiB_per_launch"],
+                      read_factor=rd / (c["FETCH_SIZE_KiB_per_launch"] * 1024), write_factor=wr / (c["WRITE_SIZE_KiB_per_launch"] * 1024))
+json.dump(cal, open(os.path.join(dst, f"{tag}_calib.json"), "w"), indent=1)
+# contiguous 8-byte lanes: the factor that turns FETCH_SIZE into bytes that crossed the memory side (row gathers
+# then show their over-fetch as traffic above the useful bytes, which is what "traffic" is for)
+RF = cal.get("k_copy8", {}).get("read_factor", 2.0)
+WF = cal.get("k_copy8", {}).get("write_factor", 1.0)
+rows = cal.get("k_rows8", {})
 
-
-fetch, nf = pmc("pmc_fetch", "FETCH_SIZE")
-write, nw = pmc("pmc_write", "WRITE_SIZE")
-stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "stats", "k_kernel_stats.csv")))}
 lines = [f"# Profile {tag}", "",
-         "Command: `python bench.py --no-cpu-baseline --no-roofline --window 8192 --steps 1 --warmup 1` under",
-         "`rocprofv3 --kernel-trace --stats` and, separately, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.", "",
-         "| kernel | calls | avg us | total ms | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (2*F+W) |",
-         "|---|---|---|---|---|---|---|"]
-out = {}
-for k, r in stats.items():
-    if not k.startswith("k_"):
+         "Bundle: `tools/profile_bundle.sh " + tag + "` on one MI355X; every counter group in its own `rocprofv3 --pmc` run, kernel times",
+         "from a separate `rocprofv3 --kernel-trace --stats` run of the same command.", "",
+         f"HBM-counter calibration (`tools/calib_hbm.hip`, 2 GiB buffers): FETCH_SIZE x {RF:.3f} = bytes read, WRITE_SIZE x {WF:.3f} = bytes written",
+         "for 8-byte-per-lane contiguous access (`k_copy8`); the 16-byte case (`k_copy16`) gives the same factors; scattered 160-byte rows",
+         f"(`k_rows8`) fetch {rows.get('FETCH_SIZE_KiB', 0) * 1024 * RF / max(1, rows.get('known_read_bytes', 1)):.2f} x their useful bytes. Details: `{tag}_calib.json`.", ""]
+out_traffic = None
+pm_all = {}
+for size, sfx, cmd in (("100k", "", "--window 8192 --steps 1 --warmup 1"), ("400k", "_400k", "--reaches 400000 --window 2048 --steps 2 --warmup 2")):
+    sdir = os.path.join(src, "stats" + sfx)
+    if not os.path.exists(os.path.join(sdir, "k_kernel_stats.csv")):
         continue
-    f = fetch.get(k, 0.0) / max(1, nf.get(k, 1)); w = write.get(k, 0.0) / max(1, nw.get(k, 1))
-    hbm = (2 * f + w) * 1024
-    lines.append(f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {f:.0f} | {w:.0f} | {hbm/1e6:.2f} |")
-    out[k] = dict(avg_us=float(r["AverageNs"]) / 1e3, fetch_kib=f, write_kib=w, hbm_bytes=hbm)
-rf = bench.get("roofline") or {}
-# The profiled command routes an untimed first window (cold start, lane classes not yet formed) and then
-# the timed ones; the HIP-event figure of the bench line is for a window in steady state.  Compare like
-# with like: the per-launch average of the LAST window's KWT launches in the kernel trace.
-steady = None
-tpath = os.path.join(src, "stats", "k_kernel_trace.csv")
-if os.path.exists(tpath) and rf.get("launches"):
-    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(tpath)) if "k_stage_kwt" in r["Kernel_Name"]]
-    n = int(rf["launches"])
-    if len(dur) >= n:
-        steady = sum(dur[-n:]) / n / 1e3
-lines += ["", "Bench line of the same build (un-profiled run):", "", "```", json.dumps(bench), "```", "",
-          f"KWT stage kernel: HIP-event average {rf.get('avg_launch_us', float('nan')):.1f} us vs rocprofv3 "
-          f"{out.get('k_stage_kwt', {}).get('avg_us', float('nan')):.1f} us per launch over all windows"
-          + (f", {steady:.1f} us over the last (steady) window" if steady else "") + "; algorithmic "
-          f"{rf.get('algorithmic_bytes_per_launch', 0)/1e6:.2f} MB/launch vs HBM counters "
-          f"{out.get('k_stage_kwt', {}).get('hbm_bytes', 0)/1e6:.2f} MB/launch."]
+    shutil.copy(os.path.join(sdir, "k_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats{sfx}.csv"))
+    bench = last_json(os.path.join(src, "bench" + sfx + ".json"))
+    if bench:
+        json.dump(bench, open(os.path.join(dst, f"{tag}_bench{sfx}.json"), "w"), indent=1)
+    pm = json.load(open(os.path.join(src, f"{tag}_{size}_pmc.json")))
+    pm = {kname(k): v for k, v in pm.items()}
+    pm_all[size] = {k: v for k, v in pm.items() if k.startswith("k_")}
+    stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(sdir, "k_kernel_stats.csv")))}
+    lines += [f"## {size} reaches (`bench.py --no-cpu-baseline --no-roofline --no-h2d --no-single-step {cmd}`)", "",
+              "| kernel | calls | avg us | total ms | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (calibrated) |", "|---|---|---|---|---|---|---|"]
+    extra = ""
+    for k, r in stats.items():
+        if not k.startswith("k_"):
+            continue
+        p = pm.get(k, {})
+        n = max(1, p.get("_dispatches", 1))
+        f, w = p.get("FETCH_SIZE", 0.0) / n, p.get("WRITE_SIZE", 0.0) / n
+        hbm = (RF * f + WF * w) * 1024
+        lines.append(f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {f:.0f} | {w:.0f} | {hbm/1e6:.2f} |")
+        if k == "k_sweep_kwt" and bench:
+            rf = bench.get("roofline") or {}
+            extra = (f"`k_sweep_kwt` at {size}: rocprofv3 average {float(r['AverageNs'])/1e3:.0f} us per launch over all windows of the profiled command "
+                     f"(first, cold window included); the bench line's HIP-event average for a steady window is {rf.get('avg_launch_us', float('nan')):.0f} us; "
+                     f"algorithmic {rf.get('algorithmic_bytes_per_launch', 0)/1e6:.0f} MB per launch vs {hbm/1e6:.0f} MB at the memory side "
+                     f"({hbm / max(1.0, rf.get('algorithmic_bytes_per_launch', 1.0)):.2f} x).")
+            if size == "100k":
+                cfg = bench["config"]
+                out_traffic = dict(tag=tag, reaches=cfg["reaches_per_gpu"], window=cfg["window_steps"], hbm_bytes_per_launch=hbm, fetch_kib_per_launch=f,
+                                   write_kib_per_launch=w, read_factor=RF, write_factor=WF,
+                                   note="(read_factor*FETCH_SIZE + write_factor*WRITE_SIZE)*1024 per k_sweep_kwt launch, separate rocprofv3 --pmc passes; factors from "
+                                        "the calibration kernels of the same bundle")
+    lines += ["", extra, ""]
+    if bench:
+        lines += ["Bench line of the same build (un-profiled run):", "", "```", json.dumps(bench), "```", ""]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
-if "k_stage_kwt" in out:
-    cfg = bench["config"]
-    json.dump(dict(tag=tag, reaches=cfg["reaches_per_gpu"], window=8192, hbm_bytes_per_launch=out["k_stage_kwt"]["hbm_bytes"],
-                   fetch_kib_per_launch=out["k_stage_kwt"]["fetch_kib"], write_kib_per_launch=out["k_stage_kwt"]["write_kib"],
-                   note="(2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes, bench.py --window 8192"),
-              open(os.path.join(dst, "kwt_hbm_traffic.json"), "w"), indent=1)
-print("\n".join(lines))
+if out_traffic:
+    json.dump(out_traffic, open(os.path.join(dst, "kwt_hbm_traffic.json"), "w"), indent=1)
+
+# ---- SQ counters
+json.dump(pm_all, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+L = [f"# SQ counters {tag}", "", "One `rocprofv3 --pmc` pass per group (tools/pmc.sh), summed over all dispatches of the profiled command; SQ_* cycle counters are in",
+     "quad-cycles (MI355X_MICROARCH.md).  Derived: VALU issue utilisation = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs);",
+     "wave residency = SQ_WAVE_CYCLES x 4 / the same denominator (wavefronts per SIMD on average); issue / wait shares are of SQ_WAVE_CYCLES.", ""]
+for size, pm in pm_all.items():
+    L += [f"## {size} reaches", "", "| kernel | VALU util | waves/SIMD | issuing | wait (s_waitcnt etc.) | wait on issue | VALU insts | SALU insts | LDS insts | VMEM rd / wr insts | FP64 share of VALU | lanes active per VALU inst |",
+          "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for k, p in pm.items():
+        if "SQ_WAVE_CYCLES" not in p or p["SQ_WAVE_CYCLES"] < 1e6:
+            continue
+        den = p["GRBM_GUI_ACTIVE"] / 8 * 1024
+        fp64 = sum(p.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        L.append(f"| {k} | {p['SQ_ACTIVE_INST_VALU']*4/den:.2f} | {p['SQ_WAVE_CYCLES']*4/den:.2f} | {p.get('SQ_ACTIVE_INST_ANY',0)/p['SQ_WAVE_CYCLES']:.2f} | "
+                 f"{p.get('SQ_WAIT_ANY',0)/p['SQ_WAVE_CYCLES']:.2f} | {p.get('SQ_WAIT_INST_ANY',0)/p['SQ_WAVE_CYCLES']:.2f} | {p.get('SQ_INSTS_VALU',0):.3g} | "
+                 f"{p.get('SQ_INSTS_SALU',0):.3g} | {p.get('SQ_INSTS_LDS',0):.3g} | {p.get('SQ_INSTS_VMEM_RD',0):.3g} / {p.get('SQ_INSTS_VMEM_WR',0):.3g} | "
+                 f"{fp64/max(1,p.get('SQ_INSTS_VALU',1)):.2f} | {p.get('SQ_THREAD_CYCLES_VALU',0)/max(1,p.get('SQ_ACTIVE_INST_VALU',1)):.1f} |")
+    L += ["", "Raw sums: `" + f"{tag}_pmc.json" + "`.", ""]
+open(os.path.join(dst, f"{tag}_pmc.md"), "w").write("\n".join(L) + "\n")
+print("\n".join(l for l in lines if not l.startswith("{"))[:6000]); print("\n".join(L))
