@@ -102,6 +102,9 @@ def main():
                     help="model time steps per batch; 0 = 8192, fewer when --steps is large (about 2M model steps in total)")
     ap.add_argument("--reaches", type=int, default=N_REACH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default="", help="write <DUMP>.rank<r>.npz with the per-reach interval mean of REACH_Q and the particle "
+                    "counts of the reaches this rank routes (tests: a partitioned run must equal the one-rank run); forcing is then "
+                    "generated for the whole network and sliced per domain, so that every partitioning routes the same thing")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-forcing leg (value_with_h2d)")
     ap.add_argument("--no-single-step", action="store_true", help="skip the mzr_step leg (single_step)")
     ap.add_argument("--no-roofline", action="store_true",
@@ -185,6 +188,12 @@ def main():
     n_stages, max_width = dom.schedule()
 
     def gen(n_steps, t0):
+        if args.dump:      # one forcing for the whole network, every domain takes the columns of its HRUs
+            glob = device_runoff(torch, net.H, n_steps, t0, 7, dev)
+            if router is None:
+                return [glob]
+            specs = [sp for d_, sp in ((router.trib, router.trib_spec), (router.main, router.main_spec)) if d_ is not None]
+            return [glob[:, torch.as_tensor(sp.hru_global, device=dev, dtype=torch.long)].contiguous() for sp in specs]
         return [device_runoff(torch, H, n_steps, t0, 7 + rank + 101 * i, dev) for i, (_, H) in enumerate(doms)]
 
     pool = [gen(W, 0), gen(W, W)]          # two forcing windows, used alternately
@@ -233,6 +242,17 @@ def main():
         elapsed = float(tmax.item())
     total_reach_steps = float(net.N) * K * W
     value = total_reach_steps / elapsed
+
+    if args.dump:      # per-reach results of everything routed so far, by global reach index
+        parts = []
+        if router is None:
+            parts.append((np.arange(net.N), dom.mean_q(m.KWT), dom.kwt_state()[0]))
+        else:
+            for d_, sp in ((router.trib, router.trib_spec), (router.main, router.main_spec)):
+                if d_ is not None:
+                    parts.append((np.asarray(sp.reach_global[:sp.n_real]), d_.mean_q(m.KWT)[:sp.n_real], d_.kwt_state()[0][:sp.n_real]))
+        np.savez(f"{args.dump}.rank{rank}.npz", reach=np.concatenate([p_[0] for p_ in parts]), q=np.concatenate([p_[1] for p_ in parts]),
+                 nw=np.concatenate([p_[2] for p_ in parts]))
 
     # ---- the same timed region with the forcing handed over in page-locked host memory (N = 1): two host
     # windows, copied by the library on its own stream while the window before is routed

@@ -224,6 +224,8 @@ struct mzr_domain {
 namespace {
 
 int fail(mzr_handle h, int code, const std::string &m) { h->msg = m; return code; }
+// checked copies of the state getters / setters: a failed copy is an error, not silently wrong state
+#define MZR_COPY(dst, src, bytes, kind, who) do { if (hipMemcpy((dst), (src), (bytes), (kind)) != hipSuccess) return fail(h, 92, std::string(who) + "/hipMemcpy failed"); } while (0)
 
 int idxOf(mzr_handle h, int method) {
   for (int i = 0; i < h->cfg.nRoutes; ++i) if (h->cfg.routeMethods[i] == method) return i;
@@ -695,7 +697,7 @@ int mzr_init_state(mzr_handle h) {
   try {
     h->runoffW.alloc(W * h->H);
     if (h->cfg.doesBasinRoute == 1) {
-      h->qi.alloc(W * N);
+      h->qi.alloc(W * N); h->qi.zero();      // halo reaches have no HRUs of their own: their rows stay zero (basin state getters)
       h->basS[0].alloc((size_t)h->ntdhBas * N); h->basS[1].alloc((size_t)h->ntdhBas * N);
       h->basS[0].zero(); h->basS[1].zero();
     }
@@ -1241,10 +1243,10 @@ int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry
   const int N = h->N;
   std::vector<int> n(N);
   std::vector<double> q((size_t)MZR_KW_CAP * N), ti(q.size()), tr(q.size());
-  (void)hipMemcpy(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(q.data(), h->kwQ.p, q.size() * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(ti.data(), h->kwTI.p, q.size() * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(tr.data(), h->kwTR.p, q.size() * sizeof(double), hipMemcpyDeviceToHost);
+  MZR_COPY(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
+  MZR_COPY(q.data(), h->kwQ.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
+  MZR_COPY(ti.data(), h->kwTI.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
+  MZR_COPY(tr.data(), h->kwTR.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
   for (int e = 0; e < N; ++e) {
     const int i = h->ext2int[e];
     numWaves[e] = n[i];
@@ -1270,16 +1272,17 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
   for (int e = 0; e < N; ++e) {
     const int i = h->ext2int[e];
     if (numWaves[e] > MZR_KW_CAP) return fail(h, 20, "mzr_set_kwt_state/more than MAXQPAR waves in a reach");
+    if (numWaves[e] < 0) return fail(h, 20, "mzr_set_kwt_state/negative number of waves in a reach");
     n[i] = numWaves[e];
     for (int k = 0; k < numWaves[e]; ++k) {
       const size_t o = (size_t)e * MZR_WCAP + k;
       q[MZR_KWI(k, i)] = qwave[o]; ti[MZR_KWI(k, i)] = tentry[o]; tr[MZR_KWI(k, i)] = texit[o];
     }
   }
-  (void)hipMemcpy(h->kwN.p, n.data(), N * sizeof(int), hipMemcpyHostToDevice);
-  (void)hipMemcpy(h->kwQ.p, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice);
-  (void)hipMemcpy(h->kwTI.p, ti.data(), q.size() * sizeof(double), hipMemcpyHostToDevice);
-  (void)hipMemcpy(h->kwTR.p, tr.data(), q.size() * sizeof(double), hipMemcpyHostToDevice);
+  MZR_COPY(h->kwN.p, n.data(), N * sizeof(int), hipMemcpyHostToDevice, "mzr_set_kwt_state");
+  MZR_COPY(h->kwQ.p, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
+  MZR_COPY(h->kwTI.p, ti.data(), q.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
+  MZR_COPY(h->kwTR.p, tr.data(), q.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
   return 0;
 }
 
@@ -1288,7 +1291,7 @@ int mzr_get_irf_state(mzr_handle h, double *qfuture) {
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
   std::vector<double> v((size_t)h->maxtdh * N);
-  (void)hipMemcpy(v.data(), h->irfQ.p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
+  MZR_COPY(v.data(), h->irfQ.p, v.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_irf_state");
   for (int e = 0; e < N; ++e) {
     const int i = h->ext2int[e];
     for (int j = 0; j < h->uhOff[e + 1] - h->uhOff[e]; ++j) qfuture[h->uhOff[e] + j] = v[(size_t)j * N + i];
@@ -1303,7 +1306,7 @@ int mzr_get_mol_state(mzr_handle h, int method, double *qout) {
   if (ix < 0 || !h->route[ix].mol.p) return fail(h, 81, "mzr_get_mol_state/method not active");
   const int N = h->N, nm = method == MZR_MC ? MZR_NMOL_MC : MZR_NMOL_KW;
   std::vector<double> v((size_t)nm * N);
-  (void)hipMemcpy(v.data(), h->route[ix].mol.p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
+  MZR_COPY(v.data(), h->route[ix].mol.p, v.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_mol_state");
   for (int e = 0; e < N; ++e) for (int j = 0; j < nm; ++j) qout[(size_t)e * nm + j] = v[(size_t)j * N + h->ext2int[e]];
   return 0;
 }
@@ -1313,7 +1316,7 @@ int mzr_get_basin_state(mzr_handle h, double *qfuture) {
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N, n = h->ntdhBas;
   std::vector<double> v((size_t)n * N);
-  (void)hipMemcpy(v.data(), h->basS[h->basCur].p, v.size() * sizeof(double), hipMemcpyDeviceToHost);
+  MZR_COPY(v.data(), h->basS[h->basCur].p, v.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_basin_state");
   for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) qfuture[(size_t)e * n + j] = v[(size_t)j * N + h->ext2int[e]];
   return 0;
 }
@@ -1328,7 +1331,7 @@ int mzr_set_irf_state(mzr_handle h, const double *qfuture) {
     const int i = h->ext2int[e];
     for (int j = 0; j < h->uhOff[e + 1] - h->uhOff[e]; ++j) v[(size_t)j * N + i] = qfuture[h->uhOff[e] + j];
   }
-  (void)hipMemcpy(h->irfQ.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  MZR_COPY(h->irfQ.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_irf_state");
   return 0;
 }
 
@@ -1340,7 +1343,7 @@ int mzr_set_mol_state(mzr_handle h, int method, const double *q) {
   const int N = h->N, nm = method == MZR_MC ? MZR_NMOL_MC : MZR_NMOL_KW;
   std::vector<double> v((size_t)nm * N);
   for (int e = 0; e < N; ++e) for (int j = 0; j < nm; ++j) v[(size_t)j * N + h->ext2int[e]] = q[(size_t)e * nm + j];
-  (void)hipMemcpy(h->route[ix].mol.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  MZR_COPY(h->route[ix].mol.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_mol_state");
   return 0;
 }
 
@@ -1353,12 +1356,12 @@ int mzr_set_basin_state(mzr_handle h, const double *qfuture, const double *basin
     if (h->cfg.doesBasinRoute != 1) return fail(h, 20, "mzr_set_basin_state/hillslope routing not active");
     std::vector<double> v((size_t)n * N);
     for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) v[(size_t)j * N + h->ext2int[e]] = qfuture[(size_t)e * n + j];
-    (void)hipMemcpy(h->basS[h->basCur].p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+    MZR_COPY(h->basS[h->basCur].p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_basin_state");
   }
   if (basin_q) {   // row lastW of qlat is BASIN_QR(1) of the last step; the next window starts from it
     std::vector<double> v(N);
     for (int e = 0; e < N; ++e) v[h->ext2int[e]] = basin_q[e];
-    (void)hipMemcpy(h->qlat.p + (size_t)h->lastW * N, v.data(), N * sizeof(double), hipMemcpyHostToDevice);
+    MZR_COPY(h->qlat.p + (size_t)h->lastW * N, v.data(), N * sizeof(double), hipMemcpyHostToDevice, "mzr_set_basin_state");
   }
   return 0;
 }
@@ -1371,7 +1374,7 @@ int mzr_set_volume(mzr_handle h, int method, const double *vol) {
   if (ix < 0) return fail(h, 81, "mzr_set_volume/method not active");
   std::vector<double> v(h->N);
   for (int e = 0; e < h->N; ++e) v[h->ext2int[e]] = vol[e];
-  (void)hipMemcpy(h->route[ix].vol.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice);
+  MZR_COPY(h->route[ix].vol.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_volume");
   return 0;
 }
 

@@ -165,14 +165,18 @@ def read_restart(path, dom):
 
 class HistoryWriter:
     """<case>.h.*.nc: one record per output interval, time-mean discharge (and optionally the last
-    volume) per active method, float32, dimensions (time, seg) (historyFile.f90:434-534)."""
+    volume) per active method, float32, dimensions (time, seg) (historyFile.f90:434-534).  `time` is the START
+    of the aggregated interval plus histTimeStamp_offset and `time_bounds` holds both ends
+    (historyFile.f90:349-373, histVars_data.f90:179-183)."""
 
     def __init__(self, path, reach_id, methods, time_units="seconds since 1970-01-01 00:00:00", calendar="standard", volumes=False):
         self.f = netcdf_file(path, "w", version=2)
         self.f.createDimension("time", None)
         self.f.createDimension("seg", len(reach_id))
+        self.f.createDimension("tbound", 2)
         self.methods, self.n = list(methods), 0
-        t = self.f.createVariable("time", "d", ("time",)); t.units = time_units; t.calendar = calendar; t.long_name = "time"
+        t = self.f.createVariable("time", "d", ("time",)); t.units = time_units; t.calendar = calendar; t.long_name = "time"; t.bounds = "time_bounds"
+        tb = self.f.createVariable("time_bounds", "d", ("time", "tbound")); tb.units = time_units; tb.calendar = calendar; tb.long_name = "time interval endpoints"
         _var(self.f, "reachID", "i", ("seg",), np.asarray(reach_id, np.int32), long_name="reach ID", units="-")
         self.vars = {}
         for m in self.methods:
@@ -182,9 +186,10 @@ class HistoryWriter:
                 w = self.f.createVariable(HIST_VOL[m], "f", ("time", "seg")); w.units = "m3"
                 self.vars[(m, "v")] = w
 
-    def append(self, time_value, dom):
-        """Write the means accumulated on the device since the last record and reset them."""
-        self.f.variables["time"][self.n] = time_value
+    def append(self, t_begin, t_end, dom, stamp_offset=0.0):
+        """Write the means accumulated on the device over [t_begin, t_end] and reset them."""
+        self.f.variables["time"][self.n] = t_begin + stamp_offset
+        self.f.variables["time_bounds"][self.n, :] = (t_begin, t_end)
         for m in self.methods:
             self.vars[(m, "q")][self.n, :] = dom.mean_q(m, reset=True).astype(np.float32)
             if (m, "v") in self.vars:

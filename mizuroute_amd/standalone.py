@@ -185,9 +185,15 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     frac = uhmod.basin_uh(dt, nml["fshape"], nml["tscale"])
     uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, nml["velo"], nml["diff"])
     W = max(1, min(window, n_steps))
+    # options of the reference this driver does not implement stop the run instead of being ignored (read_control.f90)
+    for key in ("is_lake_sim", "is_flux_wm", "is_vol_wm", "is_vol_wm_jumpstart", "lakeRegulate", "tracer", "qmodOption"):
+        v = str(ctl.get(key, "F")).strip()
+        if _truth(v) or (key == "qmodOption" and v not in ("F", "0", "")):
+            raise NotImplementedError(f"<{key}> = {v}: not supported by mizuroute_amd.standalone (lakes and water management are available through "
+                                      "mizuroute_amd.api.RoutingDomain)")
     dom = api.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=W, device=device,
                             does_basin_route=int(ctl.get("doesBasinRoute", 1)), hw_drain_point=int(ctl.get("hw_drain_point", 2)),
-                            time_conv=tc, length_conv=lc)
+                            min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc)
     # ---- forcing: concatenate the files' time axes, find the record of every simulation step
     files = _forcing_files(ctl)
     handles = [netcdf_file(p, "r", mmap=False) for p in files]
@@ -234,8 +240,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     done = 0
     qname = ctl["vname_qsim"]
     while done < n_steps:
-        w = min(W, n_steps - done)
-        w = min(w, every - (done % every)) if every < W else w             # a window never straddles an output record
+        w = min(W, n_steps - done, every - (done % every))                 # a window never straddles an output record
         rows = []
         for k in range(w):                              # forcing of every simulation step: one record, or the weighted records it overlaps
             recs, fracs = time_map(start_ro_sec, dt, dt_ro, n_ro, done + k + 1)
@@ -251,12 +256,13 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         dom.run_source_device(w, t_first + done * dt, src.data_ptr())
         dom.sync()
         done += w
-        if done % every == 0:
-            hist.append(done * dt, dom)
+        if done % every == 0:      # time = start of the aggregated interval (+ <histTimeStamp_offset>), historyFile.f90:367
+            hist.append((done - every) * dt, done * dt, dom, stamp_offset=float(ctl.get("histTimeStamp_offset", 0.0)))
     hist.close()
     out = dict(history=hname, steps=n_steps, reaches=net.N)
     if ctl.get("restart_write", "never").lower() == "last":
-        rname = os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.r.{t_end:%Y-%m-%d}-{t_end.hour * 3600:05d}.nc")
+        t_rst = t_end + _dt.timedelta(seconds=dt)        # the restart time is the END of the last step (write_restart_pio.f90:207-253,771)
+        rname = os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.r.{t_rst:%Y-%m-%d}-{t_rst.hour * 3600 + t_rst.minute * 60 + t_rst.second:05d}.nc")
         ncfiles.write_restart(rname, dom, net.reachId, (t_first + (n_steps - 1) * dt, t_first + n_steps * dt), restart_time=t_first + n_steps * dt)
         out["restart"] = rname
     for h in handles:

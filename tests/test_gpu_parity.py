@@ -7,6 +7,8 @@ Tolerance: BASELINE.json asks for per-reach discharge within 1e-6 relative of th
 device uses ROCm's FP64 pow/sqrt, which differ from glibc's in the last bits, so FP64 results are
 compared with REL_TOL = 1e-6 (helpers.REL_TOL); integer results (particle counts) must be exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -429,7 +431,7 @@ def test_restart_continues_bit_exact(tmp_path, hip_lib):
     hw = ncfiles.HistoryWriter(hpath, net.reachId, methods)
     for k in range(3):
         Q = c.run(ro[k * 24:(k + 1) * 24], t_start=k * 24 * dt)
-        hw.append((k + 1) * 24 * dt, c)
+        hw.append(k * 24 * dt, (k + 1) * 24 * dt, c)
         want = Q.mean(axis=0)
     hw.close()
     from scipy.io import netcdf_file
@@ -527,3 +529,36 @@ def test_long_window_with_chunked_hillslope_prepass(hip_lib):
     assert np.array_equal(Qa, Qb)
     assert np.array_equal(a.basin_state(), b.basin_state())
     assert all(np.array_equal(x, y) for x, y in zip(a.kwt_state(), b.kwt_state()))
+
+
+# ---- bench.py as the driver runs it for N > 1: two ranks (here on one GPU, gloo transport) must route what one rank routes
+def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--reaches", "3000", "--window", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+              "--no-h2d", "--no-single-step"]
+    env = dict(os.environ, MZR_BENCH_SINGLE_DEVICE="1", MZR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = str(tmp_path / "one")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--reaches", "6000"] + common[2:] + ["--dump", one],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    two = str(tmp_path / "two")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common + ["--dump", two],
+                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    line = [l for l in r2.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["reaches_total"] == 6000 and j["value"] > 0
+    a = np.load(one + ".rank0.npz")
+    parts = [np.load(f"{two}.rank{r}.npz") for r in range(2)]
+    reach = np.concatenate([p["reach"] for p in parts]); q = np.concatenate([p["q"] for p in parts]); nw = np.concatenate([p["nw"] for p in parts])
+    assert np.array_equal(np.sort(reach), np.arange(6000)), "every reach is routed by exactly one rank"
+    order = np.argsort(reach)
+    assert np.array_equal(nw[order], a["nw"]), "particle counts differ between the partitioned and the one-rank run"
+    assert np.array_equal(q[order], a["q"]), "interval means differ between the partitioned and the one-rank run"

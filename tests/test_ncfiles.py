@@ -52,10 +52,12 @@ def test_history_file_layout(tmp_path):
         def flux(self, m, which): return np.ones(5) * m
     path = str(tmp_path / "case.h.2001-01-01-00000.nc")
     w = ncfiles.HistoryWriter(path, np.arange(5) + 1, [api.KWT, api.IRF], volumes=True)
-    w.append(3600.0, Dom()); w.append(7200.0, Dom()); w.close()
+    w.append(0.0, 3600.0, Dom()); w.append(3600.0, 7200.0, Dom(), stamp_offset=1800.0); w.close()
     f = netcdf_file(path, "r", mmap=False)
     assert f.variables["KWTroutedRunoff"].dimensions == ("time", "seg") and f.variables["KWTroutedRunoff"][:].dtype.itemsize == 4
     assert f.variables["KWTroutedRunoff"][:].shape == (2, 5) and "IRFvolume" in f.variables
-    assert np.array_equal(f.variables["time"][:], [3600.0, 7200.0])
+    # time = start of the aggregated interval (+ stamp offset), both ends in time_bounds (historyFile.f90:349-373)
+    assert np.array_equal(f.variables["time"][:], [0.0, 3600.0 + 1800.0])
+    assert np.array_equal(f.variables["time_bounds"][:], [[0.0, 3600.0], [3600.0, 7200.0]])
     assert np.allclose(f.variables["IRFroutedRunoff"][1], np.arange(5) + 0.123456789, rtol=1e-7)
     f.close()

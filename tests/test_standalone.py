@@ -126,9 +126,21 @@ def test_run_from_files_equals_api_run(tmp_path, hip_lib):
     assert got.shape == (steps // 6, net.N)
     want = Q.reshape(steps // 6, 6, 2, net.N).sum(axis=1) / 6.0
     assert np.allclose(got, want[:, 0], rtol=2e-6, atol=1e-12) and np.allclose(irf, want[:, 1], rtol=2e-6, atol=1e-12)
+    # records are stamped with the START of their interval, both ends in time_bounds (historyFile.f90:349-373)
+    assert np.array_equal(f.variables["time"][:], np.arange(steps // 6) * 6 * dt)
+    assert np.array_equal(f.variables["time_bounds"][:], np.stack([np.arange(steps // 6) * 6 * dt, (np.arange(steps // 6) + 1) * 6 * dt], axis=1))
     f.close()
     st = __import__("mizuroute_amd.ncfiles", fromlist=["x"]).read_restart_file(out["restart"])
     assert np.array_equal(st["numWaves"], dom.kwt_state()[0])
+    # the restart file is named by the restart time = end of the last step (write_restart_pio.f90:207-253)
+    assert os.path.basename(out["restart"]).endswith(".r.2001-01-03-00000.nc"), out["restart"]
+    # a window shorter than, and not a divisor of, the output interval must give the same records
+    os.makedirs(str(tmp_path / "w4"))
+    path4 = write_case(str(tmp_path / "w4"), net, ro * 1000.0, dt, route_opt="21")
+    out4 = standalone.run(path4, window=4, log=lambda *_: None)
+    f4 = netcdf_file(out4["history"], "r", mmap=False)
+    assert np.array_equal(f4.variables["KWTroutedRunoff"][:], got) and np.array_equal(f4.variables["IRFroutedRunoff"][:], irf)
+    f4.close()
 
 
 @pytest.mark.gpu
