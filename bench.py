@@ -154,6 +154,27 @@ def main():
         from mizuroute_amd.partition import PartitionedRouter, partition_network
         P = partition_network(net, world, build_for=[rank])
 
+        lib_comm = None
+        if os.environ.get("MZR_BENCH_TRANSPORT") == "lib" and backend == "nccl":     # the library's own RCCL transport (mzr_comm_*)
+            uid = [m.api.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            lib_comm = m.api.Comm(rank, world, uid[0], device=local_rank)
+
+        class LibTransport:
+            """records travel through mzr_comm_send / mzr_comm_recv_many; `router` is filled in once it exists"""
+            router, keep = None, None
+
+            def send(self, t, dst):
+                lib_comm.sync()                      # the buffer of the send before this one may go
+                self.keep = t
+                lib_comm.send(self.router.trib, t.data_ptr(), t.numel(), dst)
+
+            def recv(self, t, src):
+                lib_comm.recv(self.router.main, t.data_ptr(), t.numel(), src)
+
+            def recv_many(self, pairs):
+                lib_comm.recv_many(self.router.main, [(t.data_ptr(), t.numel(), src) for t, src in pairs])
+
         class Transport:
             def send(self, t, dst):
                 dist.send(t if backend == "nccl" else t.cpu(), dst)
@@ -181,8 +202,10 @@ def main():
         def make(spec, **kw):
             return m.RoutingDomain(spec.net, DT, [m.KWT], frac_future=frac, max_window=W, device=local_rank, **kw)
 
-        router = PartitionedRouter(P, rank, make, Transport(),
+        transport = LibTransport() if lib_comm is not None else Transport()
+        router = PartitionedRouter(P, rank, make, transport,
                                    lambda n: torch.empty(n, dtype=torch.float64, device=dev), W)
+        transport.router = router
         dom = router.trib if router.trib is not None else router.main
         doms = [(d, sp.net.H) for d, sp in ((router.trib, router.trib_spec), (router.main, router.main_spec)) if d is not None]
     n_stages, max_width = dom.schedule()

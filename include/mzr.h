@@ -191,6 +191,26 @@ int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kerne
 int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long long *w_out,
                         long long *n_head, long long *n_route, long long *n_edges, int reset);
 
+/* ---- boundary-record transport between the partitions of one node: RCCL point-to-point over xGMI, inside the library,
+   so that a host without torch (the Fortran driver of mpi_process.f90:1217-1329) can exchange the records of
+   mzr_export_boundary_dev / mzr_import_boundary_dev.  RCCL is loaded at run time (librccl.so); nothing else of the
+   library depends on it.  One process per GPU: rank 0 calls mzr_comm_unique_id and hands the 128 bytes to the other
+   ranks by whatever the host has (MPI_Bcast in the reference's driver), then every rank calls mzr_comm_init.
+   Transfers run on the communicator's own stream: a send starts behind the handle's last mzr_export_boundary_dev (not
+   behind the window the handle has queued since), and what the handle queues after a receive (mzr_import_boundary_dev)
+   waits for it.  Buffers must stay valid until mzr_comm_sync (or the handle's mzr_sync on the receiving side). */
+typedef struct mzr_comm_s *mzr_comm;
+int mzr_comm_unique_id(char id[128]);
+int mzr_comm_init(int rank, int nRanks, const char id[128], int device, mzr_comm *out);
+int mzr_comm_send(mzr_comm c, mzr_handle h, const double *dev, long long n, int peer);
+int mzr_comm_recv(mzr_comm c, mzr_handle h, double *dev, long long n, int peer);
+/* several receives as one group: the transfers run side by side, one xGMI link per peer */
+int mzr_comm_recv_many(mzr_comm c, mzr_handle h, int nPeers, double *const *dev, const long long *n, const int *peers);
+int mzr_comm_sync(mzr_comm c);
+int mzr_comm_destroy(mzr_comm c);
+/* message of the last failed mzr_comm_* call of this thread */
+int mzr_comm_last_error(char *buf, int len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,7 +53,8 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
-           "mzr_get_sweep_info", "mzr_run_async"]
+           "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
+           "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync"]
 
 
 def load_library():
@@ -96,6 +97,14 @@ def load_library():
     L.mzr_run.argtypes = [vp, ci, cd, dp]
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_run_async.argtypes = [vp, ci, cd, vp]
+    L.mzr_comm_unique_id.argtypes = [C.c_char_p]
+    L.mzr_comm_init.argtypes = [ci, ci, C.c_char_p, ci, C.POINTER(vp)]
+    L.mzr_comm_send.argtypes = [vp, vp, vp, C.c_longlong, ci]
+    L.mzr_comm_recv.argtypes = [vp, vp, vp, C.c_longlong, ci]
+    L.mzr_comm_recv_many.argtypes = [vp, vp, ci, C.POINTER(vp), C.POINTER(C.c_longlong), C.POINTER(ci)]
+    L.mzr_comm_destroy.argtypes = [vp]
+    L.mzr_comm_sync.argtypes = [vp]
+    L.mzr_comm_last_error.argtypes = [C.c_char_p, ci]
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
     L.mzr_set_irf_state.argtypes = [vp, dp]
@@ -373,3 +382,51 @@ class RoutingDomain:
         v = [C.c_longlong(0) for _ in range(6)]
         self._check(self.L.mzr_get_kwt_traffic(self.h, *[C.byref(x) for x in v], int(reset)))
         return dict(zip(("w_in", "w_up", "w_out", "n_head", "n_route", "n_edges"), [x.value for x in v]))
+
+
+class Comm:
+    """The library's own boundary-record transport (RCCL point-to-point, include/mzr.h mzr_comm_*): what a host
+    without torch uses.  unique_id() on rank 0, the 128 bytes to every rank by the host's own means, then Comm(...)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        Comm._check(L, L.mzr_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def _check(L, rc):
+        if rc:
+            buf = C.create_string_buffer(512)
+            L.mzr_comm_last_error(buf, 512)
+            raise MzrError(rc, buf.value.decode(errors="replace"))
+
+    def __init__(self, rank, n_ranks, uid: bytes, device=0):
+        self.L = load_library()
+        self.c = C.c_void_p()
+        self._check(self.L, self.L.mzr_comm_init(int(rank), int(n_ranks), C.create_string_buffer(uid, 128), int(device), C.byref(self.c)))
+        self.rank, self.n_ranks = rank, n_ranks
+
+    def send(self, dom, dev_ptr, n, peer):
+        self._check(self.L, self.L.mzr_comm_send(self.c, dom.h, C.c_void_p(int(dev_ptr)), int(n), int(peer)))
+
+    def recv(self, dom, dev_ptr, n, peer):
+        self._check(self.L, self.L.mzr_comm_recv(self.c, dom.h, C.c_void_p(int(dev_ptr)), int(n), int(peer)))
+
+    def recv_many(self, dom, triples):
+        """triples: (device pointer, doubles, peer) -- one grouped call, transfers side by side"""
+        k = len(triples)
+        ptrs = (C.c_void_p * k)(*[C.c_void_p(int(t[0])) for t in triples])
+        ns = (C.c_longlong * k)(*[int(t[1]) for t in triples])
+        peers = (C.c_int * k)(*[int(t[2]) for t in triples])
+        self._check(self.L, self.L.mzr_comm_recv_many(self.c, dom.h, k, ptrs, ns, peers))
+
+    def sync(self):
+        self._check(self.L, self.L.mzr_comm_sync(self.c))
+
+    def close(self):
+        if self.c:
+            self.L.mzr_comm_destroy(self.c)
+            self.c = C.c_void_p()
+

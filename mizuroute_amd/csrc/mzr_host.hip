@@ -18,6 +18,8 @@
 #include <queue>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
+#include <rccl/rccl.h>     // types only: the library is loaded at run time (mzr_comm_*)
 
 #include "../../include/mzr.h"
 #include "mzr_device.h"
@@ -175,6 +177,7 @@ struct mzr_domain {
   DBuf<double> runoffW, runoffW2, qi, qlat, qr0Last, basS[2], scratchOut, wm;
   hipStream_t copyStream = nullptr;             // host -> device forcing windows of mzr_run_async, behind the sweep of the window before
   hipEvent_t rwCopied[2] = {nullptr, nullptr}, rwRead[2] = {nullptr, nullptr};
+  hipEvent_t exportDone = nullptr;              // recorded behind the last mzr_export_boundary_dev: what mzr_comm_send waits for
   bool rwUsed[2] = {false, false};
   int rwCur = 0;
   int wmSteps = 0;
@@ -406,6 +409,7 @@ int mzr_destroy(mzr_handle h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
+  if (h->exportDone) (void)hipEventDestroy(h->exportDone);
   for (int i = 0; i < 2; ++i) { if (h->rwCopied[i]) (void)hipEventDestroy(h->rwCopied[i]); if (h->rwRead[i]) (void)hipEventDestroy(h->rwRead[i]); }
   for (int ix = 0; ix < 6; ++ix) { if (h->routeStream[ix]) (void)hipStreamDestroy(h->routeStream[ix]); if (h->routeEvent[ix]) (void)hipEventDestroy(h->routeEvent[ix]); }
   for (auto &e : h->basinEvents) (void)hipEventDestroy(e);
@@ -673,6 +677,8 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
   dim3 block(64), grid((h->nExp + 63) / 64, h->lastW + 1);
   hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, h->lastW, h->nExp, h->N,
                      h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, h->kwN.p ? 1 : 0);
+  if (!h->exportDone) (void)hipEventCreateWithFlags(&h->exportDone, hipEventDisableTiming);
+  (void)hipEventRecord(h->exportDone, h->stream);
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_export_boundary/launch failed");
 }
 
@@ -1434,6 +1440,123 @@ int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long lon
   *n_head = (long long)s.n_head + h->kwtHeadSteps; *n_route = (long long)s.n_route; *n_edges = (long long)s.n_edges;
   if (reset) { (void)hipMemset(h->kwtStat.p, 0, sizeof s); h->kwtHeadSteps = 0; }
   return 0;
+}
+
+// ---- boundary-record transport: RCCL point-to-point, loaded at run time -------------------------------------
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+thread_local std::string g_commMsg;
+int commFail(int code, const std::string &m) { g_commMsg = m; return code; }
+int rcclLoad() {
+  if (g_rccl.lib) return 0;
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+  if (!g_rccl.lib) return commFail(94, std::string("mzr_comm/cannot load librccl.so: ") + dlerror());
+#define MZR_SYM(field, sym) do { *(void **)(&g_rccl.field) = dlsym(g_rccl.lib, sym); if (!g_rccl.field) { g_rccl.lib = nullptr; return commFail(94, "mzr_comm/librccl.so lacks " sym); } } while (0)
+  MZR_SYM(GetUniqueId, "ncclGetUniqueId"); MZR_SYM(CommInitRank, "ncclCommInitRank"); MZR_SYM(CommDestroy, "ncclCommDestroy");
+  MZR_SYM(Send, "ncclSend"); MZR_SYM(Recv, "ncclRecv"); MZR_SYM(GroupStart, "ncclGroupStart"); MZR_SYM(GroupEnd, "ncclGroupEnd");
+  MZR_SYM(GetErrorString, "ncclGetErrorString");
+#undef MZR_SYM
+  return 0;
+}
+int rcclCheck(ncclResult_t r, const char *what) {
+  if (r == ncclSuccess) return 0;
+  return commFail(95, std::string("mzr_comm/") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+}  // namespace
+
+struct mzr_comm_s { ncclComm_t comm = nullptr; int rank = 0, nRanks = 1, device = 0; hipStream_t stream = nullptr; hipEvent_t ev = nullptr; };
+
+int mzr_comm_last_error(char *buf, int len) {
+  if (!buf || len <= 0) return 1;
+  snprintf(buf, len, "%s", g_commMsg.c_str());
+  return 0;
+}
+
+int mzr_comm_unique_id(char id[128]) {
+  if (!id) return 1;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (int rc = rcclLoad()) return rc;
+  ncclUniqueId u;
+  if (int rc = rcclCheck(g_rccl.GetUniqueId(&u), "ncclGetUniqueId")) return rc;
+  memcpy(id, &u, 128);
+  return 0;
+}
+
+int mzr_comm_init(int rank, int nRanks, const char id[128], int device, mzr_comm *out) {
+  if (!out || !id || nRanks < 1 || rank < 0 || rank >= nRanks) return commFail(1, "mzr_comm_init/bad arguments");
+  if (int rc = rcclLoad()) return rc;
+  if (hipSetDevice(device) != hipSuccess) return commFail(90, "mzr_comm_init/hipSetDevice failed");
+  mzr_comm_s *c = new mzr_comm_s();
+  c->rank = rank; c->nRanks = nRanks; c->device = device;
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  if (int rc = rcclCheck(g_rccl.CommInitRank(&c->comm, nRanks, u, rank), "ncclCommInitRank")) { delete c; return rc; }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) {
+    delete c; return commFail(90, "mzr_comm_init/hipStreamCreate failed");
+  }
+  *out = c;
+  return 0;
+}
+
+int mzr_comm_destroy(mzr_comm c) {
+  if (!c) return 0;
+  int rc = 0;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) rc = rcclCheck(g_rccl.CommDestroy(c->comm), "ncclCommDestroy");
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->ev) (void)hipEventDestroy(c->ev);
+  delete c;
+  return rc;
+}
+
+int mzr_comm_send(mzr_comm c, mzr_handle h, const double *dev, long long n, int peer) {
+  if (!c || !h || !dev || n < 0 || peer < 0 || peer >= c->nRanks || peer == c->rank) return commFail(1, "mzr_comm_send/bad arguments");
+  (void)hipSetDevice(c->device);
+  // the record was packed by the handle's last mzr_export_boundary_dev; whatever the handle has queued since (the next
+  // window) must not hold the transfer up, so it runs on the communicator's own stream behind that export only
+  if (h->exportDone) (void)hipStreamWaitEvent(c->stream, h->exportDone, 0);
+  return rcclCheck(g_rccl.Send(dev, (size_t)n, ncclDouble, peer, c->comm, c->stream), "ncclSend");
+}
+
+int mzr_comm_sync(mzr_comm c) {
+  if (!c) return 1;
+  (void)hipSetDevice(c->device);
+  return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : commFail(92, "mzr_comm_sync/device error");
+}
+
+int mzr_comm_recv(mzr_comm c, mzr_handle h, double *dev, long long n, int peer) {
+  if (!c || !h || !dev || n < 0 || peer < 0 || peer >= c->nRanks || peer == c->rank) return commFail(1, "mzr_comm_recv/bad arguments");
+  (void)hipSetDevice(c->device);
+  if (int rc = rcclCheck(g_rccl.Recv(dev, (size_t)n, ncclDouble, peer, c->comm, c->stream), "ncclRecv")) return rc;
+  (void)hipEventRecord(c->ev, c->stream);
+  (void)hipStreamWaitEvent(h->stream, c->ev, 0);      // what the handle queues from now on (the import) sees the record
+  return 0;
+}
+
+int mzr_comm_recv_many(mzr_comm c, mzr_handle h, int nPeers, double *const *dev, const long long *n, const int *peers) {
+  if (!c || !h || nPeers < 0 || (nPeers > 0 && (!dev || !n || !peers))) return commFail(1, "mzr_comm_recv_many/bad arguments");
+  (void)hipSetDevice(c->device);
+  if (int rc = rcclCheck(g_rccl.GroupStart(), "ncclGroupStart")) return rc;
+  int rc = 0;
+  for (int i = 0; i < nPeers && !rc; ++i) {
+    if (peers[i] < 0 || peers[i] >= c->nRanks || peers[i] == c->rank) rc = commFail(1, "mzr_comm_recv_many/bad peer");
+    else rc = rcclCheck(g_rccl.Recv(dev[i], (size_t)n[i], ncclDouble, peers[i], c->comm, c->stream), "ncclRecv");
+  }
+  const int rc2 = rcclCheck(g_rccl.GroupEnd(), "ncclGroupEnd");
+  (void)hipEventRecord(c->ev, c->stream);
+  (void)hipStreamWaitEvent(h->stream, c->ev, 0);
+  return rc ? rc : rc2;
 }
 
 }  // extern "C"

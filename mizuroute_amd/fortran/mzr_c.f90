@@ -37,7 +37,8 @@ MODULE mzr_c
             mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
-            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async
+            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
+            mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync
   public :: mzr_message
 
   INTERFACE
@@ -215,6 +216,51 @@ MODULE mzr_c
       integer(c_int), value :: nSteps
       real(c_double), value :: t_start
       real(c_double), intent(in) :: runoff(*)
+    end function
+    ! boundary-record transport between partitions (RCCL point-to-point inside the library; replaces the gather / scatter
+    ! of mpi_route, mpi_process.f90:1245-1329): id from rank 0 to every rank with the host's MPI_Bcast, then mzr_comm_init
+    integer(c_int) function mzr_comm_unique_id(id) bind(C, name='mzr_comm_unique_id')
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: id(128)
+    end function
+    integer(c_int) function mzr_comm_init(rank, nRanks, id, device, comm) bind(C, name='mzr_comm_init')
+      import :: c_int, c_char, c_ptr
+      integer(c_int), value :: rank, nRanks, device
+      character(kind=c_char), intent(in) :: id(128)
+      type(c_ptr), intent(out) :: comm
+    end function
+    integer(c_int) function mzr_comm_send(comm, h, dev, n, peer) bind(C, name='mzr_comm_send')
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: comm, h, dev
+      integer(c_long_long), value :: n
+      integer(c_int), value :: peer
+    end function
+    integer(c_int) function mzr_comm_recv(comm, h, dev, n, peer) bind(C, name='mzr_comm_recv')
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: comm, h, dev
+      integer(c_long_long), value :: n
+      integer(c_int), value :: peer
+    end function
+    integer(c_int) function mzr_comm_recv_many(comm, h, nPeers, dev, n, peers) bind(C, name='mzr_comm_recv_many')
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: comm, h
+      integer(c_int), value :: nPeers
+      type(c_ptr), intent(in) :: dev(*)
+      integer(c_long_long), intent(in) :: n(*)
+      integer(c_int), intent(in) :: peers(*)
+    end function
+    integer(c_int) function mzr_comm_sync(comm) bind(C, name='mzr_comm_sync')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: comm
+    end function
+    integer(c_int) function mzr_comm_destroy(comm) bind(C, name='mzr_comm_destroy')
+      import :: c_int, c_ptr
+      type(c_ptr), value :: comm
+    end function
+    integer(c_int) function mzr_comm_last_error(buf, len) bind(C, name='mzr_comm_last_error')
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: buf(*)
+      integer(c_int), value :: len
     end function
     ! restart (read_restart.f90:152-742): state back in, the layouts of the getters
     integer(c_int) function mzr_set_irf_state(h, qfuture) bind(C, name='mzr_set_irf_state')

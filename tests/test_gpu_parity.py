@@ -562,3 +562,60 @@ def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib):
     order = np.argsort(reach)
     assert np.array_equal(nw[order], a["nw"]), "particle counts differ between the partitioned and the one-rank run"
     assert np.array_equal(q[order], a["q"]), "interval means differ between the partitioned and the one-rank run"
+
+
+# ---- the library's own transport (mzr_comm_*, RCCL loaded at run time) ----------------------------------------
+def test_comm_single_rank(hip_lib):
+    """Loads librccl, creates and destroys a one-rank communicator (all a single GPU allows); bad peers are refused."""
+    import torch
+    uid = m.api.Comm.unique_id()
+    assert len(uid) == 128
+    c = m.api.Comm(0, 1, uid, device=0)
+    net = m.make_network(50, seed=3)
+    dom = m.RoutingDomain(net, 3600.0, [m.IRF], frac_future=[1.0], uh_offset=np.arange(net.N + 1, dtype=np.int32), uh=np.ones(net.N), max_window=4)
+    buf = torch.zeros(8, dtype=torch.float64, device="cuda")
+    with pytest.raises(m.MzrError):
+        c.send(dom, buf.data_ptr(), 8, 0)          # a rank cannot send to itself
+    c.sync(); c.close()
+
+
+_COMM_PAIR = r"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import mizuroute_amd as m
+rank, path = int(sys.argv[2]), sys.argv[3]
+torch.cuda.set_device(rank)
+if rank == 0:
+    open(path + ".tmp", "wb").write(m.api.Comm.unique_id()); os.rename(path + ".tmp", path)
+while not os.path.exists(path):
+    time.sleep(0.05)
+c = m.api.Comm(rank, 2, open(path, "rb").read(), device=rank)
+net = m.make_network(50, seed=3)
+dom = m.RoutingDomain(net, 3600.0, [m.IRF], frac_future=[1.0], uh_offset=np.arange(net.N + 1, dtype=np.int32), uh=np.ones(net.N), max_window=4, device=rank)
+buf = torch.arange(1000, dtype=torch.float64, device=f"cuda:{rank}") * (1 + rank)
+if rank == 1:
+    c.send(dom, buf.data_ptr(), buf.numel(), 0); c.sync()
+else:
+    got = torch.zeros(1000, dtype=torch.float64, device="cuda:0")
+    c.recv_many(dom, [(got.data_ptr(), got.numel(), 1)]); dom.sync(); c.sync()
+    assert torch.equal(got.cpu(), torch.arange(1000, dtype=torch.float64) * 2), "record did not arrive intact"
+c.close()
+print("ok", rank)
+"""
+
+
+def test_comm_two_ranks(tmp_path, hip_lib):
+    """A boundary record from rank 1 to rank 0 through mzr_comm_send / mzr_comm_recv_many (needs two GPUs)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "pair.py"; script.write_text(_COMM_PAIR)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ps = [subprocess.Popen([sys.executable, str(script), root, str(r), str(tmp_path / "uid")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    for p in ps:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0 and "ok" in out, err[-2000:]
