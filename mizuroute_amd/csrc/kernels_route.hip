@@ -22,8 +22,11 @@ namespace {
 
 constexpr double c13 = 1.0 / 3.0, c23 = 2.0 / 3.0, c53 = 5.0 / 3.0, c103 = 10.0 / 3.0;
 
-struct Chan { double b, zc, S, n, zf, D; double Qbf, n06; };   // width, side slope, slope, Manning n, floodplain slope, bank depth;
+struct Chan { double b, zc, S, n, zf, D; double Qbf, n06;       // width, side slope, slope, Manning n, floodplain slope, bank depth;
                                                                  // per reach, once: bankfull discharge (hydraulic.f90:345) and n**0.6 (:479)
+              double sq1zc, sq1zf, sqSn, b3, bt04, Abf, Pbf, Bbf; };   // ... and the sub-expressions the Newton iterations and Muskingum-Cunge's sub-steps
+                                                                 // would evaluate again and again with the same operands: sqrt(1+zc**2), sqrt(1+zf**2),
+                                                                 // sqrt(S)/n, b**3, b**0.4 (top width of a rectangular channel below bankfull), bankfull A, P, B
 
 __device__ __forceinline__ double d_Btop(double y, const Chan &c) {
   if (y <= c.D) return c.b + 2 * y * c.zc;
@@ -31,9 +34,9 @@ __device__ __forceinline__ double d_Btop(double y, const Chan &c) {
   return bt + c.zf * (y - c.D) * 2;
 }
 __device__ __forceinline__ double d_Pwet(double y, const Chan &c) {
-  if (y <= c.D) return c.b + 2 * y * sqrt(1 + c.zc * c.zc);
-  const double p = c.b + 2 * c.D * sqrt(1 + c.zc * c.zc);
-  return p + 2 * (y - c.D) * sqrt(1 + c.zf * c.zf);
+  if (y <= c.D) return c.b + 2 * y * c.sq1zc;
+  const double p = c.b + 2 * c.D * c.sq1zc;
+  return p + 2 * (y - c.D) * c.sq1zf;
 }
 __device__ __forceinline__ double d_area(double y, const Chan &c) {
   if (y <= c.D) return y * (c.b + c.zc * y);
@@ -53,15 +56,14 @@ __device__ double d_water_height(double flowArea, const Chan &c) {
 // Newton-Raphson normal depth, hydraulic.f90:306-433 (integer powers as left-to-right products)
 __device__ double d_flow_depth(double Qin, const Chan &c) {
   if (!(Qin > 1.e-50)) return 0.0;
-  const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c), Bbf = d_Btop(c.D, c);
-  const double sqS = sqrt(c.S);
+  const double Abf = c.Abf, Pbf = c.Pbf, Bbf = c.Bbf;
   const double Qbf = c.Qbf;
   double err = 100.0, fd = 0.0;
   if (Qin < Qbf) {
-    const double t = sqS / c.n / Qin;
+    const double t = c.sqSn / Qin;
     const double Coef1 = t * t * t;
-    const double Coef2 = 2 * sqrt(c.zc * c.zc + 1.0);
-    double y0 = pow_0p2(1.0 / Coef1 / (c.b * c.b * c.b));
+    const double Coef2 = 2 * c.sq1zc;
+    double y0 = pow_0p2(1.0 / Coef1 / c.b3);
     int guard = 0;
     while (err > 0.005 && guard++ < 200) {
       const double A = d_area(y0, c), Bt = d_Btop(y0, c), P = d_Pwet(y0, c);
@@ -74,6 +76,7 @@ __device__ double d_flow_depth(double Qin, const Chan &c) {
     }
   } else {
     double y0 = c.D + 2.0;
+    const double sqS = sqrt(c.S);
     const double Coef1 = sqS / c.n / pow(Pbf, c23);
     const double Coef2 = 2 * pow(c.zf / 2, c53) * sqS / c.n / pow(c.zf * c.zf + 1.0, c13);
     int guard = 0;
@@ -97,7 +100,8 @@ __device__ double d_celerity(double Qin, double y, const Chan &c) {
   if (!(y > 0.0)) return 0.0;
   const double Bt = d_Btop(y, c);
   const double Sf = d_friction_slope(Qin, y, c);
-  return c53 * pow_0p3(Sf) * pow_0p4(Qin) / pow_0p4(Bt) / c.n06;
+  const double bt04 = (y <= c.D && c.zc == 0.0) ? c.bt04 : pow_0p4(Bt);      // rectangular below bankfull: Bt == b
+  return c53 * pow_0p3(Sf) * pow_0p4(Qin) / bt04 / c.n06;
 }
 __device__ double d_diffusivity(double Qin, double y, const Chan &c) {
   if (!(y > 0.0)) return 0.0;
@@ -176,7 +180,11 @@ __device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, dou
 
 __device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
   Chan c; c.b = d.width[r]; c.zc = d.side[r]; c.S = d.slope[r]; c.n = d.mann[r]; c.zf = d.fldp[r]; c.D = d.depth[r];
+  c.sq1zc = sqrt(1 + c.zc * c.zc); c.sq1zf = sqrt(1 + c.zf * c.zf);
+  c.sqSn = sqrt(c.S) / c.n; c.b3 = c.b * c.b * c.b;
+  c.bt04 = pow_0p4(c.b);
   const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c);
+  c.Abf = Abf; c.Pbf = Pbf; c.Bbf = d_Btop(c.D, c);
   c.Qbf = Abf * pow_2_3(Abf / Pbf) * sqrt(c.S) / c.n;      // hydraulic.f90:345
   c.n06 = pow_0p6(c.n);
   return c;
@@ -300,6 +308,11 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
           if (Cn > 1.0) { ntSub = (int)ceil(dt / L * ck); dTsub = dt / ntSub; }
           const double Y = 0.5;
           double qin_prev = Q00, qout_prev = Q01, ssum = 0.0;
+          // From the second sub-step on the inflow pair is (Q10, Q10), so a sub-step is a fixed map of the previous
+          // outflow alone, and that map contracts towards Q10: once it returns its own argument (or alternates between two
+          // neighbouring doubles) every remaining sub-step is known, and only their running sum -- the same additions in
+          // the same order -- is left to do.  With 20..200 sub-steps per step (smooth channels) most of them are skipped.
+          double qprev2 = -1.0;
           for (int ix = 1; ix <= ntSub; ++ix) {
             const double qin = Q10;
             double qo;
@@ -320,6 +333,17 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
               qo = 0.0;
             }
             ssum = ssum + qo;
+            if (ix >= 2 && ix < ntSub) {
+              if (qo == qout_prev) {                       // fixed point of the sub-step map
+                for (int k = ix + 1; k <= ntSub; ++k) ssum = ssum + qo;
+                break;
+              }
+              if (ix >= 3 && qo == qprev2) {               // two-cycle: ..., qo, qout_prev, qo, ...
+                for (int k = ix + 1; k <= ntSub; ++k) ssum = ssum + (((k - ix) & 1) ? qout_prev : qo);
+                break;
+              }
+            }
+            qprev2 = qout_prev;
             qin_prev = qin; qout_prev = qo;
           }
           Q11 = ssum / (double)ntSub;

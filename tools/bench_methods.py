@@ -14,8 +14,11 @@ frac = uhmod.basin_uh(3600.0, 2.5, 86400.0)
 uh_off, uh = uhmod.make_uh(net.params["RLENGTH"], 3600.0, 1.5, 5000.0)
 dev = torch.device("cuda", 0)
 out = {}
+sel = os.environ.get("METHODS", "")
 for name, meth in (("SUM", [m.SUM]), ("IRF", [m.IRF]), ("KWT", [m.KWT]), ("KW", [m.KW]), ("MC", [m.MC]), ("DW", [m.DW]),
                    ("SUM+IRF+KWT+KW+DW in one domain (one stream per method)", [m.SUM, m.IRF, m.KWT, m.KW, m.DW])):
+    if sel and name not in sel.split(","):
+        continue
     dom = m.RoutingDomain(net, 3600.0, meth, frac_future=frac, uh_offset=uh_off, uh=uh, max_window=W)
     ros = [bench.device_runoff(torch, net.H, W, k * W, 7, dev) for k in range(NWIN + 1)]
     torch.cuda.synchronize()
