@@ -39,6 +39,21 @@ DT = 3600.0
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+# BASELINE.json configs as one GPU sees them: c2 = the headline (~100 k reaches, KWT); c3-c5 = one of eight shards
+# (~3 M / 8 KWT; ~5 M / 8 IRF + Muskingum-Cunge; ~3 M / 8 diffusive wave, 1 % lakes, floodplains).
+# `dominant` = the method whose kernel the roofline object describes, `bytes` = SURVEY.md 8(d) bytes per reach-step
+# of that method for U immediate upstream reaches (KWT: from the particle counters instead).
+CONFIGS = {
+    "c2": dict(reaches=100_000, methods="2", window=8192, workload="synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
+    "c3": dict(reaches=375_000, methods="2", window=2048, workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
+    "c4": dict(reaches=625_000, methods="14", window=512, dominant=4, bytes=lambda U: 152 + 12 * U,
+               workload="one of 8 shards of a ~5 M-reach MERIT-like network, IRF-UH + Muskingum-Cunge (route_opt 14), dt 3600 s, hillslope UH on"),
+    "c5": dict(reaches=375_000, methods="5", window=512, dominant=5, bytes=lambda U: 440 + 12 * U, lakes=0.01, floodplain=True,
+               workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, diffusive wave (route_opt 5), 1 % lakes (Doll / Hanasaki / HYPE), "
+                        "floodplains, dt 3600 s, hillslope UH on"),
+}
+
+
 def kwt_bytes(tr):
     """Algorithmic bytes of the KWT sweep from particle counters:
     routed reach: 25*(W_in + W_up + W_out) + 68 + 44*U ; headwater reach: 53."""
@@ -68,7 +83,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240):
+def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=(2,), uh=None, lakes=None):
     """Reference Fortran solvers (oracle/_ref/ref_route) on the host cores, bounded sample of the SAME
     forcing the GPU leg routes: `sample_steps` steps timed after `spinup_steps` untimed ones (particle lists at
     steady state), OpenMP over the reference's own stream-order branches at 16 threads (the best count of the
@@ -77,17 +92,25 @@ def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240):
     if not refrun.available():
         return None
     cores = os.cpu_count() or 1
-    uh_off = np.arange(net.N + 1, dtype=np.int32)
-    uh = np.ones(net.N)
+    uh_off, uhv = uh if uh is not None else (np.arange(net.N + 1, dtype=np.int32), np.ones(net.N))
+    methods = list(methods)
     nt = max(1, min(16, cores))
     sched = refrun.streamorder_schedule(net)
-    r = refrun.run_case(net, runoff[:spinup_steps + sample_steps], DT, [2], nthreads=nt, schedule=sched,
-                        uh=(frac, uh_off, uh), dump_every=0, time_from=spinup_steps)
-    one = refrun.run_case(net, runoff[:36], DT, [2], nthreads=1, uh=(frac, uh_off, uh), dump_every=0, time_from=24)
+    kw = dict(uh=(frac, uh_off, uhv), dump_every=0)
+
+    def lk(n):      # lake forcing of the first n steps
+        return {} if lakes is None else dict(lakes=dict(lakes, evap=lakes["evap"][:n], precip=lakes["precip"][:n], ymd=lakes["ymd"][:n]))
+
+    n_all = spinup_steps + sample_steps
+    r = refrun.run_case(net, runoff[:n_all], DT, methods, nthreads=nt, schedule=sched, time_from=spinup_steps, **kw, **lk(n_all))
+    one = refrun.run_case(net, runoff[:36], DT, methods, nthreads=1, time_from=24, **kw, **lk(36))
+    if r["ierr"] or one["ierr"]:
+        raise RuntimeError(f"reference harness ierr {r['ierr']} at step {r['ierr_step']}: {r['stdout'][-300:]}")
+    # (the harness counts a reach-step per active method, as `value` does)
     return {"value": r["reach_steps_per_s"], "unit": "reaches*timesteps/s", "cores": nt, "kind": "reference",
             "host_cores": cores, "cpu_model": cpu_model(),
             "one_thread": one["reach_steps_per_s"],
-            "sample": f"same {net.N}-reach network and forcing, KWT, {sample_steps} steps timed after {spinup_steps} spin-up "
+            "sample": f"same {net.N}-reach network and forcing, route_opt {''.join(str(x) for x in methods)}, {sample_steps} steps timed after {spinup_steps} spin-up "
                       f"steps at {nt} OpenMP threads over the reference's stream-order branches (main_route.f90:356-405); "
                       f"unmodified reference kwt_route.f90/main_route.f90 built with flang -O2; one_thread = 12 steps "
                       f"timed after 24 (lists not yet at steady state: an upper bound for one core)"}
@@ -100,7 +123,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1, help="untimed batches")
     ap.add_argument("--window", type=int, default=0,
                     help="model time steps per batch; 0 = 8192, fewer when --steps is large (about 2M model steps in total)")
-    ap.add_argument("--reaches", type=int, default=N_REACH)
+    ap.add_argument("--reaches", type=int, default=0, help="reaches per GPU (default: what --config says)")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration: c2 (default, the metric's headline) or the per-GPU shard of c3 / c4 / c5 (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default="", help="write <DUMP>.rank<r>.npz with the per-reach interval mean of REACH_Q and the particle "
                     "counts of the reaches this rank routes (tests: a partitioned run must equal the one-rank run); forcing is then "
@@ -140,15 +165,31 @@ def main():
     # the mainstem owner (rank 0) once per window over RCCL point-to-point.
     frac = uhmod.basin_uh(DT, 2.5, 86400.0)
     K, KW = max(1, args.steps), max(0, args.warmup)
+    cfg = CONFIGS[args.config]
+    if world > 1 and args.config != "c2":
+        raise SystemExit("--config c3/c4/c5 are per-GPU shards: run them with --gpus 1")
+    methods = [int(c) for c in cfg["methods"]]
+    kwt_run = methods == [m.KWT]
+    DOM = cfg.get("dominant", m.KWT)          # the method the roofline object describes
     W = args.window
     if W <= 0:   # keep the whole run at about two million model time steps whatever K the caller asks for
-        W = 8192
+        W = cfg["window"]
         while W > 128 and W * (K + KW) > (1 << 21):
             W //= 2
-    net = m.make_network(args.reaches * world, seed=20240529)
+    n_reach = args.reaches or cfg["reaches"]
+    net = m.make_network(n_reach * world, seed=20240529, floodplain=bool(cfg.get("floodplain")))
     router = None
+    lakes = None
     if world == 1:
-        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W, device=local_rank)
+        extra = {}
+        if not kwt_run:
+            uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], DT, 1.5, 5000.0)
+            extra = dict(uh_offset=uh_off, uh=uhv)
+        if cfg.get("lakes"):
+            from mizuroute_amd.synthetic import make_lakes
+            lakes = make_lakes(net, W, DT, seed=9, frac=cfg["lakes"], input_option=1)     # one window of lake forcing, used for every window
+            extra["lakes"] = lakes
+        dom = m.RoutingDomain(net, DT, methods, frac_future=frac, max_window=W, device=local_rank, **extra)
         doms = [(dom, net.H)]
     else:
         from mizuroute_amd.partition import PartitionedRouter, partition_network
@@ -228,6 +269,8 @@ def main():
             ros = pool[k % 2]
             t_start = state["t"]
             if router is None:
+                if lakes is not None:
+                    dom.set_lake_forcing(0, W)
                 dom.run_device(W, t_start, ros[0].data_ptr())
             else:
                 pt = ros[0].data_ptr() if router.trib is not None else 0
@@ -246,7 +289,7 @@ def main():
     torch.cuda.synchronize()
     run_batches(KW)
     sync_all()
-    dom.timing(m.KWT, reset=True)
+    dom.timing(DOM, reset=True)
 
     if dist is not None:
         dist.barrier()
@@ -258,12 +301,12 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tm = dom.timing(m.KWT, reset=True)
+    tm = dom.timing(DOM, reset=True)
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    total_reach_steps = float(net.N) * K * W
+    total_reach_steps = float(net.N) * K * W * len(methods)      # every active method routes every reach every step
     value = total_reach_steps / elapsed
 
     if args.dump:      # per-reach results of everything routed so far, by global reach index
@@ -280,7 +323,7 @@ def main():
     # ---- the same timed region with the forcing handed over in page-locked host memory (N = 1): two host
     # windows, copied by the library on its own stream while the window before is routed
     value_h2d = None
-    if world == 1 and not args.no_h2d:
+    if world == 1 and not args.no_h2d and lakes is None:
         try:
             hosts = [torch.empty((W, net.H), dtype=torch.float64).pin_memory() for _ in range(2)]
             for hb, ro in zip(hosts, pool):
@@ -295,7 +338,7 @@ def main():
                 dom.run_async(W, state["t"], hosts[k % 2].data_ptr())
                 state["t"] += W * DT
             dom.sync()
-            value_h2d = float(net.N) * K * W / (time.perf_counter() - t1)
+            value_h2d = float(net.N) * K * W * len(methods) / (time.perf_counter() - t1)
             state["batch"] = k0 + 1 + K
             del hosts
         except Exception as e:   # reported, never required
@@ -303,7 +346,7 @@ def main():
 
     # ---- one main_route-equivalent call per model time step (mzr_step: forcing row in, sweep, sync)
     single = None
-    if world == 1 and not args.no_single_step:
+    if world == 1 and not args.no_single_step and lakes is None:
         n1 = 40
         rows = pool[0][0][:n1].cpu().numpy()
         tb = state["t"]
@@ -313,7 +356,7 @@ def main():
             dom.step(tb + k * DT, tb + (k + 1) * DT, rows[k])
         el1 = time.perf_counter() - t1
         state["t"] = tb + n1 * DT
-        single = {"value": float(net.N) * (n1 - 1) / el1, "unit": "reaches*timesteps/s", "ms_per_model_timestep": el1 / (n1 - 1) * 1e3,
+        single = {"value": float(net.N) * (n1 - 1) * len(methods) / el1, "unit": "reaches*timesteps/s", "ms_per_model_timestep": el1 / (n1 - 1) * 1e3,
                   "steps": n1 - 1, "what": "mzr_step: host forcing row -> device, one sweep over the stages, results synchronised every step"}
 
     # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
@@ -327,7 +370,7 @@ def main():
             run_batches(1)
             sync_all()
     if rank == 0 and not args.no_roofline:
-        dom.timing(m.KWT, reset=True)
+        dom.timing(DOM, reset=True)
         dom.set_profiling(1)
         torch.cuda.synchronize()
         if world > 1:
@@ -337,8 +380,18 @@ def main():
         sync_all()
         t_prof = time.perf_counter() - t_prof
         dom.set_profiling(0)
-        pt = dom.timing(m.KWT, reset=True)
+        pt = dom.timing(DOM, reset=True)
         ktf = pt["kernel_ms"] * 1e-3 / t_prof if t_prof > 0 else None
+        if not kwt_run:      # Eulerian solvers: SURVEY.md 8(d) byte model of the dominant method, one lane per reach, one launch per stage
+            U = float(net.upIndex.size) / net.N
+            per_rs = float(cfg["bytes"](U))
+            launches = max(1, pt["launches"])
+            achieved = per_rs * pt["reach_steps"] / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": f"k_stage<{DOM}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": per_rs * pt["reach_steps"] / launches, "bytes_per_reach_step": per_rs,
+                    "avg_launch_us": pt["kernel_ms"] / launches * 1e3, "launches": launches,
+                    "note": "FP64-transcendental kernel (Newton normal depth, fifth-root powers): far from the HBM roofline by construction; "
+                            "FP64 instruction counts per kernel are in profiles/*_pmc.md"}
     # particle-traffic counters (device atomics) are collected on one more window so that they do
     # not disturb the event-timed launches; bytes per reach-step of that window x the reach-steps
     # of the timed window = algorithmic bytes of the timed window
@@ -346,7 +399,7 @@ def main():
         dist.barrier()
         run_batches(1)
         sync_all()
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and kwt_run:
         dom.set_profiling(2)
         dom.kwt_traffic(reset=True)
         torch.cuda.synchronize()
@@ -382,8 +435,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         try:
-            ro_cpu = device_runoff(torch, net.H, 480, 0, 7, dev).cpu().numpy()      # the first 480 steps of the GPU leg's forcing
-            cpu = cpu_baseline(net, frac, ro_cpu)
+            n_spin = 240 if args.config == "c2" else 48                                     # the shards are 4-6 x larger: a bounded sample
+            ro_cpu = device_runoff(torch, net.H, 2 * n_spin, 0, 7, dev).cpu().numpy()      # the first steps of the GPU leg's forcing
+            cpu = cpu_baseline(net, frac, ro_cpu, n_spin, n_spin, methods, None if kwt_run else (uh_off, uhv), lakes)
         except Exception as e:   # the baseline is reported, never required
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
 
@@ -393,14 +447,14 @@ def main():
             "n_gpus": world, "steps": K, "warmup": KW,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on",
+            "config": {"workload": cfg["workload"], "baseline_config": args.config, "route_opt": cfg["methods"],
                        "reaches_per_gpu": net.N // world, "reaches_total": net.N, "stages": n_stages,
                        "max_stage_width": max_width,
                        "step": "one forcing window (batch) of window_steps model time steps",
                        "window_steps": W, "model_timesteps_timed": K * W, "ms_per_model_timestep": elapsed / (K * W) * 1e3,
                        "simulated_years_per_wallclock_day": (K * W * DT / 31536000.0) / (elapsed / 86400.0),
                        "kernel_time_fraction": ktf,
-                       "kwt_sweep": dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 else None,
+                       "kwt_sweep": dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 and m.KWT in methods else None,
                        "parallelism": ("1 domain" if world == 1 else
                                        f"{world} sub-basin partitions (reference mainstem rule), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
