@@ -101,9 +101,10 @@ int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int
    Qrate_prim Qrate_amp Qrate_phs prim_F A_avg Qsim_mode | H06_Smax alpha envfact S_ini c1 c2 exponent
    denominator c_compare frac_Sdead E_rel_ini | H06_I_Jan..Dec | H06_D_Jan..Dec | H06_purpose I_mem_F
    D_mem_F I_mem_L D_mem_L.   calendarId 0 noleap/365_day, 1 standard/gregorian.
-   Not supported: target-volume lakes (is_vol_wm) and the Hanasaki demand memory (H06_D_mem_F).
+   The Hanasaki inflow and demand memories (H06_I_mem_F, H06_D_mem_F; the demand is REACH_WM_FLUX, so it needs
+   is_flux_wm) and target-volume lakes (mzr_set_lake_target) are included.
    With several routing methods each method keeps its own copy of the mutable Hanasaki
-   parameters (the reference shares them through RPARAM).  Call after mzr_set_network. */
+   parameters (the reference shares them through RPARAM, so its methods interact).  Call after mzr_set_network. */
 #define MZR_NLAKEPAR 56
 int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, const int *lakeReach,
                   const int *modelType, const double *par);
@@ -111,6 +112,12 @@ int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, 
    and month / day / day-of-year of simDatetime(1) for every step */
 int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip,
                          const int *month, const int *day, const int *dayofyear);
+/* Lakes that follow a target volume instead of their parametric release (is_vol_wm; NETOPO%LakeTargVol,
+   lake_route.f90:197-205): targVol[nLake] flags, jumpstart = is_vol_wm_jumpstart (the first step starts from the
+   target, :140-142).  The targets of a window, REACH_WM_VOL [nSteps][nRch] in the caller's reach order
+   (main_route.f90:115-122; only lake reaches are read), are set before every mzr_run / mzr_step while a flag is on. */
+int mzr_set_lake_target(mzr_handle h, const int *targVol, int jumpstart);
+int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol);
 
 /* cold start (init_model_data.f90:399-505); must follow the setters above */
 int mzr_init_state(mzr_handle h);

@@ -50,7 +50,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing",
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_target", "mzr_set_wm_vol",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
@@ -116,6 +116,8 @@ def load_library():
     L.mzr_remap_runoff_dev.argtypes = [vp, ci, vp, vp]
     L.mzr_run_src_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_set_lakes.argtypes = [vp, ci, ci, ci, ip, ip, dp]
+    L.mzr_set_lake_target.argtypes = [vp, ip, ci]
+    L.mzr_set_wm_vol.argtypes = [vp, ci, dp]
     L.mzr_set_lake_forcing.argtypes = [vp, ci, dp, dp, ip, ip, ip]
     L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
     L.mzr_get_window_q.argtypes = [vp, ci, dp]
@@ -185,6 +187,8 @@ class RoutingDomain:
         if lakes is not None:
             self._check(L.mzr_set_lakes(self.h, int(lakes["input_option"]), int(lakes["calendar_id"]), len(lakes["reach"]),
                                         i32(lakes["reach"]), i32(lakes["model_type"]), f64(lakes["par"])))
+            if "targ_vol" in lakes:      # lakes that follow a target volume (is_vol_wm)
+                self._check(L.mzr_set_lake_target(self.h, i32(lakes["targ_vol"]), int(lakes.get("vol_jumpstart", 0))))
         self.n_export = 0 if export_reaches is None else len(export_reaches)
         self.n_halo = 0 if halo_reaches is None else len(halo_reaches)
         if self.n_export or self.n_halo:
@@ -250,6 +254,8 @@ class RoutingDomain:
         self._check(self.L.mzr_set_lake_forcing(self.h, int(w), c(lk["evap"][first:first + w], np.float64),
                                                 c(lk["precip"][first:first + w], np.float64), c(ymd[:, 1], np.int32),
                                                 c(ymd[:, 2], np.int32), c(doy, np.int32)))
+        if "targ_vol" in lk:      # REACH_WM_VOL of the window
+            self._check(self.L.mzr_set_wm_vol(self.h, int(w), c(lk["wm_vol"][first:first + w], np.float64)))
 
     def run_device(self, n_steps, t_start, runoff_dev_ptr):
         """Asynchronous window on device-resident runoff [n_steps, nHru] (e.g. a torch tensor's data_ptr())."""

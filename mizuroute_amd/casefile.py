@@ -63,7 +63,7 @@ def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_poin
                 int(net.upOffset[-1]), int(net.hruOffset[-1]), len(orderOffset) - 1, len(branchOffset) - 1,
                 1 if uh is not None else 0, len(uh[0]) if uh is not None else 0,
                 int(uh[1][-1]) if uh is not None else 0, int(dump_every), 1 if wm_flux is not None else 0,
-                1 if lakes is not None else 0]
+                (2 if "targ_vol" in lakes else 1) if lakes is not None else 0]      # 2: + target-volume section
         f.write(struct.pack(f"<{len(ints)}i", *ints))
         f.write(struct.pack("<8d", dt, min_length_route, runoff_min, fshape, tscale, velo, diff, t_start))
         for a in (net.downIndex, net.reachId, net.upOffset, net.upIndex, net.upGood, net.hruOffset, net.hruIndex):
@@ -90,5 +90,9 @@ def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_poin
             f.write(np.ascontiguousarray(lakes["par"], dtype="<f8").tobytes())
             f.write(np.ascontiguousarray(lakes["evap"], dtype="<f8").tobytes())
             f.write(np.ascontiguousarray(lakes["precip"], dtype="<f8").tobytes())
+            if "targ_vol" in lakes:      # NETOPO%LakeTargVol flags, is_vol_wm_jumpstart, REACH_WM_VOL[nSteps][N]
+                f.write(np.ascontiguousarray(lakes["targ_vol"], dtype="<i4").tobytes())
+                f.write(struct.pack("<i", int(lakes.get("vol_jumpstart", 0))))
+                f.write(np.ascontiguousarray(lakes["wm_vol"], dtype="<f8").tobytes())
 
 

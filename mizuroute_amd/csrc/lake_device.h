@@ -22,6 +22,33 @@ __device__ inline double ring_mean(const double *ring, int L, int head, int n) {
   return s / n;
 }
 
+// Hanasaki memory of one family (inflow: lake_route.f90:227-276, demand: :288-331): the new value enters the ring of
+// the current month, and the monthly means that can have changed are recomputed.  M = the family's twelve mutable
+// monthly parameters (stride nL).  The reference never updates the November inflow (:262-265) but does update the
+// November demand (:322).
+__device__ inline void h06_memory(double *ring, int *head, int L, double *M, size_t nL, int ls, bool demand, int memL, double newval,
+                                  int month, double dt, int calendarId) {
+  const double secprday = 86400.0;
+  const int L31 = (int)floor(memL * 31 * secprday / dt), L30 = (int)floor(memL * 30 * secprday / dt);
+  const int LF = calendarId == 0 ? (int)floor(memL * 28 * secprday / dt) : (int)floor(memL * 28.25 * secprday / dt);
+  const bool first = head[12] == 0;
+  if (first) {
+    for (int m = 0; m < 12; ++m) { head[m] = 0; const double v = M[(size_t)m * nL + ls]; for (int k = 0; k < L31; ++k) ring[(size_t)m * L + k] = v; }
+    head[12] = 1;
+  } else {
+    const int m = month - 1;
+    int hd = head[m] - 1; if (hd < 0) hd = L31 - 1;
+    ring[(size_t)m * L + hd] = newval; head[m] = hd;
+  }
+  // the reference recomputes every monthly mean each step; only the row just shifted can change (all rows on the first call)
+  for (int m = 0; m < 12; ++m) {
+    if (!first && m != month - 1) continue;
+    if (m == 10 && !demand) continue;
+    const int n = (m == 1) ? LF : (m == 3 || m == 5 || m == 8 || m == 10) ? L30 : L31;
+    M[(size_t)m * nL + ls] = ring_mean(ring + (size_t)m * L, L31, head[m], n);
+  }
+}
+
 // returns REACH_Q; updates vol (REACH_VOL(1)), vol0, ele, wb
 __device__ inline double lake_route(const MzrDev &d, int r, int t, int ls, const double *Qrow, double qlat,
                                     double &vol, double &vol0, double &ele, double &wb, double &wmAct, bool coherent = false) {
@@ -39,8 +66,11 @@ __device__ inline double lake_route(const MzrDev &d, int r, int t, int ls, const
       q_up = q_up + (coherent ? __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)(Qrow + u0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                               : Qrow[u0 + i]);
   }
-  if (d.iTime0 + t + 1 == 1) {   // cold start, lake_route.f90:121-144
-    vol = type == 0 ? P(P_D03_S0) : type == 1 ? P(P_D03_MaxStorage) : type == 2 ? P(P_H06_Smax)
+  const bool targ = d.lakeTarg && d.lakeTarg[ls] != 0;
+  const double wmvol = (targ && d.lakeWmVol) ? d.lakeWmVol[(size_t)t * nL + ls] : 0.0;      // REACH_WM_VOL
+  if (d.iTime0 + t + 1 == 1) {   // first step: jump start to the target volume, or cold start (lake_route.f90:139-158)
+    if (d.volJumpstart && targ) vol = wmvol;
+    else vol = type == 0 ? P(P_D03_S0) : type == 1 ? P(P_D03_MaxStorage) : type == 2 ? P(P_H06_Smax)
                                                                                  : (P(P_HYP_E_emr) - P(P_HYP_E_zero)) * P(P_HYP_A_avg);
   }
   vol0 = vol;
@@ -65,7 +95,10 @@ __device__ inline double lake_route(const MzrDev &d, int r, int t, int ls, const
     else { wmAct = vol / dt; vol = 0.0; }
   }
   double Q = 0.0;
-  if (type == 0) {
+  if (targ) {               // the lake follows the given target volume, :197-205
+    if (vol < wmvol) Q = 0;
+    else { Q = (vol - wmvol) / dt; vol = wmvol; }
+  } else if (type == 0) {
     Q = 0.0;
   } else if (type == 1) {   // Doll 2003, :208-224
     const double S0 = P(P_D03_S0);
@@ -76,31 +109,11 @@ __device__ inline double lake_route(const MzrDev &d, int r, int t, int ls, const
     vol = vol - Q * dt;
   } else if (type == 2) {   // Hanasaki 2006, :225-370
     double *Im = mut, *Dm = mut + (size_t)12 * nL;   // Im[m*nL+ls]
-    if (P(P_H06_I_mem_F) != 0.0 && d.lakeRing) {     // inflow memory, :227-276
-      const int L = d.lakeL;
-      double *ring = d.lakeRing + (size_t)ls * 12 * L;
-      int *head = d.lakeHead + (size_t)ls * 13;
-      const int memL = (int)P(P_H06_I_mem_L);
-      const int L31 = (int)floor(memL * 31 * secprday / dt), L30 = (int)floor(memL * 30 * secprday / dt);
-      const int LF = d.calendarId == 0 ? (int)floor(memL * 28 * secprday / dt) : (int)floor(memL * 28.25 * secprday / dt);
-      const bool first = head[12] == 0;
-      if (first) {
-        for (int m = 0; m < 12; ++m) { head[m] = 0; const double v = Im[(size_t)m * nL + ls]; for (int k = 0; k < L31; ++k) ring[(size_t)m * L + k] = v; }
-        head[12] = 1;
-      } else {
-        const int m = month - 1;
-        int hd = head[m] - 1; if (hd < 0) hd = L31 - 1;
-        ring[(size_t)m * L + hd] = q_up; head[m] = hd;
-      }
-      // the reference recomputes every monthly mean each step; only the row just shifted can change
-      // (all rows on the first call).  November is never updated by the reference (:262-265).
-      for (int m = 0; m < 12; ++m) {
-        if (!first && m != month - 1) continue;
-        if (m == 10) continue;
-        const int n = (m == 1) ? LF : (m == 3 || m == 5 || m == 8) ? L30 : L31;
-        Im[(size_t)m * nL + ls] = ring_mean(ring + (size_t)m * L, L31, head[m], n);
-      }
-    }
+    if (P(P_H06_I_mem_F) != 0.0 && d.lakeRing)       // inflow memory, :227-276
+      h06_memory(d.lakeRing + (size_t)ls * 12 * d.lakeL, d.lakeHead + (size_t)ls * 13, d.lakeL, Im, nL, ls, false, (int)P(P_H06_I_mem_L), q_up, month, dt, d.calendarId);
+    if (P(P_H06_D_mem_F) != 0.0 && d.lakeRingD && d.is_flux_wm && wmflux != -9999.0)      // demand memory, :288-331 (a demand cannot be negative)
+      h06_memory(d.lakeRingD + (size_t)ls * 12 * d.lakeLD, d.lakeHeadD + (size_t)ls * 13, d.lakeLD, Dm, nL, ls, true, (int)P(P_H06_D_mem_L),
+                 wmflux < 0 ? 0.0 : wmflux, month, dt, d.calendarId);
     double sI = 0.0, sD = 0.0;
     for (int m = 0; m < 12; ++m) { sI = sI + Im[(size_t)m * nL + ls]; sD = sD + Dm[(size_t)m * nL + ls]; }
     const double I_yearly = sI / 12, D_yearly = sD / 12;

@@ -119,6 +119,11 @@ struct MzrDev {
   double *lakeMut;            // [25][nLake] of the method being launched: I_months, D_months, E_rel_ini
   double *lakeRing;           // [nLake][12][lakeL] Hanasaki inflow memory of the method being launched
   int *lakeHead;              // [nLake][13] ring heads per month, [12] = initialised flag
+  double *lakeRingD;          // [nLake][12][lakeLD] Hanasaki demand memory (lake_route.f90:288-331), same layout
+  int *lakeHeadD;             // [nLake][13]
+  const int *lakeTarg;        // [nLake] the lake follows a target volume (NETOPO%LakeTargVol, lake_route.f90:197-205); null = none does
+  const double *lakeWmVol;    // [W][nLake] REACH_WM_VOL of the window
+  int volJumpstart, lakeLD;   // is_vol_wm_jumpstart (lake_route.f90:140-142); ring length of the demand memory
   const double *lakeEvap, *lakePrecip;   // [W][nLake] m3/s
   const int *calMonth, *calDay, *calDoy; // [W]
   int nLake, LakeInputOption, calendarId, lakeL;

@@ -64,7 +64,7 @@ struct RouteBufs {
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
-  DBuf<double> lakeMut, lakeRing; DBuf<int> lakeHead;   // per-method mutable Hanasaki parameters / inflow memory
+  DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
   long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
@@ -203,7 +203,9 @@ struct mzr_domain {
   DBuf<MzrKwtStat> kwtStat;
   DBuf<unsigned long long> dbgCycles;
   // lakes
-  int nLake = 0, LakeInputOption = 0, calendarId = 0, lakeL = 0, lakeSteps = 0;
+  int nLake = 0, LakeInputOption = 0, calendarId = 0, lakeL = 0, lakeLD = 0, lakeSteps = 0, volJumpstart = 0, wmVolSteps = 0;
+  bool anyLakeTarget = false;
+  DBuf<int> lakeTarg; DBuf<double> lakeWmVol;
   std::vector<double> h_lakePar; std::vector<int> h_lakeModel, h_lakeSlot;
   DBuf<int> lakeSlot, lakeModel, lakeReachInt, calMonth, calDay, calDoy;
   DBuf<double> lakePar, lakeEvap, lakePrecip, lakeFE, lakeFP;
@@ -263,7 +265,8 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
   d.lakeSlot = h->nLake ? h->lakeSlot.p : nullptr; d.lakeModel = h->lakeModel.p; d.lakePar = h->lakePar.p;
   d.lakeEvap = h->lakeEvap.p; d.lakePrecip = h->lakePrecip.p; d.calMonth = h->calMonth.p; d.calDay = h->calDay.p; d.calDoy = h->calDoy.p;
-  d.nLake = h->nLake; d.LakeInputOption = h->LakeInputOption; d.calendarId = h->calendarId; d.lakeL = h->lakeL;
+  d.nLake = h->nLake; d.LakeInputOption = h->LakeInputOption; d.calendarId = h->calendarId; d.lakeL = h->lakeL; d.lakeLD = h->lakeLD;
+  d.lakeTarg = h->anyLakeTarget ? h->lakeTarg.p : nullptr; d.lakeWmVol = h->lakeWmVol.p; d.volJumpstart = h->volJumpstart;
   d.iTime0 = h->totalSteps;
   d.haloSlot = h->nHalo ? h->haloSlot.p : nullptr; d.exportSlot = h->nExp ? h->exportSlot.p : nullptr;
   d.nHalo = h->nHalo; d.nExp = h->nExp; d.Wmax = h->cfg.maxWindow;
@@ -275,7 +278,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   RouteBufs &rb = h->route[ix];
   d.Q = rb.Q.p; d.vol = rb.vol.p; d.vol0 = rb.vol0.p; d.inflow = rb.inflow.p; d.ele = rb.ele.p;
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
-  d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p;
+  d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -579,18 +582,20 @@ int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, 
   std::vector<int> slot(N, -1), lri(nLake, 0);
   h->h_lakeModel.assign(modelType, modelType + nLake);
   h->h_lakePar.assign(par, par + (size_t)MZR_NLAKEPAR * nLake);
-  int L = 0;
+  int L = 0, LD = 0;
   for (int l = 0; l < nLake; ++l) {
     const int e = lakeReach[l] - 1;
     if (e < 0 || e >= N) return fail(h, 20, "mzr_set_lakes/lake reach index out of range");
     if (modelType[l] < 0 || modelType[l] > 3) return fail(h, 20, "lake_route/unable to identify the parametric lake model type");
     slot[h->ext2int[e]] = l; lri[l] = h->ext2int[e];
-    if (par[(size_t)53 * nLake + l] != 0.0) return fail(h, 20, "mzr_set_lakes/Hanasaki demand memory (H06_D_mem_F) is not supported");
     if (modelType[l] == 2 && par[(size_t)52 * nLake + l] != 0.0)
       L = std::max(L, (int)std::floor(par[(size_t)54 * nLake + l] * 31 * 86400.0 / h->cfg.dt));
+    if (modelType[l] == 2 && par[(size_t)53 * nLake + l] != 0.0)
+      LD = std::max(LD, (int)std::floor(par[(size_t)55 * nLake + l] * 31 * 86400.0 / h->cfg.dt));
   }
   try {
-    h->nLake = nLake; h->LakeInputOption = LakeInputOption; h->calendarId = calendarId; h->lakeL = L;
+    h->nLake = nLake; h->LakeInputOption = LakeInputOption; h->calendarId = calendarId; h->lakeL = L; h->lakeLD = LD;
+    h->anyLakeTarget = false; h->volJumpstart = 0; h->lakeTarg.upload(std::vector<int>(std::max(nLake, 1), 0));
     h->h_lakeSlot = slot;
     h->lakeSlot.upload(slot); h->lakeModel.upload(h->h_lakeModel); h->lakePar.upload(h->h_lakePar); h->lakeReachInt.upload(lri);
   } catch (const std::string &e) { return fail(h, 91, "mzr_set_lakes/" + e); }
@@ -614,6 +619,45 @@ int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const dou
   if (hipStreamSynchronize(st) != hipSuccess) return fail(h, 92, "mzr_set_lake_forcing/device error");
   h->lakeSteps = nSteps;
   return checkDeviceError(h);
+}
+
+// Lakes that follow a target volume (is_vol_wm: NETOPO%LakeTargVol, lake_route.f90:197-205; jump start :140-142)
+int mzr_set_lake_target(mzr_handle h, const int *targVol, int jumpstart) {
+  if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_lake_target/network not set") : 1;
+  if (!h->nLake) return fail(h, 20, "mzr_set_lake_target/no lakes in this domain (mzr_set_lakes first)");
+  (void)hipSetDevice(h->cfg.device);
+  std::vector<int> f(targVol, targVol + h->nLake);
+  h->anyLakeTarget = std::any_of(f.begin(), f.end(), [](int x) { return x != 0; });
+  h->volJumpstart = jumpstart != 0;
+  try { h->lakeTarg.upload(f); } catch (const std::string &e) { return fail(h, 91, "mzr_set_lake_target/" + e); }
+  return 0;
+}
+
+__global__ void k_gather_lake_rows(const double *src, double *dst, const int *lakeReachInt, const int *ext2int_unused, int N, int nLake, int rows) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (l < nLake && t < rows) dst[(size_t)t * nLake + l] = src[(size_t)t * N + lakeReachInt[l]];
+}
+
+// REACH_WM_VOL of the next window: vol[nSteps][nRch] in the caller's reach order (main_route.f90:115-122); only lake reaches are read
+int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_wm_vol/state not initialised") : 1;
+  if (!h->nLake) return fail(h, 20, "mzr_set_wm_vol/no lakes in this domain");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_wm_vol/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  const int N = h->N;
+  (void)hipMemcpyAsync(h->scratchOut.p, vol, (size_t)nSteps * N * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  // scratchOut is in the caller's order: row t, reach e -> the lake's external index
+  std::vector<int> ext(h->nLake);
+  std::vector<int> lri(h->nLake);
+  (void)hipMemcpy(lri.data(), h->lakeReachInt.p, h->nLake * sizeof(int), hipMemcpyDeviceToHost);
+  for (int l = 0; l < h->nLake; ++l) ext[l] = h->int2ext[lri[l]];
+  DBuf<int> dext; try { dext.upload(ext); } catch (const std::string &e) { return fail(h, 91, "mzr_set_wm_vol/" + e); }
+  dim3 block(64), grid((h->nLake + 63) / 64, nSteps);
+  hipLaunchKernelGGL(k_gather_lake_rows, grid, block, 0, h->stream, h->scratchOut.p, h->lakeWmVol.p, dext.p, (const int *)nullptr, N, h->nLake, nSteps);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, 92, "mzr_set_wm_vol/device error");
+  h->wmVolSteps = nSteps;
+  return 0;
 }
 
 int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach, const int *haloGood) {
@@ -717,6 +761,7 @@ int mzr_init_state(mzr_handle h) {
       h->lakeEvap.alloc(W * h->nLake); h->lakePrecip.alloc(W * h->nLake); h->lakeEvap.zero(); h->lakePrecip.zero();
       h->lakeFE.alloc(W * h->H); h->lakeFP.alloc(W * h->H);
       h->calMonth.alloc(W); h->calDay.alloc(W); h->calDoy.alloc(W);
+      h->lakeWmVol.alloc(W * h->nLake); h->lakeWmVol.zero(); h->wmVolSteps = 0;
     }
     if (h->nHalo) {
       h->imN.alloc(W * h->nHalo); h->imN.zero();
@@ -739,6 +784,7 @@ int mzr_init_state(mzr_handle h) {
         }
         rb.lakeMut.upload(mut);
         if (h->lakeL > 0) { rb.lakeRing.alloc((size_t)h->nLake * 12 * h->lakeL); rb.lakeRing.zero(); rb.lakeHead.alloc((size_t)h->nLake * 13); rb.lakeHead.zero(); }
+        if (h->lakeLD > 0) { rb.lakeRingD.alloc((size_t)h->nLake * 12 * h->lakeLD); rb.lakeRingD.zero(); rb.lakeHeadD.alloc((size_t)h->nLake * 13); rb.lakeHeadD.zero(); }
       }
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
@@ -886,6 +932,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
+  if (h->anyLakeTarget && h->wmVolSteps < W) return fail(h, 20, "mzr_run/target-volume lakes are on: call mzr_set_wm_vol for this window first");
   (void)hipSetDevice(h->cfg.device);
   if (h->kwN.p) {   // regroup after the first two windows (not before the first: no particles yet), then every 8 windows / 512 steps
     const bool early = W > 1 && (h->kwtWindows == 1 || h->kwtWindows == 2);
@@ -1010,7 +1057,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     if (multi && ix > 0) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
   }
   if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
-  h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0;
+  h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
   return 0;
 }

@@ -38,7 +38,7 @@ MODULE mzr_c
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
-            mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync
+            mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync
   public :: mzr_message
 
   INTERFACE
@@ -203,6 +203,19 @@ MODULE mzr_c
       integer(c_int), value :: nSteps
       real(c_double), intent(in) :: evap(*), precip(*)
       integer(c_int), intent(in) :: month(*), day(*), dayofyear(*)
+    end function
+    ! lakes that follow a target volume (is_vol_wm; lake_route.f90:139-142,197-205) and their targets REACH_WM_VOL per window
+    integer(c_int) function mzr_set_lake_target(h, targVol, jumpstart) bind(C, name='mzr_set_lake_target')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), intent(in) :: targVol(*)
+      integer(c_int), value :: jumpstart
+    end function
+    integer(c_int) function mzr_set_wm_vol(h, nSteps, vol) bind(C, name='mzr_set_wm_vol')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), intent(in) :: vol(*)
     end function
     integer(c_int) function mzr_run_dev(h, nSteps, t_start, runoff_dev) bind(C, name='mzr_run_dev')
       import :: c_ptr, c_int, c_double

@@ -325,7 +325,8 @@ def step_dates(n_steps: int, dt: float, start=(2001, 1, 1), calendar_id: int = 0
 
 
 def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: float = 0.02, calendar_id: int = 0,
-               input_option: int = 0, memory: bool = False, start=(2001, 1, 1)) -> dict:
+               input_option: int = 0, memory: bool = False, start=(2001, 1, 1), demand_memory: bool = False,
+               target_frac: float = 0.0, vol_jumpstart: bool = False) -> dict:
     """Synthetic lakes/reservoirs (Doll 70 %, Hanasaki 25 %, HYPE 5 %, plus an
     endorheic one), parameters in the ranges of docs/source/users_guide/lake.rst.  A lake must be
     the only upstream of its outlet reach (kwt_route.f90:551-553)."""
@@ -379,10 +380,20 @@ def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: 
         par[ix["H06_D_Jan"] + mth] = qmean * 0.3 * season[(mth + 6) % 12]
     par[ix["H06_purpose"]] = (rng.random(nl) < 0.5)
     par[ix["H06_I_mem_F"]] = 1.0 if memory else 0.0
-    par[ix["H06_D_mem_F"]] = 0.0
+    par[ix["H06_D_mem_F"]] = 1.0 if demand_memory else 0.0       # the demand is REACH_WM_FLUX: needs is_flux_wm
     par[ix["H06_I_mem_L"]] = 1; par[ix["H06_D_mem_L"]] = 1
     rngf = np.random.default_rng(seed + 77)
     precip = 3e-8 * (1.0 + rngf.random((n_steps, net.H)))
     evap = 2e-8 * (1.0 + rngf.random((n_steps, net.H)))
-    return dict(input_option=input_option, calendar_id=calendar_id, ymd=step_dates(n_steps, dt, start, calendar_id),
-                reach=reach, model_type=model, par=par, evap=evap, precip=precip)
+    out = dict(input_option=input_option, calendar_id=calendar_id, ymd=step_dates(n_steps, dt, start, calendar_id),
+               reach=reach, model_type=model, par=par, evap=evap, precip=precip)
+    if target_frac > 0:     # is_vol_wm: some lakes follow a prescribed volume (REACH_WM_VOL per step and reach)
+        rt = np.random.default_rng(seed + 99)
+        flag = (rt.random(nl) < target_frac).astype(np.int32)
+        flag[:2] = 1                                        # at least the first two lakes
+        t = np.arange(n_steps)[:, None]
+        base = qmean[None, :] * 86400.0 * 40.0
+        vol = np.zeros((n_steps, net.N))
+        vol[:, reach - 1] = base * (0.6 + 0.35 * np.sin(2 * np.pi * t / 37.0 + np.arange(nl)[None, :]))
+        out.update(targ_vol=flag, vol_jumpstart=int(vol_jumpstart), wm_vol=vol)
+    return out

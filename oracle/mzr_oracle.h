@@ -70,6 +70,8 @@ int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const
    par[ORC_NLAKEPAR=56][nLake] (row order: mizuroute_amd/casefile.py LAKE_PAR) */
 int orc_set_lakes(orc_t *o, int LakeInputOption, int calendarId, int nLake, const int *lakeReach,
                   const int *modelType, const double *par);
+/* target-volume lakes (lake_route.f90:139-142,197-205): flags[nLake], is_vol_wm_jumpstart, REACH_WM_VOL[nSteps][N] of the steps after firstStep */
+int orc_set_lake_target(orc_t *o, const int *flags, int jumpstart, int firstStep, const double *wmvol);
 /* one step with lake forcing: evap/precip [H] m/s; month, day, dayofyear of simDatetime(1) */
 int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const double *wmflux,
                   const double *evap, const double *precip, int month, int day, int dayofyear);

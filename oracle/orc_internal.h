@@ -48,6 +48,7 @@ struct orc {
   double *lakePar;           /* [nLake][ORC_NLAKEPAR] (mutable: H06 monthly means, E_rel_ini) */
   double *basinEvapo, *basinPrecip;   /* [N] m3/s */
   double **qpast, **dpast; int *qpastLen, *dpastLen;   /* Hanasaki memory [12][L] per lake */
+  int *lakeTarg, volJumpstart, wmVolFirst; const double *wmVol;   /* target-volume lakes: NETOPO%LakeTargVol, is_vol_wm_jumpstart, REACH_WM_VOL[step][N] */
   long long iTime; int month, day, dayofyear;
   /* KWT traffic statistics of the last step */
   long long w_in, w_up, w_out, n_head, n_route, n_edges;

@@ -1,5 +1,4 @@
-/* CPU oracle: lakes and reservoirs, lake_route.f90:28-472 (test infrastructure; see mzr_oracle.h).
-   Target-volume lakes (is_vol_wm) are not restated. */
+/* CPU oracle: lakes and reservoirs, lake_route.f90:28-472 (test infrastructure; see mzr_oracle.h). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -84,7 +83,11 @@ int orc_lake_route(orc_t *o, int r, int method) {
   const double dt = o->dt;
   double q_upstream = 0.0;
   for (int e = o->upOff[r]; e < o->upOff[r + 1]; e++) q_upstream = q_upstream + HYD(o, method, o->upIdx[e]).REACH_Q;
-  if (o->iTime == 1) {   /* cold start, lake_route.f90:121-144 */
+  const int targ = o->lakeTarg && o->lakeTarg[l];
+  const double wmvol = (targ && o->wmVol) ? o->wmVol[(size_t)(o->iTime - 1 - o->wmVolFirst) * o->N + r] : 0.0;   /* REACH_WM_VOL, main_route.f90:115-122 */
+  if (o->iTime == 1 && o->volJumpstart && targ) {   /* lake_route.f90:139-142 */
+    h->REACH_VOL[1] = wmvol;
+  } else if (o->iTime == 1) {   /* cold start, lake_route.f90:143-158 */
     switch (type) {
       case 0: h->REACH_VOL[1] = P[P_D03_S0]; break;
       case 1: h->REACH_VOL[1] = P[P_D03_MaxStorage]; break;
@@ -118,7 +121,14 @@ int orc_lake_route(orc_t *o, int r, int method) {
       h->REACH_VOL[1] = 0.0;
     }
   }
-  switch (type) {
+  if (targ) {   /* the lake follows the given target volume, lake_route.f90:197-205 */
+    if (h->REACH_VOL[1] < wmvol) {
+      h->REACH_Q = 0;
+    } else {
+      h->REACH_Q = (h->REACH_VOL[1] - wmvol) / dt;
+      h->REACH_VOL[1] = wmvol;
+    }
+  } else switch (type) {
     case 0: h->REACH_Q = 0.0; break;
     case 1: {
       if ((h->REACH_VOL[1] - P[P_D03_S0]) > 0) {
@@ -197,3 +207,13 @@ int orc_lake_route(orc_t *o, int r, int method) {
   }
   return 0;
 }
+
+/* target-volume lakes: flags[nLake], is_vol_wm_jumpstart, and REACH_WM_VOL[nSteps][N] for steps firstStep+1 .. (kept by reference) */
+int orc_set_lake_target(orc_t *o, const int *flags, int jumpstart, int firstStep, const double *wmvol) {
+  if (!o->is_lake_sim) return 1;
+  if (!o->lakeTarg) o->lakeTarg = (int *)calloc(o->nLake ? o->nLake : 1, sizeof(int));
+  for (int l = 0; l < o->nLake; l++) o->lakeTarg[l] = flags[l];
+  o->volJumpstart = jumpstart; o->wmVol = wmvol; o->wmVolFirst = firstStep;
+  return 0;
+}
+

@@ -44,6 +44,7 @@ def lib():
         L.orc_run.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, C.c_void_p]
         L.orc_run_wm.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, C.c_void_p, C.c_void_p]
         L.orc_set_lakes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, dp]
+        L.orc_set_lake_target.argtypes = [C.c_void_p, ip, C.c_int, C.c_int, dp]
         L.orc_run_lake.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, dp, dp, ip, C.c_void_p, C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
@@ -114,6 +115,14 @@ class Oracle:
         """lakes: dict as mizuroute_amd.casefile.write_case(lakes=...)."""
         c = lambda a, t: np.ascontiguousarray(a, dtype=t)
         self._lakes = lakes
+        rc = self._set_lakes(lakes)
+        if rc == 0 and "targ_vol" in lakes:       # target-volume lakes: flags, jump start, REACH_WM_VOL[nSteps][N]
+            self._wmvol = c(lakes["wm_vol"], np.float64)
+            rc = lib().orc_set_lake_target(self.h, c(lakes["targ_vol"], np.int32), int(lakes.get("vol_jumpstart", 0)), 0, self._wmvol)
+        return rc
+
+    def _set_lakes(self, lakes):
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
         return lib().orc_set_lakes(self.h, int(lakes["input_option"]), int(lakes["calendar_id"]), len(lakes["reach"]),
                                    c(lakes["reach"], np.int32), c(lakes["model_type"], np.int32), c(lakes["par"], np.float64))
 

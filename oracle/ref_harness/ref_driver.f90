@@ -37,7 +37,9 @@ PROGRAM ref_driver
   character(len=1024) :: fcase, fout, arg
   integer(i4b) :: uin, uout, magic, version
   integer(i4b) :: N, H, nSteps, methodsIn(6), nUpTot, nHruTot, nOrder, nBranch
-  integer(i4b) :: uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm, isLakeSim, calendarId, nLake, il
+  integer(i4b) :: uhSource, ntdhBasIn, nUhTotIn, dumpEvery, isFluxWm, isLakeSim, calendarId, nLake, il, isVolWm, volJump
+  integer(i4b), allocatable :: lakeTarg(:)
+  real(dp), allocatable :: wmvol(:,:)
   integer(i4b), allocatable :: ymd(:,:), lakeReach(:), lakeModel(:)
   real(dp), allocatable :: lakePar(:,:), evap(:,:), precip(:,:)
   real(dp)     :: fshape, tscale, velo, diff, t_start
@@ -99,6 +101,10 @@ PROGRAM ref_driver
     allocate(wmflux(N, nSteps))
     read(uin) wmflux
   end if
+  isVolWm = 0
+  if (isLakeSim == 2) then      ! lakes + a target-volume section
+    isLakeSim = 1; isVolWm = 1
+  end if
   if (isLakeSim == 1) then
     read(uin) LakeInputOption, calendarId, nLake
     allocate(ymd(3, nSteps), lakeReach(nLake), lakeModel(nLake), lakePar(nLake, 56), evap(H, nSteps), precip(H, nSteps))
@@ -108,11 +114,19 @@ PROGRAM ref_driver
     else
       calendar = 'standard'
     end if
+    if (isVolWm == 1) then      ! NETOPO%LakeTargVol flags, is_vol_wm_jumpstart, REACH_WM_VOL per step
+      allocate(lakeTarg(nLake), wmvol(N, nSteps))
+      read(uin) lakeTarg
+      read(uin) volJump
+      read(uin) wmvol
+    end if
   end if
   close(uin)
 
   ! ---- configuration the reference keeps in public_var / globalData (read_control.f90:580-600)
-  is_lake_sim = (isLakeSim == 1); is_flux_wm = (isFluxWm == 1); is_vol_wm = .false.; tracer = .false.
+  is_lake_sim = (isLakeSim == 1); is_flux_wm = (isFluxWm == 1); is_vol_wm = (isVolWm == 1); tracer = .false.
+  is_vol_wm_jumpstart = .false.
+  if (isVolWm == 1) is_vol_wm_jumpstart = (volJump /= 0)
   qmodOption = 0
   time_conv = 1._dp; length_conv = 1._dp
   allocate(routeMethods(nRoutes))
@@ -204,6 +218,7 @@ PROGRAM ref_driver
       i = lakeReach(il)
       NETOPO(i)%ISLAKE = .true.
       NETOPO(i)%LAKEMODELTYPE = lakeModel(il)
+      if (isVolWm == 1) NETOPO(i)%LAKETARGVOL = (lakeTarg(il) /= 0)
       if (onRoute(impulseResponseFunc)) then
         NETOPO(i)%UH = 0._dp; NETOPO(i)%UH(1) = 1._dp          ! process_ntopo.f90:501-505
       end if
@@ -285,7 +300,12 @@ PROGRAM ref_driver
   end do
 
   allocate(ixRch(N)); ixRch = [(i, i=1,N)]
-  allocate(basinRunoff(H), basinSolute(0), reachvol(0))
+  allocate(basinRunoff(H), basinSolute(0))
+  if (isVolWm == 1) then
+    allocate(reachvol(N))
+  else
+    allocate(reachvol(0))
+  end if
   if (is_lake_sim) then
     allocate(basinEvapo(H), basinPrecip(H))
   else
@@ -314,6 +334,7 @@ PROGRAM ref_driver
     TSEC(2) = TSEC(1) + dt
     basinRunoff = runoff(:, it)
     if (isFluxWm == 1) reachflux = wmflux(:, it)
+    if (isVolWm == 1) reachvol = wmvol(:, it)
     if (is_lake_sim) then
       basinEvapo = evap(:, it); basinPrecip = precip(:, it)
       simDatetime(1) = datetime(ymd(1,it), ymd(2,it), ymd(3,it), 0, 0, 0._dp, calendar=trim(calendar))

@@ -619,3 +619,37 @@ def test_comm_two_ranks(tmp_path, hip_lib):
     for p in ps:
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0 and "ok" in out, err[-2000:]
+
+
+# ---- lakes: target volumes (is_vol_wm) and the Hanasaki demand memory ---------------------------------------------
+@pytest.mark.parametrize("jump,window", [(False, 16), (True, 5)])
+def test_target_volume_lakes_and_demand_memory_vs_oracle(jump, window, hip_lib, oracle_lib):
+    """lake_route.f90:139-142,197-205 (target volume, jump start) and :288-331 (demand memory fed by REACH_WM_FLUX) on the
+    device against the oracle (itself bit-identical to the reference, tests/test_oracle_vs_ref.py)."""
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(800, seed=43, n_outlets=6)
+    steps, dt = 80, 21600.0
+    ro = m.make_runoff(net.H, steps, seed=6, storm_prob=0.05, storm_amp=3e-6)
+    lakes = make_lakes(net, steps, dt, seed=7, frac=0.03, memory=True, input_option=2, calendar_id=1, start=(2004, 2, 10),
+                       demand_memory=True, target_frac=0.4, vol_jumpstart=jump)
+    rng = np.random.default_rng(8)
+    wm = np.full((steps, net.N), -9999.0)
+    lr = lakes["reach"] - 1
+    wm[:, lr] = 0.3e-8 * net.params["TOTAREA"][lr][None, :] * (1.0 + np.sin(np.arange(steps) / 9.0))[:, None] * (rng.random((steps, lr.size)) - 0.15)
+    from mizuroute_amd import uh as uhmod
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    off, v = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    no_targ = {k: val for k, val in lakes.items() if k not in ("targ_vol", "vol_jumpstart", "wm_vol")}
+    # one method per domain: with several, the reference's methods share the mutable Hanasaki parameters through RPARAM and so
+    # influence each other (the memory is fed once per method and step); here every method keeps its own copy (include/mzr.h)
+    for methods, lk in (([m.IRF], lakes), ([m.DW], lakes), ([m.KWT], no_targ)):
+        dom = m.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=off, uh=v, max_window=window, lakes=lk, is_flux_wm=1)
+        Qg = dom.run(ro, wm_flux=wm)
+        orc = oracle_lib.Oracle(net, dt, methods, frac, off, v, is_flux_wm=1)
+        orc.set_lakes(lk)
+        Qo, Vo = orc.run_lake(ro, lk, want_vol=True, wm_flux=wm)
+        for ix, meth in enumerate(methods):
+            rep = parity_report(Qo[:, ix], Qg[:, ix])
+            assert rep["max_rel"] <= REL_TOL, (meth, rep)
+            vol = dom.flux(meth, m.api.F_VOL1)
+            assert np.allclose(vol[lr], Vo[-1, ix, lr], rtol=REL_TOL, atol=1e-6), meth

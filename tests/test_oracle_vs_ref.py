@@ -126,6 +126,36 @@ def test_lakes_bit_exact(memory, opt, cal, start, oracle_lib):
         assert np.array_equal(Q, out["Q"]) and np.array_equal(V, out["VOL"]), methods
 
 
+@pytest.mark.parametrize("jump", [False, True])
+def test_target_volume_lakes_and_demand_memory_bit_exact(jump, oracle_lib):
+    """is_vol_wm: some lakes follow a prescribed volume (lake_route.f90:139-142,197-205, with and without the jump start);
+    Hanasaki demand memory (lake_route.f90:288-331) fed by REACH_WM_FLUX (is_flux_wm).  Oracle == reference, bit for bit."""
+    from mizuroute_amd.synthetic import make_lakes
+    net = make_network(800, seed=43, n_outlets=6)
+    steps, dt = 80, 21600.0
+    ro = make_runoff(net.H, steps, seed=6, storm_prob=0.05, storm_amp=3e-6)
+    lakes = make_lakes(net, steps, dt, seed=7, frac=0.03, memory=True, input_option=2, calendar_id=1, start=(2004, 2, 10),
+                       demand_memory=True, target_frac=0.4, vol_jumpstart=jump)
+    assert lakes["targ_vol"].sum() >= 2 and (lakes["model_type"][lakes["targ_vol"] == 0] == 2).any()
+    rng = np.random.default_rng(8)
+    wm = np.full((steps, net.N), -9999.0)          # realMissing: no water management at this reach
+    lr = lakes["reach"] - 1
+    wm[:, lr] = 0.3e-8 * net.params["TOTAREA"][lr][None, :] * (1.0 + np.sin(np.arange(steps) / 9.0))[:, None] * (rng.random((steps, lr.size)) - 0.15)
+    # (KWT cannot route below a lake that releases nothing -- kinwav_rch's "zero flow", as below an endorheic lake -- so the
+    # particle method gets the demand memory without target volumes)
+    no_targ = {k: v for k, v in lakes.items() if k not in ("targ_vol", "vol_jumpstart", "wm_vol")}
+    for methods, lk in (([1, 5], lakes), ([2], no_targ)):
+        out = refrun.run_case(net, ro, dt, methods, lakes=lk, wm_flux=wm)
+        assert out["ierr"] == 0, out["stdout"]
+        orc = oracle_lib.Oracle(net, dt, methods, out["frac_future"], out["uh_offset"], out["uh"], is_flux_wm=1)
+        orc.set_lakes(lk)
+        Q, V = orc.run_lake(ro, lk, want_vol=True, wm_flux=wm)
+        assert np.array_equal(Q, out["Q"]) and np.array_equal(V, out["VOL"]), methods
+        if "targ_vol" in lk:
+            tl = lr[lk["targ_vol"] != 0]
+            assert (V[-1, 0, tl] <= lk["wm_vol"][-1, tl]).all(), "a target-volume lake never ends a step above its target"
+
+
 # ---- forcing remap (process_remap.f90:32-316) against the reference's own routines -------------------
 @pytest.mark.parametrize("H,n1,n2,seed", [(500, 700, 0, 3), (3000, 2500, 0, 4), (800, 40, 30, 5), (2000, 90, 64, 6)])
 def test_remap_runoff_bit_exact(H, n1, n2, seed, oracle_lib):
