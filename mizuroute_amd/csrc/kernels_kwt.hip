@@ -136,7 +136,10 @@ __device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, in
 #endif
       return false;
     }
-    __builtin_amdgcn_s_sleep(4);
+#ifndef MZR_KWT_SLEEP
+#define MZR_KWT_SLEEP 4
+#endif
+    __builtin_amdgcn_s_sleep(MZR_KWT_SLEEP);
     if ((++spins & 31) == 0) {
       if (ldx<true>(&d.err->code) != 0) return true;
       const long long now = wall_clock64();     // 100 MHz
@@ -979,13 +982,62 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         {
           // cw = ALFA*K**(1/ALFA) with K = sqrt(R_SLOPE)/R_MAN_N and ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
           const double cw = rc[3], XMX = rc[4];
+          double wcs[KS], rws[KS];     // celerity of the lane's own particles and its reciprocal
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
-            if (i >= 1 && i <= NI) { const double wc = cw * pow_0p4(Qw[i]); Xw[i] = wc; Yw[i] = 1.0 / wc; }
+            wcs[j] = 0.0; rws[j] = 0.0;
+            if (i >= 1 && i <= NI) { const double wc = cw * pow_0p4(Qw[i]); wcs[j] = wc; rws[j] = 1.0 / wc; Xw[i] = wc; Yw[i] = rws[j]; }
           }
           grp_sync();
           TSTAMP(4);
+          // Does any wave break at all?  The first pass of the shock search (:1301-1320) with every particle still its
+          // own group -- neighbours are i and i+1, entry times are the particles' own.  Shocks are rare (a handful per
+          // 10^5 reach-steps on the benchmark forcing): without one the routed list is the list itself, every particle
+          // with the exit time RLENGTH/celerity + entry time (:1363-1372, rUpdate :1409-1437), and the group machinery
+          // below is skipped.
+          bool shock = false;
+          if (NI > 1) {
+            double XB = DBL_MAX; int JXB = 0;
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) {
+              const int jw = gl + sl * G;
+              if (jw >= 1 && jw < NI) {
+                const double wcj = wcs[sl], wci = Xw[jw + 1], tj = Tw[jw], ti = Tw[jw + 1];
+                if (!(wci == 0.0 || wcj == 0.0) && !(wcj > wci && ti > tj)) {
+                  const double WDIFF = rws[sl] - Yw[jw + 1];
+                  if (!(WDIFF == 0.0) && !(wci == wcj)) {
+                    const double XXB = (ti - tj) / WDIFF;
+                    if (!(XXB < 0.0 || XXB > XMX) && XXB <= XB) { XB = XXB; JXB = jw; }
+                  }
+                }
+              }
+            }
+            grp_argmin<G, true>(XB, JXB);
+            shock = !(JXB == 0 || XB == XMX);
+          }
+          if (!shock) {
+            bool zero = false;
+            double tes[KS];
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) {
+              const int h = gl + sl * G;
+              tes[sl] = 0.0;
+              if (h >= 1 && h <= NI) {
+                if (wcs[sl] < DBL_MIN) zero = true;                                // zero flow :1365
+                else {
+                  double te = fmin(XMX / wcs[sl] + Tw[h], DBL_MAX);
+                  if (h == 1 && te <= T_START) te = T_START + 1.0;
+                  tes[sl] = te;
+                }
+              }
+            }
+            if (grp_any<G>(zero)) { mzr_raise(d, 20, r, t, 13); break; }
+            grp_sync();          // the neighbours have read the celerities this overwrites
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) { const int h = gl + sl * G; if (h >= 1 && h <= NI) Xw[h] = tes[sl]; }
+            NQ2 = NI;
+          } else {
           unsigned alive = (2u << NI) - 2u;   // bits 1..NI
           auto nextHead = [&](int h) -> int {           // next group head after h, or NI+1
             const unsigned m = alive & ~((2u << h) - 1u);
@@ -1112,6 +1164,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               if (oI[sl] == 1 && te <= T_START) te = T_START + 1.0;
               Qw[oI[sl]] = oQ[sl]; Tw[oI[sl]] = oT[sl]; Xw[oI[sl]] = te;
             }
+          }
           }
           if (gl == 0) Xw[0] = ctx[0];
           grp_sync();
