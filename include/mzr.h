@@ -167,6 +167,27 @@ int mzr_get_flux(mzr_handle h, int method, int which, double *out);
 int mzr_get_window_q(mzr_handle h, int method, double *out);
 /* device-side history accumulation (histVars_data.f90:154-246): mean REACH_Q since the last reset */
 int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset);
+/* The other history variables of the reference (histVars_data.f90:154-305; names popMetadat.f90:238-271):
+   which sums are accumulated on the device -- call before mzr_init_state.
+     MZR_H_INFLOW  <M>inflow: mean REACH_INFLOW per method (outputInflow)
+     MZR_H_HEIGHT  <M>height and <M>floodVolume: mean REACH_ELE and FLOOD_VOL(1) per method (floodplain)
+     MZR_H_RUNOFF  instRunoff, dlayRunoff (mean BASIN_QI, BASIN_QR(1), per reach) and basRunoff (mean runoff per HRU)
+   mzr_get_mean returns sum / steps since the last reset (finalize, :251-297), `which` = MZR_M_*; method is ignored for the
+   three runoff means; MZR_M_BAS_RUNOFF is [nHru] in the caller's HRU order, everything else [nRch].  The last volume
+   (<M>volume) is mzr_get_flux(..., MZR_F_VOL1).  mzr_reset_means = histVars%refresh (every sum, discharge included). */
+#define MZR_H_INFLOW 1
+#define MZR_H_HEIGHT 2
+#define MZR_H_RUNOFF 4
+#define MZR_M_Q 0
+#define MZR_M_INFLOW 1
+#define MZR_M_HEIGHT 2
+#define MZR_M_FLOODVOL 3
+#define MZR_M_INST_RUNOFF 10
+#define MZR_M_DLAY_RUNOFF 11
+#define MZR_M_BAS_RUNOFF 12
+int mzr_set_history(mzr_handle h, int flags);
+int mzr_get_mean(mzr_handle h, int method, int which, double *out);
+int mzr_reset_means(mzr_handle h);
 
 /* state in the restart-file layout (write_restart_pio.f90:1039-1290) */
 int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry, double *texit, int *routed);

@@ -17,6 +17,8 @@ import numpy as np
 
 SUM, IRF, KWT, KW, MC, DW = 0, 1, 2, 3, 4, 5
 F_Q, F_VOL0, F_VOL1, F_INFLOW, F_ELE, F_FLOODVOL, F_WB, F_BASIN_QR1, F_BASIN_QR0, F_BASIN_QI = range(10)
+H_INFLOW, H_HEIGHT, H_RUNOFF = 1, 2, 4
+M_Q, M_INFLOW, M_HEIGHT, M_FLOODVOL, M_INST_RUNOFF, M_DLAY_RUNOFF, M_BAS_RUNOFF = 0, 1, 2, 3, 10, 11, 12
 WCAP = 32
 NMOL = {KW: 20, MC: 2, DW: 20}
 
@@ -54,7 +56,8 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
-           "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync"]
+           "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync", "mzr_set_history", "mzr_get_mean",
+           "mzr_reset_means"]
 
 
 def load_library():
@@ -103,6 +106,9 @@ def load_library():
     L.mzr_comm_recv.argtypes = [vp, vp, vp, C.c_longlong, ci]
     L.mzr_comm_recv_many.argtypes = [vp, vp, ci, C.POINTER(vp), C.POINTER(C.c_longlong), C.POINTER(ci)]
     L.mzr_comm_destroy.argtypes = [vp]
+    L.mzr_set_history.argtypes = [vp, ci]
+    L.mzr_get_mean.argtypes = [vp, ci, ci, dp]
+    L.mzr_reset_means.argtypes = [vp]
     L.mzr_comm_sync.argtypes = [vp]
     L.mzr_comm_last_error.argtypes = [C.c_char_p, ci]
     L.mzr_sync.argtypes = [vp]
@@ -149,7 +155,7 @@ class RoutingDomain:
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
                  hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
                  export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0, lakes=None,
-                 time_conv=1.0, length_conv=1.0):
+                 time_conv=1.0, length_conv=1.0, history=0):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -196,6 +202,8 @@ class RoutingDomain:
             ha = i32(halo_reaches if halo_reaches is not None else [])
             hg = i32(halo_good if halo_good is not None else np.ones(len(ha)))
             self._check(L.mzr_set_boundary(self.h, len(ex), ex, len(ha), ha, hg))
+        if history:      # history sums beyond discharge: H_INFLOW | H_HEIGHT | H_RUNOFF
+            self._check(L.mzr_set_history(self.h, int(history)))
         self._check(L.mzr_init_state(self.h))
 
     # ---- plumbing
@@ -294,6 +302,15 @@ class RoutingDomain:
         out = np.zeros(self.N)
         self._check(self.L.mzr_get_mean_q(self.h, method, out, int(reset)))
         return out
+
+    def mean(self, method, which):
+        """interval mean of a history variable (include/mzr.h MZR_M_*); needs history=... at construction except for M_Q"""
+        out = np.zeros(self.H if which == M_BAS_RUNOFF else self.N)
+        self._check(self.L.mzr_get_mean(self.h, int(method), int(which), out))
+        return out
+
+    def reset_means(self):
+        self._check(self.L.mzr_reset_means(self.h))
 
     def kwt_state(self):
         nw = np.zeros(self.N, np.int32)

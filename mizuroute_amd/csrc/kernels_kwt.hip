@@ -658,6 +658,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     int n_own_v = ldx<PERS>(d.kwN + r), nrA_v = 0, nrB_v = 0;
     if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
     const double X0 = ldx<PERS>(d.kwTR + MZR_KWI(0, r));
+    const double hin = d.hInflow ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
@@ -716,7 +717,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       double *c = ctx;
       c[2] = q_up;                     // REACH_INFLOW, stored with the other results at the end
       c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
-      c[1] = qlat_r;
+      c[1] = qlat_r; c[3] = hin;
       if (d.kwtStat && !ovf) {
         atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own); atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
         atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
@@ -1200,7 +1201,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
         // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
-        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); stx<PERS>(d.kwN + r, NN2 + 1); d.inflow[r] = ctx[2]; }
+        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); stx<PERS>(d.kwN + r, NN2 + 1); d.inflow[r] = ctx[2]; if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]); }
         TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;

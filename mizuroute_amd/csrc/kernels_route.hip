@@ -215,6 +215,8 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
       const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat, vol, vol0, ele, wb, wmAct);
       Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
       if (d.wmact) d.wmact[r] = wmAct;
+      if (d.hEle) { d.hEle[r] += ele; d.hFlood[r] += d.floodvol[r]; }
+      if (d.hInflow) d.hInflow[r] += d.inflow[r];
       return;
     }
   }
@@ -416,6 +418,9 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
   d.wb[r] = d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt);
   if (d.wmact) d.wmact[r] = wmAct;
   d.qsum[r] += Qout;
+  // history sums of the other per-method fluxes (histVars_data.f90:229-246), when asked for
+  if (d.hInflow) d.hInflow[r] += p.q_up;
+  if (d.hEle) { d.hEle[r] += d.ele[r]; d.hFlood[r] += d.floodvol[r]; }
 }
 
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {

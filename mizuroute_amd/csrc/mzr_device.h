@@ -83,6 +83,7 @@ struct MzrDev {
   double *Q;                  // [W][N] REACH_Q of the method being launched
   double *vol, *vol0, *inflow, *ele, *floodvol, *wb;   // [N] latest
   double *qsum;               // [N] running sum of REACH_Q (history mean)
+  double *hInflow, *hEle, *hFlood;   // [N] running sums of REACH_INFLOW, REACH_ELE, FLOOD_VOL(1) (histVars_data.f90:229-246); null = not wanted
   // ---- IRF
   int maxtdh;
   const uint16_t *ntdh;       // [N]

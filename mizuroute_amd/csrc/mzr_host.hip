@@ -62,6 +62,7 @@ struct RouteBufs {
   int method = -1;
   DBuf<double> Q;                                   // [maxWindow][N]
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
+  DBuf<double> hInflow, hEle, hFlood;               // [N] history sums beyond discharge (mzr_set_history)
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
@@ -224,6 +225,9 @@ struct mzr_domain {
   bool profiling = false;       // HIP events around every stage launch
   bool countTraffic = false;    // KWT particle-traffic counters (atomics: not for timed runs)
   long long stepsDone = 0, totalSteps = 0;
+  int histFlags = 0;                            // MZR_H_*: which history sums beyond discharge are kept
+  long long histSteps = 0;                      // steps in the runoff sums since the last reset
+  DBuf<double> hInst, hDlay, hBas;              // [N], [N], [H] sums of BASIN_QI, BASIN_QR(1), basin runoff
 };
 
 namespace {
@@ -277,6 +281,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
 void setRoute(mzr_handle h, MzrDev &d, int ix) {
   RouteBufs &rb = h->route[ix];
   d.Q = rb.Q.p; d.vol = rb.vol.p; d.vol0 = rb.vol0.p; d.inflow = rb.inflow.p; d.ele = rb.ele.p;
+  d.hInflow = rb.hInflow.p; d.hEle = rb.hEle.p; d.hFlood = rb.hFlood.p;
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
 }
@@ -866,6 +871,13 @@ int mzr_init_state(mzr_handle h) {
         h->dbgCycles.alloc(32 * 1024 + 8 + 65536 * 8); h->dbgCycles.zero();   // counters, then (timing builds) one record per sampled pass
       }
       rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0; rb.meanSteps = 0;
+      rb.hInflow.free(); rb.hEle.free(); rb.hFlood.free();
+      if (h->histFlags & MZR_H_INFLOW) { rb.hInflow.alloc(N); rb.hInflow.zero(); }
+      if (h->histFlags & MZR_H_HEIGHT) { rb.hEle.alloc(N); rb.hEle.zero(); rb.hFlood.alloc(N); rb.hFlood.zero(); }
+    }
+    h->hInst.free(); h->hDlay.free(); h->hBas.free(); h->histSteps = 0;
+    if (h->histFlags & MZR_H_RUNOFF) {
+      h->hInst.alloc(N); h->hInst.zero(); h->hDlay.alloc(N); h->hDlay.zero(); h->hBas.alloc(h->H); h->hBas.zero();
     }
   } catch (const std::string &e) { return fail(h, 91, "mzr_init_state/" + e); }
   if (hipDeviceSynchronize() != hipSuccess) return fail(h, 92, "mzr_init_state/device error");
@@ -1057,6 +1069,13 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     if (multi && ix > 0) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
   }
   if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
+  if (h->histFlags & MZR_H_RUNOFF) {      // histVars_data.f90:196-211: basin runoff, instantaneous and delayed runoff into the reaches, step by step
+    const double *inst = (h->cfg.doesBasinRoute == 1 && h->qi.p) ? h->qi.p : h->qlat.p + N;
+    mzr_launch_accum_qsum(inst, h->hInst.p, N, W, st);
+    mzr_launch_accum_qsum(h->qlat.p + N, h->hDlay.p, N, W, st);
+    mzr_launch_accum_qsum(runoff_dev, h->hBas.p, h->H, W, st);
+    h->histSteps += W;
+  }
   h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
   return 0;
@@ -1287,6 +1306,53 @@ int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset) {
   const double n = (double)std::max<long long>(1, h->route[ix].meanSteps);      // steps accumulated in THIS method's sum
   for (int e = 0; e < h->N; ++e) out[e] /= n;
   if (reset) { h->route[ix].qsum.zero(h->stream); h->route[ix].meanSteps = 0; (void)hipStreamSynchronize(h->stream); }
+  return 0;
+}
+
+// History accumulation beyond discharge (histVars_data.f90:154-305): which sums are kept.  Takes effect at the next mzr_init_state.
+int mzr_set_history(mzr_handle h, int flags) {
+  if (!h) return 1;
+  h->histFlags = flags & (MZR_H_INFLOW | MZR_H_HEIGHT | MZR_H_RUNOFF);
+  h->haveState = false;
+  return 0;
+}
+
+int mzr_get_mean(mzr_handle h, int method, int which, double *out) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_mean/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  if (which >= MZR_M_INST_RUNOFF) {
+    if (!(h->histFlags & MZR_H_RUNOFF)) return fail(h, 20, "mzr_get_mean/runoff sums are off (mzr_set_history)");
+    const double n = (double)std::max<long long>(1, h->histSteps);
+    if (which == MZR_M_BAS_RUNOFF) {
+      MZR_COPY(out, h->hBas.p, (size_t)h->H * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_mean");
+      for (int i = 0; i < h->H; ++i) out[i] /= n;
+      return 0;
+    }
+    rc = pullRow(h, which == MZR_M_INST_RUNOFF ? h->hInst.p : h->hDlay.p, out); if (rc) return rc;
+    for (int e = 0; e < h->N; ++e) out[e] /= n;
+    return 0;
+  }
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_mean/method not active");
+  RouteBufs &rb = h->route[ix];
+  const double *src = which == MZR_M_Q ? rb.qsum.p : which == MZR_M_INFLOW ? rb.hInflow.p : which == MZR_M_HEIGHT ? rb.hEle.p : which == MZR_M_FLOODVOL ? rb.hFlood.p : nullptr;
+  if (!src) return fail(h, 20, "mzr_get_mean/this sum is off (mzr_set_history) or unknown");
+  rc = pullRow(h, src, out); if (rc) return rc;
+  const double n = (double)std::max<long long>(1, rb.meanSteps);
+  for (int e = 0; e < h->N; ++e) out[e] /= n;
+  return 0;
+}
+
+// histVars%refresh: every sum back to zero
+int mzr_reset_means(mzr_handle h) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_reset_means/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+    RouteBufs &rb = h->route[ix];
+    rb.qsum.zero(h->stream); rb.hInflow.zero(h->stream); rb.hEle.zero(h->stream); rb.hFlood.zero(h->stream); rb.meanSteps = 0;
+  }
+  h->hInst.zero(h->stream); h->hDlay.zero(h->stream); h->hBas.zero(h->stream); h->histSteps = 0;
+  (void)hipStreamSynchronize(h->stream);
   return 0;
 }
 

@@ -27,6 +27,10 @@ _MOLDIM = {api.KW: "mol_kw", api.MC: "mol_mc", api.DW: "mol_dw"}
 HIST_Q = {api.SUM: "sumUpstreamRunoff", api.IRF: "IRFroutedRunoff", api.KWT: "KWTroutedRunoff",
           api.KW: "KWroutedRunoff", api.MC: "MCroutedRunoff", api.DW: "DWroutedRunoff"}     # popMetadat.f90:240-245
 HIST_VOL = {api.IRF: "IRFvolume", api.KWT: "KWTvolume", api.KW: "KWvolume", api.MC: "MCvolume", api.DW: "DWvolume"}
+_PFX = {api.IRF: "IRF", api.KWT: "KWT", api.KW: "KW", api.MC: "MC", api.DW: "DW"}
+HIST_HEIGHT = {m: p + "height" for m, p in _PFX.items()}                 # popMetadat.f90:251-255
+HIST_FLOOD = {m: ("IRf" if m == api.IRF else p) + "floodVolume" for m, p in _PFX.items()}     # :256-260 (the reference spells IRffloodVolume)
+HIST_INFLOW = {m: p + "inflow" for m, p in _PFX.items()}                 # :261-265
 
 
 def _var(f, name, typ, dims, data, **att):
@@ -169,7 +173,10 @@ class HistoryWriter:
     of the aggregated interval plus histTimeStamp_offset and `time_bounds` holds both ends
     (historyFile.f90:349-373, histVars_data.f90:179-183)."""
 
-    def __init__(self, path, reach_id, methods, time_units="seconds since 1970-01-01 00:00:00", calendar="standard", volumes=False):
+    def __init__(self, path, reach_id, methods, time_units="seconds since 1970-01-01 00:00:00", calendar="standard", volumes=False,
+                 inflow=False, height=False, runoff=False, hru_id=None):
+        """volumes: <M>volume (last value); inflow: <M>inflow (outputInflow); height: <M>height and <M>floodVolume (floodplain);
+        runoff: instRunoff, dlayRunoff and basRunoff(hru) -- the last three need the domain built with history=H_* flags."""
         self.f = netcdf_file(path, "w", version=2)
         self.f.createDimension("time", None)
         self.f.createDimension("seg", len(reach_id))
@@ -179,21 +186,46 @@ class HistoryWriter:
         tb = self.f.createVariable("time_bounds", "d", ("time", "tbound")); tb.units = time_units; tb.calendar = calendar; tb.long_name = "time interval endpoints"
         _var(self.f, "reachID", "i", ("seg",), np.asarray(reach_id, np.int32), long_name="reach ID", units="-")
         self.vars = {}
+        self.runoff = runoff
+        if runoff:
+            if hru_id is None:
+                raise ValueError("basRunoff needs hru_id")
+            self.f.createDimension("hru", len(hru_id))
+            _var(self.f, "basinID", "i", ("hru",), np.asarray(hru_id, np.int32), long_name="basin ID", units="-")
+            for name, dims, unit in (("basRunoff", ("time", "hru"), "m/s"), ("instRunoff", ("time", "seg"), "m3/s"), ("dlayRunoff", ("time", "seg"), "m3/s")):
+                v = self.f.createVariable(name, "f", dims); v.units = unit
         for m in self.methods:
             q = self.f.createVariable(HIST_Q[m], "f", ("time", "seg")); q.units = "m3/s"
-            self.vars[(m, "q")] = q
+            self.vars[(m, api.M_Q)] = q
             if volumes and m in HIST_VOL:
                 w = self.f.createVariable(HIST_VOL[m], "f", ("time", "seg")); w.units = "m3"
                 self.vars[(m, "v")] = w
+            if inflow and m in HIST_INFLOW:
+                w = self.f.createVariable(HIST_INFLOW[m], "f", ("time", "seg")); w.units = "m3/s"
+                self.vars[(m, api.M_INFLOW)] = w
+            if height and m in HIST_HEIGHT:
+                w = self.f.createVariable(HIST_HEIGHT[m], "f", ("time", "seg")); w.units = "m"
+                self.vars[(m, api.M_HEIGHT)] = w
+                w = self.f.createVariable(HIST_FLOOD[m], "f", ("time", "seg")); w.units = "m3"
+                self.vars[(m, api.M_FLOODVOL)] = w
 
     def append(self, t_begin, t_end, dom, stamp_offset=0.0):
-        """Write the means accumulated on the device over [t_begin, t_end] and reset them."""
+        """Write the means accumulated on the device over [t_begin, t_end] and reset them (histVars finalize / refresh)."""
         self.f.variables["time"][self.n] = t_begin + stamp_offset
         self.f.variables["time_bounds"][self.n, :] = (t_begin, t_end)
-        for m in self.methods:
-            self.vars[(m, "q")][self.n, :] = dom.mean_q(m, reset=True).astype(np.float32)
-            if (m, "v") in self.vars:
-                self.vars[(m, "v")][self.n, :] = dom.flux(m, api.F_VOL1).astype(np.float32)
+        for (m, which), var in self.vars.items():
+            if which == "v":
+                var[self.n, :] = dom.flux(m, api.F_VOL1).astype(np.float32)
+            elif which == api.M_Q and not hasattr(dom, "mean"):
+                var[self.n, :] = dom.mean_q(m, reset=True).astype(np.float32)        # stand-ins in tests
+            else:
+                var[self.n, :] = dom.mean(m, which).astype(np.float32)
+        if self.runoff:
+            self.f.variables["basRunoff"][self.n, :] = dom.mean(0, api.M_BAS_RUNOFF).astype(np.float32)
+            self.f.variables["instRunoff"][self.n, :] = dom.mean(0, api.M_INST_RUNOFF).astype(np.float32)
+            self.f.variables["dlayRunoff"][self.n, :] = dom.mean(0, api.M_DLAY_RUNOFF).astype(np.float32)
+        if hasattr(dom, "reset_means"):
+            dom.reset_means()
         self.n += 1
 
     def close(self):

@@ -191,9 +191,13 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         if _truth(v) or (key == "qmodOption" and v not in ("F", "0", "")):
             raise NotImplementedError(f"<{key}> = {v}: not supported by mizuroute_amd.standalone (lakes and water management are available through "
                                       "mizuroute_amd.api.RoutingDomain)")
+    # history variables beyond discharge and volume (read_control.f90:239-262, histVars_data.f90): basRunoff defaults to T
+    want_runoff = _truth(ctl.get("basRunoff", "T")) or _truth(ctl.get("instRunoff", "F")) or _truth(ctl.get("dlayRunoff", "F"))
+    want_inflow, want_height = _truth(ctl.get("outputInflow", "F")), _truth(ctl.get("floodplain", "F"))
+    hflags = (api.H_RUNOFF if want_runoff else 0) | (api.H_INFLOW if want_inflow else 0) | (api.H_HEIGHT if want_height else 0)
     dom = api.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=W, device=device,
                             does_basin_route=int(ctl.get("doesBasinRoute", 1)), hw_drain_point=int(ctl.get("hw_drain_point", 2)),
-                            min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc)
+                            min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc, history=hflags)
     # ---- forcing: concatenate the files' time axes, find the record of every simulation step
     files = _forcing_files(ctl)
     handles = [netcdf_file(p, "r", mmap=False) for p in files]
@@ -232,9 +236,29 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     of = ctl.get("outputFrequency", "1")
     every = int(round(86400.0 / dt)) if of == "daily" else int(of)
     os.makedirs(ctl.get("output_dir", "."), exist_ok=True)
-    hname = os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.h.{t_beg:%Y-%m-%d}-{t_beg.hour * 3600 + t_beg.minute * 60 + t_beg.second:05d}.nc")
-    hist = ncfiles.HistoryWriter(hname, net.reachId, methods, time_units=f"seconds since {t_beg:%Y-%m-%d %H:%M:%S}",
-                                 volumes=any(_truth(ctl.get(k, "F")) for k in ncfiles.HIST_VOL.values()))
+    # one history file per <newFileFrequency> period (single / daily / monthly / yearly, default yearly), named by the period's
+    # first step (write_simoutput_pio.f90:328-380, period-start stamp)
+    nff = ctl.get("newFileFrequency", "yearly").strip()
+    if nff not in ("single", "daily", "monthly", "yearly"):
+        raise ValueError(f"<newFileFrequency> {nff}: expected single, daily, monthly or yearly")
+
+    def period(t):
+        return {"single": 0, "daily": (t.year, t.month, t.day), "monthly": (t.year, t.month), "yearly": t.year}[nff]
+
+    def hist_name(t):
+        stamp = {"single": f"{t:%Y-%m-%d}-{t.hour * 3600 + t.minute * 60 + t.second:05d}", "daily": f"{t:%Y-%m-%d}-{t.hour * 3600 + t.minute * 60 + t.second:05d}",
+                 "monthly": f"{t:%Y-%m}", "yearly": f"{t:%Y}"}[nff]
+        return os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.h.{stamp}.nc")
+
+    def hist_open(t):
+        return ncfiles.HistoryWriter(hist_name(t), net.reachId, methods, time_units=f"seconds since {t_beg:%Y-%m-%d %H:%M:%S}",
+                                     volumes=any(_truth(ctl.get(k, "F")) for k in ncfiles.HIST_VOL.values()), inflow=want_inflow, height=want_height,
+                                     runoff=want_runoff, hru_id=hru_id)
+
+    hfiles = [hist_name(t_beg)]
+    hname = hfiles[0]
+    hist = hist_open(t_beg)
+    hist_period = period(t_beg)
     import torch
     dev = torch.device("cuda", device)
     done = 0
@@ -257,14 +281,23 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         dom.sync()
         done += w
         if done % every == 0:      # time = start of the aggregated interval (+ <histTimeStamp_offset>), historyFile.f90:367
+            t_rec = t_beg + _dt.timedelta(seconds=(done - every) * dt)
+            if period(t_rec) != hist_period:          # the record opens a new period: new file
+                hist.close()
+                hist, hist_period = hist_open(t_rec), period(t_rec)
+                hfiles.append(hist_name(t_rec))
             hist.append((done - every) * dt, done * dt, dom, stamp_offset=float(ctl.get("histTimeStamp_offset", 0.0)))
     hist.close()
-    out = dict(history=hname, steps=n_steps, reaches=net.N)
+    out = dict(history=hname, history_files=hfiles, steps=n_steps, reaches=net.N)
     if ctl.get("restart_write", "never").lower() == "last":
         t_rst = t_end + _dt.timedelta(seconds=dt)        # the restart time is the END of the last step (write_restart_pio.f90:207-253,771)
         rname = os.path.join(ctl.get("output_dir", ""), f"{ctl['case_name']}.r.{t_rst:%Y-%m-%d}-{t_rst.hour * 3600 + t_rst.minute * 60 + t_rst.second:05d}.nc")
         ncfiles.write_restart(rname, dom, net.reachId, (t_first + (n_steps - 1) * dt, t_first + n_steps * dt), restart_time=t_first + n_steps * dt)
         out["restart"] = rname
+        # restart pointer file: names of the last restart and history files (io_rpointfile.f90:23-75)
+        with open(os.path.join(ctl.get("restart_dir", ctl.get("output_dir", "")), ctl.get("rpntfil", "rpointer.rof")), "w") as fp:
+            fp.write(rname + "\n" + hfiles[-1] + "\n")
+        out["rpointer"] = fp.name
     for h in handles:
         h.close()
     dom.close()

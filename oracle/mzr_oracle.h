@@ -72,6 +72,10 @@ int orc_set_lakes(orc_t *o, int LakeInputOption, int calendarId, int nLake, cons
                   const int *modelType, const double *par);
 /* target-volume lakes (lake_route.f90:139-142,197-205): flags[nLake], is_vol_wm_jumpstart, REACH_WM_VOL[nSteps][N] of the steps after firstStep */
 int orc_set_lake_target(orc_t *o, const int *flags, int jumpstart, int firstStep, const double *wmvol);
+/* history means since the last refresh (histVars_data.f90:154-305): which 0 discharge, 1 inflow, 2 height, 3 floodVolume,
+   4 volume (last value), 10 instRunoff, 11 dlayRunoff, 12 basRunoff [H] */
+int orc_hist_get(orc_t *o, int route, int which, double *out);
+void orc_hist_refresh(orc_t *o);
 /* one step with lake forcing: evap/precip [H] m/s; month, day, dayofyear of simDatetime(1) */
 int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const double *wmflux,
                   const double *evap, const double *precip, int month, int day, int dayofyear);

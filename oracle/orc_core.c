@@ -322,7 +322,56 @@ int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const do
       if (ierr) return ierr;
     }
   }
+  orc_hist_aggregate(o, runoff);
   return 0;
+}
+
+/* ---- history accumulation, histVars_data.f90:154-305 (aggregate / finalize / refresh).  The reference's module cannot be
+   compiled here (it USEs the ParallelIO wrappers), so this restatement is NOT pinned by execution; the arithmetic is
+   sum-then-divide in step order. */
+void orc_hist_aggregate(orc_t *o, const double *basRunoff) {
+  const int N = o->N, H = o->H, R = o->nRoutes;
+  if (!o->h_bas) {
+    o->h_bas = (double *)xcalloc(H, sizeof(double)); o->h_inst = (double *)xcalloc(N, sizeof(double)); o->h_dlay = (double *)xcalloc(N, sizeof(double));
+    o->h_q = (double *)xcalloc((size_t)N * R, sizeof(double)); o->h_vol = (double *)xcalloc((size_t)N * R, sizeof(double));
+    o->h_ele = (double *)xcalloc((size_t)N * R, sizeof(double)); o->h_flood = (double *)xcalloc((size_t)N * R, sizeof(double));
+    o->h_inflow = (double *)xcalloc((size_t)N * R, sizeof(double));
+  }
+  o->h_nt += 1;
+  for (int i = 0; i < H; i++) o->h_bas[i] = o->h_bas[i] + basRunoff[i];                 /* :196-198 */
+  for (int r = 0; r < N; r++) o->h_inst[r] = o->h_inst[r] + o->BASIN_QI[r];             /* :201-203 */
+  for (int r = 0; r < N; r++) o->h_dlay[r] = o->h_dlay[r] + o->BASIN_QR1[r];            /* :206-208 */
+  for (int ix = 0; ix < R; ix++) for (int r = 0; r < N; r++) {                          /* :211-246 */
+    const orc_hyd *h = &o->route[(size_t)ix * N + r];
+    const size_t k = (size_t)ix * N + r;
+    o->h_q[k] = o->h_q[k] + h->REACH_Q;
+    o->h_vol[k] = h->REACH_VOL[1];
+    o->h_flood[k] = o->h_flood[k] + h->FLOOD_VOL[1];
+    o->h_ele[k] = o->h_ele[k] + h->REACH_ELE;
+    o->h_inflow[k] = o->h_inflow[k] + h->REACH_INFLOW;
+  }
+}
+
+/* finalize (:251-297) of one variable: which 0 discharge, 1 inflow, 2 height, 3 floodVolume, 4 volume (last), 10 instRunoff,
+   11 dlayRunoff, 12 basRunoff [H] */
+int orc_hist_get(orc_t *o, int route, int which, double *out) {
+  if (!o->h_bas || o->h_nt < 1) return 1;
+  const int N = o->N;
+  const double nt = (double)o->h_nt;
+  if (which == 12) { for (int i = 0; i < o->H; i++) out[i] = o->h_bas[i] / nt; return 0; }
+  if (which == 10 || which == 11) { const double *s = which == 10 ? o->h_inst : o->h_dlay; for (int r = 0; r < N; r++) out[r] = s[r] / nt; return 0; }
+  const double *s = which == 0 ? o->h_q : which == 1 ? o->h_inflow : which == 2 ? o->h_ele : which == 3 ? o->h_flood : o->h_vol;
+  for (int r = 0; r < N; r++) out[r] = which == 4 ? s[(size_t)route * N + r] : s[(size_t)route * N + r] / nt;
+  return 0;
+}
+
+void orc_hist_refresh(orc_t *o) {   /* :300-305 */
+  if (!o->h_bas) return;
+  const size_t NR = (size_t)o->N * o->nRoutes;
+  memset(o->h_bas, 0, o->H * sizeof(double)); memset(o->h_inst, 0, o->N * sizeof(double)); memset(o->h_dlay, 0, o->N * sizeof(double));
+  memset(o->h_q, 0, NR * sizeof(double)); memset(o->h_vol, 0, NR * sizeof(double)); memset(o->h_ele, 0, NR * sizeof(double));
+  memset(o->h_flood, 0, NR * sizeof(double)); memset(o->h_inflow, 0, NR * sizeof(double));
+  o->h_nt = 0;
 }
 
 int orc_run_wm(orc_t *o, int nSteps, double t_start, const double *runoff, const double *wmflux, double *Qout, double *volOut);

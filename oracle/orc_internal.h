@@ -48,6 +48,7 @@ struct orc {
   double *lakePar;           /* [nLake][ORC_NLAKEPAR] (mutable: H06 monthly means, E_rel_ini) */
   double *basinEvapo, *basinPrecip;   /* [N] m3/s */
   double **qpast, **dpast; int *qpastLen, *dpastLen;   /* Hanasaki memory [12][L] per lake */
+  int h_nt; double *h_bas, *h_inst, *h_dlay, *h_q, *h_vol, *h_ele, *h_flood, *h_inflow;   /* history sums, histVars_data.f90 */
   int *lakeTarg, volJumpstart, wmVolFirst; const double *wmVol;   /* target-volume lakes: NETOPO%LakeTargVol, is_vol_wm_jumpstart, REACH_WM_VOL[step][N] */
   long long iTime; int month, day, dayofyear;
   /* KWT traffic statistics of the last step */
@@ -84,4 +85,5 @@ int orc_lake_route(orc_t *o, int r, int method);
 void orc_preamble(orc_t *o, int r, int method, double *q_upstream, double *q_upstream_mod,
                   double *Qlat, int *isHW);
 void orc_comp_reach_wb(orc_t *o, int r, int method, double Qupstream, double Qlat);
+void orc_hist_aggregate(orc_t *o, const double *basRunoff);
 #endif

@@ -45,6 +45,8 @@ def lib():
         L.orc_run_wm.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, C.c_void_p, C.c_void_p]
         L.orc_set_lakes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, dp]
         L.orc_set_lake_target.argtypes = [C.c_void_p, ip, C.c_int, C.c_int, dp]
+        L.orc_hist_get.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+        L.orc_hist_refresh.argtypes = [C.c_void_p]
         L.orc_run_lake.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, dp, dp, ip, C.c_void_p, C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
@@ -139,6 +141,16 @@ class Oracle:
         if rc:
             raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
         return (Q, V) if want_vol else Q
+
+    def hist(self, route, which):
+        """interval mean of a history variable since the last hist_refresh (mzr_oracle.h orc_hist_get)"""
+        out = np.zeros(self.H if which == 12 else self.N)
+        if lib().orc_hist_get(self.h, route, which, out):
+            raise RuntimeError("oracle: no history accumulated")
+        return out
+
+    def hist_refresh(self):
+        lib().orc_hist_refresh(self.h)
 
     def flux(self, route, which):
         out = np.zeros(self.N)

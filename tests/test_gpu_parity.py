@@ -653,3 +653,45 @@ def test_target_volume_lakes_and_demand_memory_vs_oracle(jump, window, hip_lib, 
             assert rep["max_rel"] <= REL_TOL, (meth, rep)
             vol = dom.flux(meth, m.api.F_VOL1)
             assert np.allclose(vol[lr], Vo[-1, ix, lr], rtol=REL_TOL, atol=1e-6), meth
+
+
+# ---- history variables beyond discharge (histVars_data.f90:154-305) -------------------------------------------------------
+def test_history_means_vs_oracle(tmp_path, hip_lib, oracle_lib):
+    """instRunoff, dlayRunoff, basRunoff, and per method routedRunoff, inflow, height, floodVolume (interval means) and volume
+    (last value): device accumulators against the oracle's restatement of aggregate / finalize, over two output intervals
+    cut by windows that do not divide them; then the same through the history file."""
+    from scipy.io import netcdf_file
+    from mizuroute_amd import ncfiles, uh as uhmod
+    net = m.make_network(1500, seed=61, floodplain=True)
+    dt, steps, every = 3600.0, 48, 24
+    ro = m.make_runoff(net.H, steps, seed=62, storm_prob=0.05, storm_amp=4e-6)
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    off, v = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    methods = [m.SUM, m.IRF, m.KWT, m.MC, m.DW]
+    A = m.api
+    dom = m.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=off, uh=v, max_window=10, history=A.H_INFLOW | A.H_HEIGHT | A.H_RUNOFF)
+    orc = oracle_lib.Oracle(net, dt, methods, frac, off, v)
+    hpath = str(tmp_path / "case.h.nc")
+    hw = ncfiles.HistoryWriter(hpath, net.reachId, methods, volumes=True, inflow=True, height=True, runoff=True, hru_id=np.arange(net.H) + 1)
+    done = 0
+    for k in range(steps // every):
+        orc.run(ro[k * every:(k + 1) * every], t_start=k * every * dt)
+        while done < (k + 1) * every:
+            w = min(10, (k + 1) * every - done)
+            dom.run(ro[done:done + w], t_start=done * dt)
+            done += w
+        for ix, meth in enumerate(methods):
+            for which, name in ((A.M_Q, "discharge"), (A.M_INFLOW, "inflow"), (A.M_HEIGHT, "height"), (A.M_FLOODVOL, "floodVolume")):
+                got, want = dom.mean(meth, which), orc.hist(ix, which)
+                assert np.allclose(got, want, rtol=REL_TOL, atol=1e-12), (k, meth, name, np.abs(got - want).max())
+            assert np.allclose(dom.flux(meth, A.F_VOL1), orc.hist(ix, 4), rtol=REL_TOL, atol=1e-9), (k, meth, "volume")
+        for which in (A.M_INST_RUNOFF, A.M_DLAY_RUNOFF, A.M_BAS_RUNOFF):
+            assert np.array_equal(dom.mean(0, which), orc.hist(0, which)), (k, which)       # sums of the same numbers in the same order
+        hw.append(k * every * dt, (k + 1) * every * dt, dom)
+        orc.hist_refresh()
+    hw.close()
+    f = netcdf_file(hpath, "r", mmap=False)
+    for name in ("instRunoff", "dlayRunoff", "basRunoff", "sumUpstreamRunoff", "DWinflow", "MCheight", "DWfloodVolume", "IRffloodVolume", "KWTinflow", "IRFvolume"):
+        assert name in f.variables and f.variables[name][:].shape[0] == 2 and f.variables[name][:].dtype.itemsize == 4, name
+    assert f.variables["basRunoff"].dimensions == ("time", "hru")
+    f.close()

@@ -11,7 +11,7 @@ import mizuroute_amd as m
 from mizuroute_amd import standalone
 
 
-def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None):
+def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None, new_file="single", extra=""):
     """Topology, forcing (HM HRUs = RN HRUs in shuffled order), control file and namelist of a synthetic case."""
     rng = np.random.default_rng(shuffle_seed)
     N = net.N
@@ -69,8 +69,8 @@ def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=N
 <varname_downSegId> tosegment
 <restart_write>  last
 <outputFrequency> 6
-<newFileFrequency> single
-"""
+<newFileFrequency> {new_file}
+{extra}"""
     path = os.path.join(tmp, "synth.control")
     open(path, "w").write(ctl)
     return path
@@ -141,6 +141,34 @@ def test_run_from_files_equals_api_run(tmp_path, hip_lib):
     f4 = netcdf_file(out4["history"], "r", mmap=False)
     assert np.array_equal(f4.variables["KWTroutedRunoff"][:], got) and np.array_equal(f4.variables["IRFroutedRunoff"][:], irf)
     f4.close()
+
+
+@pytest.mark.gpu
+def test_history_files_per_period_and_restart_pointer(tmp_path, hip_lib):
+    """<newFileFrequency> daily: one history file per day, named by the day (write_simoutput_pio.f90:328-380); the other history
+    variables through control keys (read_control.f90:239-262); rpointer.rof names the last restart and history files
+    (io_rpointfile.f90:23-75)."""
+    net = m.make_network(600, seed=15)
+    dt, steps = 3600.0, 48
+    ro = m.make_runoff(net.H, steps, seed=16, storm_prob=0.03, storm_amp=3e-6)
+    path = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="21", new_file="daily",
+                      extra="<outputInflow> T\n<dlayRunoff> T\n<instRunoff> T\n<KWTvolume> T\n")
+    out = standalone.run(path, window=7, log=lambda *_: None)
+    names = [os.path.basename(p) for p in out["history_files"]]
+    assert names == ["synth.h.2001-01-01-00000.nc", "synth.h.2001-01-02-00000.nc"], names
+    tot = 0
+    for k, p in enumerate(out["history_files"]):
+        f = netcdf_file(p, "r", mmap=False)
+        assert f.variables["KWTroutedRunoff"][:].shape == (4, net.N)
+        for name in ("basRunoff", "instRunoff", "dlayRunoff", "KWTinflow", "IRFinflow", "KWTvolume"):
+            assert name in f.variables, name
+        assert np.array_equal(f.variables["time"][:], (np.arange(4) + 4 * k) * 6 * dt)
+        assert (f.variables["basRunoff"][:] > 0).all() and f.variables["basRunoff"][:].shape == (4, net.H)
+        tot += f.variables["KWTroutedRunoff"][:].shape[0]
+        f.close()
+    assert tot == steps // 6
+    lines = open(out["rpointer"]).read().split()
+    assert os.path.basename(out["rpointer"]) == "rpointer.rof" and lines == [out["restart"], out["history_files"][-1]]
 
 
 @pytest.mark.gpu
