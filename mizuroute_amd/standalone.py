@@ -211,14 +211,27 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     if remap:
         m = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_remap"]), "r", mmap=False)
         mv = m.variables
-        src_id = np.asarray(handles[0].variables[ctl["vname_hruid"]][:], dtype=np.int64)
         pos_rn = {int(x): i + 1 for i, x in enumerate(hru_id)}
-        pos_src = {int(x): i + 1 for i, x in enumerate(src_id)}
-        qid = np.asarray(mv[ctl["vname_qhruid"]][:], dtype=np.int64)
-        mp = dict(hru_ix=np.array([pos_rn.get(int(x), -9999) for x in mv[ctl["vname_hruid_in_remap"]][:]], dtype=np.int32),
-                  num_qhru=np.asarray(mv[ctl["vname_num_qhru"]][:], dtype=np.int32), weight=np.asarray(mv[ctl["vname_weight"]][:], dtype=np.float64),
-                  qhru_ix=np.array([pos_src.get(int(x), -9999) for x in qid], dtype=np.int32), qhru_id=qid, src_id=src_id,
-                  n1=src_id.size, n2=0, H=net.H)
+        hix = np.array([pos_rn.get(int(x), -9999) for x in mv[ctl["vname_hruid_in_remap"]][:]], dtype=np.int32)
+        num = np.asarray(mv[ctl["vname_num_qhru"]][:], dtype=np.int32)
+        wgt = np.asarray(mv[ctl["vname_weight"]][:], dtype=np.float64)
+        vi, vj = ctl.get("vname_i_index", "i_index"), ctl.get("vname_j_index", "j_index")
+        if vi in mv and vj in mv:
+            # gridded runoff, runoff(time, lat, lon): the mapping names grid boxes (remap_2D_runoff, process_remap.f90:107-177;
+            # read_runoff.f90 option 3); i runs along <dname_xlon>, j along <dname_ylat>
+            qv = handles[0].variables[ctl["vname_qsim"]]
+            if len(qv.shape) != 3:
+                raise ValueError("the mapping file has i_index / j_index but the runoff variable is not (time, lat, lon)")
+            n2, n1 = int(qv.shape[1]), int(qv.shape[2])
+            mp = dict(hru_ix=hix, num_qhru=num, weight=wgt, i_index=np.asarray(mv[vi][:], dtype=np.int32), j_index=np.asarray(mv[vj][:], dtype=np.int32),
+                      n1=n1, n2=n2, H=net.H)
+        else:
+            src_id = np.asarray(handles[0].variables[ctl["vname_hruid"]][:], dtype=np.int64)
+            pos_src = {int(x): i + 1 for i, x in enumerate(src_id)}
+            qid = np.asarray(mv[ctl["vname_qhruid"]][:], dtype=np.int64)
+            mp = dict(hru_ix=hix, num_qhru=num, weight=wgt,
+                      qhru_ix=np.array([pos_src.get(int(x), -9999) for x in qid], dtype=np.int32), qhru_id=qid, src_id=src_id,
+                      n1=src_id.size, n2=0, H=net.H)
         m.close()
         dom.set_remap(mp)
     else:
@@ -268,7 +281,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         rows = []
         for k in range(w):                              # forcing of every simulation step: one record, or the weighted records it overlaps
             recs, fracs = time_map(start_ro_sec, dt, dt_ro, n_ro, done + k + 1)
-            get = lambda i: np.asarray(handles[frec[i]].variables[qname][lrec[i]], dtype=np.float64)
+            get = lambda i: np.asarray(handles[frec[i]].variables[qname][lrec[i]], dtype=np.float64).reshape(-1)     # (lat, lon) -> j-major cells
             if fracs is None:
                 rows.append(get(recs[0]))
             else:

@@ -219,6 +219,52 @@ def test_run_from_files_with_a_mapping_file(tmp_path, hip_lib, oracle_lib):
     assert np.allclose(got, want, rtol=2e-6, atol=1e-12)
 
 
+@pytest.mark.gpu
+def test_run_from_files_with_gridded_forcing(tmp_path, hip_lib, oracle_lib):
+    """Gridded runoff, runoff(time, lat, lon), through a mapping file with i_index / j_index (remap_2D_runoff on the device;
+    read_runoff.f90 option 3): the run from files equals the API run fed the oracle's remap of the same grid."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_remap, make_source_runoff
+    tmp = str(tmp_path)
+    net = m.make_network(900, seed=31)
+    dt, steps, nx, ny = 3600.0, 24, 40, 30
+    path = write_case(tmp, net, np.zeros((steps, net.N)), dt, route_opt="1")
+    mp = make_remap(net.H, nx, ny, seed=32, missing_frac=0.0)
+    sim = np.abs(make_source_runoff(steps, nx, ny, seed=33)) + 1e-9              # [steps, ny * nx] (or [steps, ny, nx]) mm/s
+    grid = np.asarray(sim).reshape(steps, ny, nx)
+    hru_id = (np.arange(net.N) + 50001).astype(np.int32)
+    g = netcdf_file(os.path.join(tmp, "runoff_grid.nc"), "w", version=2)
+    g.createDimension("time", None); g.createDimension("lat", ny); g.createDimension("lon", nx)
+    t = g.createVariable("time", "d", ("time",)); t.units = "hours since 2001-01-01 00:00:00"
+    q = g.createVariable("RUNOFF", "d", ("time", "lat", "lon"))
+    for k in range(steps):
+        t[k] = float(k); q[k, :, :] = grid[k]
+    g.close()
+    f = netcdf_file(os.path.join(tmp, "map2d.nc"), "w", version=2)
+    f.createDimension("hru", mp["hru_ix"].size); f.createDimension("data", mp["weight"].size)
+    rn = np.where(mp["hru_ix"] > 0, hru_id[np.maximum(mp["hru_ix"], 1) - 1], 999999).astype(np.int32)
+    v = f.createVariable("RN_hruId", "i", ("hru",)); v[:] = rn
+    v = f.createVariable("nOverlaps", "i", ("hru",)); v[:] = np.where(mp["num_qhru"] < 0, 0, mp["num_qhru"]).astype(np.int32)
+    v = f.createVariable("weight", "d", ("data",)); v[:] = mp["weight"]
+    v = f.createVariable("i_index", "i", ("data",)); v[:] = mp["i_index"].astype(np.int32)
+    v = f.createVariable("j_index", "i", ("data",)); v[:] = mp["j_index"].astype(np.int32)
+    f.close()
+    ctl = open(path).read().replace("<is_remap>       F", "<is_remap>       T").replace("<fname_qsim>     runoff.nc", "<fname_qsim>     runoff_grid.nc")
+    ctl += "<fname_remap>          map2d.nc\n<vname_hruid_in_remap> RN_hruId\n<vname_weight>         weight\n<vname_num_qhru>       nOverlaps\n<vname_i_index> i_index\n<vname_j_index> j_index\n"
+    open(path, "w").write(ctl)
+    out = standalone.run(path, window=10, log=lambda *_: None)
+    mp2 = dict(mp); mp2["num_qhru"] = np.where(mp["num_qhru"] < 0, 0, mp["num_qhru"]).astype(np.int32)
+    rc, basin = oracle_lib.remap_runoff(mp2, grid)
+    assert rc == 0
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    dom = m.RoutingDomain(net, dt, [m.IRF], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=12, length_conv=1.0e-3)
+    Q = dom.run(basin)
+    got = netcdf_file(out["history"], "r", mmap=False).variables["IRFroutedRunoff"][:]
+    want = Q[:, 0].reshape(steps // 6, 6, net.N).mean(axis=1)
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-12)
+
+
 def test_time_map_follows_the_reference_rule():
     """timeMap_sim_forc: one record when the step lies inside a forcing interval, overlap fractions otherwise."""
     tm = standalone.time_map
