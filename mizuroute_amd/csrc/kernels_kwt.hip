@@ -461,7 +461,7 @@ __device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *
 #define MZR_REC_N 65536
 #define TRECORD(G_, size_, nrem_) do { int _sz = (size_), _nr = (nrem_); for (int _o = 32; _o > 0; _o >>= 1) { _sz = max(_sz, __shfl_xor(_sz, _o, 64)); _nr = max(_nr, __shfl_xor(_nr, _o, 64)); } \
   if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { unsigned *_rb = (unsigned *)(d.dbgCycles + 32 * 1024); const unsigned _k = atomicAdd(_rb, 1u) % MZR_REC_N; unsigned *_r = _rb + 16 + (size_t)_k * 16; \
-    _r[0] = (G_); _r[1] = _sz; _r[2] = _nr; _r[3] = _sec[21]; _r[4] = _sec[0]; _r[5] = _sec[1]; _r[6] = _sec[2] + _sec[3]; _r[7] = _sec[4] + _sec[5]; _r[8] = _sec[6]; _r[9] = _sec[16] + _sec[17]; _r[10] = _sec[18] + _sec[19] + _sec[7]; _r[11] = _sec[22]; } } while (0)
+    _r[0] = (G_); _r[1] = _sz; _r[2] = _nr; _r[3] = _sec[21]; _r[4] = _sec[0]; _r[5] = _sec[1] + _sec[10] + _sec[11] + _sec[12]; _r[6] = _sec[2] + _sec[3]; _r[7] = _sec[4] + _sec[5]; _r[8] = _sec[6]; _r[9] = _sec[16] + _sec[17]; _r[10] = _sec[18] + _sec[19] + _sec[7]; _r[11] = _sec[22]; _r[12] = _sec[10]; _r[13] = _sec[11]; _r[14] = _sec[12]; } } while (0)
 #define TSTAMP_WAVE(i) do { if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], 1ull); } while (0)
 #else
 #define KCOUNT(i, v) do { } while (0)
@@ -746,6 +746,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           }
         }
         grp_sync();
+        TSTAMP(10);
 
         // ---- qexmul_rch
         int ND;
@@ -795,9 +796,36 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               CT = St[i];
               if (!(CT < T1)) slow = true;                            // error 40 in the cursor walk
               if (i > 1 && !(St[i - 1] < CT)) slow = true;            // duplicate or unordered
+              // rank among the other tributary's particles = how many of them are earlier (an equal time anywhere sends the
+              // group to the literal cursor walk, so "earlier" and "earlier or equal" need not be told apart).  Short lists:
+              // one LDS round trip for four of them; long lists: bisection (each series is checked for order by its own lanes)
               int cnt = 0;
-              for (int j = 1; j <= nO; ++j) { const double to = Ot[j]; cnt += (isA ? to < CT : to <= CT) ? 1 : 0; if (to == CT) slow = true; }
+              if ((nA > nB ? nA : nB) <= 4) {
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tv[u] = Ot[min(1 + u, nO > 0 ? nO : 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const double tu = (1 + u <= nO) ? tv[u] : DBL_MAX;
+                  cnt += tu < CT ? 1 : 0;
+                  slow = slow || tu == CT;
+                }
+              } else {
+                int lo = 0, hi = nO;                       // cnt in [lo, hi]
+                const int nbis = 32 - __clz(nA > nB ? nA : nB);
+#pragma unroll 1
+                for (int it = 0; it < nbis; ++it) {        // nO <= 19 < 32
+                  const int mid = (lo + hi) >> 1;
+                  const double tm = Ot[mid + 1 <= nO ? mid + 1 : (nO > 0 ? nO : 1)];
+                  const bool less = lo < hi && tm < CT;
+                  lo = less ? mid + 1 : lo;
+                  hi = (lo < hi && !less) ? mid : hi;
+                }
+                cnt = lo;
+                if (cnt < nO && Ot[cnt + 1] == CT) slow = true;
+              }
               pos = (i - 1) + cnt;
+              TSTAMP(11);
               Q_AGG = Q_AGG + (bs.b0q0 + bs.b0sl * (CT - T0)) * bs.bsc;
               if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
               double SOWN = Sq[i] * (isA ? scA : scB), SOTH = 0.0;
@@ -812,6 +840,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               else { Q_AGG = Q_AGG + SOTH; Q_AGG = Q_AGG + SOWN; }
             }
             QD[pos] = Q_AGG; TD[pos] = CT;
+            TSTAMP(12);
           }
           if (grp_any<G>(slow)) {
             KCOUNT(8, 1);

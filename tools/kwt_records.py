@@ -31,4 +31,4 @@ for G in (4, 8, 16):
         s2 = sel & (r[:, 1] >= lo) & (r[:, 1] <= hi)
         if s2.sum() < 5: continue
         row = " ".join(f"{nm} {r[s2, 3 + i].mean():.0f}" for i, nm in enumerate(names))
-        print(f"   size {lo}-{hi}: n {s2.sum()}  removed(mean) {r[s2,2].mean():.1f}  compute {(tot[s2]-r[s2,3]).mean():.0f} | {row}")
+        print(f"   size {lo}-{hi}: n {s2.sum()}  removed(mean) {r[s2,2].mean():.1f}  compute {(tot[s2]-r[s2,3]).mean():.0f} | {row} | of merge: wait for rows + staging {r[s2,12].mean():.0f}, rank loops {r[s2,13].mean():.0f}, rest of the loop {r[s2,14].mean():.0f}")
