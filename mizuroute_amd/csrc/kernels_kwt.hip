@@ -231,6 +231,28 @@ template <int G, bool LAST> __device__ __forceinline__ void grp_argmin(double &v
   i = grp_minmax_i<G, LAST>(c);
   v = m;
 }
+// DPP move whose "old" operand is undefined (every lane has a source for the controls used here): the compiler folds
+// it into the consuming VALU instruction (v_min_u32_dpp) instead of copying the register first
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+template <int G> __device__ __forceinline__ unsigned grp_min_u(unsigned v) {
+  static_assert(G <= 16, "one DPP row");
+  v = min(v, dpp_u<MZR_DPP_XOR1>(v));
+  v = min(v, dpp_u<MZR_DPP_XOR2>(v));
+  if (G >= 8) v = min(v, dpp_u<MZR_DPP_HALF_MIRROR>(v));
+  if (G >= 16) v = min(v, dpp_u<MZR_DPP_MIRROR>(v));
+  return v;
+}
+// MINLOC over the group of (v, i) for v >= 0 and never NaN, i >= 1 (0 = "none"): non-negative doubles order like their
+// bit patterns, so the minimum is found on the high words, then the low words of the lanes that tie, then the
+// smallest index of the lanes that still tie -- twelve one-instruction DPP steps instead of 64-bit compares and selects.
+template <int G> __device__ __forceinline__ int grp_argmin_pos(double v, int i) {
+  const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
+  const unsigned mh = grp_min_u<G>(hi);
+  const unsigned ml = grp_min_u<G>(hi == mh ? lo : 0xffffffffu);
+  return (int)grp_min_u<G>((hi == mh && lo == ml) ? (unsigned)i : 0x7fffffffu);
+}
 // flags of the group's lanes as a bit mask (bit 0 = first lane of the group)
 template <int G> __device__ __forceinline__ unsigned long long grp_bits(bool p) {
   const unsigned long long b = __ballot(p);
@@ -903,35 +925,46 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               e[j] = DBL_MAX;
               if (i >= 1 && i < NPRT) e[j] = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
             }
+            // Even lanes look at the alive set as it is (bit i = particle i) and re-evaluate the neighbour below the
+            // removed particle; odd lanes hold it bit-reversed (bit 63-i) and re-evaluate the neighbour above, so that
+            // both sides run the same "nearest alive bit below" twice; the first neighbour of the other side comes
+            // through the lane pair.
+            const bool side = gl & 1;
+            unsigned long long x = side ? __brevll(mask) : mask;
+            int ISEL = 0;
             while (MPRT >= MZR_MAXQPAR_DEV) {
-              double emin = DBL_MAX; int ISEL = 0;
+              double emin = DBL_MAX; ISEL = 0;
 #pragma unroll
               for (int j = 0; j < KT; ++j) if (e[j] < emin) { emin = e[j]; ISEL = gl + j * G; }
-              grp_argmin<G, false>(emin, ISEL);           // first minimum of ABSERR (removed entries hold +Inf)
-              if (ISEL == 0) break;                         // no finite interpolation error left (NaN/Inf input)
-              mask &= ~(1ull << (ISEL & 63));
-              const int pm = 63 - __clzll((long long)(mask & ((1ull << ISEL) - 1ull)));       // INDEX1(ISEL-1)
-              const int pn = __ffsll((long long)(mask & ~((2ull << ISEL) - 1ull))) - 1;        // INDEX1(ISEL+1)
-              const bool side = gl & 1;
-              const int c = side ? pn : pm;
-              const bool valid = side ? pn < NPRT : pm > 0;
+              ISEL = grp_argmin_pos<G>(emin, ISEL);         // first minimum of ABSERR (removed entries hold +Inf)
+              if (ISEL == 0 || ISEL == 0x7fffffff) { ISEL = 0; break; }   // no finite interpolation error left (NaN/Inf input)
+              const int sx = side ? 63 - ISEL : ISEL;
+              x &= ~(1ull << sx);
+              const int p1 = 63 - __clzll((long long)(x & ((1ull << sx) - 1ull)));   // own side: INDEX1(ISEL -+ 1)
+              const int c = side ? 63 - p1 : p1;
+              const int q1 = (int)dpp_u<MZR_DPP_XOR1>((unsigned)c);                  // the other side's
+              const bool valid = (side ? NPRT - c : c) > 0;
               double en = 0.0;
               if (valid) {   // pm: between INDEX1(pm-1) and pn; pn: between pm and INDEX1(pn+1)
-                const int a = side ? pm : 63 - __clzll((long long)(mask & ((1ull << pm) - 1ull)));
-                const int b = side ? __ffsll((long long)(mask & ~((2ull << pn) - 1ull))) - 1 : pn;
+                const int p2 = 63 - __clzll((long long)(x & ((1ull << p1) - 1ull)));
+                const int far = side ? 63 - p2 : p2;
+                const int a = side ? q1 : far, b = side ? far : q1;
                 en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
               }
               const double eo = dpp_d<MZR_DPP_XOR1>(en);   // the other side's result
               const double e_pm = side ? eo : en, e_pn = side ? en : eo;
+              int pm = side ? q1 : c, pn = side ? c : q1;
+              pm = pm > 0 ? pm : -1; pn = pn < NPRT ? pn : -1;
 #pragma unroll
               for (int j = 0; j < KT; ++j) {
                 const int i = gl + j * G;
-                if (i == pm && pm > 0) e[j] = e_pm;
-                if (i == pn && pn < NPRT) e[j] = e_pn;
+                if (i == pm) e[j] = e_pm;
+                if (i == pn) e[j] = e_pn;
                 if (i == ISEL) e[j] = INFINITY;           // removed: never the minimum again
               }
               --MPRT;
             }
+            mask = side ? __brevll(x) : x;
           } else {
           for (int i = gl; i <= NPRT; i += G) {
             double e = DBL_MAX;
