@@ -20,13 +20,14 @@
 
 namespace {
 
-constexpr double c13 = 1.0 / 3.0, c23 = 2.0 / 3.0, c53 = 5.0 / 3.0, c103 = 10.0 / 3.0;
+constexpr double c23 = 2.0 / 3.0, c53 = 5.0 / 3.0, c103 = 10.0 / 3.0;
 
-struct Chan { double b, zc, S, n, zf, D; double Qbf, n06;       // width, side slope, slope, Manning n, floodplain slope, bank depth;
-                                                                 // per reach, once: bankfull discharge (hydraulic.f90:345) and n**0.6 (:479)
-              double sq1zc, sq1zf, sqSn, b3, bt04, Abf, Pbf, Bbf; };   // ... and the sub-expressions the Newton iterations and Muskingum-Cunge's sub-steps
+struct Chan { double b, zc, S, n, zf, D; double Qbf;       // width, side slope, slope, Manning n, floodplain slope, bank depth;
+                                                                 // per reach, once: bankfull discharge (hydraulic.f90:345)
+              double sq1zc, sq1zf, sqSn, isqSn, ib3, Abf, Pbf, Bbf;
+              mutable double obC1 = -1.0, obC2 = 0.0; };   // coefficients of the above-bankfull depth iteration, on first use   // ... and the sub-expressions the Newton iterations and Muskingum-Cunge's sub-steps
                                                                  // would evaluate again and again with the same operands: sqrt(1+zc**2), sqrt(1+zf**2),
-                                                                 // sqrt(S)/n, b**3, b**0.4 (top width of a rectangular channel below bankfull), bankfull A, P, B
+                                                                 // sqrt(S)/n and its inverse, 1/b**3, bankfull A, P, B
 
 __device__ __forceinline__ double d_Btop(double y, const Chan &c) {
   if (y <= c.D) return c.b + 2 * y * c.zc;
@@ -58,34 +59,47 @@ __device__ double d_flow_depth(double Qin, const Chan &c) {
   if (!(Qin > 1.e-50)) return 0.0;
   const double Abf = c.Abf, Pbf = c.Pbf, Bbf = c.Bbf;
   const double Qbf = c.Qbf;
-  double err = 100.0, fd = 0.0;
+  double fd = 0.0;
   if (Qin < Qbf) {
-    const double t = c.sqSn / Qin;
-    const double Coef1 = t * t * t;
+    // Coef1 = (sqrt(S)/n / Q)**3, first guess (1 / Coef1 / b**3)**0.2, then Newton on h = Coef1 A**5 / P**2 - 1 with
+    // dh/dy = Coef1 (5 A**4 Bt P - 2 Coef2 A**5) / P**3 (:344-350).  h and dh/dy enter only as h / dhdy, which with
+    // u3 = 1 / Coef1 is (A**5 - u3 P**2) P / (5 A**4 Bt P - 2 Coef2 A**5): one division per iteration instead of five, and
+    // the stopping test |(fd - y0) / fd| > 0.005 without its division.  This loop is a chain of dependent FP64 operations
+    // with nothing to overlap it, and a Muskingum-Cunge reach walks through it in each of its 2-200 sub-steps per step.
+    const double u = Qin * c.isqSn, u3 = u * u * u;
     const double Coef2 = 2 * c.sq1zc;
-    double y0 = pow_0p2(1.0 / Coef1 / c.b3);
+    double y0 = pow_0p2(u3 * c.ib3);
     int guard = 0;
-    while (err > 0.005 && guard++ < 200) {
+    bool more = true;
+    while (more && guard++ < 200) {
       const double A = d_area(y0, c), Bt = d_Btop(y0, c), P = d_Pwet(y0, c);
-      const double A4 = A * A * A * A, A5 = A4 * A;
-      const double h = Coef1 * A5 / (P * P) - 1.0;
-      const double dhdy = Coef1 * (5 * A4 * Bt * P - 2 * Coef2 * A5) / (P * P * P);
-      fd = y0 - h / dhdy;
-      err = fabs((fd - y0) / fd);
+      const double A2 = A * A, A4 = A2 * A2, A5 = A4 * A;
+      fd = y0 - (A5 - u3 * (P * P)) * P / (5 * A4 * Bt * P - 2 * Coef2 * A5);
+      more = fabs(fd - y0) > 0.005 * fabs(fd);
       y0 = fd;
     }
   } else {
+    // above bankfull (:383-425).  Every power here has thirds as exponent: x**(2/3) = cbrt(x)**2, x**(5/3) = x cbrt(x)**2,
+    // ye**(10/3) / ye**(2/3) = ye**3 cbrt(ye) / cbrt(ye)**2 -- two cube roots per iteration instead of five generic
+    // pow() (a few hundred instructions each, and a flooding reach is typically also one with many Muskingum-Cunge
+    // sub-steps); the two coefficients are the reach's own and are kept for the next call.  Negative ye: NaN like pow().
     double y0 = c.D + 2.0;
-    const double sqS = sqrt(c.S);
-    const double Coef1 = sqS / c.n / pow(Pbf, c23);
-    const double Coef2 = 2 * pow(c.zf / 2, c53) * sqS / c.n / pow(c.zf * c.zf + 1.0, c13);
+    if (c.obC1 < 0.0) {
+      const double sqS = sqrt(c.S), zh = c.zf / 2, czh = cbrt(zh);
+      c.obC1 = sqS / c.n / pow_2_3(Pbf);
+      c.obC2 = 2 * (zh * (czh * czh)) * sqS / c.n / cbrt(c.zf * c.zf + 1.0);
+    }
+    const double Coef1 = c.obC1, Coef2 = c.obC2;
     int guard = 0;
-    while (err > 0.005 && guard++ < 200) {
-      const double ye = y0 - c.D;
-      const double h = Coef1 * pow(Abf + Bbf * ye, c53) + Coef2 * pow(ye, c103) / pow(ye, c23) - Qin;
-      const double dhdy = Coef1 * c53 * Bbf * pow(Abf + Bbf * ye, c23) + Coef2 * (c103 - c23) * pow(ye, c53);
+    bool more = true;
+    while (more && guard++ < 200) {
+      const double ye = y0 - c.D, X = Abf + Bbf * ye;
+      const double cx = cbrt(X), cy = ye < 0.0 ? NAN : cbrt(ye);
+      const double X23 = cx * cx, y23 = cy * cy;
+      const double h = Coef1 * (X * X23) + Coef2 * (ye * ye * ye * cy) / y23 - Qin;
+      const double dhdy = Coef1 * c53 * Bbf * X23 + Coef2 * (c103 - c23) * (ye * y23);
       fd = y0 - h / dhdy;
-      err = fabs((fd - y0) / fd);
+      more = fabs(fd - y0) > 0.005 * fabs(fd);
       y0 = fd;
     }
   }
@@ -96,12 +110,13 @@ __device__ double d_friction_slope(double Qin, double y, const Chan &c) {
   const double v = Qin * c.n / A / pow_2_3(A / P);
   return v * v;
 }
+// hydraulic.f90:438-484: ck = 5/3 Sf**0.3 Q**0.4 / Bt**0.4 / n**0.6 with Sf = (Q n / A / R**(2/3))**2 from Manning's
+// equation.  Written out, n and the thirds cancel: ck = 5/3 (Q / A) (P / Bt)**0.4 -- one power and two divisions
+// instead of four powers, a cube root and six divisions, on the critical chain of every Muskingum-Cunge sub-step.
 __device__ double d_celerity(double Qin, double y, const Chan &c) {
   if (!(y > 0.0)) return 0.0;
-  const double Bt = d_Btop(y, c);
-  const double Sf = d_friction_slope(Qin, y, c);
-  const double bt04 = (y <= c.D && c.zc == 0.0) ? c.bt04 : pow_0p4(Bt);      // rectangular below bankfull: Bt == b
-  return c53 * pow_0p3(Sf) * pow_0p4(Qin) / bt04 / c.n06;
+  const double A = d_area(y, c), P = d_Pwet(y, c), Bt = d_Btop(y, c);
+  return c53 * Qin * pow_0p4(P / Bt) / A;
 }
 __device__ double d_diffusivity(double Qin, double y, const Chan &c) {
   if (!(y > 0.0)) return 0.0;
@@ -181,12 +196,10 @@ __device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, dou
 __device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
   Chan c; c.b = d.width[r]; c.zc = d.side[r]; c.S = d.slope[r]; c.n = d.mann[r]; c.zf = d.fldp[r]; c.D = d.depth[r];
   c.sq1zc = sqrt(1 + c.zc * c.zc); c.sq1zf = sqrt(1 + c.zf * c.zf);
-  c.sqSn = sqrt(c.S) / c.n; c.b3 = c.b * c.b * c.b;
-  c.bt04 = pow_0p4(c.b);
+  c.sqSn = sqrt(c.S) / c.n; c.isqSn = c.n / sqrt(c.S); c.ib3 = 1.0 / (c.b * c.b * c.b);
   const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c);
   c.Abf = Abf; c.Pbf = Pbf; c.Bbf = d_Btop(c.D, c);
   c.Qbf = Abf * pow_2_3(Abf / Pbf) * sqrt(c.S) / c.n;      // hydraulic.f90:345
-  c.n06 = pow_0p6(c.n);
   return c;
 }
 
@@ -308,14 +321,20 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
           double Cn = ck * theta;
           int ntSub = 1; double dTsub = dt;
           if (Cn > 1.0) { ntSub = (int)ceil(dt / L * ck); dTsub = dt / ntSub; }
-          const double Y = 0.5;
+          const double Y = 0.5, SL = c.S * L, thSub = dTsub / L;
           double qin_prev = Q00, qout_prev = Q01, ssum = 0.0;
           // From the second sub-step on the inflow pair is (Q10, Q10), so a sub-step is a fixed map of the previous
           // outflow alone, and that map contracts towards Q10: once it returns its own argument (or alternates between two
           // neighbouring doubles) every remaining sub-step is known, and only their running sum -- the same additions in
           // the same order -- is left to do.  With 20..200 sub-steps per step (smooth channels) most of them are skipped.
           double qprev2 = -1.0;
+#ifdef MZR_MC_STATS
+          int _nexec = 0;
+#endif
           for (int ix = 1; ix <= ntSub; ++ix) {
+#ifdef MZR_MC_STATS
+            _nexec = ix;
+#endif
             const double qin = Q10;
             double qo;
             Qbar = (qin + qin_prev + qout_prev) / 3.0;
@@ -323,13 +342,11 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
               depth = d_flow_depth(fabs(Qbar), c);
               const double topWidth = d_Btop(depth, c);
               ck = d_celerity(fabs(Qbar), depth, c);
-              const double X = 0.5 * (1.0 - Qbar / (topWidth * c.S * ck * L));
-              Cn = ck * dTsub / L;
+              const double X = 0.5 * (1.0 - Qbar / (topWidth * SL * ck));
+              Cn = ck * thSub;
+              // C0 qin + C1 qin_prev + C2 qout_prev with the common denominator of the three coefficients (:305-312)
               const double den = 1 - X + Cn * (1 - Y);
-              const double C0 = (-X + Cn * (1 - Y)) / den;
-              const double C1 = (X + Cn * Y) / den;
-              const double C2 = (1 - X - Cn * Y) / den;
-              qo = C0 * qin + C1 * qin_prev + C2 * qout_prev;
+              qo = ((-X + Cn * (1 - Y)) * qin + (X + Cn * Y) * qin_prev + (1 - X - Cn * Y) * qout_prev) / den;
               qo = fmax(0.0, qo);
             } else {
               qo = 0.0;
@@ -344,10 +361,36 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
                 for (int k = ix + 1; k <= ntSub; ++k) ssum = ssum + (((k - ix) & 1) ? qout_prev : qo);
                 break;
               }
+              // Close to its fixed point q* the map is linear to second order, q(k) = q* + e rho**k.  Once the outflow moves by
+              // less than mcTailTol (1e-7) of itself per sub-step and the differences contract, the sub-steps still to come
+              // are added in closed form (a geometric series with rho from the last two differences).  Whatever rho is worth,
+              // the sum left out is at most |d2| / (1 - rho_true) -- the bound is on the step actually taken, not on the
+              // estimate -- and observed deviations from iterating on are ~1e-10 of the discharge (stated tolerance 1e-6).
+              // Flat short reaches (rho ~ 0.9, 50-200 sub-steps, a hundred of them in 100 k) are what this is for: they set
+              // the duration of every launch.  MZR_MC_TAIL_TOL=0 iterates every sub-step.
+              if (ix >= 3 && qo > 0.0) {
+                const double d2 = qo - qout_prev, d1 = qout_prev - qprev2;
+                if (fabs(d2) <= d.mcTailTol * qo && fabs(d2) < 0.995 * fabs(d1)) {
+                  const double rho = d2 / d1, g = rho / (1.0 - rho);
+                  const double qs = qo + d2 * g;                                  // q*
+                  const int m = ntSub - ix;
+                  double rm = exp((double)m * log(fabs(rho)));                    // |rho|**m
+                  if (rho < 0.0 && (m & 1)) rm = -rm;
+                  ssum = ssum + ((double)m * qs + (qo - qs) * g * (1.0 - rm));
+                  break;
+                }
+              }
             }
             qprev2 = qout_prev;
             qin_prev = qin; qout_prev = qo;
           }
+#ifdef MZR_MC_STATS
+          if (d.dbgCycles) {   // tools/dbg_mc.py: sub-steps asked for / executed (log2 bins), executed per reach
+            atomicAdd(&d.dbgCycles[16 + min(15, 31 - __clz(ntSub))], 1ull); atomicAdd(&d.dbgCycles[min(15, 31 - __clz(max(1, _nexec)))], 1ull);
+            d.dbgCycles[32 * 1024 + 64 + r] += (unsigned long long)_nexec;
+            atomicMax(&d.dbgCycles[32 * 1024 + 64 + 200000 + (s & 4095)], (unsigned long long)_nexec);
+          }
+#endif
           Q11 = ssum / (double)ntSub;
           if (fabs(Q11) > 0.0) {
             const double pr = fmin((vol / dt + Q10) * (double)0.999f / Q11, 1.0);   // default-real literal, :352

@@ -66,6 +66,7 @@ struct MzrDev {
   const double *kwK, *kwCW;   // KWT: K = sqrt(slope)/n and ALFA*K**(1/ALFA), precomputed on the host
   // ---- configuration
   double dt, min_length_route, runoffMin, negRunoffTol, time_conv, length_conv, t_start;
+  double mcTailTol;   // Muskingum-Cunge: closed-form tail of the sub-step sum once the outflow changes by less than this fraction of itself per sub-step (0 = iterate every sub-step)
   double T1_single;       // end of step for single-step windows (mzr_step passes TSEC(2) explicitly)
   int hw_drain_point, doesBasinRoute, is_flux_wm;
   const double *wm;           // [W][N] REACH_WM_FLUX of the window (null unless is_flux_wm)

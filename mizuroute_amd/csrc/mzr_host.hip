@@ -252,6 +252,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.basarea = h->par[8].p; d.minflow = h->par[10].p;
   d.kwK = h->kwK.p; d.kwCW = h->kwCW.p;
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
+  { const char *e = getenv("MZR_MC_TAIL_TOL"); d.mcTailTol = e ? atof(e) : 1.e-7; }
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
   d.is_flux_wm = h->cfg.is_flux_wm; d.wm = (h->cfg.is_flux_wm && h->wmSteps > 0) ? h->wm.p : nullptr;
@@ -1517,6 +1518,13 @@ int mzr_debug_records(mzr_handle h, unsigned *out, int n) {
   const int have = (int)std::min<unsigned>(all[0], 65536u), m = std::min(n, have);
   memcpy(out, all.data() + 16, (size_t)m * 16 * sizeof(unsigned));
   return m;
+}
+
+// debug: raw 64-bit words of the debug buffer
+int mzr_debug_raw(mzr_handle h, long long first, long long n, unsigned long long *out) {
+  if (!h || !h->dbgCycles.p || first < 0 || n < 0 || (size_t)(first + n) > h->dbgCycles.n) return 1;
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(out, h->dbgCycles.p + first, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 
 int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {

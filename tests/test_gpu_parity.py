@@ -401,6 +401,38 @@ def test_sort_flux_vs_oracle(hip_lib, oracle_lib):
         assert np.array_equal(dst.cpu().numpy(), oracle_lib.sort_flux(ix, fl, net.H, remove_negatives=rmneg))
 
 
+def test_mc_substep_tail_closed_form(hip_lib, oracle_lib, monkeypatch):
+    """Muskingum-Cunge on short, flat reaches (Courant number 20-150 -> as many sub-steps per step, mc_route.f90:262-300):
+    the sub-step sum with its tail in closed form (default) and iterated to the end (MZR_MC_TAIL_TOL=0), both against
+    the oracle's literal loop and against each other."""
+    net = m.make_network(3000, seed=91)
+    rng = np.random.default_rng(4)
+    pick = rng.choice(net.N, 400, replace=False)
+    net.params["RLENGTH"][pick] = rng.uniform(150.0, 600.0, pick.size)
+    net.params["R_SLOPE"][pick] = rng.uniform(2e-4, 1e-3, pick.size)
+    dt, steps = 3600.0, 60
+    ro = m.make_runoff(net.H, steps, seed=92, storm_prob=0.05, storm_amp=4e-6)
+    ff = np.array([0.6, 0.4])
+    orc = oracle_lib.Oracle(net, dt, [m.MC], ff, None, None)
+    Qo = orc.run(ro)[:, 0]
+    Q = {}
+    for tol in ("0", None):
+        if tol is None:
+            monkeypatch.delenv("MZR_MC_TAIL_TOL", raising=False)
+        else:
+            monkeypatch.setenv("MZR_MC_TAIL_TOL", tol)
+        dom = m.RoutingDomain(net, dt, [m.MC], frac_future=ff, max_window=32)
+        Q[tol] = dom.run(ro)[:, 0]
+        rep = parity_report(Qo, Q[tol])
+        print("MC tail tol", tol, rep)
+        assert rep["max_rel"] <= REL_TOL, (tol, rep)
+        dom.close()
+    big = np.abs(Qo) > 1e-12
+    rel = np.abs(Q[None] - Q["0"])[big] / np.abs(Qo[big])
+    assert rel.max() < 1e-8, float(rel.max())          # second order in the distance to the fixed point: ~1e-10 observed
+    assert parity_report(Qo, Q["0"])["max_rel"] < 1e-10  # without the tail only rounding separates the two
+
+
 # ---- restart / history files (ncfiles.py): state through a file == state kept on the device ----------
 def test_restart_continues_bit_exact(tmp_path, hip_lib):
     from mizuroute_amd import ncfiles, uh as uhmod
