@@ -250,6 +250,10 @@ class RoutingDomain:
             done += w
         return out
 
+    def set_wm_flux(self, w, wm_flux):
+        """REACH_WM_FLUX [w, nRch] of the next window (is_flux_wm; -9999 = no data for the reach)."""
+        self._check(self.L.mzr_set_wm_flux(self.h, int(w), np.ascontiguousarray(wm_flux, dtype=np.float64)))
+
     def set_lake_forcing(self, first, w):
         """Upload evaporation/precipitation and the calendar of steps [first, first+w) of self.lakes."""
         lk = self.lakes

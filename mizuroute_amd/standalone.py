@@ -17,6 +17,12 @@ Scope (what a run of the reference's SAMPLE.control needs, nothing more):
   * forcing from `<fname_qsim>` (one NetCDF file, or a text file listing them) on the simulation
     step or on any other regular step `<dt_ro>` (timeMap_sim_forc: overlap-weighted records), on the
     river-network HRUs in file order (is_remap = F -> sort_flux) or remapped (is_remap = T, 1-D);
+  * lakes (`<is_lake_sim> T`): flags `islake`, `lakeModelType`, `LakeTargVol` and the Doll / Hanasaki / HYPE parameters
+    from the topology file (popMetadat.f90:124-232 names, `<varname_*>` overrides), evaporation and precipitation from
+    the forcing files (`<vname_evapo>`, `<vname_precip>`, `<LakeInputOption>`, scale / offset / sign keys;
+    get_basin_runoff.f90:136-205), `<lakeRegulate> F` = every lake natural; water management (`<is_flux_wm>`,
+    `<is_vol_wm>`, `<is_vol_wm_jumpstart>`): `<fname_wm>` file(s) on their own step `<dt_wm>`, fluxes and target volumes
+    sorted onto the reaches by `<vname_segid_wm>` (get_basin_runoff.f90:106-109, 207-250);
   * history file(s) `<case_name>.h.<start>.nc` at `<outputFrequency>` (a multiple of the step or
     `daily`), one file per run (`<newFileFrequency> single`), restart in / out (`<fname_state_in>`,
     `<restart_write> last`).
@@ -171,6 +177,103 @@ def _forcing_files(ctl: dict):
     return [os.path.join(ctl.get("input_dir", ""), ln.strip()) for ln in open(p) if ln.strip()]
 
 
+REAL_MISSING = -9999.0
+
+
+def _wm_files(ctl: dict):
+    p = os.path.join(ctl.get("input_dir", ""), ctl["fname_wm"])
+    if p.endswith(".nc"):
+        return [p]
+    return [os.path.join(ctl.get("input_dir", ""), ln.strip()) for ln in open(p) if ln.strip()]
+
+
+class ForcingSeries:
+    """Records of one variable family over one or several NetCDF files, on their own regular step, mapped onto the
+    simulation steps (read_forcing_data + timeMap_sim_forc, get_basin_runoff.f90:262-372): a step inside one record
+    takes the record as it is, a step across records their overlap-weighted sum."""
+
+    def __init__(self, files, vname_time: str, dt_in: float, t0_sec: float):
+        self.handles = [netcdf_file(p, "r", mmap=False) for p in files]
+        taxis = np.concatenate([_time_axis(h.variables[vname_time]) for h in self.handles])
+        self.frec = np.concatenate([np.full(h.variables[vname_time].shape[0], i) for i, h in enumerate(self.handles)])
+        self.lrec = np.concatenate([np.arange(h.variables[vname_time].shape[0]) for h in self.handles])
+        self.start_sec = t0_sec - float(taxis[0])         # the first record covers [taxis[0], taxis[0] + dt_in)
+        self.n, self.dt_in = taxis.size, dt_in
+
+    def var(self, name):
+        return self.handles[0].variables[name]
+
+    def step(self, name: str, dt: float, ix_time: int) -> np.ndarray:
+        """the variable at simulation step ix_time (1-based), flattened ((lat, lon) -> j-major cells)"""
+        recs, fracs = time_map(self.start_sec, dt, self.dt_in, self.n, ix_time)
+        get = lambda i: np.asarray(self.handles[self.frec[i]].variables[name][self.lrec[i]], dtype=np.float64).reshape(-1)
+        if fracs is None:
+            return get(recs[0])
+        acc = np.zeros_like(get(recs[0]))
+        for i, fr in zip(recs, fracs):
+            acc = acc + fr * get(i)
+        return acc
+
+    def close(self):
+        for h in self.handles:
+            h.close()
+
+
+def scale_forcing(a: np.ndarray, scale: float, offset: float) -> np.ndarray:
+    """scale_forcing (get_basin_runoff.f90:375-425): only when one of the two is given; missing values stay."""
+    vs = 1.0e-12
+    if abs(scale - REAL_MISSING) < vs and abs(offset - REAL_MISSING) < vs:
+        return a
+    sc = 1.0 if abs(scale - REAL_MISSING) < vs else scale
+    of = 0.0 if abs(offset - REAL_MISSING) < vs else offset
+    return np.where(np.abs(a - REAL_MISSING) > vs, sc * a + of, a)
+
+
+def suppressed(scale: float, offset: float) -> bool:
+    """scale 0 and offset 0 or absent: the flux is not read and taken as zero (get_basin_runoff.f90:140-142, 176-178)"""
+    vs = 1.0e-12
+    return abs(scale) < vs and (abs(offset) < vs or abs(offset - REAL_MISSING) < vs)
+
+
+def sort_flux(ix_in: np.ndarray, flux: np.ndarray, n: int, remove_negatives: bool) -> np.ndarray:
+    """process_remap.f90:268-316 on the host (water-management series are nSeg values per step): entries of the data
+    set land on position ix_in (1-based, < 1 = not in the network), everything else is realMissing; negative values
+    (realMissing too) become 0 when asked."""
+    out = np.full(n, REAL_MISSING)
+    ok = ix_in >= 1
+    out[ix_in[ok] - 1] = flux[ok]
+    if remove_negatives:
+        out[out < 0.0] = 0.0
+    return out
+
+
+def read_lakes(ctl: dict, net, n_steps: int) -> dict:
+    """Lake flags and parameters of the topology file (process_ntopo.f90 / popMetadat.f90 names) as the dictionary
+    api.RoutingDomain takes: reach (1-based), model_type, par[NLAKEPAR, nLake], input_option, calendar_id."""
+    from .casefile import LAKE_PAR, NLAKEPAR
+    f = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_ntopOld"]), "r", mmap=False)
+    v = f.variables
+    name = lambda k: ctl.get("varname_" + k, k)
+    if name("islake") not in v:
+        raise ValueError(f"<is_lake_sim> T but the topology file has no '{name('islake')}'")
+    islake = np.asarray(v[name("islake")][:], dtype=np.int64) == 1
+    reach = (np.nonzero(islake)[0] + 1).astype(np.int32)
+    mtype = np.asarray(v[name("lakeModelType")][:], dtype=np.int32)[islake] if name("lakeModelType") in v else np.ones(reach.size, np.int32)
+    if not _truth(ctl.get("lakeRegulate", "T")):
+        mtype = np.ones(reach.size, np.int32)              # every lake natural (Doll), public_var.f90:105
+    par = np.zeros((NLAKEPAR, reach.size))
+    for i, k in enumerate(LAKE_PAR):
+        if name(k) in v:
+            par[i] = np.asarray(v[name(k)][:], dtype=np.float64)[islake]
+    out = dict(reach=reach, model_type=mtype, par=par, input_option=int(ctl.get("LakeInputOption", 0)),
+               calendar_id=0 if ctl.get("calendar", "standard").strip().lower() in ("noleap", "365_day") else 1)
+    if _truth(ctl.get("is_vol_wm", "F")):
+        flag = np.asarray(v[name("LakeTargVol")][:], dtype=np.int32)[islake] if name("LakeTargVol") in v else np.zeros(reach.size, np.int32)
+        out.update(targ_vol=flag, vol_jumpstart=int(_truth(ctl.get("is_vol_wm_jumpstart", "F"))))
+    f.close()
+    return out
+
+
 def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> dict:
     ctl = read_control(control_path)
     nml = read_param_nml(os.path.join(ctl.get("ancil_dir", ""), ctl["param_nml"]))
@@ -186,27 +289,34 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, nml["velo"], nml["diff"])
     W = max(1, min(window, n_steps))
     # options of the reference this driver does not implement stop the run instead of being ignored (read_control.f90)
-    for key in ("is_lake_sim", "is_flux_wm", "is_vol_wm", "is_vol_wm_jumpstart", "lakeRegulate", "tracer", "qmodOption"):
+    for key in ("tracer", "qmodOption"):
         v = str(ctl.get(key, "F")).strip()
         if _truth(v) or (key == "qmodOption" and v not in ("F", "0", "")):
-            raise NotImplementedError(f"<{key}> = {v}: not supported by mizuroute_amd.standalone (lakes and water management are available through "
-                                      "mizuroute_amd.api.RoutingDomain)")
+            raise NotImplementedError(f"<{key}> = {v}: not supported by mizuroute_amd.standalone")
+    is_lake, is_flux_wm = _truth(ctl.get("is_lake_sim", "F")), _truth(ctl.get("is_flux_wm", "F"))
+    is_vol_wm = _truth(ctl.get("is_vol_wm", "F")) and is_lake
+    lakes = read_lakes(ctl, net, n_steps) if is_lake else None
     # history variables beyond discharge and volume (read_control.f90:239-262, histVars_data.f90): basRunoff defaults to T
     want_runoff = _truth(ctl.get("basRunoff", "T")) or _truth(ctl.get("instRunoff", "F")) or _truth(ctl.get("dlayRunoff", "F"))
     want_inflow, want_height = _truth(ctl.get("outputInflow", "F")), _truth(ctl.get("floodplain", "F"))
     hflags = (api.H_RUNOFF if want_runoff else 0) | (api.H_INFLOW if want_inflow else 0) | (api.H_HEIGHT if want_height else 0)
     dom = api.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=W, device=device,
                             does_basin_route=int(ctl.get("doesBasinRoute", 1)), hw_drain_point=int(ctl.get("hw_drain_point", 2)),
-                            min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc, history=hflags)
+                            min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc, history=hflags,
+                            lakes=lakes, is_flux_wm=int(is_flux_wm))
     # ---- forcing: concatenate the files' time axes, find the record of every simulation step
-    files = _forcing_files(ctl)
-    handles = [netcdf_file(p, "r", mmap=False) for p in files]
-    taxis = np.concatenate([_time_axis(h.variables[ctl["vname_time"]]) for h in handles])
-    frec = np.concatenate([np.full(h.variables[ctl["vname_time"]].shape[0], i) for i, h in enumerate(handles)])
-    lrec = np.concatenate([np.arange(h.variables[ctl["vname_time"]].shape[0]) for h in handles])
     t0 = (t_beg - epoch).total_seconds()
-    start_ro_sec = t0 - float(taxis[0])               # the first record covers [taxis[0], taxis[0] + dt_ro)
-    n_ro = taxis.size
+    fro = ForcingSeries(_forcing_files(ctl), ctl["vname_time"], dt_ro, t0)
+    handles = fro.handles
+    fwm = None
+    if is_flux_wm or is_vol_wm:
+        fwm = ForcingSeries(_wm_files(ctl), ctl.get("vname_time_wm", "time"), float(ctl.get("dt_wm", dt)), t0)
+        wm_seg = np.asarray(fwm.var(ctl["vname_segid_wm"])[:], dtype=np.int64)
+        pos_seg = {int(x): i + 1 for i, x in enumerate(net.reachId)}
+        wm_ix = np.array([pos_seg.get(int(x), -9999) for x in wm_seg], dtype=np.int64)        # match_index, model_setup.f90:897
+    fnum = lambda k: float(str(ctl.get(k, REAL_MISSING)).lower().replace("d", "e"))
+    sc_ro, of_ro = fnum("scale_factor_runoff"), fnum("offset_value_runoff")
+    sc_ep, of_ep, sc_pr, of_pr = fnum("scale_factor_Ep"), fnum("offset_value_Ep"), fnum("scale_factor_prec"), fnum("offset_value_prec")
     remap = _truth(ctl.get("is_remap", "F"))
     if remap:
         m = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_remap"]), "r", mmap=False)
@@ -278,17 +388,32 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     qname = ctl["vname_qsim"]
     while done < n_steps:
         w = min(W, n_steps - done, every - (done % every))                 # a window never straddles an output record
-        rows = []
-        for k in range(w):                              # forcing of every simulation step: one record, or the weighted records it overlaps
-            recs, fracs = time_map(start_ro_sec, dt, dt_ro, n_ro, done + k + 1)
-            get = lambda i: np.asarray(handles[frec[i]].variables[qname][lrec[i]], dtype=np.float64).reshape(-1)     # (lat, lon) -> j-major cells
-            if fracs is None:
-                rows.append(get(recs[0]))
-            else:
-                acc = np.zeros_like(get(recs[0]))
-                for i, fr in zip(recs, fracs):
-                    acc = acc + fr * get(i)
-                rows.append(acc)
+        rows = [scale_forcing(fro.step(qname, dt, done + k + 1), sc_ro, of_ro) for k in range(w)]   # forcing of every simulation step
+        if lakes is not None:
+            # lake fluxes of the window: evaporation / precipitation through the same mapping as runoff (on the device),
+            # the calendar of every step, the target volumes (get_basin_runoff.f90:136-229)
+            lk = dom.lakes
+            days = [t_beg + _dt.timedelta(seconds=(done + k) * dt) for k in range(w)]
+            lk["ymd"] = np.array([[d.year, d.month, d.day] for d in days], dtype=np.int64)
+            for key, vname, sc, of, flip in (("evap", ctl.get("vname_evapo", "evap"), sc_ep, of_ep, _truth(ctl.get("is_Ep_upward_negative", "F"))),
+                                             ("precip", ctl.get("vname_precip", "precip"), sc_pr, of_pr, False)):
+                if lk["input_option"] == 1 or suppressed(sc, of):
+                    lk[key] = np.zeros((w, net.H))
+                    continue
+                a = np.stack([fro.step(vname, dt, done + k + 1) for k in range(w)])
+                if flip:
+                    a = scale_forcing(a, -1.0, 0.0)
+                a = scale_forcing(a, sc, of)
+                srcf = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                dstf = torch.empty((w, net.H), dtype=torch.float64, device=dev)
+                dom.remap_device(w, srcf.data_ptr(), dstf.data_ptr())
+                dom.sync()
+                lk[key] = dstf.cpu().numpy()
+            if is_vol_wm:
+                lk["wm_vol"] = np.stack([sort_flux(wm_ix, fwm.step(ctl["vname_vol_wm"], dt, done + k + 1), net.N, True) for k in range(w)])
+            dom.set_lake_forcing(0, w)
+        if is_flux_wm:
+            dom.set_wm_flux(w, np.stack([sort_flux(wm_ix, fwm.step(ctl["vname_flux_wm"], dt, done + k + 1), net.N, False) for k in range(w)]))
         src = torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(dev)
         dom.run_source_device(w, t_first + done * dt, src.data_ptr())
         dom.sync()
@@ -311,8 +436,9 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         with open(os.path.join(ctl.get("restart_dir", ctl.get("output_dir", "")), ctl.get("rpntfil", "rpointer.rof")), "w") as fp:
             fp.write(rname + "\n" + hfiles[-1] + "\n")
         out["rpointer"] = fp.name
-    for h in handles:
-        h.close()
+    fro.close()
+    if fwm is not None:
+        fwm.close()
     dom.close()
     log(f"routed {net.N} reaches x {n_steps} steps -> {hname}")
     return out

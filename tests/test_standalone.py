@@ -11,7 +11,7 @@ import mizuroute_amd as m
 from mizuroute_amd import standalone
 
 
-def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None, new_file="single", extra=""):
+def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None, new_file="single", extra="", lakes=None, wm=None):
     """Topology, forcing (HM HRUs = RN HRUs in shuffled order), control file and namelist of a synthetic case."""
     rng = np.random.default_rng(shuffle_seed)
     N = net.N
@@ -27,6 +27,17 @@ def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=N
     var("seg_id", "i", "seg", net.reachId.astype(np.int32)); var("tosegment", "i", "seg", down_id)
     var("Length", "d", "seg", net.params["RLENGTH"]); var("Slope", "d", "seg", net.params["R_SLOPE"])
     var("hruid", "i", "hru", hru_id); var("seg_hru_id", "i", "hru", seg_of_hru); var("Basin_Area", "d", "hru", net.params["BASAREA"])
+    if lakes is not None:      # lake flags and parameters under the reference's own names (popMetadat.f90:124-232)
+        from mizuroute_amd.casefile import LAKE_PAR
+        isl = np.zeros(N, np.int32); isl[lakes["reach"] - 1] = 1
+        mt = np.zeros(N, np.int32); mt[lakes["reach"] - 1] = lakes["model_type"]
+        var("islake", "i", "seg", isl); var("lakeModelType", "i", "seg", mt)
+        if "targ_vol" in lakes:
+            tv = np.zeros(N, np.int32); tv[lakes["reach"] - 1] = lakes["targ_vol"]
+            var("LakeTargVol", "i", "seg", tv)
+        for i, k in enumerate(LAKE_PAR):
+            a = np.zeros(N); a[lakes["reach"] - 1] = lakes["par"][i]
+            var(k, "d", "seg", a)
     f.close()
     perm = rng.permutation(N)                       # forcing file lists the HRUs in another order
     steps = runoff_mm_s.shape[0]
@@ -35,10 +46,25 @@ def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=N
     t = g.createVariable("time", "d", ("time",)); t.units = "hours since 2001-01-01 00:00:00"
     h = g.createVariable("hru_id", "i", ("hru",)); h[:] = hru_id[perm]
     q = g.createVariable("RUNOFF", "d", ("time", "hru"))
+    if lakes is not None:
+        ev = g.createVariable("evap", "d", ("time", "hru")); pr = g.createVariable("precip", "d", ("time", "hru"))
     for k in range(steps):
         t[k] = k * dt / 3600.0
         q[k, :] = runoff_mm_s[k, perm]
+        if lakes is not None:
+            ev[k, :] = lakes["evap"][k, perm] * 1000.0; pr[k, :] = lakes["precip"][k, perm] * 1000.0      # mm/s like the runoff
     g.close()
+    if wm is not None:         # water-management file: a subset of the reaches in its own order, on its own (coarser) step
+        segs, flux, vol, dt_wm = wm
+        w = netcdf_file(os.path.join(tmp, "wm.nc"), "w", version=2)
+        w.createDimension("time", None); w.createDimension("seg", segs.size)
+        tw = w.createVariable("time", "d", ("time",)); tw.units = "hours since 2001-01-01 00:00:00"
+        sid = w.createVariable("seg_id", "i", ("seg",)); sid[:] = net.reachId[segs].astype(np.int32)
+        fx = w.createVariable("abs_inj", "d", ("time", "seg")); tvv = w.createVariable("target_vol", "d", ("time", "seg"))
+        for k in range(flux.shape[0]):
+            tw[k] = k * dt_wm / 3600.0
+            fx[k, :] = flux[k]; tvv[k, :] = vol[k]
+        w.close()
     open(os.path.join(tmp, "param.nml"), "w").write("&HSLOPE\n fshape = 2.5\n tscale = 86400\n/\n&IRF_UH\n velo = 1.5\n diff = 5000.0\n/\n&KWT\n mann_n = 0.01\n wscale = 0.001\n/\n")
     end = np.datetime64("2001-01-01T00:00:00") + np.timedelta64(int((steps - 1) * dt), "s")
     ctl = f"""! synthetic case
@@ -276,3 +302,65 @@ def test_time_map_follows_the_reference_rule():
     assert r == [0, 1] and np.allclose(f, [0.5, 0.5])
     with pytest.raises(ValueError):
         tm(0.0, 3600.0, 3600.0, 3, 4)
+
+
+@pytest.mark.gpu
+def test_run_from_files_with_lakes_and_water_management(tmp_path, hip_lib):
+    """<is_lake_sim>, <is_flux_wm>, <is_vol_wm> from files: lake flags / parameters in the topology file, evaporation and
+    precipitation beside the runoff, abstraction / injection and target volumes in a water-management file on a 3-hourly
+    step for a subset of the reaches (get_basin_runoff.f90:106-250) -- against the same run through the API."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(1200, seed=31)
+    dt, steps, dt_wm = 3600.0, 48, 10800.0
+    ro = m.make_runoff(net.H, steps, seed=32, storm_prob=0.03, storm_amp=3e-6)
+    lakes = make_lakes(net, steps, dt, seed=6, frac=0.02, input_option=0, target_frac=0.5)
+    rng = np.random.default_rng(8)
+    others = np.setdiff1d(np.arange(net.N), lakes["reach"] - 1)
+    segs = np.concatenate([rng.choice(others, 60, replace=False), lakes["reach"] - 1])
+    rng.shuffle(segs)
+    nrec = int(steps * dt / dt_wm)
+    flux = rng.uniform(-0.02, 0.05, (nrec, segs.size))                       # m3/s taken (+) or injected (-)
+    vol3 = lakes["wm_vol"][::3][:nrec][:, segs]                              # target volumes, 3-hourly
+    path = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="5", lakes=lakes, wm=(segs, flux, vol3, dt_wm),
+                      extra="<is_lake_sim> T\n<is_flux_wm> T\n<is_vol_wm> T\n<LakeInputOption> 0\n<calendar> noleap\n<fname_wm> wm.nc\n<vname_flux_wm> abs_inj\n"
+                            "<vname_vol_wm> target_vol\n<vname_time_wm> time\n<vname_segid_wm> seg_id\n<dt_wm> 10800\n<floodplain> T\n")
+    out = standalone.run(path, window=16, log=lambda *_: None)
+    # the same through the API: per-step arrays as the driver builds them (every 3-hourly record covers three steps)
+    wm_flux = np.full((steps, net.N), -9999.0); wm_vol = np.zeros((steps, net.N))
+    for k in range(steps):
+        wm_flux[k, segs] = flux[k // 3]
+        wm_vol[k, segs] = vol3[k // 3]
+    lk = dict(lakes); lk["wm_vol"] = wm_vol
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    ctl = standalone.read_control(path)
+    net_f, _ = standalone.build_network(ctl, standalone.read_param_nml(os.path.join(str(tmp_path), "param.nml")))
+    dom = m.RoutingDomain(net_f, dt, [m.DW], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=16, lakes=lk, is_flux_wm=1)
+    Q = dom.run(ro, wm_flux=wm_flux)
+    f = netcdf_file(out["history"], "r", mmap=False)
+    got = f.variables["DWroutedRunoff"][:]
+    want = Q.reshape(steps // 6, 6, 1, net.N).sum(axis=1)[:, 0] / 6.0
+    assert np.allclose(got, want, rtol=5e-6, atol=1e-10), float(np.abs(got - want).max())
+    lake0 = lakes["reach"] - 1
+    assert np.abs(want[:, lake0]).max() > 0                                   # the lakes do release water
+    f.close()
+    # and the lakes matter: the same files without <is_lake_sim> give another answer at the lake outlets
+    os.makedirs(str(tmp_path / "nolake"))
+    p2 = write_case(str(tmp_path / "nolake"), net, ro * 1000.0, dt, route_opt="5")
+    o2 = standalone.run(p2, window=16, log=lambda *_: None)
+    f2 = netcdf_file(o2["history"], "r", mmap=False)
+    assert not np.allclose(f2.variables["DWroutedRunoff"][:][:, lake0], got[:, lake0], rtol=1e-3)
+    f2.close()
+
+
+def test_sort_flux_and_scale_forcing_follow_the_reference_rules():
+    """sort_flux (process_remap.f90:268-316) and scale_forcing (get_basin_runoff.f90:375-425) on the host side"""
+    ix = np.array([3, -9999, 1], dtype=np.int64)
+    assert np.array_equal(standalone.sort_flux(ix, np.array([5.0, 7.0, -2.0]), 4, False), [-2.0, -9999.0, 5.0, -9999.0])
+    assert np.array_equal(standalone.sort_flux(ix, np.array([5.0, 7.0, -2.0]), 4, True), [0.0, 0.0, 5.0, 0.0])
+    a = np.array([1.0, -9999.0, 2.0])
+    assert np.array_equal(standalone.scale_forcing(a, -9999.0, -9999.0), a)                    # neither given: untouched
+    assert np.array_equal(standalone.scale_forcing(a, 2.0, -9999.0), [2.0, -9999.0, 4.0])      # missing values stay
+    assert np.array_equal(standalone.scale_forcing(a, -9999.0, 0.5), [1.5, -9999.0, 2.5])
+    assert standalone.suppressed(0.0, -9999.0) and standalone.suppressed(0.0, 0.0) and not standalone.suppressed(1.0, 0.0)
