@@ -167,6 +167,11 @@ int mzr_get_flux(mzr_handle h, int method, int which, double *out);
 int mzr_get_window_q(mzr_handle h, int method, double *out);
 /* device-side history accumulation (histVars_data.f90:154-246): mean REACH_Q since the last reset */
 int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset);
+/* comp_global_wb (water_balance.f90:191-323) of the last routed step, whole domain of this handle [m3]:
+   out8 = { dVol, lateral flow, lake precipitation, -actual water take, -lake evaporation, -outflow at the outlets,
+   -demanded water take, error = [0] - ([1]+...+[5]) }; the reference warns when |error| > 1 m3.  With several
+   partitions the host adds the first seven numbers of all handles (shr_mpi_reduce in the reference). */
+int mzr_get_global_wb(mzr_handle h, int method, double *out8);
 /* The other history variables of the reference (histVars_data.f90:154-305; names popMetadat.f90:238-271):
    which sums are accumulated on the device -- call before mzr_init_state.
      MZR_H_INFLOW  <M>inflow: mean REACH_INFLOW per method (outputInflow)

@@ -52,7 +52,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_target", "mzr_set_wm_vol",
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
@@ -113,6 +113,7 @@ def load_library():
     L.mzr_comm_last_error.argtypes = [C.c_char_p, ci]
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
+    L.mzr_get_global_wb.argtypes = [vp, ci, dp]
     L.mzr_set_irf_state.argtypes = [vp, dp]
     L.mzr_set_mol_state.argtypes = [vp, ci, dp]
     L.mzr_set_basin_state.argtypes = [vp, vp, vp]
@@ -296,6 +297,12 @@ class RoutingDomain:
         out = np.zeros(self.N)
         self._check(self.L.mzr_get_flux(self.h, method, which, out))
         return out
+
+    def global_wb(self, method):
+        """comp_global_wb of the last routed step: dict of the seven domain sums [m3] and the error term."""
+        out = np.zeros(8)
+        self._check(self.L.mzr_get_global_wb(self.h, method, out))
+        return dict(zip(("dVol", "lateral", "precip", "take_actual", "evaporation", "outflow", "take_demand", "error"), out))
 
     def window_q(self, method, n_steps):
         out = np.zeros((n_steps, self.N))

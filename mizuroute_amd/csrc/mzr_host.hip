@@ -1283,6 +1283,42 @@ int mzr_get_flux(mzr_handle h, int method, int which, double *out) {
   return fail(h, 20, "mzr_get_flux/unknown field");
 }
 
+// comp_global_wb (water_balance.f90:191-323) for the last routed step: the seven sums over the whole domain and the
+// error term 8 = 1 - (2+3+4+5+6).  Reaches are summed in the library's internal order (the reference sums mainstem,
+// then tributaries, then across MPI ranks -- another order of the same additions).
+int mzr_get_global_wb(mzr_handle h, int method, double *out8) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_global_wb/state not initialised") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_global_wb/method not active");
+  if (h->lastW < 1) return fail(h, 20, "mzr_get_global_wb/no step has been routed");
+  const size_t N = h->N;
+  const int tl = h->lastW - 1;
+  RouteBufs &rb = h->route[ix];
+  std::vector<double> vol(N), vol0(N), qr(N), q(N), act(N, 0.0), dem(N, 0.0);
+  auto pull = [&](std::vector<double> &v, const double *src, size_t n) { return hipMemcpy(v.data(), src, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess; };
+  bool ok = pull(vol, rb.vol.p, N) && pull(vol0, rb.vol0.p, N) && pull(qr, h->qlat.p + (size_t)h->lastW * N, N) && pull(q, rb.Q.p + (size_t)tl * N, N);
+  const bool wm = h->cfg.is_flux_wm && h->wm.p;          // (the window's series stay in place until the next upload)
+  if (wm) ok = ok && pull(act, rb.wmact.p, N) && pull(dem, h->wm.p + (size_t)tl * N, N);
+  std::vector<double> ev(h->nLake, 0.0), pr(h->nLake, 0.0);
+  if (h->nLake && h->lakeEvap.p) ok = ok && pull(ev, h->lakeEvap.p + (size_t)tl * h->nLake, h->nLake) && pull(pr, h->lakePrecip.p + (size_t)tl * h->nLake, h->nLake);
+  if (!ok) return fail(h, 92, "mzr_get_global_wb/hipMemcpy failed");
+  const double dt = h->cfg.dt;
+  double b[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (size_t r = 0; r < N; ++r) {
+    b[0] += vol[r] - vol0[r];
+    b[1] += qr[r] * dt;
+    const int ls = h->nLake ? h->h_lakeSlot[r] : -1;
+    if (ls >= 0) { b[2] += pr[ls] * dt; b[4] -= ev[ls] * dt; }
+    if (wm) b[3] -= act[r] * dt;                            // (a reach the data set does not name carries realMissing here, as in the reference)
+    if (h->h_down[r] < 0) b[5] -= q[r] * dt;
+    if (wm) b[6] -= dem[r] * dt;
+  }
+  for (int i = 0; i < 7; ++i) out8[i] = b[i];
+  out8[7] = b[0] - (b[1] + b[2] + b[3] + b[4] + b[5]);
+  return 0;
+}
+
 int mzr_get_window_q(mzr_handle h, int method, double *out) {
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_window_q/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;

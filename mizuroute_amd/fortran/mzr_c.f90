@@ -38,7 +38,8 @@ MODULE mzr_c
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
-            mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync
+            mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
+            mzr_get_global_wb
   public :: mzr_message
 
   INTERFACE
@@ -125,6 +126,12 @@ MODULE mzr_c
       type(c_ptr), value :: h
       integer(c_int), value :: method, reset
       real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_get_global_wb(h, method, out8) bind(C, name='mzr_get_global_wb')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method
+      real(c_double), intent(out) :: out8(8)
     end function
     integer(c_int) function mzr_get_kwt_state(h, numWaves, qwave, tentry, texit, routed) bind(C, name='mzr_get_kwt_state')
       import :: c_ptr, c_int, c_double

@@ -433,6 +433,47 @@ def test_mc_substep_tail_closed_form(hip_lib, oracle_lib, monkeypatch):
     assert parity_report(Qo, Q["0"])["max_rel"] < 1e-10  # without the tail only rounding separates the two
 
 
+def test_global_water_balance(hip_lib):
+    """comp_global_wb (water_balance.f90:191-323) of the last step: the seven sums restated from the per-reach fields, and
+    the global error equal to the sum of the per-reach errors (comp_reach_wb, :22-112) -- inside the domain every
+    outflow is somebody's inflow -- for plain reaches, with water management, and with lakes."""
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(3000, seed=55)
+    dt, steps = 3600.0, 20
+    ro = m.make_runoff(net.H, steps, seed=56, storm_prob=0.05, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    outlet = net.downIndex <= 0
+    rng = np.random.default_rng(3)
+    wm = np.where(rng.random((steps, net.N)) < 0.1, rng.uniform(-0.01, 0.02, (steps, net.N)), 0.0)
+    lakes = make_lakes(net, steps, dt, seed=5, frac=0.02, input_option=0)
+    from mizuroute_amd import uh as uhmod
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    for meth, kw, wmf in ((m.IRF, {}, None), (m.DW, dict(is_flux_wm=1), wm), (m.KW, dict(lakes=lakes), None)):
+        dom = m.RoutingDomain(net, dt, [meth], frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=8, **kw)
+        dom.run(ro, wm_flux=wmf)
+        g = dom.global_wb(meth)
+        vol1, vol0 = dom.flux(meth, m.api.F_VOL1), dom.flux(meth, m.api.F_VOL0)
+        assert np.isclose(g["dVol"], (vol1 - vol0).sum(), rtol=1e-12, atol=1e-6)
+        assert np.isclose(g["lateral"], dom.flux(meth, m.api.F_BASIN_QR1).sum() * dt, rtol=1e-12)
+        assert np.isclose(g["outflow"], -dom.flux(meth, m.api.F_Q)[outlet].sum() * dt, rtol=1e-12)
+        if wmf is not None:
+            assert np.isclose(g["take_demand"], -wm[-1].sum() * dt, rtol=1e-12) and g["take_actual"] != 0.0
+        else:
+            assert g["take_demand"] == 0.0 and g["take_actual"] == 0.0
+        if "lakes" in kw:
+            assert g["precip"] > 0.0 and g["evaporation"] < 0.0
+        else:
+            assert g["precip"] == 0.0 and g["evaporation"] == 0.0
+        assert g["error"] == g["dVol"] - (g["lateral"] + g["precip"] + g["take_actual"] + g["evaporation"] + g["outflow"])
+        wb = dom.flux(meth, m.api.F_WB)
+        scale = np.abs(vol1).sum() + abs(g["lateral"])
+        if wmf is None:
+            assert abs(g["error"] - wb.sum()) <= 1e-9 * scale, (meth, g["error"], wb.sum())
+        else:      # (the per-reach balance counts an injection both in the lateral flow and in the take, like the reference's)
+            assert abs(g["error"]) <= 1e-9 * scale, (meth, g["error"])
+        dom.close()
+
+
 # ---- restart / history files (ncfiles.py): state through a file == state kept on the device ----------
 def test_restart_continues_bit_exact(tmp_path, hip_lib):
     from mizuroute_amd import ncfiles, uh as uhmod
