@@ -112,6 +112,11 @@ int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, 
    and month / day / day-of-year of simDatetime(1) for every step */
 int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip,
                          const int *month, const int *day, const int *dayofyear);
+/* the same with evaporation and precipitation already in device memory (e.g. written by mzr_remap_runoff_dev, so that
+   the two fluxes take the runoff's path from the file to the lakes without visiting the host); the calendar stays on
+   the host.  With LakeInputOption = 1 neither flux is used: both entry points accept NULL for them. */
+int mzr_set_lake_forcing_dev(mzr_handle h, int nSteps, const double *evap_dev, const double *precip_dev,
+                             const int *month, const int *day, const int *dayofyear);
 /* Lakes that follow a target volume instead of their parametric release (is_vol_wm; NETOPO%LakeTargVol,
    lake_route.f90:197-205): targVol[nLake] flags, jumpstart = is_vol_wm_jumpstart (the first step starts from the
    target, :140-142).  The targets of a window, REACH_WM_VOL [nSteps][nRch] in the caller's reach order

@@ -52,7 +52,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb",
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
@@ -126,6 +126,7 @@ def load_library():
     L.mzr_set_lake_target.argtypes = [vp, ip, ci]
     L.mzr_set_wm_vol.argtypes = [vp, ci, dp]
     L.mzr_set_lake_forcing.argtypes = [vp, ci, dp, dp, ip, ip, ip]
+    L.mzr_set_lake_forcing_dev.argtypes = [vp, ci, vp, vp, ip, ip, ip]
     L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
     L.mzr_get_window_q.argtypes = [vp, ci, dp]
     L.mzr_get_mean_q.argtypes = [vp, ci, dp, ci]
@@ -255,8 +256,10 @@ class RoutingDomain:
         """REACH_WM_FLUX [w, nRch] of the next window (is_flux_wm; -9999 = no data for the reach)."""
         self._check(self.L.mzr_set_wm_flux(self.h, int(w), np.ascontiguousarray(wm_flux, dtype=np.float64)))
 
-    def set_lake_forcing(self, first, w):
-        """Upload evaporation/precipitation and the calendar of steps [first, first+w) of self.lakes."""
+    def set_lake_forcing(self, first, w, evap_dev_ptr=None, precip_dev_ptr=None):
+        """Upload evaporation/precipitation and the calendar of steps [first, first+w) of self.lakes.  With device pointers
+        ([w, nHru] each, e.g. filled by remap_device) the two fluxes stay on the device; with LakeInputOption = 1 they
+        are not used and not moved."""
         lk = self.lakes
         ymd = np.asarray(lk["ymd"][first:first + w], dtype=np.int64)
         mdays = np.array([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])
@@ -264,9 +267,14 @@ class RoutingDomain:
         cum = np.concatenate([[0], np.cumsum(mdays)])[ymd[:, 1] - 1]
         doy = cum + ymd[:, 2] + (leap & (ymd[:, 1] > 2))
         c = lambda a, t: np.ascontiguousarray(a, dtype=t)
-        self._check(self.L.mzr_set_lake_forcing(self.h, int(w), c(lk["evap"][first:first + w], np.float64),
-                                                c(lk["precip"][first:first + w], np.float64), c(ymd[:, 1], np.int32),
-                                                c(ymd[:, 2], np.int32), c(doy, np.int32)))
+        cal = (c(ymd[:, 1], np.int32), c(ymd[:, 2], np.int32), c(doy, np.int32))
+        if evap_dev_ptr is not None:
+            self._check(self.L.mzr_set_lake_forcing_dev(self.h, int(w), C.c_void_p(int(evap_dev_ptr)), C.c_void_p(int(precip_dev_ptr)), *cal))
+        elif int(lk["input_option"]) == 1:
+            self._check(self.L.mzr_set_lake_forcing_dev(self.h, int(w), None, None, *cal))
+        else:
+            self._check(self.L.mzr_set_lake_forcing(self.h, int(w), c(lk["evap"][first:first + w], np.float64),
+                                                    c(lk["precip"][first:first + w], np.float64), *cal))
         if "targ_vol" in lk:      # REACH_WM_VOL of the window
             self._check(self.L.mzr_set_wm_vol(self.h, int(w), c(lk["wm_vol"][first:first + w], np.float64)))
 

@@ -124,12 +124,20 @@ template <bool P> __device__ __forceinline__ void stx(int *p, int v) {
 // Persistent sweep: wait until every lane's dependency counter (steps completed by an upstream or the
 // downstream reach in this window) has reached the value the lane needs.  Whole wavefront; true = give
 // up (another wavefront raised an error, or nothing moved for seconds: code 93 instead of a hung GPU).
-__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, int wneed) {
+// Progress word of a reach (kwDone): steps of the window it has completed in the low 16 bits; above them what its
+// consumers would otherwise have to load before they know how much of its rows is alive -- the particle counts of its
+// two outbox parities (5 bits each) and of its at-rest list (5 bits).
+#define MZR_KWD_STEPS(w) ((w) & 0xffff)
+#define MZR_KWD_OUT(w, par) (((w) >> (16 + 5 * (par))) & 31)
+#define MZR_KWD_OWN(w) (((w) >> 26) & 31)
+__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, int wneed, int *word = nullptr) {
   long long t0 = 0;
   int spins = 0;
   for (;;) {
     int v = wneed;
     if (wp) v = ldx<true>(wp);
+    if (word) *word = v;
+    v = MZR_KWD_STEPS(v);
     if (__ballot(v < wneed) == 0ull) {
 #ifdef MZR_KWT_TIMING
       if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + 23], spins ? 1ull : 0ull); atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + 24], (unsigned long long)spins); }
@@ -647,6 +655,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   unsigned _sec[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int _recSize = 0, _recRem = 0;
 #endif
+  int wword = 0;      // the progress word this lane polled
   if (PERS) {
     // step t of this reach needs step t of every upstream reach (their outbox rows and discharge), its own
     // step t - 1, and overwrites the outbox parity its downstream reach read in step t - 2
@@ -658,7 +667,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       else if (gl == nup && dn >= 0 && t >= 2) { wp = d.kwDone + dn; wneed = t - 1; }
       else if (gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
-    if (kwt_wait_deps(d, wp, wneed)) return 2;
+    if (kwt_wait_deps(d, wp, wneed, &wword)) return 2;
     TSTAMP(21);
   }
 
@@ -676,9 +685,23 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   for (int j = 0; j < KS; ++j) q[j] = ti[j] = 0.0;
 #pragma unroll
   for (int j = 0; j < OS; ++j) aq[j] = at[j] = bq[j] = bt[j] = 0.0;
+  // The counts that say how much of the fixed-size rows is alive came with the progress words (from the second step of
+  // a window on, binary confluence below ordinary reaches): the rows are then read up to their counts only -- about
+  // half of them -- and the count loads go away.  Otherwise counts and whole rows are fetched together.
+  const bool exact = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u)) && t >= 1;
+  int wSelf = 0;
   if (live) {
-    int n_own_v = ldx<PERS>(d.kwN + r), nrA_v = 0, nrB_v = 0;
-    if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
+    int n_own_v, nrA_v = 0, nrB_v = 0;
+    const int gbase = lane & ~(G - 1);
+    if (PERS && t >= 1) wSelf = __shfl(wword, gbase + nup + 1, 64);      // (also carries the count of the other outbox parity on)
+    if (exact) {
+      n_own_v = MZR_KWD_OWN(wSelf);
+      if (ns > 0) nrA_v = MZR_KWD_OUT(__shfl(wword, gbase + (uA - u0), 64), par);
+      if (ns > 1) nrB_v = MZR_KWD_OUT(__shfl(wword, gbase + (uB - u0), 64), par);
+    } else {
+      n_own_v = ldx<PERS>(d.kwN + r);
+      if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
+    }
     const double X0 = ldx<PERS>(d.kwTR + MZR_KWI(0, r));
     const double hin = d.hInflow ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
     const double qlat_r = qlat_cur[r];
@@ -689,14 +712,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
-      q[j] = ldx<PERS>(d.kwQ + MZR_KWI(kk, r)); ti[j] = ldx<PERS>(d.kwTI + MZR_KWI(kk, r));
+      if (!exact || k < n_own_v) { q[j] = ldx<PERS>(d.kwQ + MZR_KWI(kk, r)); ti[j] = ldx<PERS>(d.kwTI + MZR_KWI(kk, r)); }
     }
     if (!GEN && !upLake) {
 #pragma unroll
       for (int j = 0; j < OS; ++j) {
         const int k = gl + j * G, kk = k < MZR_OB_CAP ? k : 0;
-        if (ns > 0) { aq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uA)); at[j] = ldx<PERS>(obT + MZR_OBI(kk, uA)); }
-        if (ns > 1) { bq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uB)); bt[j] = ldx<PERS>(obT + MZR_OBI(kk, uB)); }
+        if (ns > 0 && (!exact || k < nrA_v)) { aq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uA)); at[j] = ldx<PERS>(obT + MZR_OBI(kk, uA)); }
+        if (ns > 1 && (!exact || k < nrB_v)) { bq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uB)); bt[j] = ldx<PERS>(obT + MZR_OBI(kk, uB)); }
       }
     }
     // ---- uniform: the work-array need
@@ -1305,7 +1328,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         TSTAMP(7); TSTAMP_WAVE(20);
         if (PERS) {   // results written through (sc1) and drained, then the step is published
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (gl == 0) stx<true>(d.kwDone + r, tq + 1);
+          if (gl == 0) {
+            const int pq = tq & 1, keep = MZR_KWD_OUT(wSelf, pq ^ 1);      // the other parity's count stays (0 in the first step)
+            const int nOut = isOut ? 0 : NR + 2;
+            stx<true>(d.kwDone + r, (tq + 1) | (nOut << (16 + 5 * pq)) | (keep << (16 + 5 * (pq ^ 1))) | ((NN2 + 1) << 26));
+          }
           TSTAMP(22);
         }
       } while (0);

@@ -609,22 +609,43 @@ int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, 
   return 0;
 }
 
-int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, const int *month, const int *day, const int *dayofyear) {
+// evaporation / precipitation of the window on the river-network HRUs (host or device memory) -> per-lake fluxes.
+// With LakeInputOption = 1 (runoff only, lake_route.f90:146-160) the two fluxes are not used and not moved.
+static int set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, bool onDevice,
+                            const int *month, const int *day, const int *dayofyear) {
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_lake_forcing/state not initialised") : 1;
   if (!h->nLake) return fail(h, 20, "mzr_set_lake_forcing/no lakes in this domain");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_lake_forcing/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
   hipStream_t st = h->stream;
-  (void)hipMemcpyAsync(h->lakeFE.p, evap, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(h->lakeFP.p, precip, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
+  const bool fluxes = h->LakeInputOption != 1;
+  if (fluxes && (!evap || !precip)) return fail(h, 20, "mzr_set_lake_forcing/evaporation and precipitation are needed unless LakeInputOption = 1");
+  const double *fe = evap, *fp = precip;
+  if (fluxes && !onDevice) {
+    const size_t need = (size_t)h->cfg.maxWindow * h->H;
+    if (h->lakeFE.n < need) {
+      try { h->lakeFE.alloc(need); h->lakeFP.alloc(need); } catch (const std::string &e) { return fail(h, 91, "mzr_set_lake_forcing/" + e); }
+    }
+    (void)hipMemcpyAsync(h->lakeFE.p, evap, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(h->lakeFP.p, precip, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
+    fe = h->lakeFE.p; fp = h->lakeFP.p;
+  }
   (void)hipMemcpyAsync(h->calMonth.p, month, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(h->calDay.p, day, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
   (void)hipMemcpyAsync(h->calDoy.p, dayofyear, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
-  MzrDev d; fillDev(h, d);
-  mzr_launch_lake_forcing(d, h->lakeReachInt.p, h->lakeFE.p, h->lakeFP.p, h->lakeEvap.p, h->lakePrecip.p, nSteps, st);
+  if (fluxes) {
+    MzrDev d; fillDev(h, d);
+    mzr_launch_lake_forcing(d, h->lakeReachInt.p, fe, fp, h->lakeEvap.p, h->lakePrecip.p, nSteps, st);
+  }
   if (hipStreamSynchronize(st) != hipSuccess) return fail(h, 92, "mzr_set_lake_forcing/device error");
   h->lakeSteps = nSteps;
   return checkDeviceError(h);
+}
+int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, const int *month, const int *day, const int *dayofyear) {
+  return set_lake_forcing(h, nSteps, evap, precip, false, month, day, dayofyear);
+}
+int mzr_set_lake_forcing_dev(mzr_handle h, int nSteps, const double *evap_dev, const double *precip_dev, const int *month, const int *day, const int *dayofyear) {
+  return set_lake_forcing(h, nSteps, evap_dev, precip_dev, true, month, day, dayofyear);
 }
 
 // Lakes that follow a target volume (is_vol_wm: NETOPO%LakeTargVol, lake_route.f90:197-205; jump start :140-142)
@@ -765,7 +786,7 @@ int mzr_init_state(mzr_handle h) {
     h->err.alloc(1); h->err.zero();
     if (h->nLake) {
       h->lakeEvap.alloc(W * h->nLake); h->lakePrecip.alloc(W * h->nLake); h->lakeEvap.zero(); h->lakePrecip.zero();
-      h->lakeFE.alloc(W * h->H); h->lakeFP.alloc(W * h->H);
+      h->lakeFE.free(); h->lakeFP.free();      // staging of host-side evaporation / precipitation: on first use
       h->calMonth.alloc(W); h->calDay.alloc(W); h->calDoy.alloc(W);
       h->lakeWmVol.alloc(W * h->nLake); h->lakeWmVol.zero(); h->wmVolSteps = 0;
     }
@@ -831,6 +852,7 @@ int mzr_init_state(mzr_handle h) {
               for (int k = 0; k < rc.nup; ++k) {
                 const int u = rc.u0 + k;
                 if (!h->h_lakeSlot.empty() && h->h_lakeSlot[u] >= 0) rc.flags |= 0x40;
+                if (h->nHalo && !h->h_haloSlot.empty() && h->h_haloSlot[u] >= 0) rc.flags |= 0x20;   // its progress word carries no particle counts
                 if (h->h_nGood[u] > 0) {
                   rc.upGood |= (uint8_t)(1u << k);
                   if (nsr == 0) rc.scA = width[u] / width[i]; else if (nsr == 1) rc.scB = width[u] / width[i];
@@ -1011,7 +1033,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   bool sweep = true;
   if (const char *e = getenv("MZR_KWT_SWEEP")) sweep = atoi(e) != 0;
   const int kwtIx = idxOf(h, MZR_KWT);
-  if (kwtIx < 0 || h->swItems < 1) sweep = false;
+  if (kwtIx < 0 || h->swItems < 1 || W > 65535) sweep = false;      // (progress words hold the step count in 16 bits)
   if (sweep) {
     kwt_sweep_tables(h, W);
     RouteBufs &rb = h->route[kwtIx];

@@ -39,7 +39,7 @@ MODULE mzr_c
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
-            mzr_get_global_wb
+            mzr_get_global_wb, mzr_set_lake_forcing_dev
   public :: mzr_message
 
   INTERFACE
@@ -209,6 +209,12 @@ MODULE mzr_c
       type(c_ptr), value :: h
       integer(c_int), value :: nSteps
       real(c_double), intent(in) :: evap(*), precip(*)
+      integer(c_int), intent(in) :: month(*), day(*), dayofyear(*)
+    end function
+    integer(c_int) function mzr_set_lake_forcing_dev(h, nSteps, evap_dev, precip_dev, month, day, dayofyear) bind(C, name='mzr_set_lake_forcing_dev')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, evap_dev, precip_dev      ! device pointers (c_null_ptr with LakeInputOption = 1)
+      integer(c_int), value :: nSteps
       integer(c_int), intent(in) :: month(*), day(*), dayofyear(*)
     end function
     ! lakes that follow a target volume (is_vol_wm; lake_route.f90:139-142,197-205) and their targets REACH_WM_VOL per window

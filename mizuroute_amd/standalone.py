@@ -395,23 +395,23 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
             lk = dom.lakes
             days = [t_beg + _dt.timedelta(seconds=(done + k) * dt) for k in range(w)]
             lk["ymd"] = np.array([[d.year, d.month, d.day] for d in days], dtype=np.int64)
+            flux_dev = {}
             for key, vname, sc, of, flip in (("evap", ctl.get("vname_evapo", "evap"), sc_ep, of_ep, _truth(ctl.get("is_Ep_upward_negative", "F"))),
                                              ("precip", ctl.get("vname_precip", "precip"), sc_pr, of_pr, False)):
+                dstf = torch.zeros((w, net.H), dtype=torch.float64, device=dev)
+                flux_dev[key] = dstf
                 if lk["input_option"] == 1 or suppressed(sc, of):
-                    lk[key] = np.zeros((w, net.H))
                     continue
                 a = np.stack([fro.step(vname, dt, done + k + 1) for k in range(w)])
                 if flip:
                     a = scale_forcing(a, -1.0, 0.0)
                 a = scale_forcing(a, sc, of)
                 srcf = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-                dstf = torch.empty((w, net.H), dtype=torch.float64, device=dev)
                 dom.remap_device(w, srcf.data_ptr(), dstf.data_ptr())
-                dom.sync()
-                lk[key] = dstf.cpu().numpy()
+            dom.sync()
             if is_vol_wm:
                 lk["wm_vol"] = np.stack([sort_flux(wm_ix, fwm.step(ctl["vname_vol_wm"], dt, done + k + 1), net.N, True) for k in range(w)])
-            dom.set_lake_forcing(0, w)
+            dom.set_lake_forcing(0, w, flux_dev["evap"].data_ptr(), flux_dev["precip"].data_ptr())
         if is_flux_wm:
             dom.set_wm_flux(w, np.stack([sort_flux(wm_ix, fwm.step(ctl["vname_flux_wm"], dt, done + k + 1), net.N, False) for k in range(w)]))
         src = torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(dev)
