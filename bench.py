@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[1]): synthetic HDMA-CONUS-like sub-basin, ~100k reaches per GPU,
 KWT routing (route_opt 2), dt = 3600 s, hillslope unit-hydrograph delay on (fshape 2.5,
 tscale 86400 s).  A bench "step" is one pass of the hot path over one BATCH of synthetic forcing =
-one forcing window of `window_steps` model time steps (8192 by default; one main_route call per
+one forcing window of `window_steps` model time steps (16384 by default; one main_route call per
 model time step in the reference; the device sweeps a window time-skewed over the stages,
 DESIGN.md 2): cold start, W untimed batches, then exactly K timed batches.  `value` counts MODEL
 time steps: reaches x K x window_steps / elapsed.  Forcing windows are generated on the device
@@ -44,11 +44,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # `dominant` = the method whose kernel the roofline object describes, `bytes` = SURVEY.md 8(d) bytes per reach-step
 # of that method for U immediate upstream reaches (KWT: from the particle counters instead).
 CONFIGS = {
-    "c2": dict(reaches=100_000, methods="2", window=8192, workload="synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
-    "c3": dict(reaches=375_000, methods="2", window=2048, workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
-    "c4": dict(reaches=625_000, methods="14", window=512, dominant=4, bytes=lambda U: 152 + 12 * U,
+    "c2": dict(reaches=100_000, methods="2", window=16384, workload="synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
+    "c3": dict(reaches=375_000, methods="2", window=4096, workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
+    "c4": dict(reaches=625_000, methods="14", window=2048, dominant=4, bytes=lambda U: 152 + 12 * U,
                workload="one of 8 shards of a ~5 M-reach MERIT-like network, IRF-UH + Muskingum-Cunge (route_opt 14), dt 3600 s, hillslope UH on"),
-    "c5": dict(reaches=375_000, methods="5", window=512, dominant=5, bytes=lambda U: 440 + 12 * U, lakes=0.01, floodplain=True,
+    "c5": dict(reaches=375_000, methods="5", window=2048, dominant=5, bytes=lambda U: 440 + 12 * U, lakes=0.01, floodplain=True,
                workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, diffusive wave (route_opt 5), 1 % lakes (Doll / Hanasaki / HYPE), "
                         "floodplains, dt 3600 s, hillslope UH on"),
 }
@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4, help="timed batches (forcing windows)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed batches")
     ap.add_argument("--window", type=int, default=0,
-                    help="model time steps per batch; 0 = 8192, fewer when --steps is large (about 2M model steps in total)")
+                    help="model time steps per batch; 0 = what --config says (16384 for c2), fewer when --steps is large (about 2M model steps in total)")
     ap.add_argument("--reaches", type=int, default=0, help="reaches per GPU (default: what --config says)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration: c2 (default, the metric's headline) or the per-GPU shard of c3 / c4 / c5 (N = 1 only)")

@@ -55,7 +55,7 @@ lines = [f"# Profile {tag}", "",
          f"(`k_rows8`) fetch {rows.get('FETCH_SIZE_KiB', 0) * 1024 * RF / max(1, rows.get('known_read_bytes', 1)):.2f} x their useful bytes. Details: `{tag}_calib.json`.", ""]
 out_traffic = None
 pm_all = {}
-for size, sfx, cmd in (("100k", "", "--window 8192 --steps 1 --warmup 1"), ("400k", "_400k", "--reaches 400000 --window 2048 --steps 2 --warmup 2")):
+for size, sfx, cmd in (("100k", "", "--window 16384 --steps 1 --warmup 1"), ("400k", "_400k", "--reaches 400000 --window 2048 --steps 2 --warmup 2")):
     sdir = os.path.join(src, "stats" + sfx)
     if not os.path.exists(os.path.join(sdir, "k_kernel_stats.csv")):
         continue

@@ -2,7 +2,7 @@
 # Debug (inside gpurun): HBM-side bytes per k_sweep_kwt launch (FETCH_SIZE / WRITE_SIZE in separate passes)
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 o=gpurun_out/traffic; rm -rf $o; mkdir -p $o
-ARGS="--no-cpu-baseline --no-roofline --no-h2d --no-single-step --window 8192 --steps 1 --warmup 1"
+ARGS="--no-cpu-baseline --no-roofline --no-h2d --no-single-step --window 16384 --steps 1 --warmup 1"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/$c -o p -- python bench.py $ARGS > $o/$c.log 2>&1
 done
