@@ -101,26 +101,6 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
   return v;
 }
 
-// Accesses to data that another wavefront of the SAME launch produces or consumes (persistent sweep):
-// relaxed agent-scope atomics = global_load / global_store ... sc1, which bypass the CU's L1 and are
-// coherent across the per-XCD L2s (MI355X_MICROARCH.md, inter-workgroup visibility).  P = false: plain.
-template <bool P> __device__ __forceinline__ double ldx(const double *p) {
-  if (P) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  return *p;
-}
-template <bool P> __device__ __forceinline__ int ldx(const int *p) {
-  if (P) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return *p;
-}
-template <bool P> __device__ __forceinline__ void stx(double *p, double v) {
-  if (P) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-template <bool P> __device__ __forceinline__ void stx(int *p, int v) {
-  if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-
 // Persistent sweep: wait until every lane's dependency counter (steps completed by an upstream or the
 // downstream reach in this window) has reached the value the lane needs.  Whole wavefront; true = give
 // up (another wavefront raised an error, or nothing moved for seconds: code 93 instead of a hung GPU).

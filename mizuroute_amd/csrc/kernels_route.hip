@@ -165,7 +165,7 @@ __device__ void d_solve_ade(double L, double dtl, double Fup, double ck, double 
 
 // shared preamble of irf/mc/dw/kw (irf_route.f90:81-100; water management is not active here)
 struct Pre { double q_up, q_up_mod, Qlat; bool isHW; };
-__device__ __forceinline__ Pre d_preamble(const MzrDev &d, int r, const double *Qrow, double qlat) {
+template <bool COH> __device__ __forceinline__ Pre d_preamble(const MzrDev &d, int r, const double *Qrow, double qlat) {
   Pre p; p.q_up = 0.0; p.isHW = true;
   const int ng = d.nGood[r];
   if (ng > 0) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ Pre d_preamble(const MzrDev &d, int r, const double *
     const uint32_t gm = d.goodMask[r];
     for (int i = 0; i < ng; ++i) {                 // do iUps=1,nUps ; cycle if .not.goodBas(iUps)
       if (!((gm >> i) & 1u)) continue;
-      p.q_up = p.q_up + Qrow[u0 + i];
+      p.q_up = p.q_up + ldx<COH>(Qrow + u0 + i);
     }
     p.q_up_mod = p.q_up; p.Qlat = qlat;
   } else if (d.hw_drain_point == 1) {
@@ -206,17 +206,16 @@ __device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-template <int METHOD>
-__global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
-  const int r = rBegin + blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rEnd) return;
-  const int t = s - d.sigma[r];
-  if (t < 0 || t >= d.W) return;
+// One reach, one step of the window.  COH: the persistent sweep -- discharge rows and the reach's own state are produced and
+// consumed by different wavefronts of the SAME launch, so they go through sc1 accesses (ldx / stx, mzr_device.h);
+// COH = false is the launch-per-stage form with plain accesses.
+template <int METHOD, bool COH>
+__device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
   const int N = d.N;
   double *Qrow = d.Q + (size_t)t * N;
   if (d.haloSlot) {          // tributary outlet computed in another partition: discharge is imported
     const int hs = d.haloSlot[r];
-    if (hs >= 0) { Qrow[r] = d.imQ[(size_t)t * d.nHalo + hs]; return; }
+    if (hs >= 0) { stx<COH>(Qrow + r, d.imQ[(size_t)t * d.nHalo + hs]); return; }
   }
   const double qlat = d.qlat[(size_t)(t + 1) * N + r];
   const double dt = d.dt;
@@ -224,12 +223,13 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
   if (METHOD != 0 && d.lakeSlot) {   // lake reach: lake_route replaces the reach solver (main_route.f90:375-381)
     const int ls = d.lakeSlot[r];
     if (ls >= 0) {
-      double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
-      const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat, vol, vol0, ele, wb, wmAct);
-      Qrow[r] = Q; d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb; d.qsum[r] += Q;
-      if (d.wmact) d.wmact[r] = wmAct;
-      if (d.hEle) { d.hEle[r] += ele; d.hFlood[r] += d.floodvol[r]; }
-      if (d.hInflow) d.hInflow[r] += d.inflow[r];
+      double vol = ldx<COH>(d.vol + r), vol0 = vol, ele = ldx<COH>(d.ele + r), wb = 0.0, wmAct = 0.0;
+      const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat, vol, vol0, ele, wb, wmAct, COH);
+      stx<COH>(Qrow + r, Q); stx<COH>(d.vol + r, vol); stx<COH>(d.vol0 + r, vol0); stx<COH>(d.ele + r, ele); stx<COH>(d.wb + r, wb);
+      stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + Q);
+      if (d.wmact) stx<COH>(d.wmact + r, wmAct);
+      if (d.hEle) { stx<COH>(d.hEle + r, ldx<COH>(d.hEle + r) + ele); stx<COH>(d.hFlood + r, ldx<COH>(d.hFlood + r) + ldx<COH>(d.floodvol + r)); }
+      if (d.hInflow) stx<COH>(d.hInflow + r, ldx<COH>(d.hInflow + r) + d.inflow[r]);     // (lake_route stores the inflow plainly)
       return;
     }
   }
@@ -240,17 +240,17 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
     if (nu > 0) {
       const int u0 = d.upStart[r];
       double qu = 0.0;
-      for (int i = 0; i < nu; ++i) qu = qu + Qrow[u0 + i];
+      for (int i = 0; i < nu; ++i) qu = qu + ldx<COH>(Qrow + u0 + i);
       q = q + qu;
     }
-    Qrow[r] = q;
-    d.qsum[r] += q;
+    stx<COH>(Qrow + r, q);
+    stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + q);
     return;
   }
 
-  Pre p = d_preamble(d, r, Qrow, qlat);
-  d.inflow[r] = p.q_up;
-  double vol = d.vol[r];
+  Pre p = d_preamble<COH>(d, r, Qrow, qlat);
+  stx<COH>(d.inflow + r, p.q_up);
+  double vol = ldx<COH>(d.vol + r);
   const double vol_prev = vol;        // REACH_VOL(0) = REACH_VOL(1)
   double vol0 = vol_prev;
   // water management: abstraction from storage, then upstream inflow, then lateral flow; injection
@@ -290,25 +290,25 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
     const int nt = d.ntdh[r];
     const double qu = p.q_up_mod;
     if (L > d.min_length_route) {
-      double q0 = d.irfQ[r] + d.uh[r] * qu;
+      double q0 = ldx<COH>(d.irfQ + r) + d.uh[r] * qu;
       const double lim = (fmax(0.0, vol) / dt + qu) * (double)0.999f;   // default-real literal, :245
       q0 = fmin(lim, q0);
       vol = vol - (q0 - qu) * dt;
       Qout = q0 + p.Qlat;
       for (int j = 1; j < nt; ++j) {
-        const double v = d.irfQ[(size_t)j * N + r] + d.uh[(size_t)j * N + r] * qu;
-        d.irfQ[(size_t)(j - 1) * N + r] = v;                             // eoshift(shift=1)
+        const double v = ldx<COH>(d.irfQ + (size_t)j * N + r) + d.uh[(size_t)j * N + r] * qu;
+        stx<COH>(d.irfQ + (size_t)(j - 1) * N + r, v);                             // eoshift(shift=1)
       }
-      d.irfQ[(size_t)(nt - 1) * N + r] = 0.0;
+      stx<COH>(d.irfQ + (size_t)(nt - 1) * N + r, 0.0);
     } else {
-      for (int j = 0; j < nt; ++j) d.irfQ[(size_t)j * N + r] = 0.0;
-      d.irfQ[r] = qu;
+      for (int j = 0; j < nt; ++j) stx<COH>(d.irfQ + (size_t)j * N + r, 0.0);
+      stx<COH>(d.irfQ + r, qu);
       Qout = qu + p.Qlat;
       vol0 = 0.0; vol = 0.0;
     }
   } else if (METHOD == 4) {   // Muskingum-Cunge, mc_route.f90:204-416
     const Chan c = d_chan(d, r);
-    const double Q00 = d.mol[r], Q01 = d.mol[(size_t)N + r];
+    const double Q00 = ldx<COH>(d.mol + r), Q01 = ldx<COH>(d.mol + (size_t)N + r);
     double Q10, Q11, flood = 0.0, ele = 0.0;
     if (!p.isHW || d.hw_drain_point == 1) {
       if (L > d.min_length_route) {
@@ -412,8 +412,8 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
     } else {
       Q10 = 0.0; Q11 = 0.0; Qout = p.Qlat; vol0 = 0.0; vol = 0.0;
     }
-    d.mol[r] = Q10; d.mol[(size_t)N + r] = Q11;
-    d.floodvol[r] = flood; d.ele[r] = ele;
+    stx<COH>(d.mol + r, Q10); stx<COH>(d.mol + (size_t)N + r, Q11);
+    stx<COH>(d.floodvol + r, flood); stx<COH>(d.ele + r, ele);
   } else {   // DW (5) and KW (3): dfw_route.f90:209-370, kwe_route.f90:205-363
     constexpr int NM = 20;
     const Chan c = d_chan(d, r);
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
       if (L > d.min_length_route) {
         double prev[NM], sol[NM];
 #pragma unroll
-        for (int i = 0; i < NM; ++i) prev[i] = d.mol[(size_t)i * N + r];
+        for (int i = 0; i < NM; ++i) prev[i] = ldx<COH>(d.mol + (size_t)i * N + r);
         const double Qbar = (Qu + prev[0] + prev[NM - 2]) / 3.0;
         const double depth = d_flow_depth(fabs(Qbar), c);
         const double ck = d_celerity(fabs(Qbar), depth, c);
@@ -442,28 +442,148 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
         ele = d_water_height(vol / L, c);
         Qout = sol[NM - 2] + p.Qlat;
 #pragma unroll
-        for (int i = 0; i < NM; ++i) d.mol[(size_t)i * N + r] = sol[i];
+        for (int i = 0; i < NM; ++i) stx<COH>(d.mol + (size_t)i * N + r, sol[i]);
       } else {
         Qout = Qu + p.Qlat;
-        for (int i = 0; i < NM - 1; ++i) d.mol[(size_t)i * N + r] = 0.0;
-        d.mol[(size_t)(NM - 1) * N + r] = Qout;
+        for (int i = 0; i < NM - 1; ++i) stx<COH>(d.mol + (size_t)i * N + r, 0.0);
+        stx<COH>(d.mol + (size_t)(NM - 1) * N + r, Qout);
         vol0 = 0.0; vol = 0.0;
       }
     } else {
       Qout = p.Qlat; vol0 = 0.0; vol = 0.0;
-      for (int i = 0; i < NM - 1; ++i) d.mol[(size_t)i * N + r] = 0.0;
-      d.mol[(size_t)(NM - 1) * N + r] = Qout;
+      for (int i = 0; i < NM - 1; ++i) stx<COH>(d.mol + (size_t)i * N + r, 0.0);
+      stx<COH>(d.mol + (size_t)(NM - 1) * N + r, Qout);
     }
-    d.floodvol[r] = flood; d.ele[r] = ele;
+    stx<COH>(d.floodvol + r, flood); stx<COH>(d.ele + r, ele);
   }
-  Qrow[r] = Qout;
-  d.vol[r] = vol; d.vol0[r] = vol0;
-  d.wb[r] = d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt);
-  if (d.wmact) d.wmact[r] = wmAct;
-  d.qsum[r] += Qout;
+  stx<COH>(Qrow + r, Qout);
+  stx<COH>(d.vol + r, vol); stx<COH>(d.vol0 + r, vol0);
+  stx<COH>(d.wb + r, d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt));
+  if (d.wmact) stx<COH>(d.wmact + r, wmAct);
+  stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + Qout);
   // history sums of the other per-method fluxes (histVars_data.f90:229-246), when asked for
-  if (d.hInflow) d.hInflow[r] += p.q_up;
-  if (d.hEle) { d.hEle[r] += d.ele[r]; d.hFlood[r] += d.floodvol[r]; }
+  if (d.hInflow) stx<COH>(d.hInflow + r, ldx<COH>(d.hInflow + r) + p.q_up);
+  if (d.hEle) { stx<COH>(d.hEle + r, ldx<COH>(d.hEle + r) + ldx<COH>(d.ele + r)); stx<COH>(d.hFlood + r, ldx<COH>(d.hFlood + r) + ldx<COH>(d.floodvol + r)); }
+}
+
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
+  const int r = rBegin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rEnd) return;
+  const int t = s - d.sigma[r];
+  if (t < 0 || t >= d.W) return;
+  stage_reach<METHOD, false>(d, r, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent sweep of an Eulerian method over a window: what one launch per stage does (k_stage), without the launches.
+// A window of W steps over S stages is S + W - 1 "launches" of the skewed schedule; with a kernel per launch every one
+// of them costs a launch latency and waits for its slowest lane, and the first and last S of them are mostly empty.
+// Here the items of all launches (up to 64 reaches of one stage each) are numbered in launch order and drawn by the
+// wavefronts from eight ticket counters (one per XCD, item i in queue i % 8); a reach's step t starts when its upstream
+// reaches have published step t and itself step t - 1 (rtDone), so a slow lane holds up its own downstream chain only.
+// Tickets depend only on tickets of earlier launches and every queue is served in order: any number of resident
+// wavefronts makes progress.  Discharge rows and per-reach state cross wavefronts through sc1 accesses (stage_reach<.., true>).
+namespace {
+// pause of a polling wavefront; true = give up (another wavefront raised an error, or nothing has moved for 4 s: code 93
+// instead of a hung GPU)
+__device__ __forceinline__ bool rt_pause(const MzrDev &d, int &spins, long long &t0) {
+  __builtin_amdgcn_s_sleep(4);
+  if ((++spins & 31) == 0) {
+    if (ldx<true>(&d.err->code) != 0) return true;
+    const long long now = wall_clock64();     // 100 MHz
+    if (!t0) t0 = now;
+    else if (now - t0 > 400000000LL) { mzr_raise(d, 93, -1, -1, 21); return true; }
+  }
+  return false;
+}
+}  // namespace
+
+template <int METHOD>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_sweep_route(MzrDev d, int sBegin, int sEnd) {
+  const int lane = threadIdx.x;
+  const int q0 = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;     // HW_REG_XCC_ID: a speed hint only
+  const int *P = d.rtP, *RAs = d.rtRA;
+#pragma unroll 1
+  for (int dq = 0; dq < 8; ++dq) {
+    const int q = (q0 + dq) & 7;
+    const int pEnd = P[sEnd * 8 + q];
+    int sCur = sBegin, pLo = P[sBegin * 8 + q], pHi = P[(sBegin + 1) * 8 + q];   // tickets [pLo, pHi) of queue q belong to launch sCur
+#pragma unroll 1
+    for (;;) {
+      int k = 0;
+      if (lane == 0) k = atomicAdd(d.rtHead + q * 16, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= pEnd) break;
+      if (k >= pHi) {
+        ++sCur; pLo = pHi; pHi = P[(sCur + 1) * 8 + q];
+        if (k >= pHi) {
+          int lo = sCur + 1, hi = sEnd - 1;          // largest s with P[s] <= k
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (P[mid * 8 + q] <= k) lo = mid; else hi = mid - 1; }
+          sCur = lo; pLo = P[sCur * 8 + q]; pHi = P[(sCur + 1) * 8 + q];
+        }
+      }
+      const int s = sCur;
+      const int a = RAs[s];
+      const int i = a + ((q - a) & 7) + 8 * (k - pLo);
+      // one 16-byte record per lane: reach, first upstream reach, number of upstream reaches | lake flag << 8, stage
+      const int4 rec = ((const int4 *)d.rtItemR)[(size_t)i * 64 + lane];
+      const int r = rec.x, u0 = rec.y, nu = rec.z & 0xff;
+      const bool lakes = __ballot((rec.z >> 8) & 1) != 0ull;
+      const int t = s - rec.w;                          // 0 <= t < W by construction of the tables
+      // its upstream reaches have published step t, itself step t - 1 (another wavefront's work): polled together
+      int spins = 0; long long tw0 = 0;
+      for (;;) {
+        bool ok = true;
+        if (r >= 0) {
+          if (t >= 1) ok = ldx<true>(d.rtDone + r) >= t;
+          for (int j = 0; j < nu; ++j) ok = ok && ldx<true>(d.rtDone + u0 + j) >= t + 1;
+        }
+        if (__ballot(!ok) == 0ull) break;
+        if (rt_pause(d, spins, tw0)) return;
+      }
+      if (lakes) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // a lake's plain state (Hanasaki memory ...)
+      if (r >= 0) stage_reach<METHOD, true>(d, r, t);
+      if (lakes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (r >= 0) stx<true>(d.rtDone + r, t + 1);
+    }
+  }
+}
+
+__global__ void k_rt_heads(MzrDev d, int sBegin) {
+  if (threadIdx.x < 8) d.rtHead[threadIdx.x * 16] = d.rtP[sBegin * 8 + threadIdx.x];
+}
+
+// wavefronts the device holds at once (the sweep runs with any number; this only sizes the grid)
+int mzr_sweep_route_capacity(int method) {
+  int dev = 0, cus = 0, perCu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  hipError_t e = hipErrorInvalidValue;
+  switch (method) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_route<0>, 64, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_route<1>, 64, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_route<3>, 64, 0); break;
+    case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_route<4>, 64, 0); break;
+    case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_route<5>, 64, 0); break;
+    default: break;
+  }
+  return e == hipSuccess ? cus * perCu : 0;
+}
+
+void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {
+  if (nWaves < 1 || sEnd <= sBegin) return;
+  hipLaunchKernelGGL(k_rt_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
+  dim3 block(64), grid(nWaves);
+  switch (method) {
+    case 0: hipLaunchKernelGGL(k_sweep_route<0>, grid, block, 0, stream, d, sBegin, sEnd); break;
+    case 1: hipLaunchKernelGGL(k_sweep_route<1>, grid, block, 0, stream, d, sBegin, sEnd); break;
+    case 3: hipLaunchKernelGGL(k_sweep_route<3>, grid, block, 0, stream, d, sBegin, sEnd); break;
+    case 4: hipLaunchKernelGGL(k_sweep_route<4>, grid, block, 0, stream, d, sBegin, sEnd); break;
+    case 5: hipLaunchKernelGGL(k_sweep_route<5>, grid, block, 0, stream, d, sBegin, sEnd); break;
+    default: break;
+  }
 }
 
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {

@@ -139,6 +139,13 @@ struct MzrDev {
   const double *imOQ, *imOT;  // [Wmax][MZR_OB_CAP][nHalo]
   int    *exN;                // [Wmax][nExp]
   double *exOQ, *exOT;        // [Wmax][MZR_OB_CAP][nExp]
+  // ---- persistent sweep of the Eulerian methods (k_sweep_route): items = up to 64 reaches of one stage, drawn in launch
+  // order from per-XCD ticket counters like the KWT sweep's; rtDone[r] = steps of the window reach r has completed
+  int *rtDone;                // [N] (of the method being launched)
+  const int *rtItemR;         // [nItems][64] reach of every lane, -1 = none
+  const int *rtItemInfo;      // [nItems] stage | 1 << 30 when the item holds lakes (their plain state needs fences)
+  const int *rtRA, *rtP;      // per launch: first active item, ticket prefix per queue (as swRA / swP)
+  int *rtHead;                // [8][16] ticket counters
   MzrKwtStat *kwtStat;
   unsigned long long *dbgCycles;   // [32] per-section wave cycles (only with -DMZR_KWT_TIMING)
   MzrErr *err;
@@ -148,4 +155,24 @@ __device__ __forceinline__ void mzr_raise(const MzrDev &d, int code, int reach, 
   if (atomicCAS(&d.err->code, 0, code) == 0) {
     d.err->reach = reach; d.err->step = step; d.err->where = where;
   }
+}
+
+// Accesses to data that another wavefront of the SAME launch produces or consumes (persistent sweep):
+// relaxed agent-scope atomics = global_load / global_store ... sc1, which bypass the CU's L1 and are
+// coherent across the per-XCD L2s (MI355X_MICROARCH.md, inter-workgroup visibility).  P = false: plain.
+template <bool P> __device__ __forceinline__ double ldx(const double *p) {
+  if (P) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool P> __device__ __forceinline__ int ldx(const int *p) {
+  if (P) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool P> __device__ __forceinline__ void stx(double *p, double v) {
+  if (P) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool P> __device__ __forceinline__ void stx(int *p, int v) {
+  if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
 }

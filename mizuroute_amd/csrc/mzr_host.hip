@@ -27,6 +27,8 @@
 void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
 void mzr_launch_basin_chunk(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
 void mzr_launch_basin_state(const MzrDev &d, hipStream_t stream);
+int mzr_sweep_route_capacity(int method);
+void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream);
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
                              double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
@@ -66,6 +68,8 @@ struct RouteBufs {
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
+  DBuf<int> rtDone, rtHead;                         // persistent sweep of an Eulerian method: progress per reach, ticket counters
+  int rtCap = 0;                                    // wavefronts the device holds of this method's sweep kernel
   long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
@@ -192,6 +196,8 @@ struct mzr_domain {
   bool kwtAllValid = false;
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
+  DBuf<int> rtItemR, rtItemInfo, rtRA, rtP;        // items of the Eulerian sweeps (k_sweep_route) and their per-launch tables
+  std::vector<int> h_rtStage; int rtItems = 0, rtTablesW = -1, rtMaxAct = 0;
   std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
   std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
   int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1;
@@ -276,6 +282,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.haloSlot = h->nHalo ? h->haloSlot.p : nullptr; d.exportSlot = h->nExp ? h->exportSlot.p : nullptr;
   d.nHalo = h->nHalo; d.nExp = h->nExp; d.Wmax = h->cfg.maxWindow;
   d.imN = h->imN.p; d.imOQ = h->imOQ.p; d.imOT = h->imOT.p;
+  d.rtItemR = h->rtItemR.p; d.rtItemInfo = nullptr; d.rtRA = h->rtRA.p; d.rtP = h->rtP.p; d.rtDone = nullptr; d.rtHead = nullptr;
   d.exN = h->exN.p; d.exOQ = h->exOQ.p; d.exOT = h->exOT.p;
 }
 
@@ -285,6 +292,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.hInflow = rb.hInflow.p; d.hEle = rb.hEle.p; d.hFlood = rb.hFlood.p;
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
+  d.rtDone = rb.rtDone.p; d.rtHead = rb.rtHead.p;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -355,6 +363,58 @@ void kwt_build_sweep(mzr_handle h) {
   if (!h->swHead.p) { h->swHead.alloc(8 * 16); h->swHead.zero(); }
   h->swItems = (int)items.size();
   h->swTablesW = -1;          // ticket tables have to be made again
+}
+
+// Items of the Eulerian sweeps (k_sweep_route): the reaches of every stage in blocks of 64, lakes in blocks of their own
+// (their plain state is handed on with fences); ordered by stage, so the items of a launch are a contiguous range.
+void rt_build_items(mzr_handle h) {
+  std::vector<int> rec;       // [nItems][64][4]: reach (-1 = none), first upstream reach, number of upstream reaches | lake << 8, stage
+  std::vector<int> upStart(h->N);
+  (void)hipMemcpy(upStart.data(), h->upStart.p, (size_t)h->N * sizeof(int), hipMemcpyDeviceToHost);
+  h->h_rtStage.clear();
+  for (int sg = 0; sg < h->nStages; ++sg) {
+    std::vector<int> plain, lakes;
+    for (int i = h->stageStart[sg]; i < h->stageStart[sg + 1]; ++i)
+      ((!h->h_lakeSlot.empty() && h->h_lakeSlot[i] >= 0) ? lakes : plain).push_back(i);
+    for (int kind = 0; kind < 2; ++kind) {
+      const std::vector<int> &v = kind ? lakes : plain;
+      for (size_t b = 0; b * 64 < v.size(); ++b) {
+        for (size_t l = 0; l < 64; ++l) {
+          const int r = b * 64 + l < v.size() ? v[b * 64 + l] : -1;
+          rec.push_back(r); rec.push_back(r >= 0 ? upStart[r] : 0); rec.push_back(r >= 0 ? ((int)h->h_nUp[r] | (kind << 8)) : 0); rec.push_back(sg);
+        }
+        h->h_rtStage.push_back(sg);
+      }
+    }
+  }
+  h->rtItems = (int)h->h_rtStage.size();
+  if (rec.empty()) rec.assign(256, -1);
+  (void)hipStreamSynchronize(h->stream);
+  h->rtItemR.upload(rec);
+  h->rtTablesW = -1;
+}
+
+// per launch of a W-step window: first active item and ticket prefix sums of the eight queues (as kwt_sweep_tables)
+void rt_sweep_tables(mzr_handle h, int W) {
+  if (h->rtTablesW == W) return;
+  const int nS = h->nStages, nL = nS + W - 1;
+  std::vector<int> ra(nL, 0), P((size_t)(nL + 1) * 8, 0);
+  int maxAct = 0;
+  for (int s = 0; s < nL; ++s) {
+    const int b = (int)(std::upper_bound(h->h_rtStage.begin(), h->h_rtStage.end(), s) - h->h_rtStage.begin());          // items with stage <= s
+    const int a = std::min(b, (int)(std::lower_bound(h->h_rtStage.begin(), h->h_rtStage.end(), s - W + 1) - h->h_rtStage.begin()));
+    ra[s] = a;
+    maxAct = std::max(maxAct, b - a);
+    for (int q = 0; q < 8; ++q) {
+      const int first = a + (((q - a) % 8 + 8) % 8);
+      P[(size_t)(s + 1) * 8 + q] = P[(size_t)s * 8 + q] + (first < b ? (b - first + 7) / 8 : 0);
+    }
+  }
+  (void)hipStreamSynchronize(h->stream);
+  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (h->routeStream[ix]) (void)hipStreamSynchronize(h->routeStream[ix]);
+  h->rtRA.upload(ra); h->rtP.upload(P);
+  h->rtMaxAct = maxAct;
+  h->rtTablesW = W;
 }
 
 // launch ranges and ticket prefix sums of a window of W steps
@@ -767,6 +827,7 @@ int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int
 }
 
 int mzr_init_state(mzr_handle h) {
+  if (h) h->rtTablesW = -1;
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_init_state/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
   const size_t N = h->N, W = h->cfg.maxWindow;
@@ -814,6 +875,11 @@ int mzr_init_state(mzr_handle h) {
         if (h->lakeLD > 0) { rb.lakeRingD.alloc((size_t)h->nLake * 12 * h->lakeLD); rb.lakeRingD.zero(); rb.lakeHeadD.alloc((size_t)h->nLake * 13); rb.lakeHeadD.zero(); }
       }
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
+      if (m != MZR_KWT) {      // persistent sweep of an Eulerian method
+        rb.rtDone.alloc(N); rb.rtDone.zero(); rb.rtHead.alloc(8 * 16); rb.rtHead.zero();
+        rb.rtCap = mzr_sweep_route_capacity(m);
+        if (h->rtTablesW != -2) { rt_build_items(h); h->rtTablesW = -2; }      // once per mzr_init_state (-2: built, tables not yet)
+      }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
       if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); }
       if (m == MZR_IRF) {
@@ -1055,8 +1121,40 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
   }
+  // The Eulerian methods have a persistent sweep as well (k_sweep_route): one kernel per chunk of the skewed schedule
+  // instead of `stages + W` launches.  It pays where launches are the cost -- single steps and short windows (mzr_step:
+  // 42 ms instead of 49 ms per step of the 625 k-reach IRF + Muskingum-Cunge shard) -- and not in long windows, where
+  // these kernels stream their per-reach state at 1.4-1.7 TB/s either way and plain cached accesses from full-width
+  // launches move more bytes than sc1 accesses from resident wavefronts (6.1 against 4.9 x 10^9 reach-steps/s on the same
+  // shard).  Default: windows of up to 8 steps; MZR_ROUTE_SWEEP=1 / 0 forces it on / off (the tests run both).
+  bool rtSweep = W <= 8;
+  if (const char *e = getenv("MZR_ROUTE_SWEEP")) rtSweep = atoi(e) != 0;
+  if (h->rtItems < 1) rtSweep = false;
+  bool anyStage = false;
+  for (int ix = 0; ix < nR; ++ix) {
+    RouteBufs &rb = h->route[ix];
+    if (rb.method == MZR_KWT) { if (!sweep) anyStage = true; continue; }
+    if (!rtSweep || rb.rtCap < 1) { anyStage = true; continue; }
+    rt_sweep_tables(h, W);
+    hipStream_t sx = rst[ix];
+    MzrDev dx = dr[ix];
+    dx.rtRA = h->rtRA.p; dx.rtP = h->rtP.p;
+    const int nLaunch = nS + W - 1;
+    const int waves = std::max(8, std::min(rb.rtCap, h->rtMaxAct));
+    (void)hipMemsetAsync(rb.rtDone.p, 0, (size_t)N * sizeof(int), sx);
+    for (int c = 0; c * CH < nLaunch; ++c) {
+      if (chunked && c > 0 && c < nChunks) (void)hipStreamWaitEvent(sx, h->basinEvents[c], 0);
+      if (prof) {
+        if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
+      }
+      mzr_launch_sweep_route(rb.method, dx, waves, c * CH, std::min(nLaunch, (c + 1) * CH), sx);
+      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+      ++rb.nLaunches;
+    }
+  }
   for (int s = 0; s < nS + W - 1; ++s) {
-    if (sweep && nR == 1) break;
+    if (!anyStage) break;
     if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
     const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
     const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
@@ -1065,6 +1163,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       RouteBufs &rb = h->route[ix];
       hipStream_t sx = rst[ix];
       if (sweep && ix == kwtIx) continue;
+      if (rb.method != MZR_KWT && rtSweep && rb.rtCap >= 1) continue;
       if (prof) {
         if (rb.evUsed == rb.events.size()) {
           hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b);

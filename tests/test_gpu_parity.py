@@ -27,9 +27,11 @@ def domain_from_golden(net, z, **kw):
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 @pytest.mark.parametrize("window,sweep", [(1000, "1"), (7, "1"), (1, "1"), (1000, "0"), (7, "0")])
 def test_matches_reference_golden(name, window, sweep, hip_lib, monkeypatch):
-    """window: steps per call (1 = mzr_step-like); sweep: "1" the persistent KWT sweep (k_sweep_kwt, progress counters),
-    "0" one launch per stage (k_stage_kwt)."""
+    """window: steps per call (1 = mzr_step-like); sweep: "1" the persistent sweeps (k_sweep_kwt, and k_sweep_route for the
+    Eulerian methods whatever the window length: progress counters instead of kernel boundaries), "0" one launch per stage
+    (k_stage_kwt, k_stage)."""
     monkeypatch.setenv("MZR_KWT_SWEEP", sweep)
+    monkeypatch.setenv("MZR_ROUTE_SWEEP", sweep)
     net, z = load_golden(name)
     dom = domain_from_golden(net, z, max_window=window)
     Q = dom.run(z["runoff"])
@@ -431,6 +433,41 @@ def test_mc_substep_tail_closed_form(hip_lib, oracle_lib, monkeypatch):
     rel = np.abs(Q[None] - Q["0"])[big] / np.abs(Qo[big])
     assert rel.max() < 1e-8, float(rel.max())          # second order in the distance to the fixed point: ~1e-10 observed
     assert parity_report(Qo, Q["0"])["max_rel"] < 1e-10  # without the tail only rounding separates the two
+
+
+@pytest.mark.parametrize("case", ["plain", "lakes_wm"])
+def test_route_sweep_equals_stage_launches(case, hip_lib, monkeypatch):
+    """The persistent sweep of the Eulerian methods (k_sweep_route: tickets, per-reach progress, sc1 accesses, fences around
+    lake state) against one launch per stage: the same arithmetic in the same order, so every result is bit-identical --
+    discharge of every step, volumes, solver state, history sums -- for windows of 1, 5 and 64 steps."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(6000, seed=71, floodplain=(case != "plain"))
+    dt, steps = 3600.0, 70
+    ro = m.make_runoff(net.H, steps, seed=72, storm_prob=0.04, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    if case == "plain":
+        methods, kw, wm = [m.SUM, m.IRF, m.KW, m.MC, m.DW], {}, None
+    else:       # one method per domain with lakes (the Hanasaki parameters are the method's own here)
+        rng = np.random.default_rng(5)
+        wm = np.where(rng.random((steps, net.N)) < 0.1, rng.uniform(-0.01, 0.02, (steps, net.N)), -9999.0)
+        methods, kw = [m.DW], dict(lakes=make_lakes(net, steps, dt, seed=8, frac=0.03, input_option=0, memory=True), is_flux_wm=1)
+    out = {}
+    for sweep, window in (("0", 64), ("1", 64), ("1", 5), ("1", 1)):
+        monkeypatch.setenv("MZR_ROUTE_SWEEP", sweep)
+        dom = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=window, history=m.api.H_INFLOW | m.api.H_HEIGHT, **kw)
+        Q = dom.run(ro, wm_flux=wm)
+        res = [Q] + [dom.flux(me, f) for me in methods for f in (m.api.F_VOL1, m.api.F_WB, m.api.F_INFLOW)] + [dom.mean_q(me) for me in methods]
+        res += [dom.mol_state(me) for me in methods if me in (m.KW, m.MC, m.DW)]
+        if m.IRF in methods:
+            res.append(dom.irf_state())
+        out[(sweep, window)] = res
+        dom.close()
+    ref = out[("0", 64)]
+    for key, res in out.items():
+        for a, b in zip(ref, res):
+            assert np.array_equal(a, b), key
 
 
 def test_global_water_balance(hip_lib):
