@@ -23,6 +23,7 @@ Scope (what a run of the reference's SAMPLE.control needs, nothing more):
     get_basin_runoff.f90:136-205), `<lakeRegulate> F` = every lake natural; water management (`<is_flux_wm>`,
     `<is_vol_wm>`, `<is_vol_wm_jumpstart>`): `<fname_wm>` file(s) on their own step `<dt_wm>`, fluxes and target volumes
     sorted onto the reaches by `<vname_segid_wm>` (get_basin_runoff.f90:106-109, 207-250);
+  * river network subset mode (`<seg_outlet>` > 0): the part of the network upstream of a segment written to `<fname_ntopNew>`;
   * history file(s) `<case_name>.h.<start>.nc` at `<outputFrequency>` (a multiple of the step or
     `daily`), one file per run (`<newFileFrequency> single`), restart in / out (`<fname_state_in>`,
     `<restart_write> last`).
@@ -170,6 +171,57 @@ def build_network(ctl: dict, nml: dict):
     return net, hru_id
 
 
+def write_subset(ctl: dict, log=print) -> dict:
+    """River-network subset mode (`<seg_outlet>` > 0; process_ntopo.f90:236 reach_mask, init_model_data.f90:718-745): the
+    reaches upstream of -- and including -- the outlet segment and their HRUs are written to `<fname_ntopNew>` with every
+    variable of the input topology file, and the run stops there ("run again using the new network topology file")."""
+    name = lambda k: ctl.get(k, DEFAULT_NAMES[k])
+    src = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_ntopOld"]), "r", mmap=False)
+    v = src.variables
+    seg_id = np.asarray(v[name("varname_segId")][:], dtype=np.int64)
+    down_id = np.asarray(v[name("varname_downSegId")][:], dtype=np.int64)
+    hru_seg = np.asarray(v[name("varname_hruSegId")][:], dtype=np.int64)
+    out_id = int(ctl["seg_outlet"])
+    ix = {int(x): i for i, x in enumerate(seg_id)}
+    if out_id not in ix:
+        raise ValueError(f"<seg_outlet> {out_id} is not a segment of {ctl['fname_ntopOld']}")
+    ups = [[] for _ in range(seg_id.size)]
+    for i, dn in enumerate(down_id):
+        j = ix.get(int(dn), -1)
+        if j >= 0:
+            ups[j].append(i)
+    keep = np.zeros(seg_id.size, bool)
+    stack = [ix[out_id]]
+    while stack:
+        i = stack.pop()
+        if not keep[i]:
+            keep[i] = True
+            stack.extend(ups[i])
+    seg_sel = np.nonzero(keep)[0]
+    hru_sel = np.nonzero(np.isin(hru_seg, seg_id[seg_sel]))[0]
+    seg_dim, hru_dim = v[name("varname_segId")].dimensions[0], v[name("varname_HRUid")].dimensions[0]
+    path = os.path.join(ctl.get("ancil_dir", ""), ctl["fname_ntopNew"])
+    dst = netcdf_file(path, "w", version=2)
+    for dname, dlen in src.dimensions.items():
+        dst.createDimension(dname, seg_sel.size if dname == seg_dim else hru_sel.size if dname == hru_dim else dlen)
+    for vname, var in v.items():
+        o = dst.createVariable(vname, var.data.dtype.char if var.data.dtype.char != "l" else "i", var.dimensions)
+        for a in getattr(var, "_attributes", {}):
+            setattr(o, a, getattr(var, a))
+        data = np.asarray(var[:])
+        if var.dimensions and var.dimensions[0] == seg_dim:
+            data = data[seg_sel]
+        elif var.dimensions and var.dimensions[0] == hru_dim:
+            data = data[hru_sel]
+        if vname == name("varname_downSegId"):       # the outlet of the subset drains nowhere
+            data = np.where(np.isin(data, seg_id[seg_sel]), data, -1).astype(data.dtype)
+            data[np.nonzero(seg_id[seg_sel] == out_id)[0]] = -1
+        o[:] = data
+    dst.close(); src.close()
+    log(f"river network subset mode: {seg_sel.size} of {seg_id.size} reaches, {hru_sel.size} HRUs -> {path}; run again using the new network topology file")
+    return dict(subset=path, reaches=int(seg_sel.size), hrus=int(hru_sel.size))
+
+
 def _forcing_files(ctl: dict):
     p = os.path.join(ctl.get("input_dir", ""), ctl["fname_qsim"])
     if p.endswith(".nc"):
@@ -276,6 +328,8 @@ def read_lakes(ctl: dict, net, n_steps: int) -> dict:
 
 def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> dict:
     ctl = read_control(control_path)
+    if int(float(ctl.get("seg_outlet", -9999))) > 0:
+        return write_subset(ctl, log)
     nml = read_param_nml(os.path.join(ctl.get("ancil_dir", ""), ctl["param_nml"]))
     net, hru_id = build_network(ctl, nml)
     dt = float(ctl.get("dt_qsim", 86400))

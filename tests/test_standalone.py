@@ -364,3 +364,29 @@ def test_sort_flux_and_scale_forcing_follow_the_reference_rules():
     assert np.array_equal(standalone.scale_forcing(a, 2.0, -9999.0), [2.0, -9999.0, 4.0])      # missing values stay
     assert np.array_equal(standalone.scale_forcing(a, -9999.0, 0.5), [1.5, -9999.0, 2.5])
     assert standalone.suppressed(0.0, -9999.0) and standalone.suppressed(0.0, 0.0) and not standalone.suppressed(1.0, 0.0)
+
+
+def test_river_network_subset_mode(tmp_path):
+    """<seg_outlet>: the reaches upstream of (and including) a segment and their HRUs go to <fname_ntopNew>; the new file
+    builds the same sub-network the generator holds (upstream closure, areas, downstream ids)."""
+    net = m.make_network(900, seed=21)
+    nup_tot = np.zeros(net.N, int)
+    order = np.argsort(-standalone.hops_to_outlet(net.downIndex.astype(np.int64) - 1))
+    for i in order:                                   # reaches upstream, leaves first
+        d = net.downIndex[i] - 1
+        if d >= 0:
+            nup_tot[d] += nup_tot[i] + 1
+    pick = int(np.argsort(nup_tot)[-20])              # a segment with a sizeable sub-basin that is not the whole network
+    path = write_case(str(tmp_path), net, np.zeros((2, net.N)), 3600.0, extra=f"<seg_outlet> {int(net.reachId[pick])}\n<fname_ntopNew> ntopo_sub.nc\n")
+    out = standalone.run(path, log=lambda *_: None)
+    assert out["reaches"] == nup_tot[pick] + 1 and out["hrus"] == out["reaches"]
+    ctl = standalone.read_control(path)
+    ctl["fname_ntopOld"] = "ntopo_sub.nc"
+    sub, hru_id = standalone.build_network(ctl, standalone.read_param_nml(os.path.join(str(tmp_path), "param.nml")))
+    assert sub.N == out["reaches"] and (sub.downIndex == 0).sum() == 1
+    assert int(sub.reachId[np.nonzero(sub.downIndex == 0)[0][0]]) == int(net.reachId[pick])
+    pos = {int(x): i for i, x in enumerate(net.reachId)}
+    full = np.array([pos[int(x)] for x in sub.reachId])
+    assert np.array_equal(sub.params["BASAREA"], net.params["BASAREA"][full])
+    assert np.array_equal(sub.params["TOTAREA"], net.params["TOTAREA"][full])      # everything upstream came along
+    assert np.array_equal(np.diff(sub.upOffset), np.diff(net.upOffset)[full])
