@@ -124,6 +124,17 @@ int mzr_set_lake_forcing_dev(mzr_handle h, int nSteps, const double *evap_dev, c
 int mzr_set_lake_target(mzr_handle h, const int *targVol, int jumpstart);
 int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol);
 
+/* Direct insertion of gauge observations (data assimilation; public_var qmodOption = 1 with qBlendPeriod and QerrTrend,
+   main_route.f90:125-148, data_assimilation.f90:28-97): after IRF, KW, MC or DW have routed a reach, the error against
+   the last observed discharge -- constant (QerrTrend 1), linearly (2), logistically (3) or exponentially (4) decaying
+   over qBlendPeriod steps -- is taken off REACH_Q; with it on, the reach water balance is not evaluated (as in the
+   reference).  gaugeReach: 1-based reach of every gauge in the caller's order, < 1 = not in this network.  Call after
+   mzr_init_state; nGauge = 0 switches it off.  mzr_set_obs hands over the observations of the next window (like
+   mzr_set_wm_flux): have[nSteps] = there is an observation time at this step, obs[nSteps][nGauge] with NaN or a
+   negative value for "none at this gauge". */
+int mzr_set_da(mzr_handle h, int qBlendPeriod, int QerrTrend, int nGauge, const int *gaugeReach);
+int mzr_set_obs(mzr_handle h, int nSteps, const int *have, const double *obs);
+
 /* cold start (init_model_data.f90:399-505); must follow the setters above */
 int mzr_init_state(mzr_handle h);
 

@@ -52,7 +52,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb",
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
@@ -114,6 +114,8 @@ def load_library():
     L.mzr_sync.argtypes = [vp]
     L.mzr_set_wm_flux.argtypes = [vp, ci, dp]
     L.mzr_get_global_wb.argtypes = [vp, ci, dp]
+    L.mzr_set_da.argtypes = [vp, ci, ci, ci, ip]
+    L.mzr_set_obs.argtypes = [vp, ci, ip, dp]
     L.mzr_set_irf_state.argtypes = [vp, dp]
     L.mzr_set_mol_state.argtypes = [vp, ci, dp]
     L.mzr_set_basin_state.argtypes = [vp, vp, vp]
@@ -244,6 +246,8 @@ class RoutingDomain:
                 self.set_lake_forcing(done, w)
             if self.is_flux_wm:
                 self._check(self.L.mzr_set_wm_flux(self.h, w, np.ascontiguousarray(wm_flux[done:done + w], dtype=np.float64)))
+            if getattr(self, "da", None) is not None:
+                self.set_obs(self._da_done, w); self._da_done += w
             self._check(self.L.mzr_run(self.h, w, float(t_start) + done * self.dt, runoff[done:done + w]))
             for ix, m in enumerate(self.methods):
                 buf = np.zeros((w, self.N))
@@ -251,6 +255,21 @@ class RoutingDomain:
                 out[done:done + w, ix, :] = buf
             done += w
         return out
+
+    def set_da(self, da):
+        """Direct insertion of gauge observations (qmodOption = 1): da = dict(blend, trend, gauge_reach[nGauge] (1-based),
+        have[nSteps], obs[nSteps, nGauge]) for the steps run() will route from now on; None switches it off."""
+        self.da, self._da_done = da, 0
+        if da is None:
+            self._check(self.L.mzr_set_da(self.h, 10, 1, 0, np.zeros(1, dtype=np.int32)))
+        else:
+            g = np.ascontiguousarray(da["gauge_reach"], dtype=np.int32)
+            self._check(self.L.mzr_set_da(self.h, int(da["blend"]), int(da["trend"]), g.size, g))
+
+    def set_obs(self, first, w):
+        """observations of steps [first, first + w) of self.da for the next window"""
+        self._check(self.L.mzr_set_obs(self.h, int(w), np.ascontiguousarray(self.da["have"][first:first + w], dtype=np.int32),
+                                       np.ascontiguousarray(self.da["obs"][first:first + w], dtype=np.float64)))
 
     def set_wm_flux(self, w, wm_flux):
         """REACH_WM_FLUX [w, nRch] of the next window (is_flux_wm; -9999 = no data for the reach)."""

@@ -206,6 +206,46 @@ __device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+// main_route.f90:125-148 (observations of this step, or one more step since the last ones) and direct_insertion
+// (data_assimilation.f90:28-97): returns REACH_Q with the decaying discharge error taken off.
+template <bool COH>
+__device__ __forceinline__ double d_direct_insertion(const MzrDev &d, int r, int t, double Q) {
+  int el = ldx<COH>(d.qelapsed + r);
+  double qobs = ldx<COH>(d.qobs + r);
+  if (d.obsHave[t]) {
+    for (int g = d.gaugeFirst[r]; g >= 0; g = d.gaugeNext[g]) {
+      const double v = d.obsVal[(size_t)t * d.nGauge + g];
+      if ((v != v) || (v < 0)) continue;
+      qobs = v; el = 0;
+    }
+  } else {
+    el = el + 1;
+  }
+  stx<COH>(d.qobs + r, qobs); stx<COH>(d.qelapsed + r, el);
+  double qerr = ldx<COH>(d.qerr + r);
+  const int B = d.qBlendPeriod;
+  if (qobs > 0.0) qerr = Q - qobs;
+  if (el > B) qerr = 0.0;
+  double Qc = 0.0;
+  if (el <= B) {
+    switch (d.QerrTrend) {
+      case 1: Qc = qerr; break;
+      case 2: Qc = qerr * (1.0 - (double)el / (double)B); break;
+      case 3: {
+        const double x0 = 0.25, y0 = (double)0.90f;      // default-real literals in the reference (:78)
+        const double k = log(1.0 / y0 - 1.0) / (B / 2.0 - B * x0);
+        Qc = qerr / (1.0 + exp(-k * (1.0 * el - B / 2.0)));
+        break;
+      }
+      default:
+        if (qerr != 0.0) { const double k = log(0.1 / fabs(qerr)) / (1.0 * B); Qc = qerr * exp(k * el); }
+        break;
+    }
+  }
+  stx<COH>(d.qerr + r, qerr);
+  return fmax(Q - Qc, 0.0);
+}
+
 // One reach, one step of the window.  COH: the persistent sweep -- discharge rows and the reach's own state are produced and
 // consumed by different wavefronts of the SAME launch, so they go through sc1 accesses (ldx / stx, mzr_device.h);
 // COH = false is the launch-per-stage form with plain accesses.
@@ -456,9 +496,10 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
     }
     stx<COH>(d.floodvol + r, flood); stx<COH>(d.ele + r, ele);
   }
+  if (d.qmod) Qout = d_direct_insertion<COH>(d, r, t, Qout);      // irf_route.f90:188-198 and alike: after the solver, before anybody reads REACH_Q
   stx<COH>(Qrow + r, Qout);
   stx<COH>(d.vol + r, vol); stx<COH>(d.vol0 + r, vol0);
-  stx<COH>(d.wb + r, d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt));
+  if (!d.qmod) stx<COH>(d.wb + r, d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt));      // the water balance only without data assimilation (:200-202)
   if (d.wmact) stx<COH>(d.wmact + r, wmAct);
   stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + Qout);
   // history sums of the other per-method fluxes (histVars_data.f90:229-246), when asked for

@@ -139,6 +139,14 @@ struct MzrDev {
   const double *imOQ, *imOT;  // [Wmax][MZR_OB_CAP][nHalo]
   int    *exN;                // [Wmax][nExp]
   double *exOQ, *exOT;        // [Wmax][MZR_OB_CAP][nExp]
+  // ---- direct insertion of gauge observations (qmodOption = 1; main_route.f90:125-148, data_assimilation.f90:28-97); qmod = 0: off
+  int qmod, qBlendPeriod, QerrTrend, nGauge;
+  const int *gaugeFirst;      // [N] first gauge of the reach or -1
+  const int *gaugeNext;       // [nGauge] next gauge of the same reach or -1 (a later gauge overrides an earlier one)
+  const int *obsHave;         // [W] there is an observation time at this step
+  const double *obsVal;       // [W][nGauge]
+  double *qobs, *qerr;        // [N] RCHFLX%Qobs, ROUTE%Qerror (of the method being launched; Qobs / Qelapsed evolve alike in every method)
+  int *qelapsed;              // [N] RCHFLX%Qelapsed
   // ---- persistent sweep of the Eulerian methods (k_sweep_route): items = up to 64 reaches of one stage, drawn in launch
   // order from per-XCD ticket counters like the KWT sweep's; rtDone[r] = steps of the window reach r has completed
   int *rtDone;                // [N] (of the method being launched)

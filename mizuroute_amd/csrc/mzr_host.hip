@@ -69,6 +69,7 @@ struct RouteBufs {
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
   DBuf<int> rtDone, rtHead;                         // persistent sweep of an Eulerian method: progress per reach, ticket counters
+  DBuf<double> qobs, qerr; DBuf<int> qelapsed;      // [N] direct insertion (mzr_set_da): RCHFLX%Qobs, ROUTE%Qerror, RCHFLX%Qelapsed
   int rtCap = 0;                                    // wavefronts the device holds of this method's sweep kernel
   long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
@@ -197,6 +198,8 @@ struct mzr_domain {
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
   DBuf<int> rtItemR, rtItemInfo, rtRA, rtP;        // items of the Eulerian sweeps (k_sweep_route) and their per-launch tables
+  int qmod = 0, qBlendPeriod = 10, QerrTrend = 1, nGauge = 0, obsSteps = 0;      // direct insertion of gauge observations (mzr_set_da / mzr_set_obs)
+  DBuf<int> gaugeFirst, gaugeNext, obsHave; DBuf<double> obsVal;
   std::vector<int> h_rtStage; int rtItems = 0, rtTablesW = -1, rtMaxAct = 0;
   std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
   std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
@@ -282,6 +285,9 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.haloSlot = h->nHalo ? h->haloSlot.p : nullptr; d.exportSlot = h->nExp ? h->exportSlot.p : nullptr;
   d.nHalo = h->nHalo; d.nExp = h->nExp; d.Wmax = h->cfg.maxWindow;
   d.imN = h->imN.p; d.imOQ = h->imOQ.p; d.imOT = h->imOT.p;
+  d.qmod = h->qmod; d.qBlendPeriod = h->qBlendPeriod; d.QerrTrend = h->QerrTrend; d.nGauge = h->nGauge;
+  d.gaugeFirst = h->gaugeFirst.p; d.gaugeNext = h->gaugeNext.p; d.obsHave = h->obsHave.p; d.obsVal = h->obsVal.p;
+  d.qobs = nullptr; d.qerr = nullptr; d.qelapsed = nullptr;
   d.rtItemR = h->rtItemR.p; d.rtItemInfo = nullptr; d.rtRA = h->rtRA.p; d.rtP = h->rtP.p; d.rtDone = nullptr; d.rtHead = nullptr;
   d.exN = h->exN.p; d.exOQ = h->exOQ.p; d.exOT = h->exOT.p;
 }
@@ -293,6 +299,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
   d.rtDone = rb.rtDone.p; d.rtHead = rb.rtHead.p;
+  d.qobs = rb.qobs.p; d.qerr = rb.qerr.p; d.qelapsed = rb.qelapsed.p;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -747,6 +754,53 @@ int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol) {
   return 0;
 }
 
+// Direct insertion of gauge observations (public_var qmodOption = 1, qBlendPeriod, QerrTrend; main_route.f90:125-148,
+// data_assimilation.f90:28-97) for IRF, KW, MC and DW (the reference's KWT and lake solvers do not call it).
+// gaugeReach: 1-based reach (caller's order) of every gauge, < 1 = the gauge is not in this network.  Resets Qobs,
+// Qelapsed and Qerror.  nGauge = 0 switches it off.
+int mzr_set_da(mzr_handle h, int qBlendPeriod, int QerrTrend, int nGauge, const int *gaugeReach) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_da/state not initialised (call mzr_init_state)") : 1;
+  if (nGauge < 0 || (nGauge > 0 && !gaugeReach)) return fail(h, 20, "mzr_set_da/bad gauge list");
+  if (nGauge > 0 && (QerrTrend < 1 || QerrTrend > 4)) return fail(h, 81, "direct_insertion/discharge error trend model must be 1(const),2(liear), or 3(logistic)");
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);
+  h->qmod = nGauge > 0 ? 1 : 0; h->qBlendPeriod = qBlendPeriod; h->QerrTrend = QerrTrend; h->nGauge = nGauge; h->obsSteps = 0;
+  if (!h->qmod) return 0;
+  const int N = h->N;
+  std::vector<int> first(N, -1), next(nGauge, -1), last(N, -1);
+  for (int g = 0; g < nGauge; ++g) {
+    const int e = gaugeReach[g] - 1;
+    if (e < 0 || e >= N) continue;
+    const int i = h->ext2int[e];
+    if (first[i] < 0) first[i] = g; else next[last[i]] = g;
+    last[i] = g;
+  }
+  try {
+    h->gaugeFirst.upload(first); h->gaugeNext.upload(next);
+    h->obsHave.alloc(h->cfg.maxWindow); h->obsVal.alloc((size_t)h->cfg.maxWindow * nGauge);
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      rb.qobs.alloc(N); rb.qobs.zero(); rb.qerr.alloc(N); rb.qerr.zero(); rb.qelapsed.alloc(N); rb.qelapsed.zero();
+    }
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_da/" + e); }
+  return 0;
+}
+
+// gauge observations of the next window: have[nSteps] (1 = there is an observation time at this step), obs[nSteps][nGauge]
+// (NaN or negative = no value at this gauge)
+int mzr_set_obs(mzr_handle h, int nSteps, const int *have, const double *obs) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_obs/state not initialised") : 1;
+  if (!h->qmod) return fail(h, 20, "mzr_set_obs/direct insertion is off (mzr_set_da)");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_obs/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);       // the window before may still read the buffers
+  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (h->routeStream[ix]) (void)hipStreamSynchronize(h->routeStream[ix]);
+  MZR_COPY(h->obsHave.p, have, (size_t)nSteps * sizeof(int), hipMemcpyHostToDevice, "mzr_set_obs");
+  MZR_COPY(h->obsVal.p, obs, (size_t)nSteps * h->nGauge * sizeof(double), hipMemcpyHostToDevice, "mzr_set_obs");
+  h->obsSteps = nSteps;
+  return 0;
+}
+
 int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach, const int *haloGood) {
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_boundary/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
@@ -1032,6 +1086,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
+  if (h->qmod && h->obsSteps < W) return fail(h, 20, "mzr_run/direct insertion is on: call mzr_set_obs for this window first");
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   if (h->anyLakeTarget && h->wmVolSteps < W) return fail(h, 20, "mzr_run/target-volume lakes are on: call mzr_set_wm_vol for this window first");
   (void)hipSetDevice(h->cfg.device);
@@ -1198,7 +1253,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     mzr_launch_accum_qsum(runoff_dev, h->hBas.p, h->H, W, st);
     h->histSteps += W;
   }
-  h->lastW = W; h->stepsDone += W; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
+  h->lastW = W; h->stepsDone += W; h->obsSteps = 0; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
   return 0;
 }

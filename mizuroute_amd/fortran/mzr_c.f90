@@ -39,7 +39,7 @@ MODULE mzr_c
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
-            mzr_get_global_wb, mzr_set_lake_forcing_dev
+            mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs
   public :: mzr_message
 
   INTERFACE
@@ -126,6 +126,19 @@ MODULE mzr_c
       type(c_ptr), value :: h
       integer(c_int), value :: method, reset
       real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_set_da(h, qBlendPeriod, QerrTrend, nGauge, gaugeReach) bind(C, name='mzr_set_da')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: qBlendPeriod, QerrTrend, nGauge
+      integer(c_int), intent(in) :: gaugeReach(*)
+    end function
+    integer(c_int) function mzr_set_obs(h, nSteps, have, obs) bind(C, name='mzr_set_obs')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      integer(c_int), intent(in) :: have(*)
+      real(c_double), intent(in) :: obs(*)
     end function
     integer(c_int) function mzr_get_global_wb(h, method, out8) bind(C, name='mzr_get_global_wb')
       import :: c_ptr, c_int, c_double

@@ -397,3 +397,22 @@ def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: 
         vol[:, reach - 1] = base * (0.6 + 0.35 * np.sin(2 * np.pi * t / 37.0 + np.arange(nl)[None, :]))
         out.update(targ_vol=flag, vol_jumpstart=int(vol_jumpstart), wm_vol=vol)
     return out
+
+
+def make_gauges(net: RiverNetwork, n_steps: int, n_gauge: int = 40, seed: int = 3, every: int = 3, blend: int = 10, trend: int = 2,
+                q_scale: float = 5.0) -> dict:
+    """Synthetic gauge observations for direct insertion (qmodOption = 1, data_assimilation.f90): gauges on non-headwater
+    reaches (one entry points outside the network), an observation time every `every`-th step with a gap in the middle
+    longer than the blending period, values around q_scale * TOTAREA-scaled flows with some missing (NaN) and negative."""
+    rng = np.random.default_rng(seed)
+    nup = np.diff(net.upOffset)
+    cand = np.nonzero(nup > 0)[0]
+    reach = (rng.choice(cand, min(n_gauge, cand.size), replace=False) + 1).astype(np.int32)
+    reach[-1] = -9999                                     # a gauge that is not linked to any reach
+    have = np.zeros(n_steps, np.int32); have[::every] = 1
+    have[n_steps // 3: n_steps // 3 + 2 * blend + 3] = 0    # a gap: the error decays and is dropped
+    area = np.where(reach > 0, net.params["TOTAREA"][np.maximum(reach, 1) - 1], 1.0)
+    obs = q_scale * 2e-8 * area[None, :] * (0.5 + rng.random((n_steps, reach.size)))
+    obs[rng.random(obs.shape) < 0.1] = np.nan
+    obs[rng.random(obs.shape) < 0.05] = -1.0
+    return dict(blend=int(blend), trend=int(trend), gauge_reach=reach, have=have, obs=obs)

@@ -72,6 +72,12 @@ int orc_set_lakes(orc_t *o, int LakeInputOption, int calendarId, int nLake, cons
                   const int *modelType, const double *par);
 /* target-volume lakes (lake_route.f90:139-142,197-205): flags[nLake], is_vol_wm_jumpstart, REACH_WM_VOL[nSteps][N] of the steps after firstStep */
 int orc_set_lake_target(orc_t *o, const int *flags, int jumpstart, int firstStep, const double *wmvol);
+/* direct insertion of gauge observations (qmodOption = 1; main_route.f90:125-148, data_assimilation.f90:28-97): gaugeReach
+   1-based reach of every gauge (< 1 = not in the network), obsHave[step] = there is an observation time at this step,
+   obsVal[step][nGauge] (NaN / negative = no value); row 0 belongs to the step with iTime = firstStep + 1.  The caller keeps
+   the two arrays alive.  QerrTrend: 1 constant, 2 linear, 3 logistic, 4 exponential decay of the error over qBlendPeriod steps. */
+int orc_set_da(orc_t *o, int qBlendPeriod, int QerrTrend, int nGauge, const int *gaugeReach, int firstStep,
+               const int *obsHave, const double *obsVal);
 /* history means since the last refresh (histVars_data.f90:154-305): which 0 discharge, 1 inflow, 2 height, 3 floodVolume,
    4 volume (last value), 10 instRunoff, 11 dlayRunoff, 12 basRunoff [H] */
 int orc_hist_get(orc_t *o, int route, int which, double *out);

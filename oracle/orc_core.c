@@ -63,6 +63,7 @@ orc_t *orc_create(int N, int H, const int *downIndex, const int *upOff, const in
 }
 
 void orc_destroy(orc_t *o) {
+  if (o) { free(o->gaugeReach); free(o->Qobs); free(o->Qelapsed); free(o->Qerror); }
   if (!o) return;
   free(o->down); free(o->upOff); free(o->upIdx); free(o->upGood); free(o->nGood);
   free(o->hruOff); free(o->hruIdx); free(o->hruW); free(o->order);
@@ -243,6 +244,60 @@ void orc_comp_reach_wb(orc_t *o, int r, int method, double Qupstream, double Qla
   h->WB = dVol - (Qin + Qlateral + precip + Qtake_actual + Qout + evapo);
 }
 
+/* data_assimilation.f90:28-97 */
+static int direct_insertion(orc_t *o, int r, int method) {
+  orc_hyd *h = &HYD(o, method, r);
+  double *Qerror = &o->Qerror[(size_t)o->idx[method] * o->N + r];
+  const int Qelapsed = o->Qelapsed[r], qBlendPeriod = o->qBlendPeriod;
+  double Qcorrect;
+  if (o->Qobs[r] > 0.0) *Qerror = h->REACH_Q - o->Qobs[r];     /* there is observation */
+  if (Qelapsed > qBlendPeriod) *Qerror = 0.0;
+  if (Qelapsed <= qBlendPeriod) {
+    switch (o->QerrTrend) {
+      case 1: Qcorrect = *Qerror; break;
+      case 2: Qcorrect = *Qerror * (1.0 - (double)Qelapsed / (double)qBlendPeriod); break;
+      case 3: {
+        const double x0 = 0.25, y0 = (double)0.90f;      /* default-real literals in the reference (:78) */
+        const double k = log(1.0 / y0 - 1.0) / (qBlendPeriod / 2.0 - qBlendPeriod * x0);
+        Qcorrect = *Qerror / (1.0 + exp(-k * (1.0 * Qelapsed - qBlendPeriod / 2.0)));
+        break;
+      }
+      case 4:
+        if (*Qerror != 0.0) {
+          const double k = log(0.1 / fabs(*Qerror)) / (1.0 * qBlendPeriod);
+          Qcorrect = *Qerror * exp(k * Qelapsed);
+        } else Qcorrect = 0.0;
+        break;
+      default:
+        snprintf(o->msg, sizeof o->msg, "direct_insertion/discharge error trend model must be 1(const),2(liear), or 3(logistic)");
+        return 81;
+    }
+  } else Qcorrect = 0.0;
+  h->REACH_Q = fmax(h->REACH_Q - Qcorrect, 0.0);
+  return 0;
+}
+
+/* the tail the four Eulerian solvers share (irf_route.f90:188-202, kwe_route.f90:183-197, mc_route.f90:183-197,
+   dfw_route.f90:187-201): direct insertion when qmodOption = 1, the reach water balance only when it is off */
+int orc_finish_rch(orc_t *o, int r, int method, double Qupstream, double Qlat) {
+  if (o->qmodOption == 1) { const int ierr = direct_insertion(o, r, method); if (ierr) return ierr; }
+  if (o->qmodOption == 0) orc_comp_reach_wb(o, r, method, Qupstream, Qlat);
+  return 0;
+}
+
+int orc_set_da(orc_t *o, int qBlendPeriod, int QerrTrend, int nGauge, const int *gaugeReach, int firstStep,
+               const int *obsHave, const double *obsVal) {
+  o->qmodOption = 1; o->qBlendPeriod = qBlendPeriod; o->QerrTrend = QerrTrend; o->nGauge = nGauge; o->obsFirst = firstStep;
+  free(o->gaugeReach); o->gaugeReach = (int *)xcalloc(nGauge > 0 ? nGauge : 1, sizeof(int));
+  for (int g = 0; g < nGauge; g++) o->gaugeReach[g] = (gaugeReach[g] >= 1 && gaugeReach[g] <= o->N) ? gaugeReach[g] - 1 : -1;
+  o->obsHave = obsHave; o->obsVal = obsVal;
+  if (!o->Qobs) {
+    o->Qobs = (double *)xcalloc(o->N, sizeof(double)); o->Qelapsed = (int *)xcalloc(o->N, sizeof(int));
+    o->Qerror = (double *)xcalloc((size_t)(o->nRoutes > 0 ? o->nRoutes : 1) * o->N, sizeof(double));
+  }
+  return 0;
+}
+
 /* irf_route.f90:40-264 */
 int orc_irf_rch(orc_t *o, int r) {
   orc_hyd *h = &HYD(o, ORC_IRF, r);
@@ -269,8 +324,7 @@ int orc_irf_rch(orc_t *o, int r) {
     h->REACH_VOL[0] = 0.0;
     h->REACH_VOL[1] = 0.0;
   }
-  orc_comp_reach_wb(o, r, ORC_IRF, q_upstream, Qlat);
-  return 0;
+  return orc_finish_rch(o, r, ORC_IRF, q_upstream, Qlat);
 }
 
 /* main_route.f90:29-268 + route_network 273-409 */
@@ -285,6 +339,20 @@ int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const do
   o->msg[0] = 0;
   if (o->is_flux_wm && wmflux) { for (int r = 0; r < N; r++) o->REACH_WM_FLUX[r] = wmflux[r]; }
   else { for (int r = 0; r < N; r++) o->REACH_WM_FLUX[r] = 0.0; }
+  if (o->qmodOption == 1) {   /* main_route.f90:125-148: gauge observations of this step, or one more step since the last ones */
+    const long long row = o->iTime - 1 - o->obsFirst;
+    if (o->obsHave[row]) {
+      for (int g = 0; g < o->nGauge; g++) {
+        const int r = o->gaugeReach[g];
+        if (r < 0) continue;
+        const double qobs = o->obsVal[(size_t)row * o->nGauge + g];
+        if ((qobs != qobs) || (qobs < 0)) continue;
+        o->Qobs[r] = qobs; o->Qelapsed[r] = 0;
+      }
+    } else {
+      for (int r = 0; r < N; r++) o->Qelapsed[r] = o->Qelapsed[r] + 1;
+    }
+  }
   double *reachRunoff = (double *)xcalloc(N, sizeof(double));
   ierr = basin2reach(o, runoff, reachRunoff);
   if (ierr) { free(reachRunoff); return ierr; }

@@ -223,8 +223,7 @@ int orc_mc_rch(orc_t *o, int r, double T0, double T1) {
     h->REACH_VOL[0] = 0.0; h->REACH_VOL[1] = 0.0; h->FLOOD_VOL[1] = 0.0; h->REACH_ELE = 0.0;
   }
   mol[0] = Q10; mol[1] = Q11;
-  orc_comp_reach_wb(o, r, ORC_MC, q_upstream, Qlat);
-  return 0;
+  return orc_finish_rch(o, r, ORC_MC, q_upstream, Qlat);
 }
 
 /* dfw_route.f90:49-370 (method == ORC_DW) and kwe_route.f90:46-363 (method == ORC_KW, dk = 0) */
@@ -272,6 +271,5 @@ int orc_dw_rch(orc_t *o, int r, int method) {
     for (int i = 0; i < nMol; i++) mol[i] = 0.0;
     mol[nMol - 1] = h->REACH_Q;
   }
-  orc_comp_reach_wb(o, r, method, Qupstream, Qlat);
-  return 0;
+  return orc_finish_rch(o, r, method, Qupstream, Qlat);
 }

@@ -51,6 +51,10 @@ struct orc {
   int h_nt; double *h_bas, *h_inst, *h_dlay, *h_q, *h_vol, *h_ele, *h_flood, *h_inflow;   /* history sums, histVars_data.f90 */
   int *lakeTarg, volJumpstart, wmVolFirst; const double *wmVol;   /* target-volume lakes: NETOPO%LakeTargVol, is_vol_wm_jumpstart, REACH_WM_VOL[step][N] */
   long long iTime; int month, day, dayofyear;
+  /* direct insertion of gauge observations (qmodOption = 1; main_route.f90:125-148, data_assimilation.f90:28-97) */
+  int qmodOption, qBlendPeriod, QerrTrend, nGauge, obsFirst; int *gaugeReach;   /* [nGauge] 0-based reach, -1 = not in the network */
+  const int *obsHave; const double *obsVal;   /* [step], [step][nGauge]: is there an observation time at this step, and the values */
+  double *Qobs, *Qerror; int *Qelapsed;       /* [N], [nRoutes][N], [N] */
   /* KWT traffic statistics of the last step */
   long long w_in, w_up, w_out, n_head, n_route, n_edges;
   /* how often the less common branches of kwt_rch ran since creation (test coverage evidence):
@@ -85,5 +89,6 @@ int orc_lake_route(orc_t *o, int r, int method);
 void orc_preamble(orc_t *o, int r, int method, double *q_upstream, double *q_upstream_mod,
                   double *Qlat, int *isHW);
 void orc_comp_reach_wb(orc_t *o, int r, int method, double Qupstream, double Qlat);
+int orc_finish_rch(orc_t *o, int r, int method, double Qupstream, double Qlat);   /* direct insertion or water balance, e.g. irf_route.f90:188-202 */
 void orc_hist_aggregate(orc_t *o, const double *basRunoff);
 #endif

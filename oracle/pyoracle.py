@@ -45,6 +45,7 @@ def lib():
         L.orc_run_wm.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, dp, C.c_void_p, C.c_void_p]
         L.orc_set_lakes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, dp]
         L.orc_set_lake_target.argtypes = [C.c_void_p, ip, C.c_int, C.c_int, dp]
+        L.orc_set_da.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip, dp]
         L.orc_hist_get.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.orc_hist_refresh.argtypes = [C.c_void_p]
         L.orc_run_lake.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, dp, dp, ip, C.c_void_p, C.c_void_p]
@@ -112,6 +113,13 @@ class Oracle:
         if rc:
             raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
         return (Q, V) if want_vol else Q
+
+    def set_da(self, da, first_step=0):
+        """direct insertion of gauge observations (qmodOption = 1): da = dict(blend, trend, gauge_reach[nGauge] (1-based),
+        have[nSteps], obs[nSteps, nGauge]); row 0 belongs to step first_step of the run."""
+        c = lambda a, t: np.ascontiguousarray(a, dtype=t)
+        self._da = (c(da["gauge_reach"], np.int32), c(da["have"], np.int32), c(da["obs"], np.float64))     # kept alive
+        return lib().orc_set_da(self.h, int(da["blend"]), int(da["trend"]), self._da[0].size, self._da[0], int(first_step), self._da[1], self._da[2])
 
     def set_lakes(self, lakes):
         """lakes: dict as mizuroute_amd.casefile.write_case(lakes=...)."""

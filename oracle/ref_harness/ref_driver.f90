@@ -31,6 +31,8 @@ PROGRAM ref_driver
   implicit none
 
   integer(i4b), parameter :: MAGIC_IN  = 1297765955   ! 'MZRC' bytes read as little-endian int32
+  integer(i4b), parameter :: MAGIC_DA  = 1145133645   ! 'MZAD': gauge-observation section
+  integer(i4b) :: daOn, daMagic, ios, nGauge, daBlend, daTrend
   integer(i4b), parameter :: MAGIC_OUT = 1297765967   ! 'MZRO'
   integer(i4b), parameter :: WCAP = 32                ! padded wave capacity in the state dump
 
@@ -121,6 +123,18 @@ PROGRAM ref_driver
       read(uin) wmvol
     end if
   end if
+  ! optional trailing section: gauge observations for direct insertion (qmodOption = 1)
+  daOn = 0
+  read(uin, iostat=ios) daMagic
+  if (ios == 0 .and. daMagic == MAGIC_DA) then
+    daOn = 1
+    read(uin) nGauge, daBlend, daTrend
+    allocate(gage_obs%link(nGauge), gage_obs%have(nSteps), gage_obs%val(nGauge, nSteps))
+    read(uin) gage_obs%link
+    read(uin) gage_obs%have
+    read(uin) gage_obs%val
+    where (gage_obs%link < 1 .or. gage_obs%link > N) gage_obs%link = integerMissing
+  end if
   close(uin)
 
   ! ---- configuration the reference keeps in public_var / globalData (read_control.f90:580-600)
@@ -128,6 +142,9 @@ PROGRAM ref_driver
   is_vol_wm_jumpstart = .false.
   if (isVolWm == 1) is_vol_wm_jumpstart = (volJump /= 0)
   qmodOption = 0
+  if (daOn == 1) then
+    qmodOption = 1; qBlendPeriod = daBlend; QerrTrend = daTrend
+  end if
   time_conv = 1._dp; length_conv = 1._dp
   allocate(routeMethods(nRoutes))
   routeMethods(1:nRoutes) = methodsIn(1:nRoutes)
@@ -333,6 +350,7 @@ PROGRAM ref_driver
     TSEC(1) = t_start + real(it-1, dp)*dt       ! init_model_data.f90:311-312,600
     TSEC(2) = TSEC(1) + dt
     basinRunoff = runoff(:, it)
+    gage_obs%step = it
     if (isFluxWm == 1) reachflux = wmflux(:, it)
     if (isVolWm == 1) reachvol = wmvol(:, it)
     if (is_lake_sim) then

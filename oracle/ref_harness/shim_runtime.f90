@@ -55,12 +55,18 @@ CONTAINS
 END MODULE model_utils
 
 MODULE obs_data
+  ! stand-in for the reference's gauge-observation reader (obs_data.f90 needs ncio_utils / netCDF): the driver puts the
+  ! observations of the case file into the object, main_route (unmodified) asks for them through the reference's interface
   USE nrtype
   USE public_var,    ONLY: integerMissing, realMissing
   USE datetime_data, ONLY: datetime
   implicit none
   type :: gageObs
-    integer(i4b) :: dummy = 0
+    integer(i4b) :: step = 0                      ! simulation step main_route is about to route (set by the driver)
+    integer(i4b) :: cur = 0                       ! record read_obs made current
+    integer(i4b), allocatable :: have(:)          ! (nSteps) 1 = there is an observation time at this step
+    integer(i4b), allocatable :: link(:)          ! (nGauge) reach index of every gauge, integerMissing = none
+    real(dp),     allocatable :: val(:,:)         ! (nGauge, nSteps)
   CONTAINS
     procedure, pass :: time_ix
     procedure, pass :: read_obs
@@ -73,6 +79,11 @@ CONTAINS
     type(datetime), intent(in) :: dt
     integer(i4b) :: ix
     ix = integerMissing
+    if (allocated(this%have)) then
+      if (this%step >= 1 .and. this%step <= size(this%have)) then
+        if (this%have(this%step) == 1) ix = this%step
+      end if
+    end if
   END FUNCTION
   SUBROUTINE read_obs(this, ierr, message, index_time)
     class(gageObs), intent(inout) :: this
@@ -80,16 +91,22 @@ CONTAINS
     character(*), intent(out) :: message
     integer(i4b), intent(in), optional :: index_time
     ierr=0; message=''
+    if (present(index_time)) this%cur = index_time
   END SUBROUTINE
   FUNCTION link_ix(this) result(ix)
     class(gageObs), intent(in) :: this
     integer(i4b), allocatable :: ix(:)
-    allocate(ix(0))
+    if (allocated(this%link)) then
+      allocate(ix(size(this%link))); ix = this%link
+    else
+      allocate(ix(0))
+    end if
   END FUNCTION
   FUNCTION get_obs(this, tix, six) result(q)
     class(gageObs), intent(in) :: this
     integer(i4b), intent(in), optional :: tix, six
     real(dp) :: q
     q = realMissing
+    if (allocated(this%val) .and. present(six)) q = this%val(six, this%cur)
   END FUNCTION
 END MODULE obs_data

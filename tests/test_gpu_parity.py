@@ -470,6 +470,46 @@ def test_route_sweep_equals_stage_launches(case, hip_lib, monkeypatch):
             assert np.array_equal(a, b), key
 
 
+@pytest.mark.parametrize("trend", [2, 3, 4])
+def test_direct_insertion_vs_oracle(trend, hip_lib, oracle_lib, monkeypatch):
+    """qmodOption = 1: gauge observations inserted into IRF, KW, MC and DW (main_route.f90:125-148, data_assimilation.f90:28-97)
+    against the oracle (pinned to the reference harness in tests/test_oracle_vs_ref.py), windows that do not divide the
+    observation cycle, both launch forms bit-identical to each other."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_gauges
+    net = m.make_network(3000, seed=41)
+    dt, steps = 3600.0, 80
+    ro = m.make_runoff(net.H, steps, seed=42, storm_prob=0.05, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    da = make_gauges(net, steps, n_gauge=120, seed=trend, every=3, blend=10, trend=trend)
+    da["gauge_reach"][1] = da["gauge_reach"][0]                    # two gauges on one reach: the later one wins
+    methods = [m.SUM, m.IRF, m.KW, m.MC, m.DW]
+    orc = oracle_lib.Oracle(net, dt, methods, ff, uh_off, uhv)
+    assert orc.set_da(da) == 0
+    Qo = orc.run(ro)
+    Q = {}
+    for sweep in ("0", "1"):
+        monkeypatch.setenv("MZR_ROUTE_SWEEP", sweep)
+        dom = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=7)
+        dom.set_da(da)
+        Q[sweep] = dom.run(ro)
+        for ix, meth in enumerate(methods):
+            rep = parity_report(Qo[:, ix], Q[sweep][:, ix])
+            print("direct insertion, trend", trend, "sweep", sweep, "method", meth, rep)
+            assert rep["max_rel"] <= REL_TOL, (meth, rep)
+        dom.close()
+    assert np.array_equal(Q["0"], Q["1"])
+    dom = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=7)
+    Qplain = dom.run(ro)
+    g = da["gauge_reach"][:-1] - 1
+    assert np.abs(Qplain[:, 1:, g] - Q["0"][:, 1:, g]).max() > 0     # the insertion does change the routed flow
+    with pytest.raises(m.api.MzrError):                              # switched on, but no observations handed over
+        dom.set_da(da); dom.da = None
+        dom.run(ro[:7])
+    dom.close()
+
+
 def test_global_water_balance(hip_lib):
     """comp_global_wb (water_balance.f90:191-323) of the last step: the seven sums restated from the per-reach fields, and
     the global error equal to the sum of the per-reach errors (comp_reach_wb, :22-112) -- inside the domain every

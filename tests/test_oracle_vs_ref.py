@@ -157,6 +157,29 @@ def test_target_volume_lakes_and_demand_memory_bit_exact(jump, oracle_lib):
 
 
 # ---- forcing remap (process_remap.f90:32-316) against the reference's own routines -------------------
+@pytest.mark.parametrize("trend", [1, 2, 3, 4])
+def test_direct_insertion_bit_exact(trend, oracle_lib):
+    """qmodOption = 1 (main_route.f90:125-148, data_assimilation.f90:28-97): observations at gauges every third step, a gap
+    longer than the blending period, missing and negative values, a gauge outside the network; all four error trends.
+    The harness hands the observations to the UNMODIFIED main_route through the gageObs interface."""
+    from mizuroute_amd.synthetic import make_gauges
+    net = make_network(800, seed=11)
+    steps, dt = 90, 3600.0
+    ro = make_runoff(net.H, steps, seed=12, storm_prob=0.05, storm_amp=3e-6)
+    da = make_gauges(net, steps, n_gauge=60, seed=trend, every=3, blend=10, trend=trend)
+    methods = [0, 1, 3, 4, 5]
+    out = refrun.run_case(net, ro, dt, methods, da=da)
+    assert out["ierr"] == 0, out["stdout"]
+    orc = oracle_lib.Oracle(net, dt, methods, out["frac_future"], out["uh_offset"], out["uh"])
+    assert orc.set_da(da) == 0
+    Q, V = orc.run(ro, want_vol=True)
+    assert np.array_equal(Q, out["Q"]) and np.array_equal(V, out["VOL"])
+    plain = refrun.run_case(net, ro, dt, methods)
+    g = da["gauge_reach"][:-1] - 1
+    assert np.abs(plain["Q"][:, 1:, g] - out["Q"][:, 1:, g]).max() > 0          # the insertion does change the routed flow
+    assert np.array_equal(plain["Q"][:, 0], out["Q"][:, 0])                      # ... but not the runoff accumulation
+
+
 @pytest.mark.parametrize("H,n1,n2,seed", [(500, 700, 0, 3), (3000, 2500, 0, 4), (800, 40, 30, 5), (2000, 90, 64, 6)])
 def test_remap_runoff_bit_exact(H, n1, n2, seed, oracle_lib):
     from mizuroute_amd.synthetic import make_remap, make_source_runoff
