@@ -26,6 +26,7 @@ import numpy as np
 
 MAGIC_IN = 1297765955
 MAGIC_DA = 1145133645       # b'MZAD': trailing gauge-observation section (direct insertion)
+MAGIC_TR = 1381259853       # b'MZTR': trailing constituent section (tracer)
 
 # lake parameter rows (RPARAM fields, dataTypes.f90:196-254), in this order
 LAKE_PAR = ("D03_MaxStorage", "D03_Coefficient", "D03_Power", "D03_S0",
@@ -50,11 +51,12 @@ def serial_schedule(net):
 
 def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_point=2,
                min_length_route=0.0, runoff_min=0.0, fshape=2.5, tscale=86400.0, velo=1.5, diff=5000.0,
-               t_start=0.0, uh=None, schedule=None, dump_every=1, wm_flux=None, lakes=None, da=None):
+               t_start=0.0, uh=None, schedule=None, dump_every=1, wm_flux=None, lakes=None, da=None, solute=None):
     """lakes: None or dict(input_option, calendar_id, ymd[nSteps,3], reach[nLake] (1-based), model_type[nLake],
     par[NLAKEPAR, nLake], evap[nSteps,H], precip[nSteps,H])."""
     """uh: None -> the harness calls the reference's basinUH/make_uh; else (frac, uhOffset, uh).
-    da: None or dict(blend, trend, gauge_reach[nGauge] (1-based), have[nSteps], obs[nSteps, nGauge]) -> qmodOption = 1."""
+    da: None or dict(blend, trend, gauge_reach[nGauge] (1-based), have[nSteps], obs[nSteps, nGauge]) -> qmodOption = 1.
+    solute: None or basin constituent mass flux [nSteps, H] -> tracer = T."""
     runoff = np.ascontiguousarray(runoff, dtype=np.float64)
     n_steps = runoff.shape[0]
     orderOffset, branchOffset, seg = schedule if schedule is not None else serial_schedule(net)
@@ -102,5 +104,8 @@ def write_case(path, net, runoff, dt, methods, does_basin_route=1, hw_drain_poin
             f.write(g.tobytes())
             f.write(np.ascontiguousarray(da["have"], dtype="<i4").tobytes())
             f.write(np.ascontiguousarray(da["obs"], dtype="<f8").tobytes())      # [nSteps][nGauge] == val(nGauge, nSteps)
+        if solute is not None:
+            f.write(struct.pack("<i", MAGIC_TR))
+            f.write(np.ascontiguousarray(solute, dtype="<f8").tobytes())         # [nSteps][H] == solute(H, nSteps)
 
 

@@ -76,6 +76,11 @@ int orc_set_lake_target(orc_t *o, const int *flags, int jumpstart, int firstStep
    1-based reach of every gauge (< 1 = not in the network), obsHave[step] = there is an observation time at this step,
    obsVal[step][nGauge] (NaN / negative = no value); row 0 belongs to the step with iTime = firstStep + 1.  The caller keeps
    the two arrays alive.  QerrTrend: 1 constant, 2 linear, 3 logistic, 4 exponential decay of the error over qBlendPeriod steps. */
+/* constituent routing (tracer = T): solute[step][H] basin mass flux, row 0 = the step with iTime = firstStep + 1 (the caller
+   keeps it alive); after a step orc_get_solute gives reach_solute_flux and reach_solute_mass(1) of a route slot */
+int orc_set_tracer(orc_t *o, double time_conv_solute, double mass_conv_solute, int firstStep, const double *solute);
+int orc_get_solute(const orc_t *o, int route, double *flux, double *mass);
+const double *orc_basin_solute(const orc_t *o);
 int orc_set_da(orc_t *o, int qBlendPeriod, int QerrTrend, int nGauge, const int *gaugeReach, int firstStep,
                const int *obsHave, const double *obsVal);
 /* history means since the last refresh (histVars_data.f90:154-305): which 0 discharge, 1 inflow, 2 height, 3 floodVolume,

@@ -63,7 +63,7 @@ orc_t *orc_create(int N, int H, const int *downIndex, const int *upOff, const in
 }
 
 void orc_destroy(orc_t *o) {
-  if (o) { free(o->gaugeReach); free(o->Qobs); free(o->Qelapsed); free(o->Qerror); }
+  if (o) { free(o->gaugeReach); free(o->Qobs); free(o->Qelapsed); free(o->Qerror); free(o->BASIN_solute); free(o->BASIN_solute_inst); free(o->solute_future); free(o->sol_mass); free(o->sol_flux); }
   if (!o) return;
   free(o->down); free(o->upOff); free(o->upIdx); free(o->upGood); free(o->nGood);
   free(o->hruOff); free(o->hruIdx); free(o->hruW); free(o->order);
@@ -156,7 +156,87 @@ static void hru_irf(orc_t *o, int r) {
   o->BASIN_QR1[r] = qf[0];
   for (int j = 1; j < n; j++) qf[j - 1] = qf[j];
   qf[n - 1] = 0.0;
+  if (o->tracer) {   /* the same fold for the constituent, basinUH.f90:130-137 */
+    double *sf = o->solute_future + (size_t)r * n;
+    for (int j = 0; j < n; j++) sf[j] = sf[j] + (lake ? (j == 0 ? 1.0 : 0.0) : o->fracFuture[j]) * o->BASIN_solute_inst[r];
+    o->BASIN_solute[r] = sf[0];
+    for (int j = 1; j < n; j++) sf[j - 1] = sf[j];
+    sf[n - 1] = 0.0;
+  }
 }
+
+/* process_remap.f90:425-500 basin2reach_mass */
+static int basin2reach_mass(orc_t *o, const double *basinSolute, double *reachSolute) {
+  for (int r = 0; r < o->N; r++) {
+    if (o->hruOff[r + 1] - o->hruOff[r] > 0) {
+      double acc = 0.0;
+      for (int e = o->hruOff[r]; e < o->hruOff[r + 1]; e++) {
+        const double s = basinSolute[o->hruIdx[e]];
+        if (s < 0.0) { snprintf(o->msg, sizeof o->msg, "basin2reach_mass/Negative solute mass flux: HRU = %d", o->hruIdx[e] + 1); return 20; }
+        acc = acc + o->hruW[e] * s * o->time_conv_solute * o->mass_conv_solute;
+      }
+      reachSolute[r] = acc * o->par[ORC_P_BASAREA][r];
+    }
+  }
+  return 0;
+}
+
+/* tracer.f90:43-207: constituent_rch + comp_mass_flux (the mass-balance check only prints) */
+static void constituent_rch(orc_t *o, int r, int method) {
+  const size_t ix = (size_t)o->idx[method];
+  const int N = o->N;
+  const int nUps = o->nGood[r];
+  int isHW = 1;
+  double Cupstream = 0.0, Clat = 0.0;
+  if (nUps > 0) {
+    isHW = 0;
+    for (int i = 0; i < nUps; i++) {
+      const int e = o->upOff[r] + i;
+      if (!o->upGood[e]) continue;
+      Cupstream = Cupstream + o->sol_flux[ix * N + o->upIdx[e]];
+    }
+    Clat = o->BASIN_solute[r];
+  } else {
+    if (o->hw_drain_point == 1) { Cupstream = Cupstream + o->BASIN_solute[r]; Clat = 0.0; }
+    else if (o->hw_drain_point == 2) Clat = o->BASIN_solute[r];
+  }
+  orc_hyd *h = &HYD(o, method, r);
+  double *mass = o->sol_mass + (ix * N + r) * 2;
+  const double dt = o->dt;
+  mass[0] = mass[1];
+  if (!isHW || o->hw_drain_point == 1) {
+    const double reach_mass = Cupstream * dt + mass[0];
+    const double reach_vol = h->REACH_INFLOW * dt + h->REACH_VOL[0];
+    double solute_per_vol = 0.0;
+    if (reach_vol > 0.0) solute_per_vol = reach_mass / reach_vol;
+    double solute_out = (h->REACH_Q - o->BASIN_QR1[r]) * solute_per_vol;
+    const double max_outMass = mass[1] / dt + Cupstream;
+    if (solute_out > max_outMass) { solute_out = max_outMass; mass[1] = 0; }
+    else mass[1] = mass[1] + (Cupstream - solute_out) * dt;
+    o->sol_flux[ix * N + r] = solute_out + Clat;
+  } else {
+    o->sol_flux[ix * N + r] = Clat;
+    mass[1] = 0.0;
+  }
+}
+
+int orc_set_tracer(orc_t *o, double time_conv_solute, double mass_conv_solute, int firstStep, const double *solute) {
+  o->tracer = 1; o->time_conv_solute = time_conv_solute; o->mass_conv_solute = mass_conv_solute;
+  o->soluteFirst = firstStep; o->solute = solute;
+  if (!o->BASIN_solute) {
+    const size_t N = o->N, R = o->nRoutes > 0 ? o->nRoutes : 1;
+    o->BASIN_solute = (double *)xcalloc(N, sizeof(double)); o->BASIN_solute_inst = (double *)xcalloc(N, sizeof(double));
+    o->solute_future = (double *)xcalloc(N * (o->ntdhBas > 0 ? o->ntdhBas : 1), sizeof(double));
+    o->sol_mass = (double *)xcalloc(R * N * 2, sizeof(double)); o->sol_flux = (double *)xcalloc(R * N, sizeof(double));
+  }
+  return 0;
+}
+int orc_get_solute(const orc_t *o, int route, double *flux, double *mass) {
+  if (!o->tracer || route < 0 || route >= o->nRoutes) return 1;
+  for (int r = 0; r < o->N; r++) { if (flux) flux[r] = o->sol_flux[(size_t)route * o->N + r]; if (mass) mass[r] = o->sol_mass[((size_t)route * o->N + r) * 2 + 1]; }
+  return 0;
+}
+const double *orc_basin_solute(const orc_t *o) { return o->BASIN_solute; }
 
 /* accum_runoff.f90:32-93 */
 int orc_sum_rch(orc_t *o, int r) {
@@ -362,12 +442,23 @@ int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const do
     if (!ierr) ierr = basin2reach(o, precip, o->basinPrecip);
     if (ierr) { free(reachRunoff); return ierr; }
   }
+  double *reachSolute = NULL;
+  if (o->tracer) {   /* main_route.f90:161-172 */
+    reachSolute = (double *)xcalloc(N, sizeof(double));
+    ierr = basin2reach_mass(o, o->solute + (size_t)(o->iTime - 1 - o->soluteFirst) * o->H, reachSolute);
+    if (ierr) { free(reachRunoff); free(reachSolute); return ierr; }
+  }
   if (o->doesBasinRoute == 1) {
-    for (int r = 0; r < N; r++) o->BASIN_QI[r] = reachRunoff[r];
+    for (int r = 0; r < N; r++) {
+      o->BASIN_QI[r] = reachRunoff[r];
+      if (o->tracer) o->BASIN_solute_inst[r] = o->BASIN_QI[r] > 0 ? reachSolute[r] : 0.0;      /* :207-213 */
+    }
     for (int r = 0; r < N; r++) hru_irf(o, r);
   } else {
     for (int r = 0; r < N; r++) { o->BASIN_QR0[r] = o->BASIN_QR1[r]; o->BASIN_QR1[r] = reachRunoff[r]; }
+    if (o->tracer) for (int r = 0; r < N; r++) o->BASIN_solute[r] = o->BASIN_QR1[r] > 0 ? reachSolute[r] : 0.0;   /* :228-236 */
   }
+  free(reachSolute);
   free(reachRunoff);
   o->w_in = o->w_up = o->w_out = o->n_head = o->n_route = o->n_edges = 0;
   for (int ix = 0; ix < o->nRoutes; ix++) {
@@ -377,6 +468,7 @@ int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const do
       if (o->is_lake_sim && o->lakeSlot[r] >= 0 && m != ORC_SUM) {   /* main_route.f90:375-381 */
         ierr = orc_lake_route(o, r, m);
         if (ierr) return ierr;
+        if (o->tracer) constituent_rch(o, r, m);
         continue;
       }
       switch (m) {
@@ -388,6 +480,7 @@ int orc_step_lake(orc_t *o, double T0, double T1, const double *runoff, const do
         case ORC_DW:  ierr = orc_dw_rch(o, r, ORC_DW); break;
       }
       if (ierr) return ierr;
+      if (o->tracer && m != ORC_SUM) constituent_rch(o, r, m);      /* main_route.f90:392-401 */
     }
   }
   orc_hist_aggregate(o, runoff);

@@ -55,6 +55,11 @@ struct orc {
   int qmodOption, qBlendPeriod, QerrTrend, nGauge, obsFirst; int *gaugeReach;   /* [nGauge] 0-based reach, -1 = not in the network */
   const int *obsHave; const double *obsVal;   /* [step], [step][nGauge]: is there an observation time at this step, and the values */
   double *Qobs, *Qerror; int *Qelapsed;       /* [N], [nRoutes][N], [N] */
+  /* constituent routing (tracer = T; main_route.f90:161-172,204-236, basinUH.f90:130-137, tracer.f90:43-207) */
+  int tracer, soluteFirst; double time_conv_solute, mass_conv_solute;
+  const double *solute;                        /* [step][H] basin constituent mass flux */
+  double *BASIN_solute, *BASIN_solute_inst, *solute_future;   /* [N], [N], [N][ntdhBas] */
+  double *sol_mass, *sol_flux;                 /* [nRoutes][N][2] reach_solute_mass(0:1), [nRoutes][N] reach_solute_flux */
   /* KWT traffic statistics of the last step */
   long long w_in, w_up, w_out, n_head, n_route, n_edges;
   /* how often the less common branches of kwt_rch ran since creation (test coverage evidence):

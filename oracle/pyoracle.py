@@ -46,6 +46,8 @@ def lib():
         L.orc_set_lakes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, ip, dp]
         L.orc_set_lake_target.argtypes = [C.c_void_p, ip, C.c_int, C.c_int, dp]
         L.orc_set_da.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, ip, C.c_int, ip, dp]
+        L.orc_set_tracer.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, dp]
+        L.orc_get_solute.argtypes = [C.c_void_p, C.c_int, dp, dp]
         L.orc_hist_get.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
         L.orc_hist_refresh.argtypes = [C.c_void_p]
         L.orc_run_lake.argtypes = [C.c_void_p, C.c_int, C.c_double, dp, C.c_void_p, dp, dp, ip, C.c_void_p, C.c_void_p]
@@ -120,6 +122,27 @@ class Oracle:
         c = lambda a, t: np.ascontiguousarray(a, dtype=t)
         self._da = (c(da["gauge_reach"], np.int32), c(da["have"], np.int32), c(da["obs"], np.float64))     # kept alive
         return lib().orc_set_da(self.h, int(da["blend"]), int(da["trend"]), self._da[0].size, self._da[0], int(first_step), self._da[1], self._da[2])
+
+    def run_tracer(self, runoff, solute, t_start=0.0, time_conv=1.0, mass_conv=1.0):
+        """tracer = T: routes runoff [nSteps, H] with the basin constituent flux solute [nSteps, H]; returns
+        (Q, flux, mass) [nSteps, nRoutes, N] -- REACH_Q, reach_solute_flux, reach_solute_mass(1) after every step."""
+        runoff = np.ascontiguousarray(runoff, dtype=np.float64)
+        self._solute = np.ascontiguousarray(solute, dtype=np.float64)
+        n, R = runoff.shape[0], len(self.methods)
+        if lib().orc_set_tracer(self.h, float(time_conv), float(mass_conv), 0, self._solute):
+            raise RuntimeError("orc_set_tracer")
+        Q, F, M = (np.zeros((n, R, self.N)) for _ in range(3))
+        q1 = np.zeros((1, R, self.N))
+        for it in range(n):
+            rc = lib().orc_run(self.h, 1, float(t_start) + it * self.dt, runoff[it:it + 1], q1.ctypes.data, None)
+            if rc:
+                raise RuntimeError(f"oracle ierr={rc}: {self.error()}")
+            Q[it] = q1[0]
+            for ix in range(R):
+                f, mm = np.zeros(self.N), np.zeros(self.N)
+                lib().orc_get_solute(self.h, ix, f, mm)
+                F[it, ix], M[it, ix] = f, mm
+        return Q, F, M
 
     def set_lakes(self, lakes):
         """lakes: dict as mizuroute_amd.casefile.write_case(lakes=...)."""

@@ -16,7 +16,7 @@ PROGRAM ref_driver
   USE globalData, ONLY: rch_routes, nRoutes, routeMethods, onRoute, &
                         idxSUM, idxIRF, idxKWT, idxKW, idxMC, idxDW, &
                         iTime, TSEC, nMolecule, isColdStart, FRAC_FUTURE, &
-                        time_conv, length_conv, maxtdh, nThreads
+                        time_conv, length_conv, maxtdh, nThreads, time_conv_solute, mass_conv_solute
   USE obs_data,   ONLY: gageObs
   USE model_utils, ONLY: harness_last_err, harness_last_msg
   USE process_param, ONLY: basinUH, make_uh
@@ -32,7 +32,9 @@ PROGRAM ref_driver
 
   integer(i4b), parameter :: MAGIC_IN  = 1297765955   ! 'MZRC' bytes read as little-endian int32
   integer(i4b), parameter :: MAGIC_DA  = 1145133645   ! 'MZAD': gauge-observation section
-  integer(i4b) :: daOn, daMagic, ios, nGauge, daBlend, daTrend
+  integer(i4b), parameter :: MAGIC_TR  = 1381259853   ! 'MZTR': constituent section
+  integer(i4b) :: daOn, daMagic, ios, nGauge, daBlend, daTrend, trOn, utr
+  real(dp), allocatable :: solute(:,:), trflux(:,:), trmass(:,:), trbas(:)
   integer(i4b), parameter :: MAGIC_OUT = 1297765967   ! 'MZRO'
   integer(i4b), parameter :: WCAP = 32                ! padded wave capacity in the state dump
 
@@ -124,21 +126,31 @@ PROGRAM ref_driver
     end if
   end if
   ! optional trailing section: gauge observations for direct insertion (qmodOption = 1)
-  daOn = 0
-  read(uin, iostat=ios) daMagic
-  if (ios == 0 .and. daMagic == MAGIC_DA) then
-    daOn = 1
-    read(uin) nGauge, daBlend, daTrend
-    allocate(gage_obs%link(nGauge), gage_obs%have(nSteps), gage_obs%val(nGauge, nSteps))
-    read(uin) gage_obs%link
-    read(uin) gage_obs%have
-    read(uin) gage_obs%val
-    where (gage_obs%link < 1 .or. gage_obs%link > N) gage_obs%link = integerMissing
-  end if
+  daOn = 0; trOn = 0
+  do      ! trailing sections, each behind its magic
+    read(uin, iostat=ios) daMagic
+    if (ios /= 0) exit
+    if (daMagic == MAGIC_DA) then
+      daOn = 1
+      read(uin) nGauge, daBlend, daTrend
+      allocate(gage_obs%link(nGauge), gage_obs%have(nSteps), gage_obs%val(nGauge, nSteps))
+      read(uin) gage_obs%link
+      read(uin) gage_obs%have
+      read(uin) gage_obs%val
+      where (gage_obs%link < 1 .or. gage_obs%link > N) gage_obs%link = integerMissing
+    else if (daMagic == MAGIC_TR) then      ! constituent: lateral mass flux per HRU and step
+      trOn = 1
+      allocate(solute(H, nSteps))
+      read(uin) solute
+    else
+      exit
+    end if
+  end do
   close(uin)
 
   ! ---- configuration the reference keeps in public_var / globalData (read_control.f90:580-600)
-  is_lake_sim = (isLakeSim == 1); is_flux_wm = (isFluxWm == 1); is_vol_wm = (isVolWm == 1); tracer = .false.
+  is_lake_sim = (isLakeSim == 1); is_flux_wm = (isFluxWm == 1); is_vol_wm = (isVolWm == 1); tracer = (trOn == 1)
+  time_conv_solute = 1._dp; mass_conv_solute = 1._dp
   is_vol_wm_jumpstart = .false.
   if (isVolWm == 1) is_vol_wm_jumpstart = (volJump /= 0)
   qmodOption = 0
@@ -273,6 +285,7 @@ PROGRAM ref_driver
   isColdStart = .true.
   do i = 1, N
     RCHFLX(i)%BASIN_QI = 0._dp; RCHFLX(i)%BASIN_QR(0) = 0._dp; RCHFLX(i)%BASIN_QR(1) = 0._dp
+    RCHFLX(i)%BASIN_solute = 0._dp; RCHFLX(i)%BASIN_solute_inst = 0._dp
     RCHFLX(i)%Qelapsed = 0; RCHFLX(i)%Qobs = 0._dp
     RCHFLX(i)%REACH_WM_FLUX = 0._dp; RCHFLX(i)%REACH_WM_VOL = 0._dp
     RCHFLX(i)%basinEvapo = 0._dp; RCHFLX(i)%basinPrecip = 0._dp
@@ -282,6 +295,7 @@ PROGRAM ref_driver
       RCHFLX(i)%ROUTE(ix)%Qerror = 0._dp;         RCHFLX(i)%ROUTE(ix)%FLOOD_VOL(0:1) = 0._dp
       RCHFLX(i)%ROUTE(ix)%REACH_ELE = 0._dp;      RCHFLX(i)%ROUTE(ix)%REACH_INFLOW = 0._dp
       RCHFLX(i)%ROUTE(ix)%WB = 0._dp;             RCHFLX(i)%ROUTE(ix)%REACH_WM_FLUX_actual = 0._dp
+      RCHFLX(i)%ROUTE(ix)%reach_solute_mass(0:1) = 0._dp; RCHFLX(i)%ROUTE(ix)%reach_solute_flux = 0._dp      ! init_model_data.f90:467-500
     end do
     if (onRoute(impulseResponseFunc)) then
       allocate(RCHFLX(i)%QFUTURE_IRF(size(NETOPO(i)%UH))); RCHFLX(i)%QFUTURE_IRF = 0._dp
@@ -317,7 +331,12 @@ PROGRAM ref_driver
   end do
 
   allocate(ixRch(N)); ixRch = [(i, i=1,N)]
-  allocate(basinRunoff(H), basinSolute(0))
+  if (trOn == 1) then
+    allocate(basinRunoff(H), basinSolute(H), trflux(N, nRoutes), trmass(N, nRoutes), trbas(N))
+    open(newunit=utr, file=trim(fout)//'.tr', access='stream', form='unformatted', status='replace', action='write')
+  else
+    allocate(basinRunoff(H), basinSolute(0))
+  end if
   if (isVolWm == 1) then
     allocate(reachvol(N))
   else
@@ -351,6 +370,7 @@ PROGRAM ref_driver
     TSEC(2) = TSEC(1) + dt
     basinRunoff = runoff(:, it)
     gage_obs%step = it
+    if (trOn == 1) basinSolute = solute(:, it)
     if (isFluxWm == 1) reachflux = wmflux(:, it)
     if (isVolWm == 1) reachvol = wmvol(:, it)
     if (is_lake_sim) then
@@ -382,10 +402,23 @@ PROGRAM ref_driver
           qr1(i) = RCHFLX(i)%BASIN_QR(1)
         end do
         write(uout) it, qout, volout, qr1
+        if (trOn == 1) then      ! constituent fluxes of the step go to a file of their own
+          do ix = 1, nRoutes
+            do i = 1, N
+              trflux(i, ix) = RCHFLX(i)%ROUTE(ix)%reach_solute_flux
+              trmass(i, ix) = RCHFLX(i)%ROUTE(ix)%reach_solute_mass(1)
+            end do
+          end do
+          do i = 1, N
+            trbas(i) = RCHFLX(i)%BASIN_solute
+          end do
+          write(utr) it, trflux, trmass, trbas
+        end if
       end if
     end if
   end do
   write(uout) -1, first_err, first_err_step, wall
+  if (trOn == 1) close(utr)
 
   ! ---- setup products and final state
   write(uout) FRAC_FUTURE

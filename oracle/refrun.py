@@ -156,6 +156,16 @@ def run_case(net, runoff, dt, methods, nthreads=1, keep=None, time_from=0, **kw)
         raise RuntimeError(f"ref_route failed rc={res.returncode}: {res.stdout}\n{res.stderr}")
     out = read_output(outp, methods)
     out["stdout"] = res.stdout
+    if os.path.exists(outp + ".tr"):        # constituent fluxes of every dumped step: flux and mass per method, lateral flux
+        r = _Reader(open(outp + ".tr", "rb").read())
+        N, nr = out["N"], len(methods)
+        fl, ms, bs = [], [], []
+        while r.p < len(r.b):
+            r.i()
+            fl.append(r.d(N * nr).reshape(nr, N)); ms.append(r.d(N * nr).reshape(nr, N)); bs.append(r.d(N))
+        out["SOLFLUX"], out["SOLMASS"], out["BASIN_SOLUTE"] = np.array(fl), np.array(ms), np.array(bs)
+        if keep is None:
+            os.remove(outp + ".tr")
     mt = re.search(r"reach_steps_per_s=\s*([0-9.E+\-]+)", res.stdout)
     out["reach_steps_per_s"] = float(mt.group(1)) if mt else None
     if keep is None:
