@@ -124,6 +124,18 @@ int mzr_set_lake_forcing_dev(mzr_handle h, int nSteps, const double *evap_dev, c
 int mzr_set_lake_target(mzr_handle h, const int *targVol, int jumpstart);
 int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol);
 
+/* Constituent routing (public_var tracer = T; main_route.f90:161-172,204-236,392-401, basinUH.f90:130-137,
+   tracer.f90:43-207): a conservative constituent enters with the runoff as a mass flux per HRU and step
+   (x time_conv_solute x mass_conv_solute x basin area), takes the hillslope delay, and is routed with the water of every
+   active method except the runoff accumulation.  mzr_set_tracer after mzr_init_state (on = 0: off; not in partitioned
+   domains); mzr_set_solute hands over solute[nSteps][nHru] (order of the runoff) before every window; after a window
+   mzr_get_solute gives reach_solute_flux of the last step (which = 0) or reach_solute_mass(1) (which = 1) and
+   mzr_get_window_solute the flux of every step, out[nSteps][nRch]. */
+int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_conv_solute);
+int mzr_set_solute(mzr_handle h, int nSteps, const double *solute);
+int mzr_get_solute(mzr_handle h, int method, int which, double *out);
+int mzr_get_window_solute(mzr_handle h, int method, double *out);
+
 /* Direct insertion of gauge observations (data assimilation; public_var qmodOption = 1 with qBlendPeriod and QerrTrend,
    main_route.f90:125-148, data_assimilation.f90:28-97): after IRF, KW, MC or DW have routed a reach, the error against
    the last observed discharge -- constant (QerrTrend 1), linearly (2), logistically (3) or exponentially (4) decaying

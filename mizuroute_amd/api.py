@@ -52,7 +52,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs",
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
@@ -116,6 +116,10 @@ def load_library():
     L.mzr_get_global_wb.argtypes = [vp, ci, dp]
     L.mzr_set_da.argtypes = [vp, ci, ci, ci, ip]
     L.mzr_set_obs.argtypes = [vp, ci, ip, dp]
+    L.mzr_set_tracer.argtypes = [vp, ci, C.c_double, C.c_double]
+    L.mzr_set_solute.argtypes = [vp, ci, dp]
+    L.mzr_get_solute.argtypes = [vp, ci, ci, dp]
+    L.mzr_get_window_solute.argtypes = [vp, ci, dp]
     L.mzr_set_irf_state.argtypes = [vp, dp]
     L.mzr_set_mol_state.argtypes = [vp, ci, dp]
     L.mzr_set_basin_state.argtypes = [vp, vp, vp]
@@ -248,12 +252,36 @@ class RoutingDomain:
                 self._check(self.L.mzr_set_wm_flux(self.h, w, np.ascontiguousarray(wm_flux[done:done + w], dtype=np.float64)))
             if getattr(self, "da", None) is not None:
                 self.set_obs(self._da_done, w); self._da_done += w
+            tr = getattr(self, "solute", None)
+            if tr is not None:
+                self._check(self.L.mzr_set_solute(self.h, w, np.ascontiguousarray(tr[self._sol_done:self._sol_done + w])))
             self._check(self.L.mzr_run(self.h, w, float(t_start) + done * self.dt, runoff[done:done + w]))
             for ix, m in enumerate(self.methods):
                 buf = np.zeros((w, self.N))
                 self._check(self.L.mzr_get_window_q(self.h, m, buf))
                 out[done:done + w, ix, :] = buf
+            if tr is not None:
+                if self._sol_done == 0 or getattr(self, "solute_flux", None) is None or self.solute_flux.shape[0] != n:
+                    self.solute_flux = np.zeros((n, len(self.methods), self.N))
+                for ix, m in enumerate(self.methods):
+                    if m != SUM:
+                        buf = np.zeros((w, self.N))
+                        self._check(self.L.mzr_get_window_solute(self.h, m, buf))
+                        self.solute_flux[done:done + w, ix, :] = buf
+                self._sol_done += w
             done += w
+        return out
+
+    def set_tracer(self, solute, time_conv=1.0, mass_conv=1.0):
+        """Constituent routing (tracer = T): solute [nSteps, nHru] is the basin mass flux of the steps run() will route from
+        now on (None switches it off); run() then also keeps reach_solute_flux of every step in self.solute_flux
+        [nSteps, nRoutes, nRch] (zeros for the runoff accumulation)."""
+        self.solute, self._sol_done = (None if solute is None else np.ascontiguousarray(solute, dtype=np.float64)), 0
+        self._check(self.L.mzr_set_tracer(self.h, int(solute is not None), float(time_conv), float(mass_conv)))
+
+    def solute_state(self, method, which=0):
+        out = np.zeros(self.N)
+        self._check(self.L.mzr_get_solute(self.h, method, which, out))
         return out
 
     def set_da(self, da):

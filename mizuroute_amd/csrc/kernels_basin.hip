@@ -69,31 +69,32 @@ __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d, int tBegin, int t
 // LDS bandwidth (one LDS serves four SIMDs) nor vector registers
 typedef const double __attribute__((address_space(4))) *mzr_cptr;
 template <bool STATE>
-__device__ __forceinline__ void hillslope_tile(const MzrDev &d, mzr_cptr Fpad, int r, int first, int count, bool active) {
+__device__ __forceinline__ void hillslope_tile(const MzrDev &d, mzr_cptr Fpad, int r, int first, int count, bool active,
+                                               const double *in, double *out, const double *S0, double *S1) {
   const int n = d.ntdhBas, N = d.N, W = d.W;
   if (!active) return;
   const bool lake = d.lakeSlot && d.lakeSlot[r] >= 0;   // lakes: impulse response, basinUH.f90:116-119
   double acc[HT];
 #pragma unroll
-  for (int j = 0; j < HT; ++j) { const int tv = first + j; acc[j] = (j < count && tv < n) ? d.basS0[(size_t)tv * N + r] : 0.0; }
+  for (int j = 0; j < HT; ++j) { const int tv = first + j; acc[j] = (j < count && tv < n) ? S0[(size_t)tv * N + r] : 0.0; }
   const int tauHi = STATE ? W - 1 : first + count - 1;          // newest input any output of the tile sees
   int tauLo = first - n + 1; if (tauLo < 0) tauLo = 0;           // oldest input of output 0
   if (!lake) {
     for (int tau = tauLo; tau <= tauHi; ++tau) {
-      const double q = d.qi[(size_t)tau * N + r];
+      const double q = in[(size_t)tau * N + r];
       mzr_cptr F = Fpad + HT + (first - tau);                    // F[j] = tap of output j (wave-uniform address)
 #pragma unroll
       for (int j = 0; j < HT; ++j) acc[j] = acc[j] + F[j] * q;
     }
   } else if (!STATE) {
 #pragma unroll
-    for (int j = 0; j < HT; ++j) if (j < count) acc[j] = acc[j] + 1.0 * d.qi[(size_t)(first + j) * N + r];
+    for (int j = 0; j < HT; ++j) if (j < count) acc[j] = acc[j] + 1.0 * in[(size_t)(first + j) * N + r];
   }
 #pragma unroll
   for (int j = 0; j < HT; ++j) {
     if (j >= count) continue;
-    if (STATE) d.basS1[(size_t)(first - W + j) * N + r] = acc[j];
-    else d.qlat[(size_t)(first + j + 1) * N + r] = acc[j];
+    if (STATE) S1[(size_t)(first - W + j) * N + r] = acc[j];
+    else out[(size_t)(first + j + 1) * N + r] = acc[j];
   }
 }
 
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d, int tBegin, int
   const bool active = r < d.N && !(d.haloSlot && d.haloSlot[r] >= 0);
   const int t0 = tBegin + blockIdx.y * HT;
   const int count = tEnd - t0 < HT ? tEnd - t0 : HT;
-  hillslope_tile<false>(d, Fpad, r, t0, count, active);
+  hillslope_tile<false>(d, Fpad, r, t0, count, active, d.qi, d.qlat, d.basS0, d.basS1);
 }
 
 // grid: x over reaches, y over tiles of HT register slots: QFUTURE(j+1) after the window
@@ -113,7 +114,51 @@ __global__ void __launch_bounds__(256) k_hillslope_state(MzrDev d) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int j0 = blockIdx.y * HT;
   const int count = d.ntdhBas - j0 < HT ? d.ntdhBas - j0 : HT;
-  hillslope_tile<true>(d, Fpad, r, d.W + j0, count, r < d.N);
+  hillslope_tile<true>(d, Fpad, r, d.W + j0, count, r < d.N, d.qi, d.qlat, d.basS0, d.basS1);
+}
+
+// ---- constituent (tracer): the same two kernels on BASIN_solute_inst / solute_future (basinUH.f90:130-137)
+__global__ void __launch_bounds__(256) k_hillslope_out_solute(MzrDev d, int tBegin, int tEnd) {
+  const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t0 = tBegin + blockIdx.y * HT;
+  const int count = tEnd - t0 < HT ? tEnd - t0 : HT;
+  hillslope_tile<false>(d, Fpad, r, t0, count, r < d.N, d.solInst, d.basSol, d.solS0, d.solS1);
+}
+__global__ void __launch_bounds__(256) k_hillslope_state_solute(MzrDev d) {
+  const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j0 = blockIdx.y * HT;
+  const int count = d.ntdhBas - j0 < HT ? d.ntdhBas - j0 : HT;
+  hillslope_tile<true>(d, Fpad, r, d.W + j0, count, r < d.N, d.solInst, d.basSol, d.solS0, d.solS1);
+}
+// basin2reach_mass (process_remap.f90:425-500) and the gates of main_route.f90:207-213 / :228-236: a reach whose runoff
+// of the step is zero drops its constituent.  grid: x over reaches, y over steps.
+__global__ void __launch_bounds__(256) k_basin2reach_mass(MzrDev d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (r >= d.N) return;
+  const int e0 = d.hruOff[r], e1 = d.hruOff[r + 1];
+  double rs = 0.0;
+  if (e1 > e0) {
+    for (int e = e0; e < e1; ++e) {
+      const double v = d.solSrc[(size_t)t * d.H + d.hruIdx[e]];
+      if (v < 0.0) mzr_raise(d, 20, r, t, 2);
+      rs = rs + d.hruW[e] * v * d.time_conv_solute * d.mass_conv_solute;
+    }
+    rs = rs * d.basarea[r];
+  }
+  if (d.doesBasinRoute == 1) d.solInst[(size_t)t * d.N + r] = d.qi[(size_t)t * d.N + r] > 0 ? rs : 0.0;
+  else d.basSol[(size_t)(t + 1) * d.N + r] = d.qlat[(size_t)(t + 1) * d.N + r] > 0 ? rs : 0.0;
+}
+void mzr_launch_basin_solute(const MzrDev &d, hipStream_t stream) {
+  dim3 block(256), grid((d.N + 255) / 256, d.W);
+  hipLaunchKernelGGL(k_basin2reach_mass, grid, block, 0, stream, d);
+  if (d.doesBasinRoute == 1) {
+    dim3 gridO((d.N + 255) / 256, (d.W + HT - 1) / HT), gridS((d.N + 255) / 256, (d.ntdhBas + HT - 1) / HT);
+    hipLaunchKernelGGL(k_hillslope_out_solute, gridO, block, 0, stream, d, 0, d.W);
+    hipLaunchKernelGGL(k_hillslope_state_solute, gridS, block, 0, stream, d);
+  }
 }
 
 // evaporation / precipitation of the lake reaches through the HRU mapping (main_route.f90:172-200);

@@ -549,6 +549,7 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
           double vol = d.vol[r], vol0 = vol, ele = d.ele[r], wb = 0.0, wmAct = 0.0;
           const double Q = mzr_lake::lake_route(d, r, t, ls, k.Qrow, k.qlat_cur[r], vol, vol0, ele, wb, wmAct, PERS);
           stx<PERS>(k.Qrow + r, Q); d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb;
+          if (d.trVol0) d.trVol0[(size_t)t * N + r] = vol0;      // REACH_VOL(0) of the step, for the constituent pass (zero for river reaches under KWT)
           if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
         }
       }

@@ -265,6 +265,7 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
     if (ls >= 0) {
       double vol = ldx<COH>(d.vol + r), vol0 = vol, ele = ldx<COH>(d.ele + r), wb = 0.0, wmAct = 0.0;
       const double Q = mzr_lake::lake_route(d, r, t, ls, Qrow, qlat, vol, vol0, ele, wb, wmAct, COH);
+      if (d.trVol0) d.trVol0[(size_t)t * N + r] = vol0;
       stx<COH>(Qrow + r, Q); stx<COH>(d.vol + r, vol); stx<COH>(d.vol0 + r, vol0); stx<COH>(d.ele + r, ele); stx<COH>(d.wb + r, wb);
       stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + Q);
       if (d.wmact) stx<COH>(d.wmact + r, wmAct);
@@ -499,6 +500,7 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
   if (d.qmod) Qout = d_direct_insertion<COH>(d, r, t, Qout);      // irf_route.f90:188-198 and alike: after the solver, before anybody reads REACH_Q
   stx<COH>(Qrow + r, Qout);
   stx<COH>(d.vol + r, vol); stx<COH>(d.vol0 + r, vol0);
+  if (d.trVol0) d.trVol0[(size_t)t * N + r] = vol0;      // REACH_VOL(0) of the step, for the constituent pass
   if (!d.qmod) stx<COH>(d.wb + r, d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt));      // the water balance only without data assimilation (:200-202)
   if (d.wmact) stx<COH>(d.wmact + r, wmAct);
   stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + Qout);
@@ -625,6 +627,61 @@ void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin,
     case 5: hipLaunchKernelGGL(k_sweep_route<5>, grid, block, 0, stream, d, sBegin, sEnd); break;
     default: break;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// constituent_rch + comp_mass_flux (tracer.f90:43-207) as a pass of its own over the routed window: it needs, per reach and
+// step, what the solvers left in the window's rows -- REACH_Q, BASIN_QR(1), REACH_VOL(0), and the upstream reaches'
+// constituent flux of the same step -- so it follows a method's sweep in the same skewed order, one launch per stage.
+// REACH_INFLOW is the sum the solver made (good upstream reaches in UREACHI order; plus the lateral flow for a headwater
+// poured in at the top; 0 for a KWT headwater and for lakes, whose solver never sets it).
+__global__ void __launch_bounds__(256) k_tracer_stage(MzrDev d, int method, int s, int rBegin, int rEnd) {
+  const int r = rBegin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rEnd) return;
+  const int t = s - d.sigma[r];
+  if (t < 0 || t >= d.W) return;
+  const int N = d.N;
+  const double dt = d.dt;
+  const double *Qrow = d.Q + (size_t)t * N, *Frow = d.solFlux + (size_t)t * N;
+  const double bsol = d.basSol[(size_t)(t + 1) * N + r], qr1 = d.qlat[(size_t)(t + 1) * N + r];
+  const int ng = d.nGood[r], u0 = d.upStart[r];
+  const uint32_t gm = d.goodMask[r];
+  const bool isHW = ng == 0;
+  const bool lake = d.lakeSlot && d.lakeSlot[r] >= 0;
+  double Cup = 0.0, Clat = 0.0, qin = 0.0;
+  if (!isHW) {
+    for (int i = 0; i < ng; ++i) { if (!((gm >> i) & 1u)) continue; Cup = Cup + Frow[u0 + i]; qin = qin + Qrow[u0 + i]; }
+    Clat = bsol;
+  } else if (d.hw_drain_point == 1) {
+    Cup = Cup + bsol; Clat = 0.0;
+    if (method != 2) qin = qin + qr1;
+  } else {
+    Clat = bsol;
+  }
+  if (lake) qin = 0.0;
+  double mass1 = d.solMass[r];
+  const double mass0 = mass1;
+  double flux;
+  if (!isHW || d.hw_drain_point == 1) {
+    const double reach_mass = Cup * dt + mass0;
+    const double reach_vol = qin * dt + d.trVol0[(size_t)t * N + r];
+    double per_vol = 0.0;
+    if (reach_vol > 0.0) per_vol = reach_mass / reach_vol;
+    double out = (Qrow[r] - qr1) * per_vol;
+    const double maxOut = mass1 / dt + Cup;
+    if (out > maxOut) { out = maxOut; mass1 = 0; }
+    else mass1 = mass1 + (Cup - out) * dt;
+    flux = out + Clat;
+  } else {
+    flux = Clat; mass1 = 0.0;
+  }
+  d.solFlux[(size_t)t * N + r] = flux;
+  d.solMass[r] = mass1;
+}
+void mzr_launch_tracer_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {
+  const int n = rEnd - rBegin;
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_tracer_stage, dim3((n + 255) / 256), dim3(256), 0, stream, d, method, s, rBegin, rEnd);
 }
 
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {

@@ -139,6 +139,15 @@ struct MzrDev {
   const double *imOQ, *imOT;  // [Wmax][MZR_OB_CAP][nHalo]
   int    *exN;                // [Wmax][nExp]
   double *exOQ, *exOT;        // [Wmax][MZR_OB_CAP][nExp]
+  // ---- constituent routing (tracer = T; main_route.f90:161-172,204-236,392-401, basinUH.f90:130-137, tracer.f90:43-207); null = off
+  const double *solSrc;       // [W][H] basin constituent mass flux of the window
+  double *solInst;            // [W][N] BASIN_solute_inst (hillslope routing on)
+  double *basSol;             // [W+1][N] BASIN_solute, row t+1 = step t (as qlat)
+  const double *solS0; double *solS1;   // [ntdhBas][N] solute_future before / after the window
+  double *solFlux;            // [W][N] reach_solute_flux of the method being launched
+  double *solMass;            // [N] reach_solute_mass(1)
+  double *trVol0;             // [W][N] REACH_VOL(0) of every step (the solvers write it while routing); null = tracer off
+  double time_conv_solute, mass_conv_solute;
   // ---- direct insertion of gauge observations (qmodOption = 1; main_route.f90:125-148, data_assimilation.f90:28-97); qmod = 0: off
   int qmod, qBlendPeriod, QerrTrend, nGauge;
   const int *gaugeFirst;      // [N] first gauge of the reach or -1

@@ -27,6 +27,8 @@
 void mzr_launch_basin(const MzrDev &d, hipStream_t stream);
 void mzr_launch_basin_chunk(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
 void mzr_launch_basin_state(const MzrDev &d, hipStream_t stream);
+void mzr_launch_basin_solute(const MzrDev &d, hipStream_t stream);
+void mzr_launch_tracer_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
 int mzr_sweep_route_capacity(int method);
 void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream);
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
@@ -69,6 +71,7 @@ struct RouteBufs {
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
   DBuf<int> rtDone, rtHead;                         // persistent sweep of an Eulerian method: progress per reach, ticket counters
+  DBuf<double> solFlux, solMass, trVol0;            // constituent routing (mzr_set_tracer): [maxWindow][N], [N], [maxWindow][N]
   DBuf<double> qobs, qerr; DBuf<int> qelapsed;      // [N] direct insertion (mzr_set_da): RCHFLX%Qobs, ROUTE%Qerror, RCHFLX%Qelapsed
   int rtCap = 0;                                    // wavefronts the device holds of this method's sweep kernel
   long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
@@ -198,6 +201,8 @@ struct mzr_domain {
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
   DBuf<int> rtItemR, rtItemInfo, rtRA, rtP;        // items of the Eulerian sweeps (k_sweep_route) and their per-launch tables
+  int tracer = 0, solSteps = 0, solCur = 0; double time_conv_solute = 1.0, mass_conv_solute = 1.0;      // constituent routing (mzr_set_tracer / mzr_set_solute)
+  DBuf<double> solSrc, solInst, basSol, solS[2]; hipEvent_t trEvent = nullptr;
   int qmod = 0, qBlendPeriod = 10, QerrTrend = 1, nGauge = 0, obsSteps = 0;      // direct insertion of gauge observations (mzr_set_da / mzr_set_obs)
   DBuf<int> gaugeFirst, gaugeNext, obsHave; DBuf<double> obsVal;
   std::vector<int> h_rtStage; int rtItems = 0, rtTablesW = -1, rtMaxAct = 0;
@@ -285,6 +290,8 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.haloSlot = h->nHalo ? h->haloSlot.p : nullptr; d.exportSlot = h->nExp ? h->exportSlot.p : nullptr;
   d.nHalo = h->nHalo; d.nExp = h->nExp; d.Wmax = h->cfg.maxWindow;
   d.imN = h->imN.p; d.imOQ = h->imOQ.p; d.imOT = h->imOT.p;
+  d.solSrc = h->solSrc.p; d.solInst = h->solInst.p; d.basSol = h->basSol.p; d.solS0 = h->solS[h->solCur].p; d.solS1 = h->solS[h->solCur ^ 1].p;
+  d.solFlux = nullptr; d.solMass = nullptr; d.trVol0 = nullptr; d.time_conv_solute = h->time_conv_solute; d.mass_conv_solute = h->mass_conv_solute;
   d.qmod = h->qmod; d.qBlendPeriod = h->qBlendPeriod; d.QerrTrend = h->QerrTrend; d.nGauge = h->nGauge;
   d.gaugeFirst = h->gaugeFirst.p; d.gaugeNext = h->gaugeNext.p; d.obsHave = h->obsHave.p; d.obsVal = h->obsVal.p;
   d.qobs = nullptr; d.qerr = nullptr; d.qelapsed = nullptr;
@@ -300,6 +307,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
   d.rtDone = rb.rtDone.p; d.rtHead = rb.rtHead.p;
   d.qobs = rb.qobs.p; d.qerr = rb.qerr.p; d.qelapsed = rb.qelapsed.p;
+  d.solFlux = rb.solFlux.p; d.solMass = rb.solMass.p; d.trVol0 = h->tracer ? rb.trVol0.p : nullptr;
 }
 
 int checkDeviceError(mzr_handle h) {
@@ -754,6 +762,76 @@ int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol) {
   return 0;
 }
 
+static int pullRow(mzr_handle h, const double *src, double *out);
+// Constituent routing (public_var tracer = T): a conservative constituent enters with the runoff (mass flux per HRU and
+// step), takes the hillslope delay and is routed reach by reach with the water of every active method except the runoff
+// accumulation (main_route.f90:161-172,204-236,392-401, basinUH.f90:130-137, tracer.f90:43-207).  Call after
+// mzr_init_state; on = 0 switches it off.  Costs three more window buffers per method and a second pass over the window.
+int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_conv_solute) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_tracer/state not initialised (call mzr_init_state)") : 1;
+  if (on && (h->nHalo || h->nExp)) return fail(h, 20, "mzr_set_tracer/not available in a partitioned domain");
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);
+  h->tracer = on ? 1 : 0; h->time_conv_solute = time_conv_solute; h->mass_conv_solute = mass_conv_solute; h->solSteps = 0; h->solCur = 0;
+  if (!h->tracer) return 0;
+  const size_t N = h->N, W = h->cfg.maxWindow;
+  try {
+    h->solSrc.alloc(W * h->H); h->basSol.alloc((W + 1) * N); h->basSol.zero();
+    if (h->cfg.doesBasinRoute == 1) {
+      h->solInst.alloc(W * N);
+      h->solS[0].alloc((size_t)h->ntdhBas * N); h->solS[1].alloc((size_t)h->ntdhBas * N); h->solS[0].zero(); h->solS[1].zero();
+    }
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      if (rb.method == MZR_SUM) continue;
+      rb.solFlux.alloc(W * N); rb.solFlux.zero(); rb.solMass.alloc(N); rb.solMass.zero(); rb.trVol0.alloc(W * N); rb.trVol0.zero();
+    }
+    if (!h->trEvent) (void)hipEventCreateWithFlags(&h->trEvent, hipEventDisableTiming);
+  } catch (const std::string &e) { return fail(h, 91, "mzr_set_tracer/" + e); }
+  return 0;
+}
+
+// basin constituent mass flux of the next window, solute[nSteps][nHru] in the order of the runoff
+int mzr_set_solute(mzr_handle h, int nSteps, const double *solute) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_solute/state not initialised") : 1;
+  if (!h->tracer) return fail(h, 20, "mzr_set_solute/constituent routing is off (mzr_set_tracer)");
+  if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_solute/nSteps exceeds maxWindow");
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);
+  MZR_COPY(h->solSrc.p, solute, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, "mzr_set_solute");
+  h->solSteps = nSteps;
+  return 0;
+}
+
+// which = 0: reach_solute_flux of the last routed step, 1: reach_solute_mass(1) (caller's reach order)
+int mzr_get_solute(mzr_handle h, int method, int which, double *out) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_solute/state not initialised") : 1;
+  if (!h->tracer) return fail(h, 20, "mzr_get_solute/constituent routing is off");
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0 || method == MZR_SUM) return fail(h, 81, "mzr_get_solute/method not active (or the runoff accumulation)");
+  if (h->lastW < 1) return fail(h, 20, "mzr_get_solute/no step has been routed");
+  RouteBufs &rb = h->route[ix];
+  return pullRow(h, which == 0 ? rb.solFlux.p + (size_t)(h->lastW - 1) * h->N : rb.solMass.p, out);
+}
+
+// reach_solute_flux of every step of the last window, out[nSteps][nRch]
+int mzr_get_window_solute(mzr_handle h, int method, double *out) {
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_window_solute/state not initialised") : 1;
+  if (!h->tracer) return fail(h, 20, "mzr_get_window_solute/constituent routing is off");
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int ix = idxOf(h, method);
+  if (ix < 0 || method == MZR_SUM) return fail(h, 81, "mzr_get_window_solute/method not active (or the runoff accumulation)");
+  const int N = h->N, W = h->lastW;
+  if (W < 1) return fail(h, 20, "mzr_get_window_solute/no window has been run");
+  dim3 block(256), grid((N + 255) / 256, W);
+  hipLaunchKernelGGL(k_gather_rows, grid, block, 0, h->stream, h->route[ix].solFlux.p, h->scratchOut.p, h->d_ext2int.p, N, W);
+  if (hipMemcpyAsync(out, h->scratchOut.p, (size_t)W * N * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
+    return fail(h, 92, "mzr_get_window_solute/hipMemcpy failed");
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, 92, "mzr_get_window_solute/sync failed");
+  return 0;
+}
+
 // Direct insertion of gauge observations (public_var qmodOption = 1, qBlendPeriod, QerrTrend; main_route.f90:125-148,
 // data_assimilation.f90:28-97) for IRF, KW, MC and DW (the reference's KWT and lake solvers do not call it).
 // gaugeReach: 1-based reach (caller's order) of every gauge, < 1 = the gauge is not in this network.  Resets Qobs,
@@ -1087,6 +1165,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   if (h->cfg.is_flux_wm && h->wmSteps < W) return fail(h, 20, "mzr_run/is_flux_wm is on: call mzr_set_wm_flux for this window first");
   if (h->qmod && h->obsSteps < W) return fail(h, 20, "mzr_run/direct insertion is on: call mzr_set_obs for this window first");
+  if (h->tracer && h->solSteps < W) return fail(h, 20, "mzr_run/constituent routing is on: call mzr_set_solute for this window first");
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   if (h->anyLakeTarget && h->wmVolSteps < W) return fail(h, 20, "mzr_run/target-volume lakes are on: call mzr_set_wm_vol for this window first");
   (void)hipSetDevice(h->cfg.device);
@@ -1239,6 +1318,28 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       ++rb.nLaunches;
     }
   }
+  if (h->tracer) {
+    // constituent: lateral mass flux and its hillslope delay for the whole window (after the water's), then, behind every
+    // method's routing, the constituent pass over the same skewed schedule
+    if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);
+    if (h->lastW > 0 && h->basSol.p)
+      hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->basSol.p, h->lastW, N, (const int *)nullptr);
+    MzrDev dt2 = d;
+    dt2.solS0 = h->solS[h->solCur].p; dt2.solS1 = h->solS[h->solCur ^ 1].p;
+    mzr_launch_basin_solute(dt2, st);
+    if (h->cfg.doesBasinRoute == 1) h->solCur ^= 1;
+    (void)hipEventRecord(h->trEvent, st);
+    for (int ix = 0; ix < nR; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      if (rb.method == MZR_SUM) continue;
+      hipStream_t sx = rst[ix];
+      if (sx != st) (void)hipStreamWaitEvent(sx, h->trEvent, 0);
+      for (int s = 0; s < nS + W - 1; ++s) {
+        const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
+        mzr_launch_tracer_stage(rb.method, dr[ix], s, h->stageStart[sLo], h->stageStart[sHi + 1], sx);
+      }
+    }
+  }
   for (int ix = 0; ix < nR; ++ix) {
     if (h->route[ix].method == MZR_KWT) mzr_launch_accum_qsum(h->route[ix].Q.p, h->route[ix].qsum.p, N, W, rst[ix]);
     h->route[ix].reachSteps += (long long)N * W;
@@ -1253,7 +1354,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     mzr_launch_accum_qsum(runoff_dev, h->hBas.p, h->H, W, st);
     h->histSteps += W;
   }
-  h->lastW = W; h->stepsDone += W; h->obsSteps = 0; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
+  h->lastW = W; h->stepsDone += W; h->obsSteps = 0; h->solSteps = 0; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
   if (hipGetLastError() != hipSuccess) return fail(h, 92, "mzr_run/kernel launch failed");
   return 0;
 }

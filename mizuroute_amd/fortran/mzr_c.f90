@@ -39,7 +39,8 @@ MODULE mzr_c
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
-            mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs
+            mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs, &
+            mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute
   public :: mzr_message
 
   INTERFACE
@@ -125,6 +126,30 @@ MODULE mzr_c
       import :: c_ptr, c_int, c_double
       type(c_ptr), value :: h
       integer(c_int), value :: method, reset
+      real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_set_tracer(h, on, time_conv_solute, mass_conv_solute) bind(C, name='mzr_set_tracer')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: on
+      real(c_double), value :: time_conv_solute, mass_conv_solute
+    end function
+    integer(c_int) function mzr_set_solute(h, nSteps, solute) bind(C, name='mzr_set_solute')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), intent(in) :: solute(*)
+    end function
+    integer(c_int) function mzr_get_solute(h, method, which, out) bind(C, name='mzr_get_solute')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method, which
+      real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_get_window_solute(h, method, out) bind(C, name='mzr_get_window_solute')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method
       real(c_double), intent(out) :: out(*)
     end function
     integer(c_int) function mzr_set_da(h, qBlendPeriod, QerrTrend, nGauge, gaugeReach) bind(C, name='mzr_set_da')

@@ -510,6 +510,41 @@ def test_direct_insertion_vs_oracle(trend, hip_lib, oracle_lib, monkeypatch):
     dom.close()
 
 
+@pytest.mark.parametrize("hw_drain,basin_route,window", [(2, 1, 9), (1, 1, 64), (2, 0, 1)])
+def test_tracer_vs_oracle(hw_drain, basin_route, window, hip_lib, oracle_lib):
+    """tracer = T: the constituent through the HRU mapping, the hillslope delay and every routing method, KWT included
+    (main_route.f90:161-172,204-236,392-401, tracer.f90:43-207), windows that cut the series anywhere: flux of every step
+    and the mass left in every reach against the oracle (bit-identical to the reference harness, tests/test_oracle_vs_ref.py)."""
+    from mizuroute_amd import uh as uhmod
+    net = m.make_network(2500, seed=61)
+    dt, steps = 3600.0, 50
+    ro = m.make_runoff(net.H, steps, seed=62, storm_prob=0.05, storm_amp=3e-6)
+    rng = np.random.default_rng(63)
+    sol = rng.uniform(0.0, 2e-3, (steps, net.H)) * (rng.random((steps, net.H)) < 0.7)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    methods = [m.SUM, m.IRF, m.KWT, m.KW, m.MC, m.DW]
+    orc = oracle_lib.Oracle(net, dt, methods, ff, uh_off, uhv, does_basin_route=basin_route, hw_drain_point=hw_drain)
+    Qo, Fo, Mo = orc.run_tracer(ro, sol)
+    dom = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=window,
+                          does_basin_route=basin_route, hw_drain_point=hw_drain)
+    dom.set_tracer(sol)
+    Q = dom.run(ro)
+    F = dom.solute_flux
+    assert (F[:, 0] == 0).all() and F[:, 1:].max() > 0
+    for ix, meth in enumerate(methods):
+        repq, repf = parity_report(Qo[:, ix], Q[:, ix]), parity_report(Fo[:, ix], F[:, ix], floor=1e-12)
+        print("tracer", hw_drain, basin_route, "method", meth, repq, repf)
+        assert repq["max_rel"] <= REL_TOL and repf["max_rel"] <= REL_TOL, (meth, repq, repf)
+        if meth != m.SUM:
+            mass = dom.solute_state(meth, 1)
+            assert np.allclose(mass, Mo[-1, ix], rtol=REL_TOL, atol=1e-9), meth
+    with pytest.raises(m.api.MzrError):          # on, but no constituent handed over for the window
+        dom.solute = None
+        dom.run(ro[:window])
+    dom.close()
+
+
 def test_global_water_balance(hip_lib):
     """comp_global_wb (water_balance.f90:191-323) of the last step: the seven sums restated from the per-reach fields, and
     the global error equal to the sum of the per-reach errors (comp_reach_wb, :22-112) -- inside the domain every
