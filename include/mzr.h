@@ -130,7 +130,8 @@ int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol);
    active method except the runoff accumulation.  mzr_set_tracer after mzr_init_state (on = 0: off; not in partitioned
    domains); mzr_set_solute hands over solute[nSteps][nHru] (order of the runoff) before every window; after a window
    mzr_get_solute gives reach_solute_flux of the last step (which = 0) or reach_solute_mass(1) (which = 1) and
-   mzr_get_window_solute the flux of every step, out[nSteps][nRch]. */
+   mzr_get_window_solute the flux of every step, out[nSteps][nRch] (method < 0: BASIN_solute, the lateral mass flux into
+   the reaches after the hillslope delay). */
 int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_conv_solute);
 int mzr_set_solute(mzr_handle h, int nSteps, const double *solute);
 int mzr_get_solute(mzr_handle h, int method, int which, double *out);

@@ -820,12 +820,13 @@ int mzr_get_window_solute(mzr_handle h, int method, double *out) {
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_window_solute/state not initialised") : 1;
   if (!h->tracer) return fail(h, 20, "mzr_get_window_solute/constituent routing is off");
   int rc = mzr_sync(h); if (rc) return rc;
-  const int ix = idxOf(h, method);
-  if (ix < 0 || method == MZR_SUM) return fail(h, 81, "mzr_get_window_solute/method not active (or the runoff accumulation)");
+  const int ix = method < 0 ? -1 : idxOf(h, method);
+  if (method >= 0 && (ix < 0 || method == MZR_SUM)) return fail(h, 81, "mzr_get_window_solute/method not active (or the runoff accumulation)");
   const int N = h->N, W = h->lastW;
   if (W < 1) return fail(h, 20, "mzr_get_window_solute/no window has been run");
   dim3 block(256), grid((N + 255) / 256, W);
-  hipLaunchKernelGGL(k_gather_rows, grid, block, 0, h->stream, h->route[ix].solFlux.p, h->scratchOut.p, h->d_ext2int.p, N, W);
+  const double *src = method < 0 ? h->basSol.p + N : h->route[ix].solFlux.p;      // method < 0: BASIN_solute (rows 1..W)
+  hipLaunchKernelGGL(k_gather_rows, grid, block, 0, h->stream, src, h->scratchOut.p, h->d_ext2int.p, N, W);
   if (hipMemcpyAsync(out, h->scratchOut.p, (size_t)W * N * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
     return fail(h, 92, "mzr_get_window_solute/hipMemcpy failed");
   if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, 92, "mzr_get_window_solute/sync failed");

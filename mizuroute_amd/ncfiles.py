@@ -174,9 +174,11 @@ class HistoryWriter:
     (historyFile.f90:349-373, histVars_data.f90:179-183)."""
 
     def __init__(self, path, reach_id, methods, time_units="seconds since 1970-01-01 00:00:00", calendar="standard", volumes=False,
-                 inflow=False, height=False, runoff=False, hru_id=None):
+                 inflow=False, height=False, runoff=False, hru_id=None, solute=False):
         """volumes: <M>volume (last value); inflow: <M>inflow (outputInflow); height: <M>height and <M>floodVolume (floodplain);
-        runoff: instRunoff, dlayRunoff and basRunoff(hru) -- the last three need the domain built with history=H_* flags."""
+        runoff: instRunoff, dlayRunoff and basRunoff(hru) -- the last three need the domain built with history=H_* flags;
+        solute: localSolute, and per method soluteFlux (interval mean) / soluteMass (last value) -- the reference writes the
+        diffusive wave's under these names (popMetadat.f90:266-268), the other methods' get the method's prefix."""
         self.f = netcdf_file(path, "w", version=2)
         self.f.createDimension("time", None)
         self.f.createDimension("seg", len(reach_id))
@@ -208,6 +210,24 @@ class HistoryWriter:
                 self.vars[(m, api.M_HEIGHT)] = w
                 w = self.f.createVariable(HIST_FLOOD[m], "f", ("time", "seg")); w.units = "m3"
                 self.vars[(m, api.M_FLOODVOL)] = w
+
+        self.solute = solute
+        if solute:
+            v = self.f.createVariable("localSolute", "f", ("time", "seg")); v.units = "mg/s"
+            for m in self.methods:
+                if m == api.SUM:
+                    continue
+                pre = "" if m == api.DW else HIST_Q[m].replace("routedRunoff", "")
+                v = self.f.createVariable(pre + "soluteFlux", "f", ("time", "seg")); v.units = "mg/s"
+                v = self.f.createVariable(pre + "soluteMass", "f", ("time", "seg")); v.units = "mg"
+
+    def append_solute(self, local_mean, flux_mean, mass):
+        """constituent of the record append() writes next: local_mean [seg], flux_mean / mass {method: [seg]}"""
+        self.f.variables["localSolute"][self.n, :] = np.asarray(local_mean, np.float32)
+        for m in flux_mean:
+            pre = "" if m == api.DW else HIST_Q[m].replace("routedRunoff", "")
+            self.f.variables[pre + "soluteFlux"][self.n, :] = np.asarray(flux_mean[m], np.float32)
+            self.f.variables[pre + "soluteMass"][self.n, :] = np.asarray(mass[m], np.float32)
 
     def append(self, t_begin, t_end, dom, stamp_offset=0.0):
         """Write the means accumulated on the device over [t_begin, t_end] and reset them (histVars finalize / refresh)."""

@@ -24,6 +24,8 @@ Scope (what a run of the reference's SAMPLE.control needs, nothing more):
     `<is_vol_wm>`, `<is_vol_wm_jumpstart>`): `<fname_wm>` file(s) on their own step `<dt_wm>`, fluxes and target volumes
     sorted onto the reaches by `<vname_segid_wm>` (get_basin_runoff.f90:106-109, 207-250);
   * river network subset mode (`<seg_outlet>` > 0): the part of the network upstream of a segment written to `<fname_ntopNew>`;
+  * constituent routing (`<tracer> T`): `<vname_solute>` beside the runoff, `<units_cc>` mass / time, through the runoff's mapping;
+    history variables `localSolute`, `soluteFlux`, `soluteMass` (popMetadat.f90:266-268; other methods than DW with their prefix);
   * history file(s) `<case_name>.h.<start>.nc` at `<outputFrequency>` (a multiple of the step or
     `daily`), one file per run (`<newFileFrequency> single`), restart in / out (`<fname_state_in>`,
     `<restart_write> last`).
@@ -343,10 +345,18 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, nml["velo"], nml["diff"])
     W = max(1, min(window, n_steps))
     # options of the reference this driver does not implement stop the run instead of being ignored (read_control.f90)
-    for key in ("tracer", "qmodOption"):
-        v = str(ctl.get(key, "F")).strip()
-        if _truth(v) or (key == "qmodOption" and v not in ("F", "0", "")):
-            raise NotImplementedError(f"<{key}> = {v}: not supported by mizuroute_amd.standalone")
+    v = str(ctl.get("qmodOption", "0")).strip()
+    if v not in ("F", "0", ""):
+        raise NotImplementedError(f"<qmodOption> = {v}: gauge files are not read by mizuroute_amd.standalone (direct insertion is available through "
+                                  "mizuroute_amd.api.RoutingDomain.set_da)")
+    tracer = _truth(ctl.get("tracer", "F"))
+    if tracer:      # units of the constituent flux, read_control.f90:476-506
+        cc = ctl.get("units_cc", "mg/s")
+        if "/" not in cc:
+            raise ValueError(f'expect the character "/" exists in the mass flux units string [units={cc}]')
+        c_mass, c_time = [u.strip() for u in cc.split("/", 1)]
+        mass_conv = {"mg": 1.0, "g": 1000.0, "kg": 1000000.0}[c_mass]
+        time_conv_sol = {"d": 1.0 / 86400.0, "day": 1.0 / 86400.0, "h": 1.0 / 3600.0, "hr": 1.0 / 3600.0, "hour": 1.0 / 3600.0, "s": 1.0, "sec": 1.0, "second": 1.0}[c_time]
     is_lake, is_flux_wm = _truth(ctl.get("is_lake_sim", "F")), _truth(ctl.get("is_flux_wm", "F"))
     is_vol_wm = _truth(ctl.get("is_vol_wm", "F")) and is_lake
     lakes = read_lakes(ctl, net, n_steps) if is_lake else None
@@ -358,6 +368,10 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
                             does_basin_route=int(ctl.get("doesBasinRoute", 1)), hw_drain_point=int(ctl.get("hw_drain_point", 2)),
                             min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc, history=hflags,
                             lakes=lakes, is_flux_wm=int(is_flux_wm))
+    if tracer:
+        dom._check(dom.L.mzr_set_tracer(dom.h, 1, time_conv_sol, mass_conv))
+        sol_sum = {mm: np.zeros(net.N) for mm in methods if mm != api.SUM}
+        sol_local = np.zeros(net.N)
     # ---- forcing: concatenate the files' time axes, find the record of every simulation step
     t0 = (t_beg - epoch).total_seconds()
     fro = ForcingSeries(_forcing_files(ctl), ctl["vname_time"], dt_ro, t0)
@@ -430,7 +444,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     def hist_open(t):
         return ncfiles.HistoryWriter(hist_name(t), net.reachId, methods, time_units=f"seconds since {t_beg:%Y-%m-%d %H:%M:%S}",
                                      volumes=any(_truth(ctl.get(k, "F")) for k in ncfiles.HIST_VOL.values()), inflow=want_inflow, height=want_height,
-                                     runoff=want_runoff, hru_id=hru_id)
+                                     runoff=want_runoff, hru_id=hru_id, solute=tracer)
 
     hfiles = [hist_name(t_beg)]
     hname = hfiles[0]
@@ -468,9 +482,21 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
             dom.set_lake_forcing(0, w, flux_dev["evap"].data_ptr(), flux_dev["precip"].data_ptr())
         if is_flux_wm:
             dom.set_wm_flux(w, np.stack([sort_flux(wm_ix, fwm.step(ctl["vname_flux_wm"], dt, done + k + 1), net.N, False) for k in range(w)]))
+        if tracer:      # the constituent takes the runoff's path from the file to the river-network HRUs (get_basin_runoff.f90:111-134)
+            a = np.stack([fro.step(ctl.get("vname_solute", "solute"), dt, done + k + 1) for k in range(w)])
+            srcs = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            dsts = torch.empty((w, net.H), dtype=torch.float64, device=dev)
+            dom.remap_device(w, srcs.data_ptr(), dsts.data_ptr())
+            dom.sync()
+            dom._check(dom.L.mzr_set_solute(dom.h, w, np.ascontiguousarray(dsts.cpu().numpy())))
         src = torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(dev)
         dom.run_source_device(w, t_first + done * dt, src.data_ptr())
         dom.sync()
+        if tracer:      # interval sums of the constituent fluxes (the history file holds their means)
+            buf = np.zeros((w, net.N))
+            dom._check(dom.L.mzr_get_window_solute(dom.h, -1, buf)); sol_local += buf.sum(axis=0)
+            for mm in sol_sum:
+                dom._check(dom.L.mzr_get_window_solute(dom.h, mm, buf)); sol_sum[mm] += buf.sum(axis=0)
         done += w
         if done % every == 0:      # time = start of the aggregated interval (+ <histTimeStamp_offset>), historyFile.f90:367
             t_rec = t_beg + _dt.timedelta(seconds=(done - every) * dt)
@@ -478,6 +504,11 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
                 hist.close()
                 hist, hist_period = hist_open(t_rec), period(t_rec)
                 hfiles.append(hist_name(t_rec))
+            if tracer:
+                hist.append_solute(sol_local / every, {mm: v / every for mm, v in sol_sum.items()}, {mm: dom.solute_state(mm, 1) for mm in sol_sum})
+                sol_local[:] = 0.0
+                for v in sol_sum.values():
+                    v[:] = 0.0
             hist.append((done - every) * dt, done * dt, dom, stamp_offset=float(ctl.get("histTimeStamp_offset", 0.0)))
     hist.close()
     out = dict(history=hname, history_files=hfiles, steps=n_steps, reaches=net.N)

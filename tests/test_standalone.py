@@ -11,7 +11,7 @@ import mizuroute_amd as m
 from mizuroute_amd import standalone
 
 
-def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None, new_file="single", extra="", lakes=None, wm=None):
+def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=None, new_file="single", extra="", lakes=None, wm=None, solute=None):
     """Topology, forcing (HM HRUs = RN HRUs in shuffled order), control file and namelist of a synthetic case."""
     rng = np.random.default_rng(shuffle_seed)
     N = net.N
@@ -48,9 +48,13 @@ def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=N
     q = g.createVariable("RUNOFF", "d", ("time", "hru"))
     if lakes is not None:
         ev = g.createVariable("evap", "d", ("time", "hru")); pr = g.createVariable("precip", "d", ("time", "hru"))
+    if solute is not None:
+        so = g.createVariable("solute", "d", ("time", "hru"))
     for k in range(steps):
         t[k] = k * dt / 3600.0
         q[k, :] = runoff_mm_s[k, perm]
+        if solute is not None:
+            so[k, :] = solute[k, perm]
         if lakes is not None:
             ev[k, :] = lakes["evap"][k, perm] * 1000.0; pr[k, :] = lakes["precip"][k, perm] * 1000.0      # mm/s like the runoff
     g.close()
@@ -390,3 +394,32 @@ def test_river_network_subset_mode(tmp_path):
     assert np.array_equal(sub.params["BASAREA"], net.params["BASAREA"][full])
     assert np.array_equal(sub.params["TOTAREA"], net.params["TOTAREA"][full])      # everything upstream came along
     assert np.array_equal(np.diff(sub.upOffset), np.diff(net.upOffset)[full])
+
+
+@pytest.mark.gpu
+def test_run_from_files_with_a_constituent(tmp_path, hip_lib):
+    """<tracer> T: the constituent flux beside the runoff, g/hour units (read_control.f90:476-506), the history variables
+    localSolute / soluteFlux / soluteMass against the same run through the API."""
+    from mizuroute_amd import uh as uhmod
+    net = m.make_network(1000, seed=51)
+    dt, steps = 3600.0, 36
+    ro = m.make_runoff(net.H, steps, seed=52, storm_prob=0.05, storm_amp=3e-6)
+    rng = np.random.default_rng(53)
+    sol = rng.uniform(0.0, 5.0, (steps, net.H))                                  # g/hour/m2 in the file
+    path = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="51", solute=sol,
+                      extra="<tracer> T\n<vname_solute> solute\n<units_cc> g/hour\n")
+    out = standalone.run(path, window=7, log=lambda *_: None)
+    ctl = standalone.read_control(path)
+    net_f, _ = standalone.build_network(ctl, standalone.read_param_nml(os.path.join(str(tmp_path), "param.nml")))
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    dom = m.RoutingDomain(net_f, dt, [m.DW, m.IRF], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=12)
+    dom.set_tracer(sol, time_conv=1.0 / 3600.0, mass_conv=1000.0)
+    dom.run(ro)
+    F = dom.solute_flux.reshape(steps // 6, 6, 2, net.N).sum(axis=1) / 6.0
+    f = netcdf_file(out["history"], "r", mmap=False)
+    assert np.allclose(f.variables["soluteFlux"][:], F[:, 0], rtol=5e-6, atol=1e-9)           # the diffusive wave's, under the reference's name
+    assert np.allclose(f.variables["IRFsoluteFlux"][:], F[:, 1], rtol=5e-6, atol=1e-9)
+    assert np.allclose(f.variables["soluteMass"][:][-1], dom.solute_state(m.DW, 1), rtol=5e-6, atol=1e-6)
+    assert f.variables["localSolute"][:].max() > 0 and F.max() > 0
+    f.close()
