@@ -26,6 +26,7 @@ Scope (what a run of the reference's SAMPLE.control needs, nothing more):
   * river network subset mode (`<seg_outlet>` > 0): the part of the network upstream of a segment written to `<fname_ntopNew>`;
   * constituent routing (`<tracer> T`): `<vname_solute>` beside the runoff, `<units_cc>` mass / time, through the runoff's mapping;
     history variables `localSolute`, `soluteFlux`, `soluteMass` (popMetadat.f90:266-268; other methods than DW with their prefix);
+  * direct insertion of gauge observations (`<qmodOption> 1`, `<qBlendPeriod>`, `<QerrTrend>`): `<gageMetaFile>` + `<fname_gageObs>`;
   * history file(s) `<case_name>.h.<start>.nc` at `<outputFrequency>` (a multiple of the step or
     `daily`), one file per run (`<newFileFrequency> single`), restart in / out (`<fname_state_in>`,
     `<restart_write> last`).
@@ -328,6 +329,38 @@ def read_lakes(ctl: dict, net, n_steps: int) -> dict:
     return out
 
 
+def read_gauges(ctl: dict, net, t_beg, dt: float, n_steps: int) -> dict:
+    """Gauge observations for direct insertion (`<qmodOption> 1`): `<gageMetaFile>` (csv with a header naming `gage_id` and
+    `reach_id`, gageMeta_data.f90:52-68) links the sites of `<fname_gageObs>` (`<vname_gageSite>` character array,
+    `<vname_gageTime>`, `<vname_gageFlow>(time, site)`) to reaches (obs_data.f90:717-743); a simulation step has observations
+    when its start time is one of the file's times (get_time_ix).  Returns gauge_reach (1-based, -9999 = not in the
+    network), have[nSteps], obs[nSteps, nGauge]."""
+    import csv
+    with open(os.path.join(ctl.get("ancil_dir", ""), ctl["gageMetaFile"])) as fp:
+        rows = list(csv.DictReader(fp, skipinitialspace=True))
+    site2reach = {r["gage_id"].strip(): int(float(r["reach_id"])) for r in rows}
+    f = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_gageObs"]), "r", mmap=False)
+    raw = np.asarray(f.variables[ctl.get("vname_gageSite", "site")][:])
+    sites = [b"".join(np.atleast_1d(x).astype("S1").tolist()).decode().strip().strip("\x00") for x in raw] if raw.dtype.kind == "S" and raw.ndim == 2 \
+        else [str(x).strip() for x in raw]
+    tobs = _time_axis(f.variables[ctl.get("vname_gageTime", "time")])
+    flow = np.asarray(f.variables[ctl.get("vname_gageFlow", "flow")][:], dtype=np.float64)
+    fill = getattr(f.variables[ctl.get("vname_gageFlow", "flow")], "_FillValue", None)
+    if fill is not None:
+        flow = np.where(flow == fill, np.nan, flow)
+    f.close()
+    pos = {int(x): i + 1 for i, x in enumerate(net.reachId)}
+    gauge_reach = np.array([pos.get(site2reach.get(sn, -1), -9999) for sn in sites], dtype=np.int32)
+    t0 = (t_beg - _dt.datetime(1970, 1, 1)).total_seconds()
+    rec = {float(t): i for i, t in enumerate(tobs)}
+    have = np.zeros(n_steps, np.int32); obs = np.full((n_steps, len(sites)), np.nan)
+    for k in range(n_steps):
+        i = rec.get(t0 + k * dt)
+        if i is not None:
+            have[k] = 1; obs[k] = flow[i]
+    return dict(gauge_reach=gauge_reach, have=have, obs=obs)
+
+
 def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> dict:
     ctl = read_control(control_path)
     if int(float(ctl.get("seg_outlet", -9999))) > 0:
@@ -345,10 +378,10 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, nml["velo"], nml["diff"])
     W = max(1, min(window, n_steps))
     # options of the reference this driver does not implement stop the run instead of being ignored (read_control.f90)
-    v = str(ctl.get("qmodOption", "0")).strip()
-    if v not in ("F", "0", ""):
-        raise NotImplementedError(f"<qmodOption> = {v}: gauge files are not read by mizuroute_amd.standalone (direct insertion is available through "
-                                  "mizuroute_amd.api.RoutingDomain.set_da)")
+    qmod = str(ctl.get("qmodOption", "0")).strip()
+    if qmod not in ("F", "0", "", "1"):
+        raise ValueError(f"<qmodOption> = {qmod}: expected 0 (none) or 1 (direct insertion), main_route.f90:125-148")
+    qmod = qmod == "1"
     tracer = _truth(ctl.get("tracer", "F"))
     if tracer:      # units of the constituent flux, read_control.f90:476-506
         cc = ctl.get("units_cc", "mg/s")
@@ -368,6 +401,10 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
                             does_basin_route=int(ctl.get("doesBasinRoute", 1)), hw_drain_point=int(ctl.get("hw_drain_point", 2)),
                             min_length_route=float(ctl.get("min_length_route", 0.0)), time_conv=tc, length_conv=lc, history=hflags,
                             lakes=lakes, is_flux_wm=int(is_flux_wm))
+    gauges = None
+    if qmod:
+        gauges = read_gauges(ctl, net, t_beg, dt, n_steps)
+        dom.set_da(dict(blend=int(ctl.get("qBlendPeriod", 10)), trend=int(ctl.get("QerrTrend", 1)), **gauges))
     if tracer:
         dom._check(dom.L.mzr_set_tracer(dom.h, 1, time_conv_sol, mass_conv))
         sol_sum = {mm: np.zeros(net.N) for mm in methods if mm != api.SUM}
@@ -489,6 +526,8 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
             dom.remap_device(w, srcs.data_ptr(), dsts.data_ptr())
             dom.sync()
             dom._check(dom.L.mzr_set_solute(dom.h, w, np.ascontiguousarray(dsts.cpu().numpy())))
+        if gauges is not None:
+            dom.set_obs(done, w)
         src = torch.from_numpy(np.ascontiguousarray(np.stack(rows))).to(dev)
         dom.run_source_device(w, t_first + done * dt, src.data_ptr())
         dom.sync()

@@ -423,3 +423,51 @@ def test_run_from_files_with_a_constituent(tmp_path, hip_lib):
     assert np.allclose(f.variables["soluteMass"][:][-1], dom.solute_state(m.DW, 1), rtol=5e-6, atol=1e-6)
     assert f.variables["localSolute"][:].max() > 0 and F.max() > 0
     f.close()
+
+
+@pytest.mark.gpu
+def test_run_from_files_with_gauge_observations(tmp_path, hip_lib):
+    """<qmodOption> 1: gauge metadata csv + observation file (sites as character arrays, 3-hourly times), against the same
+    run through the API."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_gauges
+    net = m.make_network(900, seed=71)
+    dt, steps = 3600.0, 36
+    ro = m.make_runoff(net.H, steps, seed=72, storm_prob=0.05, storm_amp=3e-6)
+    da = make_gauges(net, steps, n_gauge=30, seed=5, every=3, blend=6, trend=2)
+    tmp = str(tmp_path)
+    names = [f"G{i:05d}" for i in range(da["gauge_reach"].size)]
+    with open(os.path.join(tmp, "gages.csv"), "w") as fp:
+        fp.write("gage_id, reach_id, lat, lon\n")
+        for nm, r in zip(names, da["gauge_reach"]):
+            fp.write(f"{nm}, {int(net.reachId[r - 1]) if r > 0 else 987654321}, 0.0, 0.0\n")
+    rec = np.nonzero(da["have"])[0]
+    g = netcdf_file(os.path.join(tmp, "obs.nc"), "w", version=2)
+    g.createDimension("time", None); g.createDimension("site", len(names)); g.createDimension("strlen", 10)
+    t = g.createVariable("time", "d", ("time",)); t.units = "hours since 2001-01-01 00:00:00"
+    sv = g.createVariable("site", "c", ("site", "strlen"))
+    for i, nm in enumerate(names):
+        sv[i, :] = np.array(list(nm.ljust(10)), dtype="S1")
+    fl = g.createVariable("flow", "d", ("time", "site")); fl._FillValue = -999.0
+    for k, it in enumerate(rec):
+        t[k] = it * dt / 3600.0
+        fl[k, :] = np.where(np.isnan(da["obs"][it]), -999.0, da["obs"][it])
+    g.close()
+    path = write_case(tmp, net, ro * 1000.0, dt, route_opt="15",
+                      extra="<qmodOption> 1\n<qBlendPeriod> 6\n<QerrTrend> 2\n<gageMetaFile> gages.csv\n<fname_gageObs> obs.nc\n"
+                            "<vname_gageFlow> flow\n<vname_gageSite> site\n<vname_gageTime> time\n")
+    out = standalone.run(path, window=8, log=lambda *_: None)
+    ctl = standalone.read_control(path)
+    net_f, _ = standalone.build_network(ctl, standalone.read_param_nml(os.path.join(tmp, "param.nml")))
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    dom = m.RoutingDomain(net_f, dt, [m.IRF, m.DW], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=12)
+    dom.set_da(da)
+    Q = dom.run(ro)
+    want = Q.reshape(steps // 6, 6, 2, net.N).sum(axis=1) / 6.0
+    f = netcdf_file(out["history"], "r", mmap=False)
+    assert np.allclose(f.variables["IRFroutedRunoff"][:], want[:, 0], rtol=5e-6, atol=1e-10)
+    assert np.allclose(f.variables["DWroutedRunoff"][:], want[:, 1], rtol=5e-6, atol=1e-10)
+    f.close()
+    dom2 = m.RoutingDomain(net_f, dt, [m.IRF], frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=12)
+    assert np.abs(dom2.run(ro)[:, 0] - Q[:, 0]).max() > 0                     # the observations did change the answer
