@@ -136,6 +136,10 @@ int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_co
 int mzr_set_solute(mzr_handle h, int nSteps, const double *solute);
 int mzr_get_solute(mzr_handle h, int method, int which, double *out);
 int mzr_get_window_solute(mzr_handle h, int method, double *out);
+/* constituent state for restarts (tfuture(seg, tdh), solute_mass(seg): write_restart_pio.f90:941-971,1292-): tfuture
+   [nRch][ntdhBas] in the layout of mzr_get_basin_state, mass [nRch] of one method; a null pointer leaves that part out */
+int mzr_get_tracer_state(mzr_handle h, int method, double *tfuture, double *mass);
+int mzr_set_tracer_state(mzr_handle h, int method, const double *tfuture, const double *mass);
 
 /* Direct insertion of gauge observations (data assimilation; public_var qmodOption = 1 with qBlendPeriod and QerrTrend,
    main_route.f90:125-148, data_assimilation.f90:28-97): after IRF, KW, MC or DW have routed a reach, the error against

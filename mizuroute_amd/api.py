@@ -52,7 +52,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
-           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute",
+           "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute", "mzr_get_tracer_state", "mzr_set_tracer_state",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
@@ -120,6 +120,8 @@ def load_library():
     L.mzr_set_solute.argtypes = [vp, ci, dp]
     L.mzr_get_solute.argtypes = [vp, ci, ci, dp]
     L.mzr_get_window_solute.argtypes = [vp, ci, dp]
+    L.mzr_get_tracer_state.argtypes = [vp, ci, vp, vp]
+    L.mzr_set_tracer_state.argtypes = [vp, ci, vp, vp]
     L.mzr_set_irf_state.argtypes = [vp, dp]
     L.mzr_set_mol_state.argtypes = [vp, ci, dp]
     L.mzr_set_basin_state.argtypes = [vp, vp, vp]
@@ -277,7 +279,30 @@ class RoutingDomain:
         now on (None switches it off); run() then also keeps reach_solute_flux of every step in self.solute_flux
         [nSteps, nRoutes, nRch] (zeros for the runoff accumulation)."""
         self.solute, self._sol_done = (None if solute is None else np.ascontiguousarray(solute, dtype=np.float64)), 0
+        self.tracer_on = solute is not None
         self._check(self.L.mzr_set_tracer(self.h, int(solute is not None), float(time_conv), float(mass_conv)))
+
+    def tracer_state(self):
+        """dict(tfuture [nRch, ntdhBas] if the hillslope is routed, mass {method: [nRch]}) -- what a restart file keeps"""
+        st = {"mass": {}}
+        if self.does_basin_route == 1:
+            tf = np.zeros((self.N, self.ntdh_bas))
+            self._check(self.L.mzr_get_tracer_state(self.h, -1, tf.ctypes.data_as(C.c_void_p), None))
+            st["tfuture"] = tf
+        for m in self.methods:
+            if m != SUM:
+                a = np.zeros(self.N)
+                self._check(self.L.mzr_get_tracer_state(self.h, m, None, a.ctypes.data_as(C.c_void_p)))
+                st["mass"][m] = a
+        return st
+
+    def set_tracer_state(self, st):
+        if "tfuture" in st:
+            tf = np.ascontiguousarray(st["tfuture"], dtype=np.float64)
+            self._check(self.L.mzr_set_tracer_state(self.h, -1, tf.ctypes.data_as(C.c_void_p), None))
+        for m, a in st["mass"].items():
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self._check(self.L.mzr_set_tracer_state(self.h, m, None, a.ctypes.data_as(C.c_void_p)))
 
     def solute_state(self, method, which=0):
         out = np.zeros(self.N)

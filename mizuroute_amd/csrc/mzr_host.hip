@@ -1800,6 +1800,47 @@ int mzr_set_basin_state(mzr_handle h, const double *qfuture, const double *basin
   return 0;
 }
 
+// Constituent state (restart variables tfuture(seg, tdh) and solute_mass(seg), write_restart_pio.f90:941-971,1292-):
+// tfuture [nRch][ntdhBas] (hillslope routing on) and / or the mass in the reaches of one method; null = leave out.
+// The lateral flux of the last step (BASIN_solute) is not part of the reference's restart and is not needed: every step
+// derives it anew.
+int mzr_get_tracer_state(mzr_handle h, int method, double *tfuture, double *mass) {
+  if (!h || !h->haveState || !h->tracer) return h ? fail(h, 20, "mzr_get_tracer_state/constituent routing is off") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N, n = h->ntdhBas;
+  if (tfuture) {
+    if (h->cfg.doesBasinRoute != 1) return fail(h, 20, "mzr_get_tracer_state/hillslope routing not active");
+    std::vector<double> v((size_t)n * N);
+    MZR_COPY(v.data(), h->solS[h->solCur].p, v.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_tracer_state");
+    for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) tfuture[(size_t)e * n + j] = v[(size_t)j * N + h->ext2int[e]];
+  }
+  if (mass) {
+    const int ix = idxOf(h, method);
+    if (ix < 0 || method == MZR_SUM) return fail(h, 81, "mzr_get_tracer_state/method not active (or the runoff accumulation)");
+    return pullRow(h, h->route[ix].solMass.p, mass);
+  }
+  return 0;
+}
+int mzr_set_tracer_state(mzr_handle h, int method, const double *tfuture, const double *mass) {
+  if (!h || !h->haveState || !h->tracer) return h ? fail(h, 20, "mzr_set_tracer_state/constituent routing is off") : 1;
+  int rc = mzr_sync(h); if (rc) return rc;
+  const int N = h->N, n = h->ntdhBas;
+  if (tfuture) {
+    if (h->cfg.doesBasinRoute != 1) return fail(h, 20, "mzr_set_tracer_state/hillslope routing not active");
+    std::vector<double> v((size_t)n * N);
+    for (int e = 0; e < N; ++e) for (int j = 0; j < n; ++j) v[(size_t)j * N + h->ext2int[e]] = tfuture[(size_t)e * n + j];
+    MZR_COPY(h->solS[h->solCur].p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_tracer_state");
+  }
+  if (mass) {
+    const int ix = idxOf(h, method);
+    if (ix < 0 || method == MZR_SUM) return fail(h, 81, "mzr_set_tracer_state/method not active (or the runoff accumulation)");
+    std::vector<double> v(N);
+    for (int e = 0; e < N; ++e) v[h->ext2int[e]] = mass[e];
+    MZR_COPY(h->route[ix].solMass.p, v.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice, "mzr_set_tracer_state");
+  }
+  return 0;
+}
+
 // REACH_VOL(1) of a method (volume_<method> of the restart file)
 int mzr_set_volume(mzr_handle h, int method, const double *vol) {
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_volume/state not initialised") : 1;

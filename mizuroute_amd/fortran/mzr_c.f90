@@ -40,7 +40,7 @@ MODULE mzr_c
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
             mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs, &
-            mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute
+            mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute, mzr_get_tracer_state, mzr_set_tracer_state
   public :: mzr_message
 
   INTERFACE
@@ -151,6 +151,16 @@ MODULE mzr_c
       type(c_ptr), value :: h
       integer(c_int), value :: method
       real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_get_tracer_state(h, method, tfuture, mass) bind(C, name='mzr_get_tracer_state')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, tfuture, mass        ! c_loc of real(c_double) arrays, or c_null_ptr
+      integer(c_int), value :: method
+    end function
+    integer(c_int) function mzr_set_tracer_state(h, method, tfuture, mass) bind(C, name='mzr_set_tracer_state')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, tfuture, mass
+      integer(c_int), value :: method
     end function
     integer(c_int) function mzr_set_da(h, qBlendPeriod, QerrTrend, nGauge, gaugeReach) bind(C, name='mzr_set_da')
       import :: c_ptr, c_int

@@ -60,6 +60,12 @@ def collect_state(dom) -> dict:
             st.update(numWaves=nw, qwave=qf, tentry=ti, texit=tr, routed=rf)
         else:
             st[f"q_sub_{_SUFFIX[m]}"] = dom.mol_state(m)
+    if getattr(dom, "tracer_on", False):      # constituent: tfuture(seg, tdh) and solute_mass(seg) (write_restart_pio.f90:941-971,1292-)
+        ts = dom.tracer_state()
+        if "tfuture" in ts:
+            st["tfuture"] = ts["tfuture"]
+        for m, a in ts["mass"].items():
+            st["solute_mass" if m == api.DW else f"solute_mass_{_SUFFIX[m]}"] = a      # the reference keeps the diffusive wave's only
     return st
 
 
@@ -75,6 +81,15 @@ def apply_state(dom, st: dict):
             dom.set_kwt_state(st["numWaves"], st["qwave"], st["tentry"], st["texit"], st["routed"])
         else:
             dom.set_mol_state(m, st[f"q_sub_{_SUFFIX[m]}"])
+    if getattr(dom, "tracer_on", False) and any(k.startswith("solute_mass") or k == "tfuture" for k in st):
+        ts = {"mass": {}}
+        if "tfuture" in st:
+            ts["tfuture"] = st["tfuture"]
+        for m in dom.methods:
+            key = "solute_mass" if m == api.DW else f"solute_mass_{_SUFFIX.get(m, '')}"
+            if m != api.SUM and key in st:
+                ts["mass"][m] = st[key]
+        dom.set_tracer_state(ts)
 
 
 def write_restart_file(path, st: dict, reach_id, uh_offset, time_bound, restart_time=0.0,
@@ -94,6 +109,12 @@ def write_restart_file(path, st: dict, reach_id, uh_offset, time_bound, restart_
         _var(f, "qfuture", "d", ("tdh", "seg"), st["qfuture"].T, long_name="future flow series", units="m3/s")
     for key in sorted(k for k in st if k.startswith("volume_")):
         _var(f, key, "d", ("seg",), st[key], long_name="volume in reach/lake", units="m3")
+    if "tfuture" in st:
+        if "tdh" not in f.dimensions:
+            f.createDimension("tdh", st["tfuture"].shape[1])
+        _var(f, "tfuture", "d", ("tdh", "seg"), st["tfuture"].T, long_name="future tracer mass series", units="mg/s")
+    for key in sorted(k for k in st if k.startswith("solute_mass")):
+        _var(f, key, "d", ("seg",), st[key], long_name="mass in reach/lake", units="mg")
     if "irf_qfuture" in st:
         off = np.asarray(uh_offset, np.int64)
         nq = np.diff(off).astype(np.int32)
@@ -131,6 +152,11 @@ def read_restart_file(path) -> dict:
     N = st["reachID"].size
     if "qfuture" in v:
         st["qfuture"] = v["qfuture"][:].T.copy()
+    if "tfuture" in v:
+        st["tfuture"] = v["tfuture"][:].T.copy()
+    for key in v:
+        if key.startswith("solute_mass"):
+            st[key] = v[key][:].copy()
     for k in v:
         if k.startswith("volume_") or k.startswith("q_sub_"):
             st[k] = v[k][:].T.copy() if v[k][:].ndim == 2 else v[k][:].copy()

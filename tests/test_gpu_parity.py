@@ -545,6 +545,33 @@ def test_tracer_vs_oracle(hw_drain, basin_route, window, hip_lib, oracle_lib):
     dom.close()
 
 
+def test_tracer_restart_continues_bit_exact(tmp_path, hip_lib):
+    """a constituent run cut in two with the state going through a restart file (tfuture, solute_mass; write_restart_pio.f90:
+    941-971,1292-) gives the same fluxes as the uninterrupted run"""
+    from mizuroute_amd import ncfiles, uh as uhmod
+    net = m.make_network(1500, seed=81)
+    dt, n1, n2 = 3600.0, 30, 25
+    ro = m.make_runoff(net.H, n1 + n2, seed=82, storm_prob=0.05, storm_amp=3e-6)
+    sol = np.random.default_rng(83).uniform(0.0, 2e-3, (n1 + n2, net.H))
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    methods = [m.KWT, m.IRF, m.DW]
+    mk = lambda: m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=16)
+    whole = mk(); whole.set_tracer(sol); whole.run(ro)
+    Fw = whole.solute_flux.copy()
+    a = mk(); a.set_tracer(sol[:n1]); a.run(ro[:n1])
+    path = str(tmp_path / "tr.r.nc")
+    ncfiles.write_restart(path, a, net.reachId, ((n1 - 1) * dt, n1 * dt), restart_time=n1 * dt)
+    st = ncfiles.read_restart_file(path)
+    assert "tfuture" in st and "solute_mass" in st and "solute_mass_kwt" in st and "solute_mass_irf" in st
+    b = mk(); b.set_tracer(sol[n1:])
+    ncfiles.read_restart(path, b)
+    b.run(ro[n1:], t_start=n1 * dt)
+    assert np.array_equal(b.solute_flux, Fw[n1:])
+    for meth in methods:
+        assert np.array_equal(b.solute_state(meth, 1), whole.solute_state(meth, 1)), meth
+
+
 def test_global_water_balance(hip_lib):
     """comp_global_wb (water_balance.f90:191-323) of the last step: the seven sums restated from the per-reach fields, and
     the global error equal to the sum of the per-reach errors (comp_reach_wb, :22-112) -- inside the domain every
