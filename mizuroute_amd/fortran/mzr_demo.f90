@@ -1,6 +1,6 @@
 ! Minimal Fortran host for the C-ABI: routes a small network read from a case file step by step,
 ! the way mizuRoute's time loop (standalone/route_runoff.f90:80-108) calls mpi_route/main_route.
-! usage: mzr_demo <case.bin> <out.bin>     (case format: mizuroute_amd/casefile.py, uhSource=1)
+! usage: mzr_demo <case.bin> <out.bin>     (case format: the flat binary file the test harness writes, tests/ + INTEGRATION.md; uhSource=1)
 ! Writes REACH_Q of every step: int32 N, nSteps, nRoutes; float64 Q(N, nRoutes, nSteps).
 PROGRAM mzr_demo
   USE, INTRINSIC :: iso_c_binding

@@ -305,7 +305,7 @@ def sort_flux(ix_in: np.ndarray, flux: np.ndarray, n: int, remove_negatives: boo
 def read_lakes(ctl: dict, net, n_steps: int) -> dict:
     """Lake flags and parameters of the topology file (process_ntopo.f90 / popMetadat.f90 names) as the dictionary
     api.RoutingDomain takes: reach (1-based), model_type, par[NLAKEPAR, nLake], input_option, calendar_id."""
-    from .casefile import LAKE_PAR, NLAKEPAR
+    from .lakepar import LAKE_PAR, NLAKEPAR
     f = netcdf_file(os.path.join(ctl.get("ancil_dir", ""), ctl["fname_ntopOld"]), "r", mmap=False)
     v = f.variables
     name = lambda k: ctl.get("varname_" + k, k)

@@ -330,7 +330,7 @@ def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: 
     """Synthetic lakes/reservoirs (Doll 70 %, Hanasaki 25 %, HYPE 5 %, plus an
     endorheic one), parameters in the ranges of docs/source/users_guide/lake.rst.  A lake must be
     the only upstream of its outlet reach (kwt_route.f90:551-553)."""
-    from .casefile import LAKE_PAR, NLAKEPAR
+    from .lakepar import LAKE_PAR, NLAKEPAR
     rng = np.random.default_rng(seed)
     down0 = net.downIndex.astype(np.int64) - 1
     nup = np.diff(net.upOffset)

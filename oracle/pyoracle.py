@@ -145,7 +145,7 @@ class Oracle:
         return Q, F, M
 
     def set_lakes(self, lakes):
-        """lakes: dict as mizuroute_amd.casefile.write_case(lakes=...)."""
+        """lakes: dict as oracle.casefile.write_case(lakes=...)."""
         c = lambda a, t: np.ascontiguousarray(a, dtype=t)
         self._lakes = lakes
         rc = self._set_lakes(lakes)

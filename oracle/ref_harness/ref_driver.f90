@@ -1,6 +1,6 @@
 ! Harness driver for the reference routing hot path (test infrastructure; not product code).
 !
-! Reads a binary "case" file written by mizuroute_amd/testing/casefile.py, fills the reference's
+! Reads a binary "case" file written by oracle/casefile.py, fills the reference's
 ! own derived types the way put_data_struct / init_state_data do
 ! (process_ntopo.f90:354-504, init_model_data.f90:399-505), calls the UNMODIFIED reference
 ! `main_route` (main_route.f90:29) once per time step and dumps per-step discharge/volume plus the

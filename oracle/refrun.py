@@ -15,7 +15,7 @@ import tempfile
 
 import numpy as np
 
-from mizuroute_amd.casefile import MAGIC_IN, serial_schedule, write_case  # noqa: F401
+from oracle.casefile import MAGIC_IN, serial_schedule, write_case  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EXE = os.path.join(HERE, "_ref", "ref_route")

@@ -28,7 +28,7 @@ def write_case(tmp, net, runoff_mm_s, dt, route_opt="2", shuffle_seed=3, remap=N
     var("Length", "d", "seg", net.params["RLENGTH"]); var("Slope", "d", "seg", net.params["R_SLOPE"])
     var("hruid", "i", "hru", hru_id); var("seg_hru_id", "i", "hru", seg_of_hru); var("Basin_Area", "d", "hru", net.params["BASAREA"])
     if lakes is not None:      # lake flags and parameters under the reference's own names (popMetadat.f90:124-232)
-        from mizuroute_amd.casefile import LAKE_PAR
+        from mizuroute_amd.lakepar import LAKE_PAR
         isl = np.zeros(N, np.int32); isl[lakes["reach"] - 1] = 1
         mt = np.zeros(N, np.int32); mt[lakes["reach"] - 1] = lakes["model_type"]
         var("islake", "i", "seg", isl); var("lakeModelType", "i", "seg", mt)
