@@ -459,6 +459,7 @@ def main():
                                        f"{world} sub-basin partitions (reference mainstem rule), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
             "value_with_h2d": value_h2d, "single_step": single,
+            "kwt_sweep_arrivals": dict(zip(("arrived_last", "joined_last", "start_delay_hist_log2_10ns"), dom.sweep_arrivals())) if world == 1 and m.KWT in methods else None,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

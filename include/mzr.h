@@ -54,6 +54,17 @@ typedef struct mzr_config {
   int    maxWindow;           /* largest number of time steps per mzr_run call             */
   int    device;              /* HIP device ordinal                                        */
   int    is_flux_wm;          /* 1: water-management abstraction/injection fluxes are applied */
+  int    reserved0;           /* (padding, keep 0)                                         */
+  double mcTailTol;           /* Muskingum-Cunge: once the outflow of a sub-step (mc_route.f90:246-330) moves by less than
+                                 this fraction of itself and the differences contract, the rest of the sub-step sum is
+                                 added in closed form.  Default 1e-7 (deviation from iterating on: <= 1.4e-10 of the
+                                 discharge, measured); 0 = iterate every sub-step, the reference's arithmetic.         */
+  double sweepShare;          /* share of the device's wavefront slots the persistent sweeps of THIS handle may fill (default
+                                 1).  Handles whose windows run side by side on one GPU (a tributary and the mainstem
+                                 domain of rank 0) must share them out: the grids of concurrently running sweeps must
+                                 fit the device together                                               */
+  double sweepTimeout;        /* seconds without any progress on the reaches it waits for after which a wavefront of a
+                                 persistent sweep gives up with ierr 93 instead of hanging the device (default 8)      */
 } mzr_config;
 
 void mzr_default_config(mzr_config *cfg);
@@ -245,6 +256,10 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
 /* KWT persistent sweep: wavefronts the sweep kernel is launched with (0 = not in use), wavefronts the device
    holds at once, items (blocks of reaches) dealt to them */
 int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems);
+/* KWT persistent sweep, start of its wavefronts: how many of the last launch arrived and how many of them joined (a
+   wavefront that starts more than 10 us after the first one of its launch leaves at once), and since
+   mzr_init_state the number of wavefronts by start delay: hist32[k] counts delays below 2^k ticks of 10 ns */
+int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long long *hist32);
 /* measurement modes (bit mask, default 0):
    1  kernel-time accounting of the routing sweep: launches and summed device time [ms] per method
       (HIP events around every stage launch on the handle's stream), read with mzr_get_timing;

@@ -41,7 +41,8 @@ class MzrConfig(C.Structure):
                 ("doesBasinRoute", C.c_int), ("hw_drain_point", C.c_int),
                 ("min_length_route", C.c_double), ("runoffMin", C.c_double), ("negRunoffTol", C.c_double),
                 ("time_conv", C.c_double), ("length_conv", C.c_double), ("maxWindow", C.c_int), ("device", C.c_int),
-                ("is_flux_wm", C.c_int)]
+                ("is_flux_wm", C.c_int), ("reserved0", C.c_int), ("mcTailTol", C.c_double), ("sweepShare", C.c_double),
+                ("sweepTimeout", C.c_double)]
 
 
 _lib = None
@@ -57,7 +58,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
            "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync", "mzr_set_history", "mzr_get_mean",
-           "mzr_reset_means"]
+           "mzr_reset_means", "mzr_get_sweep_arrivals"]
 
 
 def load_library():
@@ -145,6 +146,7 @@ def load_library():
     L.mzr_get_basin_state.argtypes = [vp, dp]
     L.mzr_get_schedule.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.mzr_get_sweep_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.mzr_get_sweep_arrivals.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_longlong)]
     L.mzr_set_profiling.argtypes = [vp, ci]
     LL = C.POINTER(C.c_longlong)
     L.mzr_get_timing.argtypes = [vp, ci, LL, C.POINTER(cd), LL, ci]
@@ -165,7 +167,7 @@ class RoutingDomain:
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
                  hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
                  export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0, lakes=None,
-                 time_conv=1.0, length_conv=1.0, history=0):
+                 time_conv=1.0, length_conv=1.0, history=0, sweep_share=1.0):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -180,6 +182,7 @@ class RoutingDomain:
         cfg.min_length_route = float(min_length_route); cfg.runoffMin = float(runoff_min)
         cfg.maxWindow = int(max_window); cfg.device = int(device); cfg.is_flux_wm = int(is_flux_wm)
         cfg.time_conv = float(time_conv); cfg.length_conv = float(length_conv)   # runoff units -> m/s
+        cfg.sweepShare = float(sweep_share)     # share of the device's wavefront slots this domain's persistent sweeps fill
         self.is_flux_wm = int(is_flux_wm)
         self.max_window = int(max_window)
         self.h = C.c_void_p()
@@ -219,8 +222,8 @@ class RoutingDomain:
     # ---- plumbing
     def _check(self, rc):
         if rc != 0:
-            buf = C.create_string_buffer(1024)
-            self.L.mzr_last_error(self.h, buf, 1024)
+            buf = C.create_string_buffer(4096)
+            self.L.mzr_last_error(self.h, buf, 4096)
             raise MzrError(rc, buf.value.decode(errors="replace"))
 
     def close(self):
@@ -451,6 +454,13 @@ class RoutingDomain:
         a, b = C.c_int(0), C.c_int(0)
         self._check(self.L.mzr_get_schedule(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def sweep_arrivals(self):
+        """(arrived, joined) wavefronts of the last KWT sweep launch, and the histogram of start delays since init (bucket k: < 2^k x 10 ns)"""
+        a, j = C.c_int(0), C.c_int(0)
+        hist = (C.c_longlong * 32)()
+        self._check(self.L.mzr_get_sweep_arrivals(self.h, C.byref(a), C.byref(j), hist))
+        return a.value, j.value, [int(x) for x in hist]
 
     def sweep_info(self):
         """(wavefronts of the persistent KWT sweep, wavefronts the device holds at once, items dealt to them)"""

@@ -45,6 +45,7 @@
 // among the groups of a wavefront by need.
 // Bound by HBM traffic of the particle rows: see DESIGN.md for the bytes-per-reach-step model.
 #include <float.h>
+#include <algorithm>
 #include "mzr_device.h"
 #include "lake_device.h"
 #include "mzr_math.h"
@@ -95,6 +96,7 @@ __device__ int d_interp_rch(const double *TOLD, const double *QOLD, int NOLD, do
 }
 
 
+__device__ __forceinline__ int mzr_lane();
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -107,32 +109,64 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 // Progress word of a reach (kwDone): steps of the window it has completed in the low 16 bits; above them what its
 // consumers would otherwise have to load before they know how much of its rows is alive -- the particle counts of its
 // two outbox parities (5 bits each) and of its at-rest list (5 bits).
+// debugging aid (MZR_SWEEP_DEBUG=1): slot `k` of this wavefront's record of what it is doing
+__device__ __forceinline__ void kwt_beat(const MzrDev &d, int k, int v) {
+#ifdef MZR_SWEEP_TRACE
+  if (d.swBeat && (threadIdx.x & 63) == 0) __hip_atomic_store(d.swBeat + (size_t)blockIdx.x * MZR_BEAT + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+#ifdef MZR_SWEEP_TRACE
+#define MZR_BEAT_ON(d) ((d).swBeat != nullptr)
+#else
+#define MZR_BEAT_ON(d) false
+#endif
 #define MZR_KWD_STEPS(w) ((w) & 0xffff)
 #define MZR_KWD_OUT(w, par) (((w) >> (16 + 5 * (par))) & 31)
 #define MZR_KWD_OWN(w) (((w) >> 26) & 31)
-__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, int wneed, int *word = nullptr) {
+__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, int wneed, int *word = nullptr, int s = -1, int reach = -1) {
   long long t0 = 0;
-  int spins = 0;
+  int spins = 0, vlast = 0;
   for (;;) {
-    int v = wneed;
-    if (wp) v = ldx<true>(wp);
-    if (word) *word = v;
-    v = MZR_KWD_STEPS(v);
+    int w = wneed;
+    if (wp) w = ldx<true>(wp);
+    if (word) *word = w;
+    const int v = MZR_KWD_STEPS(w);
     if (__ballot(v < wneed) == 0ull) {
 #ifdef MZR_KWT_TIMING
       if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + 23], spins ? 1ull : 0ull); atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + 24], (unsigned long long)spins); }
 #endif
+      asm volatile("" ::: "memory");      // what the progress words guard is read after them (compiler order; the loads are sc1)
+      kwt_beat(d, 3, 3);
+      if (MZR_BEAT_ON(d)) kwt_beat(d, 7, (int)wall_clock64());
       return false;
     }
 #ifndef MZR_KWT_SLEEP
 #define MZR_KWT_SLEEP 4
 #endif
-    __builtin_amdgcn_s_sleep(MZR_KWT_SLEEP);
+    // How soon to look again depends on how far the slowest dependency is behind: one step short, it can be there any
+    // moment (the hand-off is on the window's critical path: poll at once); d >= 2 steps short, the reach still has d - 1
+    // whole passes of >= 8 us each in front of it, and the wavefront -- one that drew a ticket launches ahead of the
+    // frontier, as most of the waiting ones have -- sleeps through part of that.  Polling them all at the fast rate
+    // (4 000 wavefronts x 64 lanes every microsecond) is what starved the passes at the frontier of their own memory
+    // accesses for seconds at a time (profiles/r03_soak.md).
+    if (__ballot(v + 1 < wneed) == 0ull) __builtin_amdgcn_s_sleep(MZR_KWT_SLEEP);
+    else {
+      const int n = __ballot(v + 8 < wneed) != 0ull ? 8 : __ballot(v + 4 < wneed) != 0ull ? 4 : __ballot(v + 2 < wneed) != 0ull ? 2 : 1;
+      for (int k = 0; k < n; ++k) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks = 3.4 us each
+    }
     if ((++spins & 31) == 0) {
       if (ldx<true>(&d.err->code) != 0) return true;
+      if (spins == 32) kwt_beat(d, 3, 2);
       const long long now = wall_clock64();     // 100 MHz
-      if (!t0) t0 = now;
-      else if (now - t0 > 400000000LL) { mzr_raise(d, 93, -1, -1, 20); return true; }
+      if (!t0 || __ballot(v != vlast) != 0ull) t0 = now;      // something this wavefront polls has moved: not stuck
+      else if (now - t0 > d.stallTicks) {
+        const unsigned long long bad = __ballot(v < wneed);
+        const int first = __ffsll((long long)bad) - 1;
+        if (mzr_lane() == first)
+          mzr_raise_stall(d, 20, reach, s, wp ? (int)(wp - d.kwDone) : -1, w, wneed, -1, first, __popcll(bad), now - t0, d.swHead);
+        return true;
+      }
+      vlast = v;
     }
   }
 }
@@ -473,6 +507,14 @@ __device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *
   if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { unsigned *_rb = (unsigned *)(d.dbgCycles + 32 * 1024); const unsigned _k = atomicAdd(_rb, 1u) % MZR_REC_N; unsigned *_r = _rb + 16 + (size_t)_k * 16; \
     _r[0] = (G_); _r[1] = _sz; _r[2] = _nr; _r[3] = _sec[21]; _r[4] = _sec[0]; _r[5] = _sec[1] + _sec[10] + _sec[11] + _sec[12]; _r[6] = _sec[2] + _sec[3]; _r[7] = _sec[4] + _sec[5]; _r[8] = _sec[6]; _r[9] = _sec[16] + _sec[17]; _r[10] = _sec[18] + _sec[19] + _sec[7]; _r[11] = _sec[22]; _r[12] = _sec[10]; _r[13] = _sec[11]; _r[14] = _sec[12]; } } while (0)
 #define TSTAMP_WAVE(i) do { if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], 1ull); } while (0)
+#elif defined(MZR_SWEEP_TRACE)
+// debugging build (make EXTRA=-DMZR_SWEEP_TRACE, run with MZR_SWEEP_DEBUG=1): every wavefront keeps a record of what it is
+// doing (kwt_beat), the schedule tables and records are checked against memory, and every section boundary leaves the
+// clock in the record (slots 8 + i), so that a pass that took seconds can say where
+#define KCOUNT(i, v) do { } while (0)
+#define TSTAMP(i) do { if (PERS && d.swBeat && (i) != 11 && (i) != 12) kwt_beat(d, 8 + (i), (int)wall_clock64()); } while (0)
+#define TSTAMP_WAVE(i) do { } while (0)
+#define TRECORD(G_, size_, nrem_) do { } while (0)
 #else
 #define KCOUNT(i, v) do { } while (0)
 #define TSTAMP(i) do { } while (0)
@@ -517,9 +559,9 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
     const bool halo = act && FULL && d.haloSlot && d.haloSlot[r] >= 0;
     const int nu = (act && !halo) ? (int)d.nUp[r] : 0, u0 = act ? d.upStart[r] : 0;
     const int dn = (halo && t >= 2) ? d.down[r] : -1;
-    for (int i = 0; __ballot(i < nu) != 0ull; ++i) if (kwt_wait_deps(d, i < nu ? d.kwDone + u0 + i : nullptr, t + 1)) return true;
-    if (kwt_wait_deps(d, dn >= 0 ? d.kwDone + dn : nullptr, t - 1)) return true;
-    if (kwt_wait_deps(d, (act && t >= 1) ? d.kwDone + r : nullptr, t)) return true;      // its own previous step
+    for (int i = 0; __ballot(i < nu) != 0ull; ++i) if (kwt_wait_deps(d, i < nu ? d.kwDone + u0 + i : nullptr, t + 1, nullptr, s, r)) return true;
+    if (kwt_wait_deps(d, dn >= 0 ? d.kwDone + dn : nullptr, t - 1, nullptr, s, r)) return true;
+    if (kwt_wait_deps(d, (act && t >= 1) ? d.kwDone + r : nullptr, t, nullptr, s, r)) return true;      // its own previous step
     // a lake's own state (volume, Hanasaki memory) was written by whichever wavefront took its last step
     if (__ballot(act && !halo) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
@@ -602,13 +644,19 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   bool ovf = false;
   // The sweep is as fast as its slowest chain of passes, and those are the wide ones (long particle lists, thinning):
   // they go first whenever the SIMD has a choice.
-  if (G >= 16) __builtin_amdgcn_s_setprio(2);
+#ifndef MZR_NO_PRIO
+  if (G >= 16 && !PERS) __builtin_amdgcn_s_setprio(2);      // (the persistent sweep raises it after its wait: a wavefront that polls has no business in front of one that computes)
+#endif
   // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line), fetched by eight lanes of
   // the group into LDS (ctx[4..11]) and read from there when a field is needed, not held in registers
   double *rc = ctx + 4;
   for (int k = gl; k < 8; k += G) rc[k] = ((const double *)(recs + (have ? item : lastItem)))[k];
   grp_sync();
   const int *rci = (const int *)rc;      // r, sigma | u0, nup flags upGood goodMask | width | CW | length | scA | scB | down, -
+  if (PERS && MZR_BEAT_ON(d) && have && gl < 4) {      // debugging aid: the record as the caches hold it against what memory holds
+    const int fresh = ldx<true>((const int *)(recs + item) + gl);
+    if (fresh != rci[gl]) mzr_raise_stall(d, 40 + gl, rci[0], s, item, rci[gl], fresh, -1, lane, 0, 0, d.swHead);
+  }
   const int r = uni<G>(rci[0]);
   const int t = uni<G>(have ? s - rci[1] : -1);
   const unsigned rcb = (unsigned)rci[3];
@@ -648,7 +696,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       else if (gl == nup && dn >= 0 && t >= 2) { wp = d.kwDone + dn; wneed = t - 1; }
       else if (gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
-    if (kwt_wait_deps(d, wp, wneed, &wword)) return 2;
+    if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
+#ifndef MZR_NO_PRIO
+    if (G >= 16) __builtin_amdgcn_s_setprio(2);
+#endif
     TSTAMP(21);
   }
 
@@ -912,7 +963,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #endif
           // a pass that has to thin is the slowest kind, and the sweep is as fast as its slowest chain of passes:
           // it goes first whenever the SIMD has a choice
+#ifndef MZR_NO_PRIO
           __builtin_amdgcn_s_setprio(3);
+#endif
           const int NPRT = size - 1;
           const bool big = GEN && NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
           unsigned long long mask = NPRT >= 63 ? ~0ull : ((2ull << NPRT) - 1ull);   // bits 0..NPRT
@@ -1315,6 +1368,18 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             stx<true>(d.kwDone + r, (tq + 1) | (nOut << (16 + 5 * pq)) | (keep << (16 + 5 * (pq ^ 1))) | ((NN2 + 1) << 26));
           }
           TSTAMP(22);
+          kwt_beat(d, 3, 4);
+          if (MZR_BEAT_ON(d) && lane == 0) {      // debugging aid: a pass that took unreasonably long between the end of its wait and its publish
+            const int *bt = d.swBeat + (size_t)blockIdx.x * MZR_BEAT;
+            const int now = (int)wall_clock64(), dt = now - ldx<true>(bt + 7);
+            if (dt > 1000000) {
+              const int k = atomicAdd(&d.err->nSlow, 1);
+              if (k < 32) {
+                for (int j = 0; j < 24; ++j) d.err->slowT[k][j] = ldx<true>(bt + 8 + j) - ldx<true>(bt + 7);
+                int *o = d.err->slow[k]; o[0] = blockIdx.x; o[1] = s; o[2] = ldx<true>(bt + 1); o[3] = dt; o[4] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4); o[5] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7; o[6] = now; o[7] = G;
+              }
+            }
+          }
         }
       } while (0);
     }
@@ -1443,8 +1508,18 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   constexpr int CAPB = GB * 4 - 1 < GPB ? GB * 4 - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
   __shared__ double sCtx[RC][MZR_CTX];
+#ifdef MZR_LDS_PAD      // experiment: more LDS per workgroup, so that fewer of them fit a CU
+  __shared__ double sPad[MZR_LDS_PAD];
+  if (sEnd == -12345) { sPad[threadIdx.x] = 1.0; __syncthreads(); if (sPad[(threadIdx.x + 1) & 63] != 1.0) return; }
+#endif
+  if (sEnd < 0) { mzr_census(d0.swHead + 8 * 16); return; }      // host: mzr_sweep_kwt_capacity
+  if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
+  const int arr = mzr_sweep_join(d0.swHead);      // (a wavefront that starts behind time does not join)
+  if (arr < 0) return;
   const int Wm1 = d0.W - 1;
-  const int q0 = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;     // HW_REG_XCC_ID: a speed hint only
+  const int q0 = arr < 64 ? (arr & 7) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7);     // HW_REG_XCC_ID: a speed hint only
+  kwt_beat(d0, 5, q0); kwt_beat(d0, 3, 1); kwt_beat(d0, 4, 0);
+  int nDone = 0;
   IntK P = (IntK)d0.swP, RAs = (IntK)d0.swRA;
 #pragma unroll 1
   for (int dq = 0; dq < 8; ++dq) {
@@ -1472,6 +1547,18 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       const int a = RAs[s];
       const int i = a + ((q - a) & 7) + 8 * (k - pLo);
       if (s < d.swLo[i] || s > d.swHi[i] + Wm1) continue;        // none of the item's reaches has a step in this launch
+      if (MZR_BEAT_ON(d)) {
+        kwt_beat(d, 0, s); kwt_beat(d, 1, i); kwt_beat(d, 2, q); kwt_beat(d, 6, k); kwt_beat(d, 3, 1); kwt_beat(d, 4, ++nDone);
+        // debugging aid: the schedule tables as the scalar cache holds them against what memory holds (sc1 vector loads)
+        const int c0 = pLo, c1 = pHi, c2 = a, c3 = d.swLo[i], c4 = d.swHi[i], c5 = d.swItem[i];
+        const int f0 = ldx<true>(d.swP + sCur * 8 + q), f1 = ldx<true>(d.swP + (sCur + 1) * 8 + q), f2 = ldx<true>(d.swRA + s);
+        const int f3 = ldx<true>(d.swLo + i), f4 = ldx<true>(d.swHi + i), f5 = ldx<true>(d.swItem + i);
+        const int bad = c0 != f0 ? 0 : c1 != f1 ? 1 : c2 != f2 ? 2 : c3 != f3 ? 3 : c4 != f4 ? 4 : c5 != f5 ? 5 : -1;
+        if (bad >= 0 && mzr_lane() == 0) {
+          const int cv[6] = {c0, c1, c2, c3, c4, c5}, fv[6] = {f0, f1, f2, f3, f4, f5};
+          mzr_raise_stall(d, 30 + bad, -1, s, i, cv[bad], fv[bad], q, k, 0, 0, d.swHead);
+        }
+      }
       const int lane = mzr_lane(), g16 = lane / GA;
       const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
       const int cls = it >> 28, bi = it & 0x0fffffff;      // 0 A, 1 B, 2 generic, 3 lake / halo, 4 C
@@ -1517,12 +1604,14 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       } while (ovfMask);
     }
   }
+  kwt_beat(d0, 3, 9);
 }
 
 // Start of a KWT window in persistent mode: progress counters back to zero, and the headwater reaches
 // (kwt_route.f90:181-205: REACH_Q = BASIN_QR(1), one sentinel particle) for every step of the window.
 template <bool FULL>
 __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, int tEnd, int first) {
+  if (d.err->code != 0) return;      // a window that failed stays as it is
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (first && blockIdx.y == 0) {   // first slab of the first chunk of steps: also the per-reach bookkeeping
     for (int r = i; r < d.N; r += gridDim.x * blockDim.x) d.kwDone[r] = 0;
@@ -1544,6 +1633,7 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
 }
 // second, tiny kernel (after the zeroing above has finished): headwaters are complete for the whole window
 __global__ void __launch_bounds__(256) k_kwt_head_done(MzrDev d) {
+  if (d.err->code != 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < d.nHead) d.kwDone[d.kwtHead[i]] = d.W;
 }
@@ -1585,15 +1675,34 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
 // ---- persistent sweep, host side
 static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm); }
 
-// wavefronts of k_sweep_kwt that are resident at once on this device (the sweep needs all of its wavefronts running)
-int mzr_sweep_kwt_capacity(bool full) {
+// Wavefronts of k_sweep_kwt the device really holds at once.  The grid of a sweep must not exceed this: a persistent
+// kernel with workgroups still waiting for a slot was measured (profiles/r03_soak.md) to freeze, now and then and for
+// as long as the others keep running, the vector-memory instructions of some of its last-launched resident wavefronts
+// -- every other wavefront then waits on them and the sweep's watchdog fires (ierr 93).  The occupancy query is one
+// workgroup per CU high for this kernel (17 against 16), so the number is measured: the kernel itself is launched in
+// census mode (sEnd < 0: every wavefront counts itself in, stays 300 us, counts itself out; the peak is the answer).
+// cnt: two ints of device memory (swHead + 128).  Measured once per process, device and kernel flavour.
+int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream) {
+  static int cached[16][2];
   int dev = 0, cus = 0, perCu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 16 && cached[dev][full]) return cached[dev][full];
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   const hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<true, 240>, 64, 0)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<false, 240>, 64, 0);
   if (e != hipSuccess) return 0;
-  return cus * perCu;
+  const int api = cus * perCu;
+  int peak[2] = {0, 0};
+  int *cnt = d.swHead + 8 * 16;
+  if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) return 0;
+  const int grid = api + api / 4;
+  if (full) hipLaunchKernelGGL((k_sweep_kwt<true, 240>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
+  else hipLaunchKernelGGL((k_sweep_kwt<false, 240>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
+  if (hipStreamSynchronize(stream) != hipSuccess) return 0;
+  if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
+  if (dev >= 0 && dev < 16) cached[dev][full] = cap;
+  return cap;
 }
 
 // headwater reaches for steps [tBegin, tEnd) of the window; tBegin == 0 also resets the progress counters
@@ -1609,7 +1718,9 @@ void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream
 }
 
 __global__ void k_sweep_heads(MzrDev d, int sBegin) {
+  if (d.err->code != 0) return;
   if (threadIdx.x < 8) d.swHead[threadIdx.x * 16] = d.swP[sBegin * 8 + threadIdx.x];
+  mzr_sweep_join_reset(d.swHead);
 }
 
 void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {

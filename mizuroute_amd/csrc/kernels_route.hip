@@ -528,15 +528,23 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
 // Tickets depend only on tickets of earlier launches and every queue is served in order: any number of resident
 // wavefronts makes progress.  Discharge rows and per-reach state cross wavefronts through sc1 accesses (stage_reach<.., true>).
 namespace {
-// pause of a polling wavefront; true = give up (another wavefront raised an error, or nothing has moved for 4 s: code 93
-// instead of a hung GPU)
-__device__ __forceinline__ bool rt_pause(const MzrDev &d, int &spins, long long &t0) {
+// pause of a polling wavefront; true = give up (another wavefront raised an error, or none of the progress words this
+// wavefront polls has changed for d.stallTicks: code 93 with a record of the wait instead of a hung GPU).
+// sig = sum of the words the lane polled, bad* = the first dependency of the lane that is not there yet.
+__device__ __forceinline__ bool rt_pause(const MzrDev &d, int &spins, long long &t0, int sig, int &sigLast, bool waiting,
+                                         int r, int s, int q, int badReach, int badSeen, int badNeed) {
   __builtin_amdgcn_s_sleep(4);
   if ((++spins & 31) == 0) {
     if (ldx<true>(&d.err->code) != 0) return true;
     const long long now = wall_clock64();     // 100 MHz
-    if (!t0) t0 = now;
-    else if (now - t0 > 400000000LL) { mzr_raise(d, 93, -1, -1, 21); return true; }
+    if (!t0 || __ballot(sig != sigLast) != 0ull) t0 = now;
+    else if (now - t0 > d.stallTicks) {
+      const unsigned long long bad = __ballot(waiting);
+      const int first = __ffsll((long long)bad) - 1;
+      if ((int)threadIdx.x == first) mzr_raise_stall(d, 21, r, s, badReach, badSeen, badNeed, q, first, __popcll(bad), now - t0, d.rtHead);
+      return true;
+    }
+    sigLast = sig;
   }
   return false;
 }
@@ -544,8 +552,12 @@ __device__ __forceinline__ bool rt_pause(const MzrDev &d, int &spins, long long 
 
 template <int METHOD>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_sweep_route(MzrDev d, int sBegin, int sEnd) {
+  if (sEnd < 0) { mzr_census(d.rtHead + 8 * 16); return; }      // host: mzr_sweep_route_capacity
+  if (ldx<true>(&d.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
+  const int arr = mzr_sweep_join(d.rtHead);      // (a wavefront that starts behind time does not join)
+  if (arr < 0) return;
   const int lane = threadIdx.x;
-  const int q0 = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;     // HW_REG_XCC_ID: a speed hint only
+  const int q0 = arr < 64 ? (arr & 7) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7);     // the first 64 take queue j % 8; otherwise HW_REG_XCC_ID, a speed hint only
   const int *P = d.rtP, *RAs = d.rtRA;
 #pragma unroll 1
   for (int dq = 0; dq < 8; ++dq) {
@@ -575,16 +587,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       const bool lakes = __ballot((rec.z >> 8) & 1) != 0ull;
       const int t = s - rec.w;                          // 0 <= t < W by construction of the tables
       // its upstream reaches have published step t, itself step t - 1 (another wavefront's work): polled together
-      int spins = 0; long long tw0 = 0;
+      int spins = 0, sigLast = 0; long long tw0 = 0;
       for (;;) {
         bool ok = true;
+        int sig = 0, badReach = -1, badSeen = 0, badNeed = 0;
         if (r >= 0) {
-          if (t >= 1) ok = ldx<true>(d.rtDone + r) >= t;
-          for (int j = 0; j < nu; ++j) ok = ok && ldx<true>(d.rtDone + u0 + j) >= t + 1;
+          if (t >= 1) { const int w = ldx<true>(d.rtDone + r); sig += w; if (w < t) { ok = false; badReach = r; badSeen = w; badNeed = t; } }
+          for (int j = 0; j < nu; ++j) {
+            const int w = ldx<true>(d.rtDone + u0 + j);
+            sig += w;
+            if (w < t + 1) { if (ok) { badReach = u0 + j; badSeen = w; badNeed = t + 1; } ok = false; }
+          }
         }
         if (__ballot(!ok) == 0ull) break;
-        if (rt_pause(d, spins, tw0)) return;
+        if (rt_pause(d, spins, tw0, sig, sigLast, !ok, r, s, q, badReach, badSeen, badNeed)) return;
       }
+      asm volatile("" ::: "memory");      // what the progress words guard is read after them
       if (lakes) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                  // a lake's plain state (Hanasaki memory ...)
       if (r >= 0) stage_reach<METHOD, true>(d, r, t);
       if (lakes) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -596,12 +614,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 __global__ void k_rt_heads(MzrDev d, int sBegin) {
   if (threadIdx.x < 8) d.rtHead[threadIdx.x * 16] = d.rtP[sBegin * 8 + threadIdx.x];
+  mzr_sweep_join_reset(d.rtHead);
 }
 
-// wavefronts the device holds at once (the sweep runs with any number; this only sizes the grid)
-int mzr_sweep_route_capacity(int method) {
+// wavefronts of a method's sweep kernel the device really holds at once (measured: see mzr_sweep_kwt_capacity);
+// d.rtHead must point at 8 * 16 + 2 ints
+int mzr_sweep_route_capacity(int method, const MzrDev &d, hipStream_t stream) {
+  static int cached[16][6];
   int dev = 0, cus = 0, perCu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (method < 0 || method > 5 || hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 16 && cached[dev][method]) return cached[dev][method];
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   hipError_t e = hipErrorInvalidValue;
   switch (method) {
@@ -612,7 +634,25 @@ int mzr_sweep_route_capacity(int method) {
     case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_route<5>, 64, 0); break;
     default: break;
   }
-  return e == hipSuccess ? cus * perCu : 0;
+  if (e != hipSuccess) return 0;
+  const int api = cus * perCu;
+  int peak[2] = {0, 0};
+  int *cnt = d.rtHead + 8 * 16;
+  if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) return 0;
+  dim3 block(64), grid(api + api / 4);
+  switch (method) {
+    case 0: hipLaunchKernelGGL(k_sweep_route<0>, grid, block, 0, stream, d, 0, -1); break;
+    case 1: hipLaunchKernelGGL(k_sweep_route<1>, grid, block, 0, stream, d, 0, -1); break;
+    case 3: hipLaunchKernelGGL(k_sweep_route<3>, grid, block, 0, stream, d, 0, -1); break;
+    case 4: hipLaunchKernelGGL(k_sweep_route<4>, grid, block, 0, stream, d, 0, -1); break;
+    case 5: hipLaunchKernelGGL(k_sweep_route<5>, grid, block, 0, stream, d, 0, -1); break;
+    default: break;
+  }
+  if (hipStreamSynchronize(stream) != hipSuccess) return 0;
+  if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
+  if (dev >= 0 && dev < 16) cached[dev][method] = cap;
+  return cap;
 }
 
 void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {

@@ -25,8 +25,23 @@
 #define MZR_NMOL_DW  20
 #define MZR_NLAKEPAR_DEV 56
 
-// error record written by the first failing lane (atomicCAS on code)
-struct MzrErr { int code; int reach; int step; int where; };
+// error record written by the first failing lane (atomicCAS on code).  The fields behind `where` are filled in by a
+// persistent sweep that gives up waiting (code 93): which wait it was and what it saw, so that the host can tell a
+// result that never became visible from one that was never produced (mzr_host.hip, stallReport).
+#define MZR_BEAT 32   // ints per wavefront in swBeat
+struct MzrErr {
+  int code; int reach; int step; int where;
+  int s;            // launch of the skewed schedule the waiting item belongs to
+  int depReach;     // reach whose progress word the lane polled (internal index)
+  int seen, need;   // the word it last saw, the step count it needs
+  int queue, xcc;   // ticket queue the wavefront was serving / XCC it runs on
+  int lane, nBad;   // first unsatisfied lane of the wavefront, number of unsatisfied lanes
+  long long waited; // ticks of the 100 MHz clock since the polled words last changed
+  int heads[8];     // ticket heads at the time
+  int nSlow; int raisedAt;            // (MZR_SWEEP_DEBUG) passes that took longer than 10 ms from the end of their wait to their publish; low word of the clock at the raise
+  int slowT[32][24];                  // ... and (builds with -DMZR_SWEEP_TRACE) the clock at every section boundary of that pass, relative to the end of its wait
+  int slow[32][8];                    // wavefront, launch, item, ticks, HW_ID, XCC, low word of the clock at the publish, -
+};
 
 // Static description of a reach that routes KWT particles, packed by the host into one 64-byte line
 // (kwt_route.f90 reads the same values from NETOPO / RPARAM): everything the kernel would otherwise
@@ -163,6 +178,8 @@ struct MzrDev {
   const int *rtItemInfo;      // [nItems] stage | 1 << 30 when the item holds lakes (their plain state needs fences)
   const int *rtRA, *rtP;      // per launch: first active item, ticket prefix per queue (as swRA / swP)
   int *rtHead;                // [8][16] ticket counters
+  int *swBeat;                // [wavefronts][8] what every wavefront of a persistent sweep is doing (launch, item, queue, phase, items done): only with MZR_SWEEP_DEBUG=1
+  long long stallTicks;       // a polling wavefront gives up (code 93) when nothing it polls has changed for this many ticks of the 100 MHz clock
   MzrKwtStat *kwtStat;
   unsigned long long *dbgCycles;   // [32] per-section wave cycles (only with -DMZR_KWT_TIMING)
   MzrErr *err;
@@ -172,6 +189,59 @@ __device__ __forceinline__ void mzr_raise(const MzrDev &d, int code, int reach, 
   if (atomicCAS(&d.err->code, 0, code) == 0) {
     d.err->reach = reach; d.err->step = step; d.err->where = where;
   }
+}
+// a wavefront of a persistent sweep gives up waiting: the record says what it waited for (one lane calls this)
+__device__ __noinline__ void mzr_raise_stall(const MzrDev &d, int where, int reach, int s, int depReach, int seen, int need, int queue,
+                                             int lane, int nBad, long long waited, const int *heads) {
+  if (atomicCAS(&d.err->code, 0, 93) == 0) {
+    MzrErr *e = d.err;
+    e->reach = reach; e->step = -1; e->where = where; e->s = s; e->depReach = depReach; e->seen = seen; e->need = need;
+    e->queue = queue; e->xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7; e->lane = lane; e->nBad = nBad; e->waited = waited;
+    e->raisedAt = (int)wall_clock64();
+    for (int q = 0; q < 8; ++q) e->heads[q] = heads ? __hip_atomic_load(heads + q * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+  }
+}
+
+// Census mode of a persistent sweep kernel: every wavefront counts itself in (cnt[0]), notes the highest count seen
+// (cnt[1]), stays for 300 us and counts itself out; workgroups the device cannot hold start after others have left.
+__device__ __forceinline__ void mzr_census(int *cnt) {
+  if ((threadIdx.x & 63) == 0) {
+    const int n = atomicAdd(cnt, 1) + 1;
+    atomicMax(cnt + 1, n);
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 30000) __builtin_amdgcn_s_sleep(32);
+    atomicSub(cnt, 1);
+  }
+}
+
+// Start of a wavefront of a persistent sweep (whole wavefront calls; head = the sweep's ticket heads, whose words 8*16+2 ..
+// hold the launch's arrival count, the number of wavefronts that joined, the time of the first arrival (two words) and,
+// from 8*16+16 on, a histogram of the start delays).  Returns the wavefront's number among those that joined, or -1 when it started late
+// -- more than MZR_SWEEP_LATE_TICKS (100 MHz) after the first wavefront of the launch, because its workgroup had to wait
+// for a slot (the grid did not fit the device, or another kernel held the slot) -- and must not join: the tickets do not
+// need it, and a persistent kernel with workgroups launched behind time was measured (profiles/r03_soak.md) to freeze, now
+// and then, the memory instructions of exactly those wavefronts for as long as the others keep running.
+#ifndef MZR_SWEEP_LATE_TICKS
+#define MZR_SWEEP_LATE_TICKS 2000
+#endif
+__device__ __forceinline__ int mzr_sweep_join(int *head) {
+  int j = 0;
+  if ((threadIdx.x & 63) == 0) {
+    const long long now = wall_clock64();
+    const unsigned long long t0 = atomicCAS((unsigned long long *)(head + 8 * 16 + 4), 0ull, (unsigned long long)now);
+    const int arr = atomicAdd(head + 8 * 16 + 2, 1);
+    const long long dt = t0 ? now - (long long)t0 : 0;
+    atomicAdd(head + 8 * 16 + 16 + (dt <= 0 ? 0 : min(31, 64 - __clzll(dt))), 1);      // delays below 2^k ticks
+    // (the first 64 to arrive always join -- a launch on a GPU that has just woken up can be slow as a whole -- so that
+    // every queue has servers whatever happens: joiners 0..63 take queue j % 8)
+    if (dt > MZR_SWEEP_LATE_TICKS && arr >= 64) j = -1;
+    else j = atomicAdd(head + 8 * 16 + 3, 1);
+  }
+  return __builtin_amdgcn_readfirstlane(j);
+}
+// before every launch of a sweep: arrival counters and start time back to zero (threads 8..11 of the heads kernel)
+__device__ __forceinline__ void mzr_sweep_join_reset(int *head) {
+  if (threadIdx.x >= 8 && threadIdx.x < 12) head[8 * 16 + 2 + (threadIdx.x - 8)] = 0;
 }
 
 // Accesses to data that another wavefront of the SAME launch produces or consumes (persistent sweep):

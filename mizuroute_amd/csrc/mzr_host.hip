@@ -29,7 +29,7 @@ void mzr_launch_basin_chunk(const MzrDev &d, int tBegin, int tEnd, hipStream_t s
 void mzr_launch_basin_state(const MzrDev &d, hipStream_t stream);
 void mzr_launch_basin_solute(const MzrDev &d, hipStream_t stream);
 void mzr_launch_tracer_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
-int mzr_sweep_route_capacity(int method);
+int mzr_sweep_route_capacity(int method, const MzrDev &d, hipStream_t stream);
 void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream);
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
                              double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
@@ -43,7 +43,7 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
                           int ltBegin, int ltEnd, hipStream_t stream);
 
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream);
-int mzr_sweep_kwt_capacity(bool full);
+int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
 void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream);
 
@@ -200,6 +200,7 @@ struct mzr_domain {
   bool kwtAllValid = false;
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
+  DBuf<int> swBeat;                                // [swCap][8] per-wavefront record of the sweep (MZR_SWEEP_DEBUG=1)
   DBuf<int> rtItemR, rtItemInfo, rtRA, rtP;        // items of the Eulerian sweeps (k_sweep_route) and their per-launch tables
   int tracer = 0, solSteps = 0, solCur = 0; double time_conv_solute = 1.0, mass_conv_solute = 1.0;      // constituent routing (mzr_set_tracer / mzr_set_solute)
   DBuf<double> solSrc, solInst, basSol, solS[2]; hipEvent_t trEvent = nullptr;
@@ -207,6 +208,7 @@ struct mzr_domain {
   DBuf<int> gaugeFirst, gaugeNext, obsHave; DBuf<double> obsVal;
   std::vector<int> h_rtStage; int rtItems = 0, rtTablesW = -1, rtMaxAct = 0;
   std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
+  std::vector<int> h_sigma, h_swCode, h_swP, h_swRA;   // host copies for the stall report of a sweep that gave up (code 93)
   std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
   int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1;
   long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
@@ -266,7 +268,8 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.basarea = h->par[8].p; d.minflow = h->par[10].p;
   d.kwK = h->kwK.p; d.kwCW = h->kwCW.p;
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
-  { const char *e = getenv("MZR_MC_TAIL_TOL"); d.mcTailTol = e ? atof(e) : 1.e-7; }
+  d.mcTailTol = h->cfg.mcTailTol >= 0.0 ? h->cfg.mcTailTol : 0.0;
+  d.stallTicks = (long long)((h->cfg.sweepTimeout > 0.0 ? h->cfg.sweepTimeout : 8.0) * 1.e8);      // wall_clock64: 100 MHz
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
   d.is_flux_wm = h->cfg.is_flux_wm; d.wm = (h->cfg.is_flux_wm && h->wmSteps > 0) ? h->wm.p : nullptr;
@@ -278,7 +281,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
   d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtRoutedC = h->kwtRoutedC.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
   d.kwDone = h->kwDone.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
-  d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p;
+  d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p; d.swBeat = h->swBeat.p;
   d.kwtHead = h->kwtHead.p; d.nHead = (int)h->h_kwtHead.size(); d.nDepLight = (int)h->h_kwtDepLight.size();
   d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nC = (int)h->h_swC.size(); d.nG = (int)h->h_kwtGeneric.size();
   d.kwtStat = h->countTraffic ? h->kwtStat.p : nullptr; d.err = h->err.p; d.dbgCycles = h->dbgCycles.p;
@@ -310,6 +313,135 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.solFlux = rb.solFlux.p; d.solMass = rb.solMass.p; d.trVol0 = h->tracer ? rb.trVol0.p : nullptr;
 }
 
+
+// A wavefront of the persistent KWT sweep gave up waiting (code 93).  What it recorded, set against the progress words
+// and ticket heads as they are in memory now and against the host's copy of the schedule, tells the cases apart:
+// the step it waited for IS in memory (a result that did not become visible to the poller), the ticket that would
+// produce it was drawn and never finished, or it was never drawn (a queue nobody serves).
+std::string stallReportKwt(mzr_handle h, const MzrErr &e) {
+  char b[512];
+  std::string out;
+  const int N = h->N;
+  std::vector<int> done(N, 0), heads(8 * 16 + 16, 0);
+  if (h->kwDone.p) (void)hipMemcpy(done.data(), h->kwDone.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost);
+  if (h->swHead.p) (void)hipMemcpy(heads.data(), h->swHead.p, heads.size() * sizeof(int), hipMemcpyDeviceToHost);
+  const int W = h->swTablesW;
+  auto steps = [&](int r) { return (r >= 0 && r < N) ? (done[r] & 0xffff) : -1; };
+  auto sig = [&](int r) { return (r >= 0 && r < N && !h->h_sigma.empty()) ? h->h_sigma[r] : -1; };
+  // reach -> item of the sweep
+  std::vector<int> itemOf(N, -1);
+  {
+    const std::vector<MzrKwtRec> *lists[5] = {&h->h_swA, &h->h_swB, &h->h_kwtGeneric, nullptr, &h->h_swC};
+    const int per[5] = {4, 8, 1, 64, 16};
+    for (size_t i = 0; i < h->h_swCode.size(); ++i) {
+      const int cls = h->h_swCode[i] >> 28, bi = h->h_swCode[i] & 0x0fffffff;
+      if (cls == 3) { for (size_t k = (size_t)bi * 64; k < std::min(h->h_kwtDepLight.size(), (size_t)(bi + 1) * 64); ++k) itemOf[h->h_kwtDepLight[k]] = (int)i; continue; }
+      if (cls < 0 || cls > 4 || !lists[cls]) continue;
+      const std::vector<MzrKwtRec> &v = *lists[cls];
+      for (size_t k = (size_t)bi * per[cls]; k < std::min(v.size(), (size_t)(bi + 1) * per[cls]); ++k) if (v[k].r >= 0 && v[k].r < N) itemOf[v[k].r] = (int)i;
+    }
+  }
+  const int nL = (int)h->h_swRA.size();
+  auto ticketOf = [&](int item, int s, int &q) {      // ticket number of (item, launch s) in its queue, -1 if outside the tables
+    q = item & 7;
+    if (item < 0 || s < 0 || s >= nL) return -1;
+    const int a = h->h_swRA[s];
+    const int first = a + (((q - a) % 8 + 8) % 8);
+    if (item < first) return -1;
+    return h->h_swP[(size_t)s * 8 + q] + (item - first) / 8;
+  };
+  auto launchOfHead = [&](int q) {      // launch the next ticket of queue q belongs to
+    const int k = heads[q * 16];
+    int lo = 0, hi = nL;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (h->h_swP[(size_t)mid * 8 + q] <= k) lo = mid; else hi = mid - 1; }
+    return lo;
+  };
+  snprintf(b, sizeof b, "MZR STALL kwt sweep: window of %d steps, %d stages, %d items, %d wavefronts; waiting reach %d (stage %d) in launch %d = its step %d, "
+           "lane %d of %d unsatisfied lanes, XCC %d, %.2f s without progress; ", W, h->nStages, h->swItems, h->swWaves, e.reach, sig(e.reach), e.s,
+           e.s - sig(e.reach), e.lane, e.nBad, e.xcc, (double)e.waited * 1.e-8);
+  out += b;
+  const int u = e.depReach;
+  const char *rel = u == e.reach ? "itself" : (e.reach >= 0 && e.reach < N && h->h_down[e.reach] == u) ? "its downstream reach" : "an upstream reach";
+  snprintf(b, sizeof b, "polled %s %d (stage %d): saw word 0x%08x = %d steps, needs %d; in memory now 0x%08x = %d steps -> %s; ", rel, u, sig(u), (unsigned)e.seen,
+           e.seen & 0xffff, e.need, (u >= 0 && u < N) ? (unsigned)done[u] : 0u, steps(u),
+           steps(u) >= e.need ? "PRODUCED BUT NOT SEEN by the poller" : "not produced");
+  out += b;
+  if (u >= 0 && u < N && steps(u) < e.need) {
+    const int su = steps(u) + sig(u);      // launch of the step the reach has not finished
+    int q = 0;
+    const int it = itemOf[u], tk = it >= 0 ? ticketOf(it, su, q) : -1;
+    snprintf(b, sizeof b, "its next step %d is launch %d, item %d (class %d), queue %d ticket %d, head of that queue now %d -> %s; ", steps(u), su, it,
+             it >= 0 ? h->h_swCode[it] >> 28 : -1, q, tk, heads[q * 16], tk < 0 ? "?" : heads[q * 16] > tk ? "ticket DRAWN, step not published" : "ticket NOT DRAWN");
+    out += b;
+    // what that step itself waits for
+    if (u < (int)h->h_down.size()) {
+      std::vector<int> up(1, 0);
+      int u0 = 0, nu = 0;
+      (void)hipMemcpy(&u0, h->upStart.p + u, sizeof(int), hipMemcpyDeviceToHost);
+      nu = h->h_nUp[u];
+      std::string deps;
+      for (int k = 0; k < nu; ++k) { snprintf(b, sizeof b, " up %d:%d", u0 + k, steps(u0 + k)); deps += b; }
+      snprintf(b, sizeof b, " down %d:%d", h->h_down[u], steps(h->h_down[u])); deps += b;
+      out += "its own dependencies (reach:steps)" + deps + "; ";
+    }
+  }
+  // frontier: the lowest launch that still has an unfinished routed reach
+  long long lowest = 1LL << 60; int nLow = 0, rLow = -1;
+  for (int r = 0; r < N; ++r) {
+    if (itemOf[r] < 0) continue;
+    const int st = steps(r);
+    if (st >= W) continue;
+    const long long l = (long long)st + sig(r);
+    if (l < lowest) { lowest = l; nLow = 1; rLow = r; } else if (l == lowest) ++nLow;
+  }
+  snprintf(b, sizeof b, "frontier: launch %lld has %d unfinished reaches (e.g. %d); heads (queue:ticket@launch) now", lowest, nLow, rLow);
+  out += b;
+  for (int q = 0; q < 8; ++q) { snprintf(b, sizeof b, " %d:%d@%d", q, heads[q * 16], nL > 0 ? launchOfHead(q) : -1); out += b; }
+  snprintf(b, sizeof b, "; wavefronts of the launch that arrived %d, joined %d", heads[8 * 16 + 2], heads[8 * 16 + 3]);
+  out += b;
+  out += "; heads when the wavefront gave up";
+  for (int q = 0; q < 8; ++q) { snprintf(b, sizeof b, " %d", e.heads[q]); out += b; }
+  if (rLow >= 0) {
+    int q = 0;
+    const int it = itemOf[rLow], tk = ticketOf(it, (int)lowest, q);
+    snprintf(b, sizeof b, "; frontier reach %d: item %d queue %d ticket %d (%s)", rLow, it, q, tk, tk < 0 ? "?" : heads[q * 16] > tk ? "drawn" : "not drawn");
+    out += b;
+  }
+  if (h->swBeat.p) {      // what every wavefront was doing: launch, item, queue, phase (1 drew a ticket, 2 waiting, 3 computing, 4 published, 9 left), items done, XCC, ticket
+    const int nw = std::max(h->swWaves, 0);
+    std::vector<int> bt8((size_t)nw * MZR_BEAT, 0), bt((size_t)nw * 8, 0);
+    if (nw) (void)hipMemcpy(bt8.data(), h->swBeat.p, bt8.size() * sizeof(int), hipMemcpyDeviceToHost);
+    for (int w = 0; w < nw; ++w) for (int k = 0; k < 8; ++k) bt[(size_t)w * 8 + k] = bt8[(size_t)w * MZR_BEAT + k];
+    int phase[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, perX[8] = {0, 0, 0, 0, 0, 0, 0, 0}, servQ[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long minS[8], maxS[8];
+    for (int q = 0; q < 8; ++q) { minS[q] = 1LL << 60; maxS[q] = -1; }
+    for (int w = 0; w < nw; ++w) {
+      const int *x = &bt[(size_t)w * 8];
+      ++phase[std::min(std::max(x[3], 0), 9)];
+      if (x[3] == 0) continue;
+      ++perX[x[5] & 7];
+      if (x[3] != 9 && x[4] > 0) { ++servQ[x[2] & 7]; minS[x[2] & 7] = std::min<long long>(minS[x[2] & 7], x[0]); maxS[x[2] & 7] = std::max<long long>(maxS[x[2] & 7], x[0]); }
+    }
+    snprintf(b, sizeof b, "; wavefronts by phase: never started %d, drew %d, waiting %d, computing %d, published %d, left %d; per XCC", phase[0], phase[1], phase[2], phase[3], phase[4], phase[9]);
+    out += b;
+    for (int q = 0; q < 8; ++q) { snprintf(b, sizeof b, " %d", perX[q]); out += b; }
+    out += "; serving queue (count, launches held)";
+    for (int q = 0; q < 8; ++q) { snprintf(b, sizeof b, " %d:%d[%lld..%lld]", q, servQ[q], servQ[q] ? minS[q] : -1, maxS[q]); out += b; }
+    // who holds the frontier's unfinished items
+    int shown = 0;
+    for (int r = 0; r < N && shown < 6; ++r) {
+      if (itemOf[r] < 0 || steps(r) >= W || (long long)steps(r) + sig(r) != lowest) continue;
+      int holder = -1;
+      for (int w = 0; w < nw; ++w) if (bt[(size_t)w * 8 + 3] != 0 && bt[(size_t)w * 8] == (int)lowest && bt[(size_t)w * 8 + 1] == itemOf[r]) { holder = w; break; }
+      if (holder >= 0) snprintf(b, sizeof b, "; frontier reach %d item %d held by wavefront %d (XCC %d, phase %d, ticket %d, items done %d)", r, itemOf[r], holder, bt[(size_t)holder * 8 + 5],
+                                bt[(size_t)holder * 8 + 3], bt[(size_t)holder * 8 + 6], bt[(size_t)holder * 8 + 4]);
+      else snprintf(b, sizeof b, "; frontier reach %d item %d held by NO wavefront", r, itemOf[r]);
+      out += b; ++shown;
+    }
+  }
+  return out;
+}
+
 int checkDeviceError(mzr_handle h) {
   MzrErr e;
   if (hipMemcpy(&e, h->err.p, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, 99, "mzr/hipMemcpy(err) failed");
@@ -332,10 +464,44 @@ int checkDeviceError(mzr_handle h) {
     case 15: what = "kwt_rch/interp_rch/bad bounds"; break;
     case 17: what = "kwt_rch/extract_from_rch/interp_rch/bad bounds"; break;
     case 18: what = "kwt_rch/getusq_rch/lake outlet reach should have one upstream lake"; break;
+    case 20: what = "persistent KWT sweep gave up waiting for a reach it depends on"; break;
+    case 21: what = "persistent sweep of an Eulerian method gave up waiting for a reach it depends on"; break;
   }
-  char buf[512];
-  snprintf(buf, sizeof buf, "main_routing/route_network/%s [reach index %d id %d, window step %d]", what, ext + 1, id, e.step);
-  return fail(h, e.code, buf);
+  char buf[768];
+  snprintf(buf, sizeof buf, "main_routing/route_network/%s [where %d, reach index %d id %d, window step %d]", what, e.where, ext + 1, id, e.step);
+  std::string msg = buf;
+  if (e.code == 93) {
+    snprintf(buf, sizeof buf, " [KWT windows run %lld, steps since the last regrouping %lld]", h->kwtWindows, h->kwtStepsSince);
+    msg += buf;
+    if (e.where >= 30 && e.where < 50) {
+      static const char *tab[] = {"swP[s][q]", "swP[s+1][q]", "swRA[s]", "swLo[item]", "swHi[item]", "swItem[item]", "", "", "", "",
+                                  "record.r", "record.sigma", "record.u0", "record.flags"};
+      snprintf(buf, sizeof buf, " MZR STALE %s: launch %d, index %d, cached value %d, memory holds %d; queue %d, ticket/lane %d, XCC %d", tab[e.where - 30], e.s, e.depReach,
+               e.seen, e.need, e.queue, e.lane, e.xcc);
+      msg += buf;
+    } else
+    if (e.where == 20) {
+      msg += " " + stallReportKwt(h, e);
+      snprintf(buf, sizeof buf, "; slow passes (wait end -> publish > 10 ms): %d", e.nSlow);
+      msg += buf;
+      for (int k = 0; k < std::min(e.nSlow, 32); ++k) {
+        const int *o = e.slow[k];
+        snprintf(buf, sizeof buf, " [wavefront %d launch %d item %d G %d: %.3f s, published %.3f s %s the raise, HW_ID 0x%04x (wave %d simd %d cu %d sh %d se %d) XCC %d]", o[0], o[1], o[2], o[7], o[3] * 1.e-8,
+                 std::abs(o[6] - e.raisedAt) * 1.e-8, (o[6] - e.raisedAt) >= 0 ? "after" : "before", o[4] & 0xffff, o[4] & 15, (o[4] >> 4) & 3, (o[4] >> 8) & 15, (o[4] >> 12) & 1, (o[4] >> 13) & 7, o[5]);
+        msg += buf;
+        msg += " sections(ms since wait end)";
+        for (int j = 0; j < 24; ++j) if (e.slowT[k][j] != 0) { snprintf(buf, sizeof buf, " %d:%.3f", j, e.slowT[k][j] * 1.e-5); msg += buf; }
+      }
+    }
+    else {
+      snprintf(buf, sizeof buf, " MZR STALL route sweep: waiting reach %d in launch %d, lane %d of %d unsatisfied, queue %d, XCC %d, %.2f s without progress; polled reach %d: saw %d, needs %d; heads",
+               e.reach, e.s, e.lane, e.nBad, e.queue, e.xcc, (double)e.waited * 1.e-8, e.depReach, e.seen, e.need);
+      msg += buf;
+      for (int q = 0; q < 8; ++q) { snprintf(buf, sizeof buf, " %d", e.heads[q]); msg += buf; }
+    }
+    fprintf(stderr, "%s\n", msg.c_str());
+  }
+  return fail(h, e.code, msg);
 }
 
 // ---- persistent KWT sweep: host side ------------------------------------------------------------
@@ -344,11 +510,22 @@ int checkDeviceError(mzr_handle h) {
 // The items of launch s are a contiguous range of that list, and the tickets of the kernel number them launch
 // after launch in eight queues (item i belongs to queue i % 8): kwt_sweep_tables makes the per-launch ranges
 // and ticket prefix sums for a window length.
+// Grid of a persistent sweep from the wavefronts the device holds of its kernel (measured, mzr_sweep_*_capacity): a
+// margin below it -- other kernels of the window (hillslope chunks, history sums) come and go beside the sweep, and a
+// sweep with workgroups left waiting for a slot can stall -- times the handle's share of the device.
+int sweepGrid(mzr_handle h, int held) {
+  if (held < 1) return 8;
+  const double share = (h->cfg.sweepShare > 0.0 && h->cfg.sweepShare <= 1.0) ? h->cfg.sweepShare : 1.0;
+  const int g = (int)((held - std::max(64, held / 50)) * share);
+  return std::max(8, g & ~7);
+}
+
 void kwt_build_sweep(mzr_handle h) {
   const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
-  int cap = mzr_sweep_kwt_capacity(full);
-  if (cap < 1) cap = 1024;
-  if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = std::min(cap, v); }
+  if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }      // eight ticket heads (one cache line each), census and arrival counters, histogram of the start delays
+  int cap = 0;
+  { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream)); }
+  if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = v; }      // experiments only: any grid, also one the device does not hold
   h->swCap = cap;
   struct It { int code, lo, hi; };
   std::vector<It> items;
@@ -375,8 +552,9 @@ void kwt_build_sweep(mzr_handle h) {
   if (code.empty()) { code.push_back(0); hi.push_back(-1); }
   (void)hipStreamSynchronize(h->stream);
   h->swItem.upload(code); h->swLo.upload(lo.empty() ? std::vector<int>(1, 1 << 30) : lo); h->swHi.upload(hi);
-  if (!h->swHead.p) { h->swHead.alloc(8 * 16); h->swHead.zero(); }
+  if (!h->swBeat.p && getenv("MZR_SWEEP_DEBUG") && atoi(getenv("MZR_SWEEP_DEBUG")) != 0) { h->swBeat.alloc((size_t)std::max(cap, 8) * MZR_BEAT); h->swBeat.zero(); }
   h->swItems = (int)items.size();
+  h->h_swCode = code;
   h->swTablesW = -1;          // ticket tables have to be made again
 }
 
@@ -451,6 +629,7 @@ void kwt_sweep_tables(mzr_handle h, int W) {
   (void)nI;
   (void)hipStreamSynchronize(h->stream);     // a sweep still in flight reads the old tables
   h->swRA.upload(ra); h->swP.upload(P);
+  h->h_swRA = ra; h->h_swP = P;
   h->swWaves = h->swItems > 0 ? std::max(8, std::min(h->swCap, maxAct)) : 0;
   h->swTablesW = W;
 }
@@ -464,6 +643,12 @@ void mzr_default_config(mzr_config *c) {
   c->dt = 3600.0; c->nRoutes = 1; c->routeMethods[0] = MZR_KWT;
   c->doesBasinRoute = 1; c->hw_drain_point = 2; c->min_length_route = 0.0; c->runoffMin = 0.0;
   c->negRunoffTol = -1.e-3; c->time_conv = 1.0; c->length_conv = 1.0; c->maxWindow = 64; c->device = 0;
+  // the two knobs below can be preset from the environment (tests, tools); a host sets the fields
+  c->mcTailTol = 1.e-7;
+  if (const char *e = getenv("MZR_MC_TAIL_TOL")) c->mcTailTol = atof(e);
+  c->sweepShare = 1.0;
+  c->sweepTimeout = 8.0;
+  if (const char *e = getenv("MZR_SWEEP_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->sweepTimeout = v; }
 }
 
 int mzr_create(const mzr_config *cfg, mzr_handle *out) {
@@ -593,6 +778,7 @@ int mzr_set_network(mzr_handle h, int N, int H, const int *downIndex, const int 
     }
     h->reachId.assign(N, 0);
     for (int i = 0; i < N; ++i) h->reachId[i] = reachId ? reachId[i] : i + 1;
+    h->h_sigma = sigma;
     h->sigma.upload(sigma); h->upStart.upload(upStart); h->nUp.upload(nUp); h->nGood.upload(nGood);
     h->goodMask.upload(gmask); h->isOutlet.upload(isOut);
     h->hruOff.upload(hOff); h->hruIdx.upload(hIdx); h->hruW.upload(hW);
@@ -1009,8 +1195,8 @@ int mzr_init_state(mzr_handle h) {
       }
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
       if (m != MZR_KWT) {      // persistent sweep of an Eulerian method
-        rb.rtDone.alloc(N); rb.rtDone.zero(); rb.rtHead.alloc(8 * 16); rb.rtHead.zero();
-        rb.rtCap = mzr_sweep_route_capacity(m);
+        rb.rtDone.alloc(N); rb.rtDone.zero(); rb.rtHead.alloc(8 * 16 + 16 + 32); rb.rtHead.zero();
+        { MzrDev dc; memset(&dc, 0, sizeof dc); dc.rtHead = rb.rtHead.p; dc.err = h->err.p; rb.rtCap = sweepGrid(h, mzr_sweep_route_capacity(m, dc, h->stream)); }
         if (h->rtTablesW != -2) { rt_build_items(h); h->rtTablesW = -2; }      // once per mzr_init_state (-2: built, tables not yet)
       }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
@@ -1183,6 +1369,23 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // hold the imported row 0 of this window)
   if (h->lastW > 0)
     hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot);
+  // Which methods go through a persistent sweep (decided here because it decides their stream).  KWT: always (one launch
+  // per chunk of the skewed schedule, progress words instead of kernel boundaries; single steps too: 842 dependent stages
+  // cost 15 ms per step as hand-offs, 18 ms as launches); MZR_KWT_SWEEP=0 keeps one launch per stage (k_stage_kwt), the
+  // form the sweep is tested against.  The Eulerian methods (k_sweep_route): where launches are the cost -- single steps
+  // and short windows (mzr_step: 42 ms instead of 49 ms per step of the 625 k-reach IRF + Muskingum-Cunge shard) -- and not
+  // in long windows, where these kernels stream their per-reach state at 1.4-1.7 TB/s either way and plain cached accesses
+  // from full-width launches move more bytes than sc1 accesses from resident wavefronts (6.1 against 4.9 x 10^9
+  // reach-steps/s on the same shard).  Default: windows of up to 8 steps; MZR_ROUTE_SWEEP=1 / 0 forces it (tests run both).
+  bool sweep = true;
+  if (const char *e = getenv("MZR_KWT_SWEEP")) sweep = atoi(e) != 0;
+  const int kwtIx = idxOf(h, MZR_KWT);
+  if (kwtIx < 0 || h->swItems < 1 || W > 65535) sweep = false;      // (progress words hold the step count in 16 bits)
+  bool rtSweep = W <= 8;
+  if (const char *e = getenv("MZR_ROUTE_SWEEP")) rtSweep = atoi(e) != 0;
+  if (h->rtItems < 1) rtSweep = false;
+  bool anyPersistent = sweep;
+  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (h->route[ix].method != MZR_KWT && rtSweep && h->route[ix].rtCap >= 1) anyPersistent = true;
   // hillslope pre-pass.  The fold is causal and launch s of the sweep only touches steps <= s, so only the
   // first chunk has to be ready before the sweep starts; the others are produced on a second stream
   // while the sweep runs and the sweep waits for chunk c right before launch s = c * chunk.
@@ -1191,7 +1394,11 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // several routing methods are independent of each other once the hillslope series exist: each gets its own
   // stream (their stage launches are small and latency-bound, so they fill each other's gaps)
   const bool multi = h->cfg.nRoutes > 1;
-  bool chunked = nChunks > 2 && !multi;
+  // ... unless the window goes through a persistent sweep: that is ONE launch for the whole window, made when nothing else
+  // is being dispatched -- a sweep some of whose workgroups start behind time (because another kernel holds their slots
+  // for a while) was measured to freeze the memory instructions of exactly those wavefronts now and then, for as long as
+  // the others keep running (ierr 93; profiles/r03_soak.md).  The whole hillslope pre-pass then runs first.
+  bool chunked = nChunks > 2 && !multi && !anyPersistent;
   if (const char *e = getenv("MZR_BASIN_CHUNKED")) chunked = chunked && atoi(e) != 0;   // debugging aid
   if (!chunked) mzr_launch_basin(d, st);
   else {
@@ -1214,7 +1421,10 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   MzrDev dr[6];
   for (int ix = 0; ix < nR; ++ix) {
     rst[ix] = st;
-    if (multi && ix > 0) {
+    // persistent sweeps of several methods run one after the other on the handle's stream: each is sized to fill the
+    // device, and a sweep whose grid does not fit beside another one can stall
+    const bool persistent = h->route[ix].method == MZR_KWT ? sweep : (rtSweep && h->route[ix].rtCap >= 1);
+    if (multi && ix > 0 && !persistent) {
       if (!h->routeStream[ix]) { (void)hipStreamCreateWithFlags(&h->routeStream[ix], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&h->routeEvent[ix], hipEventDisableTiming); }
       rst[ix] = h->routeStream[ix];
     }
@@ -1225,16 +1435,9 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (multi) {
     if (!h->routeEvent[0]) (void)hipEventCreateWithFlags(&h->routeEvent[0], hipEventDisableTiming);
     (void)hipEventRecord(h->routeEvent[0], st);                    // hillslope series of the window (and everything before) done
-    for (int ix = 1; ix < nR; ++ix) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
+    for (int ix = 1; ix < nR; ++ix) if (rst[ix] != st) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
   }
   const bool prof = h->profiling;
-  // KWT goes through the persistent sweep (one launch per chunk of the skewed schedule, progress counters instead
-  // of kernel boundaries), single steps too: 842 dependent stages cost 15 ms per step as hand-offs, 18 ms as
-  // launches.  MZR_KWT_SWEEP=0 keeps one launch per stage (k_stage_kwt), the form the sweep is tested against.
-  bool sweep = true;
-  if (const char *e = getenv("MZR_KWT_SWEEP")) sweep = atoi(e) != 0;
-  const int kwtIx = idxOf(h, MZR_KWT);
-  if (kwtIx < 0 || h->swItems < 1 || W > 65535) sweep = false;      // (progress words hold the step count in 16 bits)
   if (sweep) {
     kwt_sweep_tables(h, W);
     RouteBufs &rb = h->route[kwtIx];
@@ -1243,28 +1446,16 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     dk.swRA = h->swRA.p; dk.swP = h->swP.p;
     dk.kwtLight = h->kwtDepLight.p;
     const int nLaunch = nS + W - 1;
-    for (int c = 0; c * CH < nLaunch; ++c) {
-      if (chunked && c > 0 && c < nChunks) (void)hipStreamWaitEvent(sx, h->basinEvents[c], 0);
-      if (c * CH < W) mzr_launch_kwt_window_init(dk, c * CH, std::min(W, (c + 1) * CH), sx);
-      if (prof) {
-        if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
-        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
-      }
-      mzr_launch_sweep_kwt(dk, h->swWaves, c * CH, std::min(nLaunch, (c + 1) * CH), sx);
-      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
-      ++rb.nLaunches;
+    mzr_launch_kwt_window_init(dk, 0, W, sx);
+    if (prof) {
+      if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+      (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
     }
+    mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
+    if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+    ++rb.nLaunches;
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
   }
-  // The Eulerian methods have a persistent sweep as well (k_sweep_route): one kernel per chunk of the skewed schedule
-  // instead of `stages + W` launches.  It pays where launches are the cost -- single steps and short windows (mzr_step:
-  // 42 ms instead of 49 ms per step of the 625 k-reach IRF + Muskingum-Cunge shard) -- and not in long windows, where
-  // these kernels stream their per-reach state at 1.4-1.7 TB/s either way and plain cached accesses from full-width
-  // launches move more bytes than sc1 accesses from resident wavefronts (6.1 against 4.9 x 10^9 reach-steps/s on the same
-  // shard).  Default: windows of up to 8 steps; MZR_ROUTE_SWEEP=1 / 0 forces it on / off (the tests run both).
-  bool rtSweep = W <= 8;
-  if (const char *e = getenv("MZR_ROUTE_SWEEP")) rtSweep = atoi(e) != 0;
-  if (h->rtItems < 1) rtSweep = false;
   bool anyStage = false;
   for (int ix = 0; ix < nR; ++ix) {
     RouteBufs &rb = h->route[ix];
@@ -1277,16 +1468,13 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     const int nLaunch = nS + W - 1;
     const int waves = std::max(8, std::min(rb.rtCap, h->rtMaxAct));
     (void)hipMemsetAsync(rb.rtDone.p, 0, (size_t)N * sizeof(int), sx);
-    for (int c = 0; c * CH < nLaunch; ++c) {
-      if (chunked && c > 0 && c < nChunks) (void)hipStreamWaitEvent(sx, h->basinEvents[c], 0);
-      if (prof) {
-        if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
-        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
-      }
-      mzr_launch_sweep_route(rb.method, dx, waves, c * CH, std::min(nLaunch, (c + 1) * CH), sx);
-      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
-      ++rb.nLaunches;
+    if (prof) {
+      if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+      (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
     }
+    mzr_launch_sweep_route(rb.method, dx, waves, 0, nLaunch, sx);
+    if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+    ++rb.nLaunches;
   }
   for (int s = 0; s < nS + W - 1; ++s) {
     if (!anyStage) break;
@@ -1345,7 +1533,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     if (h->route[ix].method == MZR_KWT) mzr_launch_accum_qsum(h->route[ix].Q.p, h->route[ix].qsum.p, N, W, rst[ix]);
     h->route[ix].reachSteps += (long long)N * W;
     h->route[ix].meanSteps += W;
-    if (multi && ix > 0) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
+    if (multi && ix > 0 && rst[ix] != st) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
   }
   if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
   if (h->histFlags & MZR_H_RUNOFF) {      // histVars_data.f90:196-211: basin runoff, instantaneous and delayed runoff into the reaches, step by step
@@ -1891,6 +2079,16 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth) {
 int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems) {
   if (!h || !h->haveState) return 1;
   *nWaves = h->swWaves; *capacity = h->swCap; *nItems = h->swItems;
+  return 0;
+}
+
+int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long long *hist32) {
+  if (!h || !h->swHead.p) return 1;
+  int v[16 + 32];
+  if (hipMemcpy(v, h->swHead.p + 8 * 16, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, 92, "mzr_get_sweep_arrivals/hipMemcpy failed");
+  if (arrivedLast) *arrivedLast = v[2];
+  if (joinedLast) *joinedLast = v[3];
+  if (hist32) for (int k = 0; k < 32; ++k) hist32[k] = v[16 + k];
   return 0;
 }
 

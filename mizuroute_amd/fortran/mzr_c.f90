@@ -28,6 +28,10 @@ MODULE mzr_c
     integer(c_int)  :: maxWindow
     integer(c_int)  :: device
     integer(c_int)  :: is_flux_wm
+    integer(c_int)  :: reserved0
+    real(c_double)  :: mcTailTol       ! Muskingum-Cunge closed-form tail of the sub-step sum (0 = iterate every sub-step)
+    real(c_double)  :: sweepShare      ! share of the device's wavefront slots this handle's persistent sweeps fill (1 = all)
+    real(c_double)  :: sweepTimeout    ! seconds without progress before a persistent sweep gives up (ierr 93)
   end type mzr_config
 
   public :: mzr_default_config, mzr_create, mzr_destroy, mzr_last_error, mzr_set_network, mzr_set_param, &

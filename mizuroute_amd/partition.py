@@ -178,12 +178,15 @@ class PartitionedRouter:
         self.part, self.rank, self.transport, self.alloc, self.W = part, rank, transport, alloc, max_window
         td = part.trib[rank]
         self.trib_spec = td
-        self.trib = make_domain(td, export_reaches=td.export_local) if td.n_real > 0 else None
         self.main_spec = part.main if (rank == 0 and part.main is not None) else None
+        # rank 0 routes its tributary window k and the mainstem window k-1 side by side on one GPU: the two persistent
+        # sweeps share the device's wavefront slots out (a sweep whose grid does not fit the device can stall)
+        both = td.n_real > 0 and self.main_spec is not None
+        self.trib = make_domain(td, export_reaches=td.export_local, sweep_share=0.8 if both else 1.0) if td.n_real > 0 else None
         self.main = None
         if self.main_spec is not None:
             ms = self.main_spec
-            self.main = make_domain(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good)
+            self.main = make_domain(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good, sweep_share=0.2 if both else 1.0)
         self.n_routes = None
         self._pending = None            # (w, t_start, runoff_main_ptr, record, keep) of the window whose exchange is still due
 

@@ -140,3 +140,37 @@ def test_config_parity_50k(cfg, hip_lib, oracle_lib):
         assert rep["max_rel"] <= REL_TOL, (cfg, meth, rep)
     if m.KWT in methods:
         assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
+
+
+def test_bench_operating_point_sweep_equals_stage_launches(hip_lib, monkeypatch):
+    """The driver's bench command at its own operating point: 100 000 reaches, windows of 16 384 steps, 25 windows queued
+    without a synchronisation in between (5 + 20, as `bench.py --steps 20 --warmup 5` does), with the regroupings that
+    fall into them (before windows 2, 3, 11 and 19).  The persistent sweep must finish (no ierr 93) and leave the same bits
+    as one launch per stage (MZR_KWT_SWEEP=0): particle state, last discharge and the interval mean of every reach."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    N, W, NWIN = 100_000, 16384, 25
+    net = m.make_network(N, seed=20240529)
+    frac, _, _ = _uh(net)
+    pool = [bench.device_runoff(torch, net.H, W, k * W, 7, dev) for k in range(2)]
+    torch.cuda.synchronize()
+
+    def route(sweep):
+        monkeypatch.setenv("MZR_KWT_SWEEP", "1" if sweep else "0")
+        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W)
+        for k in range(NWIN):
+            dom.run_device(W, k * W * DT, pool[k % 2].data_ptr())
+            if k == 4:
+                dom.sync()                      # end of the bench's warm-up
+        dom.sync()
+        out = dom.kwt_state(), dom.flux(m.KWT, m.api.F_Q), dom.mean_q(m.KWT)
+        assert dom.sweep_info()[2] > 1000
+        dom.close()
+        return out
+
+    sa, Qa, Ma = route(True)
+    sb, Qb, Mb = route(False)
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), "particle state differs between the sweep and one launch per stage"
+    assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb)
+    assert np.isfinite(Qa).all() and (Qa >= 0).all() and sa[0].max() <= 20
