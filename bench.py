@@ -286,28 +286,43 @@ def main():
         for d, _ in doms:
             d.sync()
 
-    torch.cuda.synchronize()
-    run_batches(KW)
-    sync_all()
-    dom.timing(DOM, reset=True)
+    # The line below is printed whatever happens: a failure of the timed region (e.g. ierr 93, the sweep's watchdog) ends up
+    # in its "error" field with value null, and the process exits with 1.
+    error = None
+    elapsed, value, tm = None, None, None
+    try:
+        torch.cuda.synchronize()
+        run_batches(KW)
+        sync_all()
+        dom.timing(DOM, reset=True)
 
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_batches(K)
-    sync_all()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    tm = dom.timing(DOM, reset=True)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    total_reach_steps = float(net.N) * K * W * len(methods)      # every active method routes every reach every step
-    value = total_reach_steps / elapsed
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_batches(K)
+        sync_all()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        tm = dom.timing(DOM, reset=True)
+        if dist is not None:
+            tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        total_reach_steps = float(net.N) * K * W * len(methods)      # every active method routes every reach every step
+        value = total_reach_steps / elapsed
+    except Exception as e:
+        error = f"{type(e).__name__}: {e}"
+    if error is not None:
+        if rank == 0:
+            print(json.dumps({"metric": "reaches*timesteps/s", "value": None, "unit": "reaches*timesteps/s", "n_gpus": world, "steps": K, "warmup": KW,
+                              "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": cfg["workload"], "baseline_config": args.config, "window_steps": W}, "roofline": None,
+                              "cpu_baseline": None, "error": error}))
+        sys.stdout.flush()
+        os._exit(1)
 
     if args.dump:      # per-reach results of everything routed so far, by global reach index
         parts = []
@@ -344,94 +359,125 @@ def main():
         except Exception as e:   # reported, never required
             value_h2d = f"failed: {e}"
 
-    # ---- one main_route-equivalent call per model time step (mzr_step: forcing row in, sweep, sync)
+    # ---- one main_route-equivalent call per model time step (mzr_step), the reference driver's loop
+    # (standalone/route_runoff.f90:80-108): (a) stepBatch = 1, every call routes its step and synchronises (the
+    # coupled-model use); (b) stepBatch = 4096 on a second handle: the calls put their rows aside, the library routes
+    # them as windows, results are fetched once at the end (output frequency) -- host rows, H2D and the Python call
+    # overhead of every step included
     single = None
     if world == 1 and not args.no_single_step and lakes is None:
         n1 = 40
-        rows = pool[0][0][:n1].cpu().numpy()
-        tb = state["t"]
-        dom.step(tb, tb + DT, rows[0])
-        t1 = time.perf_counter()
-        for k in range(1, n1):
-            dom.step(tb + k * DT, tb + (k + 1) * DT, rows[k])
-        el1 = time.perf_counter() - t1
-        state["t"] = tb + n1 * DT
-        single = {"value": float(net.N) * (n1 - 1) * len(methods) / el1, "unit": "reaches*timesteps/s", "ms_per_model_timestep": el1 / (n1 - 1) * 1e3,
-                  "steps": n1 - 1, "what": "mzr_step: host forcing row -> device, one sweep over the stages, results synchronised every step"}
+        try:
+            rows = pool[0][0][:n1].cpu().numpy()
+            tb = state["t"]
+            dom.step(tb, tb + DT, rows[0])
+            t1 = time.perf_counter()
+            for k in range(1, n1):
+                dom.step(tb + k * DT, tb + (k + 1) * DT, rows[k])
+            el1 = time.perf_counter() - t1
+            state["t"] = tb + n1 * DT
+            single = {"value": float(net.N) * (n1 - 1) * len(methods) / el1, "unit": "reaches*timesteps/s", "ms_per_model_timestep": el1 / (n1 - 1) * 1e3,
+                      "steps": n1 - 1, "what": "mzr_step, stepBatch 1: host forcing row -> device, one sweep over the stages, results synchronised every step"}
+        except Exception as e:
+            single = {"value": None, "what": f"failed: {e}"}
+        try:
+            nb, batch = 3 * 4096, 4096
+            rows = pool[1][0][:4096].cpu().numpy()
+            dom2 = m.RoutingDomain(net, DT, methods, frac_future=frac, max_window=batch, device=local_rank, step_batch=batch, **extra)
+            for k in range(batch):                      # one untimed batch: buffers, tables, regrouping
+                dom2.step(k * DT, (k + 1) * DT, rows[k % 4096])
+            dom2.sync()
+            t1 = time.perf_counter()
+            for k in range(batch, batch + nb):
+                dom2.step(k * DT, (k + 1) * DT, rows[k % 4096])
+            q_last = dom2.flux(methods[0])               # fetching a result routes what is pending and synchronises
+            el2 = time.perf_counter() - t1
+            single["pipelined"] = {"value": float(net.N) * nb * len(methods) / el2, "unit": "reaches*timesteps/s", "ms_per_model_timestep": el2 / nb * 1e3,
+                                   "steps": nb, "step_batch": batch, "finite": bool(np.isfinite(q_last).all()),
+                                   "what": "mzr_step, stepBatch 4096: one call per model time step with its host forcing row, routed as windows of 4096, "
+                                           "results fetched once at the end"}
+            dom2.close()
+        except Exception as e:   # reported, never required
+            single["pipelined"] = f"failed: {e}"
 
     # ---- roofline of the dominant kernel (KWT stage sweep), measured live with HIP events around
     # every stage launch on the library's stream, on the window that follows the timed region
     roof, ktf = None, None
-    if args.no_roofline:
-        pass
-    elif world > 1:      # every rank takes part in the profiled window (the exchange is collective)
-        if rank != 0:
+    post_error = None
+    try:
+        if args.no_roofline:
+            pass
+        elif world > 1:      # every rank takes part in the profiled window (the exchange is collective)
+            if rank != 0:
+                dist.barrier()
+                run_batches(1)
+                sync_all()
+        if rank == 0 and not args.no_roofline:
+            dom.timing(DOM, reset=True)
+            dom.set_profiling(1)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t_prof = time.perf_counter()
+            run_batches(1)
+            sync_all()
+            t_prof = time.perf_counter() - t_prof
+            dom.set_profiling(0)
+            pt = dom.timing(DOM, reset=True)
+            ktf = pt["kernel_ms"] * 1e-3 / t_prof if t_prof > 0 else None
+            if not kwt_run:      # Eulerian solvers: SURVEY.md 8(d) byte model of the dominant method, one lane per reach, one launch per stage
+                U = float(net.upIndex.size) / net.N
+                per_rs = float(cfg["bytes"](U))
+                launches = max(1, pt["launches"])
+                achieved = per_rs * pt["reach_steps"] / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
+                roof = {"bound": "hbm", "kernel": f"k_stage<{DOM}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "algorithmic_bytes_per_launch": per_rs * pt["reach_steps"] / launches, "bytes_per_reach_step": per_rs,
+                        "avg_launch_us": pt["kernel_ms"] / launches * 1e3, "launches": launches,
+                        "note": "FP64-transcendental kernel (Newton normal depth, fifth-root powers): far from the HBM roofline by construction; "
+                                "FP64 instruction counts per kernel are in profiles/*_pmc.md"}
+        # particle-traffic counters (device atomics) are collected on one more window so that they do
+        # not disturb the event-timed launches; bytes per reach-step of that window x the reach-steps
+        # of the timed window = algorithmic bytes of the timed window
+        if world > 1 and rank != 0 and not args.no_roofline:
             dist.barrier()
             run_batches(1)
             sync_all()
-    if rank == 0 and not args.no_roofline:
-        dom.timing(DOM, reset=True)
-        dom.set_profiling(1)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t_prof = time.perf_counter()
-        run_batches(1)
-        sync_all()
-        t_prof = time.perf_counter() - t_prof
-        dom.set_profiling(0)
-        pt = dom.timing(DOM, reset=True)
-        ktf = pt["kernel_ms"] * 1e-3 / t_prof if t_prof > 0 else None
-        if not kwt_run:      # Eulerian solvers: SURVEY.md 8(d) byte model of the dominant method, one lane per reach, one launch per stage
-            U = float(net.upIndex.size) / net.N
-            per_rs = float(cfg["bytes"](U))
+        if rank == 0 and not args.no_roofline and kwt_run:
+            dom.set_profiling(2)
+            dom.kwt_traffic(reset=True)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            run_batches(1)
+            sync_all()
+            dom.set_profiling(0)
+            tr = dom.kwt_traffic(reset=True)
+            per_rs = kwt_bytes(tr) / max(1, tr["n_route"] + tr["n_head"])
+            bytes_total = per_rs * pt["reach_steps"]
             launches = max(1, pt["launches"])
-            achieved = per_rs * pt["reach_steps"] / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
-            roof = {"bound": "hbm", "kernel": f"k_stage<{DOM}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": per_rs * pt["reach_steps"] / launches, "bytes_per_reach_step": per_rs,
-                    "avg_launch_us": pt["kernel_ms"] / launches * 1e3, "launches": launches,
-                    "note": "FP64-transcendental kernel (Newton normal depth, fifth-root powers): far from the HBM roofline by construction; "
-                            "FP64 instruction counts per kernel are in profiles/*_pmc.md"}
-    # particle-traffic counters (device atomics) are collected on one more window so that they do
-    # not disturb the event-timed launches; bytes per reach-step of that window x the reach-steps
-    # of the timed window = algorithmic bytes of the timed window
-    if world > 1 and rank != 0 and not args.no_roofline:
-        dist.barrier()
-        run_batches(1)
-        sync_all()
-    if rank == 0 and not args.no_roofline and kwt_run:
-        dom.set_profiling(2)
-        dom.kwt_traffic(reset=True)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        run_batches(1)
-        sync_all()
-        dom.set_profiling(0)
-        tr = dom.kwt_traffic(reset=True)
-        per_rs = kwt_bytes(tr) / max(1, tr["n_route"] + tr["n_head"])
-        bytes_total = per_rs * pt["reach_steps"]
-        launches = max(1, pt["launches"])
-        avg_ms = pt["kernel_ms"] / launches
-        achieved = bytes_total / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "kwt_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if world == 1 and tj.get("reaches") == net.N and tj.get("window") == W:
-                    traffic = tj["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
-        sw = dom.sweep_info()
-        roof = {"bound": "hbm", "kernel": "k_sweep_kwt" if sw[0] > 0 and os.environ.get("MZR_KWT_SWEEP", "1") != "0" else "k_stage_kwt",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_total / launches,
-                "bytes_per_reach_step": per_rs,
-                "avg_launch_us": avg_ms * 1e3, "launches": launches,
-                "particles_per_routed_reach": (tr["w_in"] + tr["w_up"] + tr["w_out"]) / max(1, tr["n_route"])}
+            avg_ms = pt["kernel_ms"] / launches
+            achieved = bytes_total / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "kwt_hbm_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    if world == 1 and tj.get("reaches") == net.N and tj.get("window") == W:
+                        traffic = tj["hbm_bytes_per_launch"]
+                except Exception:
+                    traffic = None
+            sw = dom.sweep_info()
+            roof = {"bound": "hbm", "kernel": "k_sweep_kwt" if sw[0] > 0 and os.environ.get("MZR_KWT_SWEEP", "1") != "0" else "k_stage_kwt",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": bytes_total / launches,
+                    "bytes_per_reach_step": per_rs,
+                    "avg_launch_us": avg_ms * 1e3, "launches": launches,
+                    "particles_per_routed_reach": (tr["w_in"] + tr["w_up"] + tr["w_out"]) / max(1, tr["n_route"])}
 
+
+    except Exception as e:      # reported in "error"; the headline value above stands
+        post_error = f"roofline legs: {type(e).__name__}: {e}"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # reported at N=1 only
         try:
@@ -460,7 +506,7 @@ def main():
                                        "one boundary-record message per partition per window over RCCL p2p")},
             "value_with_h2d": value_h2d, "single_step": single,
             "kwt_sweep_arrivals": dict(zip(("arrived_last", "joined_last", "start_delay_hist_log2_10ns"), dom.sweep_arrivals())) if world == 1 and m.KWT in methods else None,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "error": post_error,
         }
         print(json.dumps(out))
     if dist is not None:

@@ -63,6 +63,10 @@ typedef struct mzr_config {
                                  1).  Handles whose windows run side by side on one GPU (a tributary and the mainstem
                                  domain of rank 0) must share them out: the grids of concurrently running sweeps must
                                  fit the device together                                               */
+  int    stepBatch;           /* mzr_step: 1 (default) = every call routes its step and returns its ierr; n > 1 = up to n
+                                 steps (and at most maxWindow) are put aside and routed as one window when the batch is
+                                 full or anything else is asked of the handle; errors then surface at that later call  */
+  int    reserved1;           /* (padding, keep 0)                                         */
   double sweepTimeout;        /* seconds without any progress on the reaches it waits for after which a wavefront of a
                                  persistent sweep gives up with ierr 93 instead of hanging the device (default 8)      */
 } mzr_config;
@@ -166,7 +170,8 @@ int mzr_set_obs(mzr_handle h, int nSteps, const int *have, const double *obs);
 /* cold start (init_model_data.f90:399-505); must follow the setters above */
 int mzr_init_state(mzr_handle h);
 
-/* One time step == one main_route call (main_route.f90:29): T0,T1 = TSEC(1:2). runoff[nHru]. */
+/* One time step == one main_route call (main_route.f90:29): T0,T1 = TSEC(1:2). runoff[nHru].  With cfg.stepBatch > 1 the
+   call only puts the step aside (see mzr_config); results are identical, bit for bit. */
 int mzr_step(mzr_handle h, double T0, double T1, const double *runoff);
 /* nSteps <= maxWindow steps in one call, time-skewed over the level schedule.
    runoff[nSteps][nHru]; step k covers [t_start + k*dt, t_start + (k+1)*dt]. */

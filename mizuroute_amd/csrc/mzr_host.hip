@@ -241,6 +241,10 @@ struct mzr_domain {
   bool profiling = false;       // HIP events around every stage launch
   bool countTraffic = false;    // KWT particle-traffic counters (atomics: not for timed runs)
   long long stepsDone = 0, totalSteps = 0;
+  // steps handed over one at a time (mzr_step with stepBatch > 1): rows wait in page-locked host memory (two buffers, filled
+  // alternately) until the batch is full or somebody asks for a result, and are then routed as one window
+  double *stepHost[2] = {nullptr, nullptr}; hipEvent_t stepCopied[2] = {nullptr, nullptr}; bool stepInFlight[2] = {false, false};
+  int stepCur = 0, stepN = 0, stepCap = 0; double stepT0 = 0.0, stepT1 = 0.0;
   int histFlags = 0;                            // MZR_H_*: which history sums beyond discharge are kept
   long long histSteps = 0;                      // steps in the runoff sums since the last reset
   DBuf<double> hInst, hDlay, hBas;              // [N], [N], [H] sums of BASIN_QI, BASIN_QR(1), basin runoff
@@ -636,6 +640,10 @@ void kwt_sweep_tables(mzr_handle h, int W) {
 
 }  // namespace
 
+static int flushSteps(mzr_handle h);
+// steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first
+#define MZR_FLUSH(h) do { if ((h) && (h)->stepN > 0) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
+
 extern "C" {
 
 void mzr_default_config(mzr_config *c) {
@@ -647,6 +655,7 @@ void mzr_default_config(mzr_config *c) {
   c->mcTailTol = 1.e-7;
   if (const char *e = getenv("MZR_MC_TAIL_TOL")) c->mcTailTol = atof(e);
   c->sweepShare = 1.0;
+  c->stepBatch = 1;
   c->sweepTimeout = 8.0;
   if (const char *e = getenv("MZR_SWEEP_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->sweepTimeout = v; }
 }
@@ -679,6 +688,7 @@ int mzr_destroy(mzr_handle h) {
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   if (h->exportDone) (void)hipEventDestroy(h->exportDone);
+  for (int i = 0; i < 2; ++i) { if (h->stepHost[i]) (void)hipHostFree(h->stepHost[i]); if (h->stepCopied[i]) (void)hipEventDestroy(h->stepCopied[i]); }
   for (int i = 0; i < 2; ++i) { if (h->rwCopied[i]) (void)hipEventDestroy(h->rwCopied[i]); if (h->rwRead[i]) (void)hipEventDestroy(h->rwRead[i]); }
   for (int ix = 0; ix < 6; ++ix) { if (h->routeStream[ix]) (void)hipStreamDestroy(h->routeStream[ix]); if (h->routeEvent[ix]) (void)hipEventDestroy(h->routeEvent[ix]); }
   for (auto &e : h->basinEvents) (void)hipEventDestroy(e);
@@ -695,6 +705,7 @@ int mzr_last_error(mzr_handle h, char *buf, int len) {
 int mzr_set_network(mzr_handle h, int N, int H, const int *downIndex, const int *upOffset, const int *upIndex,
                     const int *upGood, const int *hruOffset, const int *hruIndex, const double *hruWeight,
                     const int *reachId) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   (void)hipSetDevice(h->cfg.device);
   try {
@@ -790,6 +801,7 @@ int mzr_set_network(mzr_handle h, int N, int H, const int *downIndex, const int 
 }
 
 int mzr_set_param(mzr_handle h, const char *name, const double *values) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_param/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
   for (int p = 0; p < 11; ++p) {
@@ -809,6 +821,7 @@ int mzr_set_param(mzr_handle h, const char *name, const double *values) {
 }
 
 int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_uh/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
@@ -830,6 +843,7 @@ int mzr_set_uh(mzr_handle h, const int *uhOffset, const double *uh) {
 }
 
 int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
+  MZR_FLUSH(h);
   if (!h || n < 1) return 1;
   (void)hipSetDevice(h->cfg.device);
   h->ntdhBas = n;
@@ -843,6 +857,7 @@ int mzr_set_frac_future(mzr_handle h, int n, const double *frac) {
 }
 
 int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, const int *lakeReach, const int *modelType, const double *par) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_lakes/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
@@ -903,14 +918,17 @@ static int set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const 
   return checkDeviceError(h);
 }
 int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, const int *month, const int *day, const int *dayofyear) {
+  MZR_FLUSH(h);
   return set_lake_forcing(h, nSteps, evap, precip, false, month, day, dayofyear);
 }
 int mzr_set_lake_forcing_dev(mzr_handle h, int nSteps, const double *evap_dev, const double *precip_dev, const int *month, const int *day, const int *dayofyear) {
+  MZR_FLUSH(h);
   return set_lake_forcing(h, nSteps, evap_dev, precip_dev, true, month, day, dayofyear);
 }
 
 // Lakes that follow a target volume (is_vol_wm: NETOPO%LakeTargVol, lake_route.f90:197-205; jump start :140-142)
 int mzr_set_lake_target(mzr_handle h, const int *targVol, int jumpstart) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_lake_target/network not set") : 1;
   if (!h->nLake) return fail(h, 20, "mzr_set_lake_target/no lakes in this domain (mzr_set_lakes first)");
   (void)hipSetDevice(h->cfg.device);
@@ -929,6 +947,7 @@ __global__ void k_gather_lake_rows(const double *src, double *dst, const int *la
 
 // REACH_WM_VOL of the next window: vol[nSteps][nRch] in the caller's reach order (main_route.f90:115-122); only lake reaches are read
 int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_wm_vol/state not initialised") : 1;
   if (!h->nLake) return fail(h, 20, "mzr_set_wm_vol/no lakes in this domain");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_wm_vol/nSteps exceeds maxWindow");
@@ -954,6 +973,7 @@ static int pullRow(mzr_handle h, const double *src, double *out);
 // accumulation (main_route.f90:161-172,204-236,392-401, basinUH.f90:130-137, tracer.f90:43-207).  Call after
 // mzr_init_state; on = 0 switches it off.  Costs three more window buffers per method and a second pass over the window.
 int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_conv_solute) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_tracer/state not initialised (call mzr_init_state)") : 1;
   if (on && (h->nHalo || h->nExp)) return fail(h, 20, "mzr_set_tracer/not available in a partitioned domain");
   (void)hipSetDevice(h->cfg.device);
@@ -979,6 +999,7 @@ int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_co
 
 // basin constituent mass flux of the next window, solute[nSteps][nHru] in the order of the runoff
 int mzr_set_solute(mzr_handle h, int nSteps, const double *solute) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_solute/state not initialised") : 1;
   if (!h->tracer) return fail(h, 20, "mzr_set_solute/constituent routing is off (mzr_set_tracer)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_solute/nSteps exceeds maxWindow");
@@ -991,6 +1012,7 @@ int mzr_set_solute(mzr_handle h, int nSteps, const double *solute) {
 
 // which = 0: reach_solute_flux of the last routed step, 1: reach_solute_mass(1) (caller's reach order)
 int mzr_get_solute(mzr_handle h, int method, int which, double *out) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_solute/state not initialised") : 1;
   if (!h->tracer) return fail(h, 20, "mzr_get_solute/constituent routing is off");
   int rc = mzr_sync(h); if (rc) return rc;
@@ -1003,6 +1025,7 @@ int mzr_get_solute(mzr_handle h, int method, int which, double *out) {
 
 // reach_solute_flux of every step of the last window, out[nSteps][nRch]
 int mzr_get_window_solute(mzr_handle h, int method, double *out) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_window_solute/state not initialised") : 1;
   if (!h->tracer) return fail(h, 20, "mzr_get_window_solute/constituent routing is off");
   int rc = mzr_sync(h); if (rc) return rc;
@@ -1024,6 +1047,7 @@ int mzr_get_window_solute(mzr_handle h, int method, double *out) {
 // gaugeReach: 1-based reach (caller's order) of every gauge, < 1 = the gauge is not in this network.  Resets Qobs,
 // Qelapsed and Qerror.  nGauge = 0 switches it off.
 int mzr_set_da(mzr_handle h, int qBlendPeriod, int QerrTrend, int nGauge, const int *gaugeReach) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_da/state not initialised (call mzr_init_state)") : 1;
   if (nGauge < 0 || (nGauge > 0 && !gaugeReach)) return fail(h, 20, "mzr_set_da/bad gauge list");
   if (nGauge > 0 && (QerrTrend < 1 || QerrTrend > 4)) return fail(h, 81, "direct_insertion/discharge error trend model must be 1(const),2(liear), or 3(logistic)");
@@ -1054,6 +1078,7 @@ int mzr_set_da(mzr_handle h, int qBlendPeriod, int QerrTrend, int nGauge, const 
 // gauge observations of the next window: have[nSteps] (1 = there is an observation time at this step), obs[nSteps][nGauge]
 // (NaN or negative = no value at this gauge)
 int mzr_set_obs(mzr_handle h, int nSteps, const int *have, const double *obs) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_obs/state not initialised") : 1;
   if (!h->qmod) return fail(h, 20, "mzr_set_obs/direct insertion is off (mzr_set_da)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_obs/nSteps exceeds maxWindow");
@@ -1067,6 +1092,7 @@ int mzr_set_obs(mzr_handle h, int nSteps, const int *have, const double *obs) {
 }
 
 int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach, const int *haloGood) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_boundary/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
@@ -1119,6 +1145,7 @@ long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach) {
 }
 
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_export_boundary/state not initialised") : 1;
   if (h->nExp == 0) return 0;
   if (h->lastW < 1) return fail(h, 20, "mzr_export_boundary/no window has been run");
@@ -1133,6 +1160,7 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
 }
 
 int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_import_boundary/state not initialised") : 1;
   if (nSrc == 0) return 0;
   if (haloBase < 0 || haloBase + nSrc > h->nHalo) return fail(h, 20, "mzr_import_boundary/halo slot range out of bounds");
@@ -1146,6 +1174,7 @@ int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int
 }
 
 int mzr_init_state(mzr_handle h) {
+  MZR_FLUSH(h);
   if (h) h->rtTablesW = -1;
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_init_state/network not set") : 1;
   (void)hipSetDevice(h->cfg.device);
@@ -1549,6 +1578,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
 }
 
 int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_wm_flux/state not initialised") : 1;
   if (!h->cfg.is_flux_wm) return fail(h, 20, "mzr_set_wm_flux/is_flux_wm is off in the configuration");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_wm_flux/nSteps exceeds maxWindow");
@@ -1563,6 +1593,7 @@ int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
 }
 
 int mzr_sync(mzr_handle h) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   (void)hipSetDevice(h->cfg.device);
   const hipError_t e = hipStreamSynchronize(h->stream);
@@ -1578,11 +1609,13 @@ int mzr_sync(mzr_handle h) {
 }
 
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   return run_window(h, nSteps, t_start, t_start + h->cfg.dt, runoff_dev);
 }
 
 int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
@@ -1596,8 +1629,7 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
 // The stand-alone driver's loop (standalone/route_runoff.f90:80-108) reads forcing and routes, step after step;
 // here a whole window of forcing is handed over in host memory and the call returns at once: the copy runs on its
 // own stream into one of two device buffers while the window before is still being routed.
-int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff) {
-  if (!h) return 1;
+static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_single, const double *runoff, hipEvent_t copied) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
@@ -1614,17 +1646,25 @@ int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff
   if (hipMemcpyAsync(buf, runoff, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, h->copyStream) != hipSuccess)
     return fail(h, 92, "mzr_run_async/hipMemcpyAsync failed");
   (void)hipEventRecord(h->rwCopied[k], h->copyStream);
+  if (copied) (void)hipEventRecord(copied, h->copyStream);      // (the caller's host buffer is free again)
   (void)hipStreamWaitEvent(h->stream, h->rwCopied[k], 0);
-  const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, buf);
+  const int rc = run_window(h, nSteps, t_start, T1_single, buf);
   if (rc) return rc;
   (void)hipEventRecord(h->rwRead[k], h->stream);
   h->rwUsed[k] = true; h->rwCur = k ^ 1;
   return 0;
 }
 
+int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff) {
+  MZR_FLUSH(h);
+  if (!h) return 1;
+  return run_async_impl(h, nSteps, t_start, t_start + h->cfg.dt, runoff, nullptr);
+}
+
 int mzr_set_remap(mzr_handle h, int kind, int nMap, const int *hru_ix, const int *num_qhru, int nOverlap, const int *qhru_ix,
                   const int *i_index, const int *j_index, const double *weight, int n1, int n2,
                   const long long *qhru_id, const long long *src_id) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_remap/network not set") : 1;
   if (kind != 1 && kind != 2) return fail(h, 20, "mzr_set_remap/kind must be 1 (polygon vector) or 2 (grid)");
   if ((kind == 1 && !qhru_ix) || (kind == 2 && (!i_index || !j_index || n2 < 1)) || n1 < 1) return fail(h, 20, "mzr_set_remap/missing index arrays");
@@ -1664,6 +1704,7 @@ int mzr_set_remap(mzr_handle h, int kind, int nMap, const int *hru_ix, const int
 }
 
 int mzr_set_sort_map(mzr_handle h, int nSrc, const int *ix_in, int remove_negatives) {
+  MZR_FLUSH(h);
   if (!h || !h->haveNet) return h ? fail(h, 20, "mzr_set_sort_map/network not set") : 1;
   if (nSrc < 1 || !ix_in) return fail(h, 20, "mzr_set_sort_map/empty map");
   (void)hipSetDevice(h->cfg.device);
@@ -1680,6 +1721,7 @@ int mzr_set_sort_map(mzr_handle h, int nSrc, const int *ix_in, int remove_negati
 }
 
 int mzr_remap_runoff_dev(mzr_handle h, int nSteps, const double *src_dev, double *dst_dev) {
+  MZR_FLUSH(h);
   if (!h || !h->remapKind) return h ? fail(h, 20, "mzr_remap_runoff/no mapping set (mzr_set_remap / mzr_set_sort_map)") : 1;
   if (nSteps < 1) return fail(h, 20, "mzr_remap_runoff/nSteps must be positive");
   (void)hipSetDevice(h->cfg.device);
@@ -1698,6 +1740,7 @@ int mzr_remap_runoff_dev(mzr_handle h, int nSteps, const double *src_dev, double
 }
 
 int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_dev) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
@@ -1706,15 +1749,66 @@ int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_
   return run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
 }
 
+// One time step == one main_route call.  stepBatch = 1 (default): routed and synchronised at once, errors come back with
+// the call, as the reference's driver expects (standalone/route_runoff.f90:80-108 calls handle_err after every step).
+// stepBatch > 1: the row is put aside and the call returns; the steps are routed as ONE window (time-skewed over the
+// stages) when stepBatch of them have come together, or as soon as anything is asked of the handle (a getter,
+// mzr_sync, a setter) -- a host that keeps its time loop and fetches results at output frequency then runs at the speed
+// of the windows.  Results are bit-identical either way.  A step whose (T0, T1) does not continue the pending ones by
+// exactly dt, and any configuration with per-window inputs (lakes, water management, observations, constituents),
+// is routed as before.
 int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
   if (!h) return 1;
   if (!h->haveState) return fail(h, 20, "mzr_step/state not initialised (call mzr_init_state)");
   (void)hipSetDevice(h->cfg.device);
-  (void)hipMemcpyAsync(h->runoffW.p, runoff, (size_t)h->H * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  const int rc = run_window(h, 1, T0, T1, h->runoffW.p);
-  if (rc) return rc;
-  return mzr_sync(h);
+  int cap = std::min(h->cfg.stepBatch, h->cfg.maxWindow);
+  if (h->cfg.is_flux_wm || h->nLake || h->qmod || h->tracer) cap = 1;
+  if (cap <= 1) {
+    MZR_FLUSH(h);
+    (void)hipMemcpyAsync(h->runoffW.p, runoff, (size_t)h->H * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    const int rc = run_window(h, 1, T0, T1, h->runoffW.p);
+    if (rc) return rc;
+    return mzr_sync(h);
+  }
+  const double dt = h->cfg.dt;
+  // not the continuation of what is pending, or a step of another length (a window of its own: the kernels take TSEC(2) of a
+  // single step as given and T0 + dt otherwise)
+  if (h->stepN > 0 && (!(T0 == h->stepT0 + (double)h->stepN * dt) || !(T1 == T0 + dt))) MZR_FLUSH(h);
+  if (!h->stepHost[0] || h->stepCap != cap) {
+    MZR_FLUSH(h);
+    for (int i = 0; i < 2; ++i) {
+      if (h->stepInFlight[i]) { (void)hipEventSynchronize(h->stepCopied[i]); h->stepInFlight[i] = false; }
+      if (h->stepHost[i]) { (void)hipHostFree(h->stepHost[i]); h->stepHost[i] = nullptr; }
+      if (hipHostMalloc((void **)&h->stepHost[i], (size_t)cap * h->H * sizeof(double), hipHostMallocDefault) != hipSuccess) { h->stepHost[i] = nullptr; return fail(h, 91, "mzr_step/hipHostMalloc failed"); }
+      if (!h->stepCopied[i]) (void)hipEventCreateWithFlags(&h->stepCopied[i], hipEventDisableTiming);
+    }
+    h->stepCap = cap;
+  }
+  if (h->stepN == 0) {
+    h->stepT0 = T0;
+    if (h->stepInFlight[h->stepCur]) { (void)hipEventSynchronize(h->stepCopied[h->stepCur]); h->stepInFlight[h->stepCur] = false; }      // its last copy has left
+  }
+  memcpy(h->stepHost[h->stepCur] + (size_t)h->stepN * h->H, runoff, (size_t)h->H * sizeof(double));
+  h->stepT1 = T1;
+  ++h->stepN;
+  if (h->stepN == cap || !(T1 == T0 + dt)) return flushSteps(h);
+  return 0;
 }
+
+}  // extern "C"
+
+static int flushSteps(mzr_handle h) {
+  const int n = h->stepN;
+  if (n < 1) return 0;
+  h->stepN = 0;
+  const int k = h->stepCur;
+  h->stepCur ^= 1;
+  h->stepInFlight[k] = true;
+  const double T1_single = n == 1 ? h->stepT1 : h->stepT0 + h->cfg.dt;
+  return run_async_impl(h, n, h->stepT0, T1_single, h->stepHost[k], h->stepCopied[k]);
+}
+
+extern "C" {
 
 // ---- getters: device (internal order) -> host (caller order)
 static int pullRow(mzr_handle h, const double *src, double *out) {
@@ -1725,6 +1819,7 @@ static int pullRow(mzr_handle h, const double *src, double *out) {
 }
 
 int mzr_get_flux(mzr_handle h, int method, int which, double *out) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_flux/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const size_t N = h->N;
@@ -1753,6 +1848,7 @@ int mzr_get_flux(mzr_handle h, int method, int which, double *out) {
 // error term 8 = 1 - (2+3+4+5+6).  Reaches are summed in the library's internal order (the reference sums mainstem,
 // then tributaries, then across MPI ranks -- another order of the same additions).
 int mzr_get_global_wb(mzr_handle h, int method, double *out8) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_global_wb/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int ix = idxOf(h, method);
@@ -1786,6 +1882,7 @@ int mzr_get_global_wb(mzr_handle h, int method, double *out8) {
 }
 
 int mzr_get_window_q(mzr_handle h, int method, double *out) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_window_q/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int ix = idxOf(h, method);
@@ -1801,6 +1898,7 @@ int mzr_get_window_q(mzr_handle h, int method, double *out) {
 }
 
 int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_mean_q/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int ix = idxOf(h, method);
@@ -1814,6 +1912,7 @@ int mzr_get_mean_q(mzr_handle h, int method, double *out, int reset) {
 
 // History accumulation beyond discharge (histVars_data.f90:154-305): which sums are kept.  Takes effect at the next mzr_init_state.
 int mzr_set_history(mzr_handle h, int flags) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   h->histFlags = flags & (MZR_H_INFLOW | MZR_H_HEIGHT | MZR_H_RUNOFF);
   h->haveState = false;
@@ -1821,6 +1920,7 @@ int mzr_set_history(mzr_handle h, int flags) {
 }
 
 int mzr_get_mean(mzr_handle h, int method, int which, double *out) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_mean/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   if (which >= MZR_M_INST_RUNOFF) {
@@ -1848,6 +1948,7 @@ int mzr_get_mean(mzr_handle h, int method, int which, double *out) {
 
 // histVars%refresh: every sum back to zero
 int mzr_reset_means(mzr_handle h) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_reset_means/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
@@ -1860,6 +1961,7 @@ int mzr_reset_means(mzr_handle h) {
 }
 
 int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry, double *texit, int *routed) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || !h->kwN.p) return h ? fail(h, 20, "mzr_get_kwt_state/KWT not active") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
@@ -1885,6 +1987,7 @@ int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry
 }
 
 int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, const double *tentry, const double *texit, const int *routed) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || !h->kwN.p) return h ? fail(h, 20, "mzr_set_kwt_state/KWT not active") : 1;
   (void)routed;
   int rc = mzr_sync(h); if (rc) return rc;
@@ -1909,6 +2012,7 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
 }
 
 int mzr_get_irf_state(mzr_handle h, double *qfuture) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || !h->irfQ.p) return h ? fail(h, 20, "mzr_get_irf_state/IRF not active") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
@@ -1922,6 +2026,7 @@ int mzr_get_irf_state(mzr_handle h, double *qfuture) {
 }
 
 int mzr_get_mol_state(mzr_handle h, int method, double *qout) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_get_mol_state/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int ix = idxOf(h, method);
@@ -1934,6 +2039,7 @@ int mzr_get_mol_state(mzr_handle h, int method, double *qout) {
 }
 
 int mzr_get_basin_state(mzr_handle h, double *qfuture) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || h->cfg.doesBasinRoute != 1) return h ? fail(h, 20, "mzr_get_basin_state/hillslope routing not active") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N, n = h->ntdhBas;
@@ -1945,6 +2051,7 @@ int mzr_get_basin_state(mzr_handle h, double *qfuture) {
 
 // ---- state setters (restart, read_restart.f90:152-742): caller order -> device (internal order)
 int mzr_set_irf_state(mzr_handle h, const double *qfuture) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || !h->irfQ.p) return h ? fail(h, 20, "mzr_set_irf_state/IRF not active") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
@@ -1958,6 +2065,7 @@ int mzr_set_irf_state(mzr_handle h, const double *qfuture) {
 }
 
 int mzr_set_mol_state(mzr_handle h, int method, const double *q) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_mol_state/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int ix = idxOf(h, method);
@@ -1971,6 +2079,7 @@ int mzr_set_mol_state(mzr_handle h, int method, const double *q) {
 
 // qfuture[nRch][n] = hillslope QFUTURE, basin_q[nRch] = BASIN_QR(1) (read_restart.f90:190,246)
 int mzr_set_basin_state(mzr_handle h, const double *qfuture, const double *basin_q) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_basin_state/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N, n = h->ntdhBas;
@@ -1993,6 +2102,7 @@ int mzr_set_basin_state(mzr_handle h, const double *qfuture, const double *basin
 // The lateral flux of the last step (BASIN_solute) is not part of the reference's restart and is not needed: every step
 // derives it anew.
 int mzr_get_tracer_state(mzr_handle h, int method, double *tfuture, double *mass) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || !h->tracer) return h ? fail(h, 20, "mzr_get_tracer_state/constituent routing is off") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N, n = h->ntdhBas;
@@ -2010,6 +2120,7 @@ int mzr_get_tracer_state(mzr_handle h, int method, double *tfuture, double *mass
   return 0;
 }
 int mzr_set_tracer_state(mzr_handle h, int method, const double *tfuture, const double *mass) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState || !h->tracer) return h ? fail(h, 20, "mzr_set_tracer_state/constituent routing is off") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N, n = h->ntdhBas;
@@ -2031,6 +2142,7 @@ int mzr_set_tracer_state(mzr_handle h, int method, const double *tfuture, const 
 
 // REACH_VOL(1) of a method (volume_<method> of the restart file)
 int mzr_set_volume(mzr_handle h, int method, const double *vol) {
+  MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_volume/state not initialised") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   const int ix = idxOf(h, method);
@@ -2083,6 +2195,7 @@ int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems) {
 }
 
 int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long long *hist32) {
+  MZR_FLUSH(h);
   if (!h || !h->swHead.p) return 1;
   int v[16 + 32];
   if (hipMemcpy(v, h->swHead.p + 8 * 16, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, 92, "mzr_get_sweep_arrivals/hipMemcpy failed");
@@ -2095,6 +2208,7 @@ int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long
 int mzr_set_profiling(mzr_handle h, int mode) { if (!h) return 1; h->profiling = (mode & 1) != 0; h->countTraffic = (mode & 2) != 0; return 0; }
 
 int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset) {
+  MZR_FLUSH(h);
   if (!h) return 1;
   const int ix = idxOf(h, method);
   if (ix < 0) return fail(h, 81, "mzr_get_timing/method not active");
@@ -2106,6 +2220,7 @@ int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kerne
 
 int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long long *w_out, long long *n_head,
                         long long *n_route, long long *n_edges, int reset) {
+  MZR_FLUSH(h);
   if (!h || !h->kwtStat.p) return h ? fail(h, 20, "mzr_get_kwt_traffic/KWT not active") : 1;
   int rc = mzr_sync(h); if (rc) return rc;
   MzrKwtStat s;
@@ -2195,6 +2310,7 @@ int mzr_comm_destroy(mzr_comm c) {
 }
 
 int mzr_comm_send(mzr_comm c, mzr_handle h, const double *dev, long long n, int peer) {
+  MZR_FLUSH(h);
   if (!c || !h || !dev || n < 0 || peer < 0 || peer >= c->nRanks || peer == c->rank) return commFail(1, "mzr_comm_send/bad arguments");
   (void)hipSetDevice(c->device);
   // the record was packed by the handle's last mzr_export_boundary_dev; whatever the handle has queued since (the next
@@ -2210,6 +2326,7 @@ int mzr_comm_sync(mzr_comm c) {
 }
 
 int mzr_comm_recv(mzr_comm c, mzr_handle h, double *dev, long long n, int peer) {
+  MZR_FLUSH(h);
   if (!c || !h || !dev || n < 0 || peer < 0 || peer >= c->nRanks || peer == c->rank) return commFail(1, "mzr_comm_recv/bad arguments");
   (void)hipSetDevice(c->device);
   if (int rc = rcclCheck(g_rccl.Recv(dev, (size_t)n, ncclDouble, peer, c->comm, c->stream), "ncclRecv")) return rc;
@@ -2219,6 +2336,7 @@ int mzr_comm_recv(mzr_comm c, mzr_handle h, double *dev, long long n, int peer) 
 }
 
 int mzr_comm_recv_many(mzr_comm c, mzr_handle h, int nPeers, double *const *dev, const long long *n, const int *peers) {
+  MZR_FLUSH(h);
   if (!c || !h || nPeers < 0 || (nPeers > 0 && (!dev || !n || !peers))) return commFail(1, "mzr_comm_recv_many/bad arguments");
   (void)hipSetDevice(c->device);
   if (int rc = rcclCheck(g_rccl.GroupStart(), "ncclGroupStart")) return rc;

@@ -31,6 +31,8 @@ MODULE mzr_c
     integer(c_int)  :: reserved0
     real(c_double)  :: mcTailTol       ! Muskingum-Cunge closed-form tail of the sub-step sum (0 = iterate every sub-step)
     real(c_double)  :: sweepShare      ! share of the device's wavefront slots this handle's persistent sweeps fill (1 = all)
+    integer(c_int)  :: stepBatch       ! mzr_step: steps put aside and routed as one window (1 = every call routes its step)
+    integer(c_int)  :: reserved1
     real(c_double)  :: sweepTimeout    ! seconds without progress before a persistent sweep gives up (ierr 93)
   end type mzr_config
 
@@ -44,7 +46,8 @@ MODULE mzr_c
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
             mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs, &
-            mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute, mzr_get_tracer_state, mzr_set_tracer_state
+            mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute, mzr_get_tracer_state, mzr_set_tracer_state, &
+            mzr_set_history, mzr_get_mean, mzr_reset_means, mzr_get_sweep_arrivals
   public :: mzr_message
 
   INTERFACE
@@ -217,6 +220,29 @@ MODULE mzr_c
       import :: c_ptr, c_int
       type(c_ptr), value :: h
       integer(c_int), intent(out) :: nStages, maxStageWidth
+    end function
+    ! history sums beyond discharge (histVars_data.f90:154-305): flags MZR_H_INFLOW = 1, MZR_H_HEIGHT = 2, MZR_H_RUNOFF = 4, before
+    ! mzr_init_state; which = MZR_M_Q 0, INFLOW 1, HEIGHT 2, FLOODVOL 3, INST_RUNOFF 10, DLAY_RUNOFF 11, BAS_RUNOFF 12 (per HRU)
+    integer(c_int) function mzr_set_history(h, flags) bind(C, name='mzr_set_history')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+      integer(c_int), value :: flags
+    end function
+    integer(c_int) function mzr_get_mean(h, method, which, out) bind(C, name='mzr_get_mean')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: method, which
+      real(c_double), intent(out) :: out(*)
+    end function
+    integer(c_int) function mzr_reset_means(h) bind(C, name='mzr_reset_means')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    integer(c_int) function mzr_get_sweep_arrivals(h, arrivedLast, joinedLast, hist32) bind(C, name='mzr_get_sweep_arrivals')
+      import :: c_ptr, c_int, c_long_long
+      type(c_ptr), value :: h
+      integer(c_int), intent(out) :: arrivedLast, joinedLast
+      integer(c_long_long), intent(out) :: hist32(32)
     end function
     integer(c_int) function mzr_get_sweep_info(h, nWaves, capacity, nItems) bind(C, name='mzr_get_sweep_info')
       import :: c_ptr, c_int

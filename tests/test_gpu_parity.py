@@ -81,6 +81,43 @@ def test_step_by_step_equals_window(hip_lib):
             assert np.array_equal(b.flux(meth), Qa[it, ix]), (it, meth)
 
 
+def test_pipelined_steps_equal_a_window(hip_lib):
+    """mzr_step with stepBatch > 1 puts the steps aside and routes them as windows: the host's time loop
+    (standalone/route_runoff.f90:80-108) at the speed of the windows.  N steps handed over one by one must leave the same
+    bits as one N-step window and as N synchronous steps -- also when the batch does not divide N (a getter flushes what
+    is pending), when a gap in time or a step of another length interrupts the sequence, and for every method."""
+    net, z = load_golden("tree150_all")
+    dt = float(z["dt"])
+    ro = z["runoff"]
+    n = 50
+    a = domain_from_golden(net, z, max_window=64)
+    Qa = a.run(ro[:n])
+    b = domain_from_golden(net, z, max_window=64, step_batch=16)      # 3 full batches + 2 steps flushed by the getter
+    c = domain_from_golden(net, z, max_window=64, step_batch=1)
+    for it in range(n):
+        b.step(it * dt, (it + 1) * dt, ro[it])
+        c.step(it * dt, (it + 1) * dt, ro[it])
+    for ix, meth in enumerate(a.methods):
+        assert np.array_equal(b.flux(meth), Qa[n - 1, ix]), meth
+        assert np.array_equal(c.flux(meth), Qa[n - 1, ix]), meth
+        assert np.array_equal(b.mean_q(meth), a.mean_q(meth)), meth
+    assert all(np.array_equal(x, y) for x, y in zip(a.kwt_state(), b.kwt_state()))
+    assert np.array_equal(a.irf_state(), b.irf_state())
+    assert np.array_equal(a.basin_state(), b.basin_state())
+    # an interrupted sequence: 5 steps, a step that is shorter than dt, 6 more steps (each part is a window of its own)
+    d1 = domain_from_golden(net, z, max_window=64, step_batch=8)
+    d2 = domain_from_golden(net, z, max_window=64, step_batch=1)
+    t = 0.0
+    for it in range(12):
+        length = 0.5 * dt if it == 5 else dt
+        for d in (d1, d2):
+            d.step(t, t + length, ro[it])
+        t += length
+    for meth in a.methods:
+        assert np.array_equal(d1.flux(meth), d2.flux(meth)), meth
+    assert all(np.array_equal(x, y) for x, y in zip(d1.kwt_state(), d2.kwt_state()))
+
+
 @pytest.mark.parametrize("N,seed,dt,kw", [
     (3000, 21, 3600.0, dict(p3=0.03)),
     (20000, 22, 3600.0, dict()),
