@@ -286,6 +286,13 @@ class RoutingDomain:
         self.tracer_on = solute is not None
         self._check(self.L.mzr_set_tracer(self.h, int(solute is not None), float(time_conv), float(mass_conv)))
 
+    def enable_tracer(self, time_conv=1.0, mass_conv=1.0):
+        """Switch constituent routing on for a host that hands the solute over window by window itself (mzr_set_solute),
+        as the stand-alone driver does: restart files then carry tfuture / solute_mass (ncfiles gates on tracer_on)."""
+        self.solute, self._sol_done = None, 0
+        self.tracer_on = True
+        self._check(self.L.mzr_set_tracer(self.h, 1, float(time_conv), float(mass_conv)))
+
     def tracer_state(self):
         """dict(tfuture [nRch, ntdhBas] if the hillslope is routed, mass {method: [nRch]}) -- what a restart file keeps"""
         st = {"mass": {}}

@@ -5,10 +5,11 @@ Replaces, on the reference side,
                                   route/build/src/domain_decomposition.f90:41-163,450-590,724-819
   the per-step gather/scatter of  mpi_route  (route/build/src/mpi_process.f90:1245-1329)
 
-Same decomposition rule as the reference: a reach is MAINSTEM when it has more than N/nParts reaches
-upstream (domain_decomposition.f90:507-519); every sub-tree hanging on the mainstem (and every
-basin without mainstem) is a TRIBUTARY domain; tributaries are dealt to partitions largest-first
-onto the least-loaded partition, the mainstem counting towards partition 0, which also routes it.
+Same decomposition as the reference (`reference_domains` below restates classify_river_basin and assign_node and is
+compared with the compiled reference routines): a reach is MAINSTEM when more than N/nParts reaches lie upstream of its
+outlet, itself counted (domain_decomposition.f90:507-519); every sub-tree hanging on the mainstem (and every basin
+without mainstem) is a TRIBUTARY domain; the smallest tributaries go to partition 0 -- which also routes the mainstem --
+until they hold an even share, the others are dealt largest-first onto the least-loaded of the other partitions.
 
 What differs from the reference is the exchange.  There, rank 0 gathers outlet discharge and KWT
 particles every step and scatters the stripped particles back.  Here every reach strips its own
@@ -61,6 +62,127 @@ def subtree_sizes(net: RiverNetwork) -> np.ndarray:
     return cnt
 
 
+def nr_indexx(arr) -> np.ndarray:
+    """Index array that sorts `arr` ascending, element for element what the reference's `indexx` returns
+    (nr_utils.f90:114-190: quicksort on the index with median of three, insertion sort below 15 elements; NOT stable, and
+    assign_node's treatment of equally large domains follows its order).  0-based result."""
+    a = np.asarray(arr)
+    n = a.size
+    idx = list(range(n + 1))                 # 1-based like the source: idx[1..n] hold 1-based positions
+    A = lambda i: a[i - 1]
+    NN = 15
+    stack = []
+    l, r = 1, n
+    while True:
+        if r - l < NN:
+            for j in range(l + 1, r + 1):
+                indext = idx[j]
+                av = A(indext)
+                i = j - 1
+                while i >= 1:
+                    if A(idx[i]) <= av:
+                        break
+                    idx[i + 1] = idx[i]
+                    i -= 1
+                idx[i + 1] = indext
+            if not stack:
+                break
+            r = stack.pop(); l = stack.pop()
+        else:
+            k = (l + r) // 2
+            if k != l + 1:
+                idx[k], idx[l + 1] = idx[l + 1], idx[k]
+            if A(idx[r]) < A(idx[l]):
+                idx[l], idx[r] = idx[r], idx[l]
+            if A(idx[r]) < A(idx[l + 1]):
+                idx[l + 1], idx[r] = idx[r], idx[l + 1]
+            if A(idx[l + 1]) < A(idx[l]):
+                idx[l], idx[l + 1] = idx[l + 1], idx[l]
+            i, j = l + 1, r
+            indext = idx[l + 1]
+            av = A(indext)
+            while True:
+                i += 1
+                while A(idx[i]) < av:
+                    i += 1
+                j -= 1
+                while A(idx[j]) > av:
+                    j -= 1
+                if j < i:
+                    break
+                if i != j:
+                    idx[i], idx[j] = idx[j], idx[i]
+            idx[l + 1] = idx[j]
+            idx[j] = indext
+            if r - i + 1 >= j - l:
+                stack.append(i); stack.append(r)
+                r = j - 1
+            else:
+                stack.append(l); stack.append(j - 1)
+                l = i
+    return np.array(idx[1:], dtype=np.int64) - 1
+
+
+def reference_domains(net: RiverNetwork, n_nodes: int):
+    """The reference's MPI domains and their nodes (domain_decomposition.f90): `classify_river_basin` / `decomposeDomain`
+    (:450-590, :600-720) make, in this order, one tributary domain per basin whose outlet has at most nSeg/nNodes reaches
+    upstream (itself counted), the mainstem domain (every reach with more than that), and one tributary domain per reach
+    that drains into the mainstem; `assign_node` (:724-819) gives the smallest tributaries to node 0 until they hold more
+    than nTribSeg/nNodes reaches, takes the LAST nNodes-1 domains of the list back out (by position in the list, as the
+    source does), and deals what is left, largest first, the mainstem to the root (-1) and every tributary to the node
+    of 1..nNodes-1 with the least work so far.  Returns (kind[nDom] 1 tributary / 2 mainstem, outlet reach [nDom] (0-based,
+    -1 for the mainstem), size[nDom], node[nDom], is_mainstem[N], root_of[N])."""
+    N = net.N
+    down0 = net.downIndex.astype(np.int64) - 1
+    cnt = subtree_sizes(net)
+    max_segs = N // max(1, n_nodes)
+    is_main = cnt > max_segs                            # :507-519 (allUpSegIndices holds the reach itself)
+    kind, outlet, size = [], [], []
+    for r in np.nonzero(down0 < 0)[0]:                  # basins without mainstem, in reach order
+        if cnt[r] <= max_segs:
+            kind.append(1); outlet.append(int(r)); size.append(int(cnt[r]))
+    if is_main.any():
+        kind.append(2); outlet.append(-1); size.append(int(is_main.sum()))
+        trib_out = (~is_main) & (down0 >= 0) & is_main[np.maximum(down0, 0)]      # lgc_tributary_outlet
+        for r in np.nonzero(trib_out)[0]:
+            kind.append(1); outlet.append(int(r)); size.append(int(cnt[r]))
+    kind, outlet, size = np.array(kind, np.int64), np.array(outlet, np.int64), np.array(size, np.int64)
+    n_dom = kind.size
+    rank = nr_indexx(size)
+    node = np.full(n_dom, -99, np.int64)
+    assigned = np.zeros(n_dom, bool)
+    n_even = int(size[kind == 1].sum()) // max(1, n_nodes)
+    small = 0
+    for ixx in rank:
+        if kind[ixx] == 1:
+            small += int(size[ixx]); node[ixx] = 0; assigned[ixx] = True
+            if small > n_even:
+                break
+    if n_nodes > 1:
+        assigned[max(0, n_dom - n_nodes + 1):] = False    # isAssigned(nDomain-nNodes+2:nDomain) = .false.
+    work = np.zeros(max(0, n_nodes - 1), np.int64)
+    for ixx in rank[::-1]:
+        if assigned[ixx]:
+            continue
+        if kind[ixx] == 2:
+            node[ixx] = -1
+        else:
+            k = int(np.argmin(work)) if work.size else -1       # minloc: the first minimum
+            if k >= 0:
+                work[k] += int(size[ixx])
+            node[ixx] = k + 1
+        assigned[ixx] = True
+    # root (domain outlet) of every non-mainstem reach
+    root_of = np.full(N, -1, dtype=np.int64)
+    outs = outlet[kind == 1]
+    root_of[outs] = outs
+    dist = hops_to_outlet(down0)
+    for r in np.argsort(dist, kind="stable"):
+        if root_of[r] < 0 and not is_main[r]:
+            root_of[r] = root_of[down0[r]]
+    return kind, outlet, size, node, is_main, root_of
+
+
 def _local_network(net: RiverNetwork, real: np.ndarray, halos: np.ndarray) -> tuple:
     """Local RiverNetwork over reaches `real` (routed here) followed by `halos` (tributary outlets
     routed elsewhere).  UREACHI order is preserved; a reach whose downstream is not local becomes an
@@ -99,30 +221,12 @@ def partition_network(net: RiverNetwork, n_parts: int, build_for=None) -> Partit
     A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full."""
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
-    cnt = subtree_sizes(net)
-    if n_parts <= 1:
-        is_main = np.zeros(N, bool)
-    else:
-        is_main = cnt > (N // n_parts)                 # domain_decomposition.f90:507-519
-    # tributary roots: non-mainstem reaches draining into the mainstem or straight to an outlet
-    root_mask = (~is_main) & ((down0 < 0) | is_main[np.maximum(down0, 0)])
-    roots = np.nonzero(root_mask)[0]
-    # label every non-mainstem reach with its root (walk down the levels from the roots)
-    root_of = np.full(N, -1, dtype=np.int64)
-    root_of[roots] = roots
-    dist = hops_to_outlet(down0)
-    order = np.argsort(dist, kind="stable")
-    for r in order:
-        if root_of[r] < 0 and not is_main[r]:
-            root_of[r] = root_of[down0[r]]
-    # largest-first onto the least-loaded partition; the mainstem is partition 0's initial load
-    load = np.zeros(n_parts, dtype=np.int64)
-    load[0] = int(is_main.sum())
-    part_of_root = {}
-    for r in roots[np.argsort(-cnt[roots], kind="stable")]:
-        p = int(np.argmin(load))
-        part_of_root[int(r)] = p
-        load[p] += cnt[r]
+    # domains and their nodes exactly as the reference makes them (pinned against the compiled reference routines,
+    # tests/test_oracle_vs_ref.py::test_domain_decomposition_matches_the_reference); partition p = node p, the mainstem
+    # (node -1, "handled in root proc") goes to partition 0
+    kind, outlet, size, node, is_main, root_of = reference_domains(net, n_parts)
+    roots = np.sort(outlet[kind == 1])
+    part_of_root = {int(o): int(max(nd, 0)) for o, nd, k in zip(outlet, node, kind) if k == 1}
     part_of_reach = np.zeros(N, dtype=np.int64)
     nm = ~is_main
     part_of_reach[nm] = np.array([part_of_root[int(x)] for x in root_of[nm]], dtype=np.int64) if nm.any() else 0

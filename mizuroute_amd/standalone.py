@@ -142,6 +142,19 @@ def build_network(ctl: dict, nml: dict):
     hru_seg = np.asarray(v[name("varname_hruSegId")][:], dtype=np.int64)
     hru_area = np.asarray(v[name("varname_area")][:], dtype=np.float64)
     f.close()
+    return augment_topology(seg_id, down_id, length, slope, hru_id, hru_seg, hru_area, nml), hru_id
+
+
+def augment_topology(seg_id, down_id, length, slope, hru_id, hru_seg, hru_area, nml):
+    """What the reference derives at start-up from the raw topology (augment_ntopo, process_ntopo.f90:39-266, with
+    hru2segment / up2downSegment / reachOrder / reach_list of network_topo.f90): downstream indices, upstream lists in
+    reach order, the HRUs of every reach in file order with their area weights (network_topo.f90:188), BASAREA / TOTAREA,
+    goodBas (upstream reaches with a contributing area), hydraulic geometry from wscale (no floodplain: depth = high_depth),
+    channel storage, and the slope floor of put_data_struct (process_ntopo.f90:274).  Compared with the compiled reference
+    routines in tests/test_oracle_vs_ref.py::test_network_augmentation_matches_the_reference."""
+    seg_id, down_id = np.asarray(seg_id, dtype=np.int64), np.asarray(down_id, dtype=np.int64)
+    length, slope = np.asarray(length, dtype=np.float64), np.asarray(slope, dtype=np.float64)
+    hru_id, hru_seg, hru_area = np.asarray(hru_id, dtype=np.int64), np.asarray(hru_seg, dtype=np.int64), np.asarray(hru_area, dtype=np.float64)
     N, H = seg_id.size, hru_id.size
     ix = {int(s): i for i, s in enumerate(seg_id)}
     downIndex = np.array([ix.get(int(dn), -1) + 1 for dn in down_id], dtype=np.int32)   # 0: outlet / not in the network
@@ -153,14 +166,21 @@ def build_network(ctl: dict, nml: dict):
     cnt = np.bincount(seg_of_hru[order], minlength=N)
     hruOffset = np.zeros(N + 1, dtype=np.int32); hruOffset[1:] = np.cumsum(cnt)
     hruIndex = (order + 1).astype(np.int32)
-    basarea = np.bincount(seg_of_hru[order], weights=hru_area[order], minlength=N)
+    # the reference sums a reach's HRU areas one after the other in file order (network_topo.f90:160-190)
+    basarea = np.zeros(N)
+    for h in order:
+        basarea[seg_of_hru[h]] = basarea[seg_of_hru[h]] + hru_area[h]
     w = np.where(basarea[seg_of_hru[order]] > 0, hru_area[order] / np.where(basarea[seg_of_hru[order]] > 0, basarea[seg_of_hru[order]], 1.0), 0.0)
-    totarea = basarea.copy()
     down0 = downIndex.astype(np.int64) - 1
     dist = hops_to_outlet(down0)
-    for dlev in range(int(dist.max()), 0, -1):
-        idx = np.nonzero(dist == dlev)[0]
-        np.add.at(totarea, down0[idx], totarea[idx])
+    # area above a reach: its upstream reaches' total areas added in upstream-list order, headwaters first (reachOrder)
+    totarea = basarea.copy()
+    for dlev in range(int(dist.max()), -1, -1):
+        for r in np.nonzero(dist == dlev)[0]:
+            ups = 0.0
+            for e in range(upOffset[r], upOffset[r + 1]):
+                ups = ups + totarea[upIndex[e] - 1]
+            totarea[r] = basarea[r] + ups
     width = nml["wscale"] * np.sqrt(totarea)
     rdepth = np.full(N, HIGH_DEPTH)
     side = np.zeros(N)
@@ -168,10 +188,10 @@ def build_network(ctl: dict, nml: dict):
                   RLENGTH=length, R_STORAGE=rdepth * (width + side * rdepth) * length, SIDE_SLOPE=side,
                   FLDP_SLOPE=np.full(N, 1000.0), BASAREA=basarea, TOTAREA=totarea, MINFLOW=np.zeros(N))
     good = (totarea > VERY_SMALL).astype(np.int32)
-    net = RiverNetwork(N=N, H=H, downIndex=downIndex, reachId=seg_id.astype(np.int32), upOffset=upOffset, upIndex=upIndex,
-                       upGood=np.repeat(good, np.diff(upOffset)).astype(np.int32), hruOffset=hruOffset, hruIndex=hruIndex,
-                       hruWeight=w, params=params)
-    return net, hru_id
+    return RiverNetwork(N=N, H=H, downIndex=downIndex, reachId=seg_id.astype(np.int32), upOffset=upOffset, upIndex=upIndex,
+                        # (goodBasin of every upstream slot follows the reach's OWN total area: network_topo.f90:771-775)
+                        upGood=np.repeat(good, np.diff(upOffset)).astype(np.int32),
+                        hruOffset=hruOffset, hruIndex=hruIndex, hruWeight=w, params=params)
 
 
 def write_subset(ctl: dict, log=print) -> dict:
@@ -406,7 +426,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         gauges = read_gauges(ctl, net, t_beg, dt, n_steps)
         dom.set_da(dict(blend=int(ctl.get("qBlendPeriod", 10)), trend=int(ctl.get("QerrTrend", 1)), **gauges))
     if tracer:
-        dom._check(dom.L.mzr_set_tracer(dom.h, 1, time_conv_sol, mass_conv))
+        dom.enable_tracer(time_conv_sol, mass_conv)      # (before read_restart: the file's tfuture / solute_mass are taken only then)
         sol_sum = {mm: np.zeros(net.N) for mm in methods if mm != api.SUM}
         sol_local = np.zeros(net.N)
     # ---- forcing: concatenate the files' time axes, find the record of every simulation step

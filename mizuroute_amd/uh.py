@@ -124,10 +124,11 @@ def make_uh(length: np.ndarray, dt: float, velo: float, diff: float):
         inte = float(np.cumsum(H)[-1])
         UHM = H / inte if inte > 0.0 else H
         cs = np.cumsum(UHM)
-        idx = np.nonzero(cs > 0.99999)[0]
+        # (the thresholds are default-real literals in the source: process_param.f90:184,190,222)
+        idx = np.nonzero(cs > float(np.float32(0.99999)))[0]
         iHrLast = int(idx[0]) + 1 if idx.size else nHr
         csr = np.cumsum(UHM[::-1])
-        idx = np.nonzero(csr > 0.99999)[0]
+        idx = np.nonzero(csr > float(np.float32(0.99999)))[0]
         iHrStrt = nHr - int(idx[0]) if idx.size else 1
         UHQ = np.zeros(nHr)
         for jHr in range(1, nHr + 1):
@@ -143,7 +144,7 @@ def make_uh(length: np.ndarray, dt: float, velo: float, diff: float):
         if inte > 0.0:
             UHQ = UHQ / inte
         cs = np.cumsum(UHQ)
-        idx = np.nonzero(cs > 0.9999)[0]
+        idx = np.nonzero(cs > float(np.float32(0.9999)))[0]
         iHrLast = int(idx[0]) + 1 if idx.size else nHr
         UHQ = UHQ / cs[iHrLast - 1]
         ntdh = (iHrLast + nTsub - 1) // nTsub

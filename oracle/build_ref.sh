@@ -17,7 +17,7 @@ cd "$OUT/obj"
 FFLAGS="-O2 -ffp-contract=off -fopenmp"
 H="$HERE/ref_harness"
 SRCS="$S/nrtype.f90 $S/public_var.f90 $S/nr_utils.f90 $S/datetime_data.f90 $S/dataTypes.f90
- $S/base_route.f90 $H/shim_globalData.f90 $H/shim_runtime.f90 $S/var_lookup.f90
+ $S/base_route.f90 $S/var_lookup.f90 $H/shim_globalData.f90 $H/shim_runtime.f90
  $S/hydraulic.f90 $S/advection_diffusion.f90 $S/gamma_func.f90 $S/process_param.f90
  $S/water_balance.f90 $S/data_assimilation.f90 $S/accum_runoff.f90 $S/basinUH.f90
  $S/lake_route.f90 $S/irf_route.f90 $S/kwt_route.f90 $S/kwe_route.f90 $S/mc_route.f90
@@ -32,6 +32,15 @@ $FC $FFLAGS $OBJS -o "$OUT/ref_route"
 # second harness: the reference's forcing remap (remap_runoff, sort_flux) on its own
 $FC $FFLAGS -c "$H/ref_remap_driver.f90" -o ref_remap_driver.o
 $FC $FFLAGS ${OBJS/ ref_driver.o/} ref_remap_driver.o -o "$OUT/ref_remap"
+# third harness: the reference's start-up routines for the river network (augment_ntopo with the network_topo.f90 routines
+# it calls, mpi_domain_decomposition = classify_river_basin + assign_node), unmodified, on a plain-text case
+TOPO_OBJS=""
+for f in $S/pfafstetter.f90 $S/network_topo.f90 $S/process_ntopo.f90 $S/domain_decomposition.f90 $H/ref_topo_driver.f90; do
+  o="$(basename "${f%.f90}").o"
+  $FC $FFLAGS -c "$f" -o "$o"
+  TOPO_OBJS="$TOPO_OBJS $o"
+done
+$FC $FFLAGS ${OBJS/ ref_driver.o/} $TOPO_OBJS -o "$OUT/ref_topo"
 $FC --version | head -1 > "$OUT/BUILD_INFO.txt"
 echo "flags: $FFLAGS" >> "$OUT/BUILD_INFO.txt"
-echo "built $OUT/ref_route $OUT/ref_remap"
+echo "built $OUT/ref_route $OUT/ref_remap $OUT/ref_topo"

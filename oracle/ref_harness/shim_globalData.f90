@@ -10,7 +10,8 @@ MODULE globalData
   USE nrtype
   USE public_var
   USE datetime_data, ONLY: datetime
-  USE dataTypes,     ONLY: RCHTOPO, STRFLX, cMolecule, subbasin_mpi
+  USE dataTypes,     ONLY: RCHTOPO, STRFLX, cMolecule, subbasin_mpi, var_info
+  USE var_lookup,    ONLY: nVarsSEG
   USE base_route,    ONLY: routeContainer
   implicit none
   save
@@ -42,4 +43,15 @@ MODULE globalData
   type(subbasin_mpi), allocatable   :: domains_mpi(:)
   integer(i4b)                      :: nDomain_mpi
   integer(i4b), allocatable         :: nTribOutlet
+  ! what augment_ntopo (process_ntopo.f90:61-67) imports: spatially constant routing parameters (globalData.f90:181-188,
+  ! same defaults) and the metadata flags "read from the file or computed" of the reach properties (globalData.f90:204)
+  real(dp)                          :: fshape
+  real(dp)                          :: tscale
+  real(dp)                          :: velo
+  real(dp)                          :: diff
+  real(dp)                          :: mann_n
+  real(dp)                          :: wscale
+  real(dp)                          :: dscale=0.000045
+  real(dp)                          :: floodplainSlope=1000
+  type(var_info)                    :: meta_SEG(nVarsSEG)
 END MODULE globalData

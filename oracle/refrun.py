@@ -218,3 +218,58 @@ def run_remap(mp, sim, kind=None, remove_negatives=True):
     out = np.frombuffer(raw, dtype=np.float64, offset=4, count=H * nSteps).reshape(nSteps, H).copy()
     os.remove(case); os.remove(outp); os.rmdir(tmpdir)
     return ierr, out
+
+
+# ---- the reference's start-up routines for the river network (oracle/_ref/ref_topo: augment_ntopo, mpi_domain_decomposition)
+TOPO_EXE = os.path.join(HERE, "_ref", "ref_topo")
+
+
+def topo_available():
+    return os.path.exists(TOPO_EXE)
+
+
+def run_topo(seg_id, down_id, length, slope, hru_id, hru_seg, hru_area, n_nodes=1, dt=3600.0, fshape=2.5, tscale=86400.0,
+             velo=1.5, diff=5000.0, mann_n=0.01, wscale=0.001, dscale=0.0036, floodplain=False, irf=True, workdir=None):
+    """Raw topology (what the topology file holds) through the UNMODIFIED augment_ntopo and mpi_domain_decomposition.
+    Returns per-reach scalars and ragged lists (1-based indices as the reference holds them) and the MPI domains."""
+    import tempfile
+    seg_id, down_id = np.asarray(seg_id, np.int64), np.asarray(down_id, np.int64)
+    n_seg, n_hru = seg_id.size, np.asarray(hru_id).size
+    tmp = workdir or tempfile.mkdtemp(prefix="mzr_topo_")
+    fin, fout = os.path.join(tmp, "topo_case.txt"), os.path.join(tmp, "topo_out.txt")
+    with open(fin, "w") as f:
+        f.write(f"{n_seg} {n_hru} {int(n_nodes)}\n")
+        f.write(f"{dt!r} {fshape!r} {tscale!r} {velo!r} {diff!r} {mann_n!r} {wscale!r} {dscale!r} {int(floodplain)} {int(irf)}\n")
+        for a, fmt in ((seg_id, "%d"), (down_id, "%d"), (length, "%.17g"), (slope, "%.17g"), (hru_id, "%d"), (hru_seg, "%d"), (hru_area, "%.17g")):
+            f.write(" ".join(fmt % x for x in np.asarray(a)) + "\n")
+    r = subprocess.run([TOPO_EXE, fin, fout], capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(fout):
+        raise RuntimeError(f"ref_topo failed ({r.returncode}): {r.stdout[-400:]} {r.stderr[-400:]}")
+    lines = open(fout).read().split("\n")
+    it = iter(lines)
+    head = next(it).split()
+    assert head[0] == "augment_ntopo" and int(head[1]) == 0, head
+    tot = [int(x) for x in next(it).split()]
+    sc = np.array([next(it).split() for _ in range(n_seg)], dtype=object)
+    out = dict(tot_hru=tot[0], tot_upseg=tot[1], tot_upstream=tot[2], tot_uh=tot[3],
+               downSegIndex=sc[:, 1].astype(np.int64), nHRU=sc[:, 2].astype(np.int64), nUp=sc[:, 3].astype(np.int64),
+               nAllUp=sc[:, 4].astype(np.int64), rchOrder=sc[:, 5].astype(np.int64), streamOrder=sc[:, 6].astype(np.int64),
+               basArea=sc[:, 7].astype(np.float64), upsArea=sc[:, 8].astype(np.float64), totalArea=sc[:, 9].astype(np.float64),
+               width=sc[:, 10].astype(np.float64), depth=sc[:, 11].astype(np.float64), storage=sc[:, 12].astype(np.float64),
+               man_n=sc[:, 13].astype(np.float64), floodplainSlope=sc[:, 14].astype(np.float64),
+               hruContribIx=[], weight=[], upSegIndices=[], goodBasin=[], allUpSegIndices=[], timeDelayHist=[])
+    ints = lambda s: np.array(s.split(), dtype=np.int64)
+    flts = lambda s: np.array(s.split(), dtype=np.float64)
+    for _ in range(n_seg):
+        out["hruContribIx"].append(ints(next(it))); out["weight"].append(flts(next(it)))
+        out["upSegIndices"].append(ints(next(it))); out["goodBasin"].append(ints(next(it)))
+        out["allUpSegIndices"].append(ints(next(it))); out["timeDelayHist"].append(flts(next(it)))
+    head = next(it).split()
+    assert head[0] == "mpi_domain_decomposition" and int(head[1]) == 0, head
+    n_dom, n_contrib = [int(x) for x in next(it).split()]
+    doms = []
+    for _ in range(n_dom):
+        bt, node, ns, nh = [int(x) for x in next(it).split()]
+        doms.append(dict(basinType=bt, idNode=node, segIndex=ints(next(it)), hruIndex=ints(next(it))))
+    out["domains"], out["nContribHRU"] = doms, n_contrib
+    return out

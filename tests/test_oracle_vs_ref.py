@@ -246,3 +246,94 @@ def test_sort_flux_bit_exact(oracle_lib):
         ierr, ref = refrun.run_remap(dict(ix_in=ix, H=520), fl, remove_negatives=rm)
         assert ierr == 0
         assert np.array_equal(ref, oracle_lib.sort_flux(ix, fl, 520, remove_negatives=rm))
+
+
+# ---- the reference's start-up routines for the river network (oracle/_ref/ref_topo): augmentation and MPI domains
+def _raw_topology(net, seed, zero_area=0.0, orphans=0):
+    """what a topology file holds for `net`: ids, downstream ids, lengths, slopes, and the HRUs in a shuffled order (some with
+    zero area, some draining to a segment that is not in the network)"""
+    rng = np.random.default_rng(seed)
+    N = net.N
+    hru_id = (np.arange(N) + 50001).astype(np.int64)
+    seg_of_hru = np.zeros(N, np.int64)
+    for r in range(N):
+        seg_of_hru[net.hruIndex[net.hruOffset[r]:net.hruOffset[r + 1]] - 1] = net.reachId[r]
+    area = net.params["BASAREA"].copy()
+    # a reach may have several HRUs: split some areas over two HRUs of the same reach
+    extra = rng.choice(N, size=N // 5, replace=False)
+    hru_id = np.concatenate([hru_id, 900001 + np.arange(extra.size)])
+    seg_of_hru = np.concatenate([seg_of_hru, net.reachId[extra].astype(np.int64)])
+    area = np.concatenate([area, rng.uniform(1e5, 5e6, extra.size)])
+    if zero_area > 0:
+        area[rng.random(area.size) < zero_area] = 0.0
+    perm = rng.permutation(hru_id.size)
+    down_id = np.where(net.downIndex > 0, net.reachId[np.maximum(net.downIndex, 1) - 1], -1).astype(np.int64)
+    return dict(seg_id=net.reachId.astype(np.int64), down_id=down_id, length=net.params["RLENGTH"], slope=net.params["R_SLOPE"],
+                hru_id=hru_id[perm], hru_seg=seg_of_hru[perm], hru_area=area[perm])
+
+
+@pytest.mark.parametrize("N,seed,zero_area", [(60, 3, 0.0), (700, 4, 0.0), (2500, 5, 0.3)])
+def test_network_augmentation_matches_the_reference(N, seed, zero_area):
+    """mizuroute_amd.standalone.augment_topology against the UNMODIFIED augment_ntopo (process_ntopo.f90:39-266) and the
+    network_topo.f90 routines it calls: downstream indices, upstream lists, HRU lists and weights, areas, goodBasin,
+    hydraulic geometry and storage -- integers equal, reals bit for bit."""
+    from oracle import refrun
+    if not refrun.topo_available():
+        pytest.skip("oracle/_ref/ref_topo not built")
+    import mizuroute_amd as m
+    from mizuroute_amd import standalone
+    net0 = m.make_network(N, seed=seed)
+    raw = _raw_topology(net0, seed + 100, zero_area)
+    nml = dict(wscale=0.0017, mann_n=0.03)
+    ref = refrun.run_topo(**raw, n_nodes=1, wscale=nml["wscale"], mann_n=nml["mann_n"], irf=True)
+    net = standalone.augment_topology(nml=nml, **raw)
+    assert np.array_equal(np.where(net.downIndex > 0, net.downIndex, -1), ref["downSegIndex"])
+    assert np.array_equal(np.diff(net.upOffset), ref["nUp"]) and np.array_equal(np.diff(net.hruOffset), ref["nHRU"])
+    for r in range(net.N):
+        assert np.array_equal(net.upIndex[net.upOffset[r]:net.upOffset[r + 1]], ref["upSegIndices"][r]), r
+        assert np.array_equal(net.upGood[net.upOffset[r]:net.upOffset[r + 1]], ref["goodBasin"][r]), r
+        assert np.array_equal(net.hruIndex[net.hruOffset[r]:net.hruOffset[r + 1]], ref["hruContribIx"][r]), r
+        if net.params["BASAREA"][r] > 0.0:
+            assert np.array_equal(net.hruWeight[net.hruOffset[r]:net.hruOffset[r + 1]], ref["weight"][r]), r
+        else:      # HRUs without any area: the reference divides 0 by 0 (network_topo.f90:188), here the weights are 0
+            assert np.isnan(ref["weight"][r]).all() and (net.hruWeight[net.hruOffset[r]:net.hruOffset[r + 1]] == 0.0).all(), r
+    for name, key in (("BASAREA", "basArea"), ("TOTAREA", "totalArea"), ("R_WIDTH", "width"), ("R_DEPTH", "depth"), ("R_STORAGE", "storage"),
+                      ("R_MAN_N", "man_n"), ("FLDP_SLOPE", "floodplainSlope")):
+        assert np.array_equal(net.params[name], ref[key]), name
+    from mizuroute_amd.partition import subtree_sizes
+    assert np.array_equal(subtree_sizes(net), ref["nAllUp"])
+    # the reach unit hydrographs of the same call (make_uh)
+    from mizuroute_amd import uh as uhmod
+    off, uhv = uhmod.make_uh(net.params["RLENGTH"], 3600.0, 1.5, 5000.0)
+    for r in range(net.N):      # (numpy's exp / power against flang's: last bits)
+        assert off[r + 1] - off[r] == ref["timeDelayHist"][r].size and np.allclose(uhv[off[r]:off[r + 1]], ref["timeDelayHist"][r], rtol=1e-12, atol=1e-300), r
+
+
+@pytest.mark.parametrize("N,seed,nodes", [(300, 5, 4), (3000, 6, 8), (3000, 7, 3), (20000, 8, 8), (500, 9, 2), (400, 10, 1)])
+def test_domain_decomposition_matches_the_reference(N, seed, nodes):
+    """mizuroute_amd.partition against the UNMODIFIED mpi_domain_decomposition (classify_river_basin + assign_node,
+    domain_decomposition.f90:41-163,450-590,724-819): the same domains in the same order, the same reaches in each, the
+    same node for each (ties between equally large domains included), and the partitions that follow from it."""
+    from oracle import refrun
+    if not refrun.topo_available():
+        pytest.skip("oracle/_ref/ref_topo not built")
+    import mizuroute_amd as m
+    from mizuroute_amd.partition import reference_domains, partition_network
+    net = m.make_network(N, seed=seed)
+    raw = _raw_topology(net, seed + 200)
+    ref = refrun.run_topo(**raw, n_nodes=nodes, irf=False)
+    kind, outlet, size, node, is_main, root_of = reference_domains(net, nodes)
+    doms = [d for d in ref["domains"] if d["basinType"] != 3]
+    assert len(doms) == kind.size
+    assert [d["basinType"] for d in doms] == list(kind)
+    assert [d["segIndex"].size for d in doms] == list(size)
+    assert [d["idNode"] for d in doms] == list(node)
+    for k, d in enumerate(doms):
+        mine = np.nonzero(is_main)[0] if kind[k] == 2 else np.nonzero(root_of == outlet[k])[0]
+        assert np.array_equal(np.sort(d["segIndex"]) - 1, mine), k
+    P = partition_network(net, nodes, build_for=[])
+    want = np.zeros(net.N, np.int64)
+    for d in doms:
+        want[d["segIndex"] - 1] = max(d["idNode"], 0)
+    assert np.array_equal(P.part_of_reach, want)
+    assert np.array_equal(P.is_mainstem, is_main)

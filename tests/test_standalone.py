@@ -426,6 +426,34 @@ def test_run_from_files_with_a_constituent(tmp_path, hip_lib):
 
 
 @pytest.mark.gpu
+def test_constituent_run_restarted_from_a_file_continues(tmp_path, hip_lib):
+    """<tracer> T with <restart_write> last and <fname_state_in>: the restart file must carry the constituent state
+    (tfuture, solute_mass), and a run cut in two must end where the uninterrupted run ends."""
+    net = m.make_network(800, seed=61)
+    dt, steps, cut = 3600.0, 36, 18
+    ro = m.make_runoff(net.H, steps, seed=62, storm_prob=0.05, storm_amp=3e-6)
+    sol = np.random.default_rng(63).uniform(0.0, 5.0, (steps, net.H))
+    base = "<tracer> T\n<vname_solute> solute\n<units_cc> g/hour\n<restart_write> last\n<outputFrequency> 6\n"
+    t = lambda k: str(np.datetime64("2001-01-01T00:00:00") + np.timedelta64(int(k * dt), "s")).replace("T", " ")
+    whole = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="15", solute=sol, extra=base + "<case_name> whole\n")
+    out_w = standalone.run(whole, window=7, log=lambda *_: None)
+    first = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="15", solute=sol,
+                       extra=base + f"<case_name> first\n<sim_end> {t(cut - 1)}\n")
+    out_1 = standalone.run(first, window=5, log=lambda *_: None)
+    f = netcdf_file(out_1["restart"], "r", mmap=False)
+    assert "tfuture" in f.variables and any(k.startswith("solute_mass") for k in f.variables), list(f.variables)
+    f.close()
+    second = write_case(str(tmp_path), net, ro * 1000.0, dt, route_opt="15", solute=sol,
+                        extra=base + f"<case_name> second\n<sim_start> {t(cut)}\n<fname_state_in> {os.path.basename(out_1['restart'])}\n")
+    out_2 = standalone.run(second, window=7, log=lambda *_: None)
+    fw, f2 = netcdf_file(out_w["restart"], "r", mmap=False), netcdf_file(out_2["restart"], "r", mmap=False)
+    for k in fw.variables:
+        a, b = np.asarray(fw.variables[k][:]), np.asarray(f2.variables[k][:])
+        assert np.array_equal(a, b), k
+    fw.close(); f2.close()
+
+
+@pytest.mark.gpu
 def test_run_from_files_with_gauge_observations(tmp_path, hip_lib):
     """<qmodOption> 1: gauge metadata csv + observation file (sites as character arrays, 3-hourly times), against the same
     run through the API."""
