@@ -222,7 +222,7 @@ def partition_network(net: RiverNetwork, n_parts: int, build_for=None) -> Partit
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
     # domains and their nodes exactly as the reference makes them (pinned against the compiled reference routines,
-    # tests/test_oracle_vs_ref.py::test_domain_decomposition_matches_the_reference); partition p = node p, the mainstem
+    # the test test_domain_decomposition_matches_the_reference); partition p = node p, the mainstem
     # (node -1, "handled in root proc") goes to partition 0
     kind, outlet, size, node, is_main, root_of = reference_domains(net, n_parts)
     roots = np.sort(outlet[kind == 1])

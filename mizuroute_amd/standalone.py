@@ -151,7 +151,7 @@ def augment_topology(seg_id, down_id, length, slope, hru_id, hru_seg, hru_area, 
     reach order, the HRUs of every reach in file order with their area weights (network_topo.f90:188), BASAREA / TOTAREA,
     goodBas (upstream reaches with a contributing area), hydraulic geometry from wscale (no floodplain: depth = high_depth),
     channel storage, and the slope floor of put_data_struct (process_ntopo.f90:274).  Compared with the compiled reference
-    routines in tests/test_oracle_vs_ref.py::test_network_augmentation_matches_the_reference."""
+    routines in the test test_network_augmentation_matches_the_reference."""
     seg_id, down_id = np.asarray(seg_id, dtype=np.int64), np.asarray(down_id, dtype=np.int64)
     length, slope = np.asarray(length, dtype=np.float64), np.asarray(slope, dtype=np.float64)
     hru_id, hru_seg, hru_area = np.asarray(hru_id, dtype=np.int64), np.asarray(hru_seg, dtype=np.int64), np.asarray(hru_area, dtype=np.float64)
