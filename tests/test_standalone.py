@@ -132,7 +132,10 @@ def test_network_augmentation_matches_the_generator(tmp_path):
     pos = net.params["TOTAREA"] > 0      # (the generator gives zero-area reaches a 1 mm wide channel; the reference formula gives 0)
     for k in net.PARAM_ORDER:
         sel = pos if k in ("R_WIDTH", "R_STORAGE") else slice(None)
-        assert np.array_equal(got.params[k][sel], net.params[k][sel]), k
+        if k in ("TOTAREA", "R_WIDTH", "R_STORAGE"):      # the generator adds the upstream areas level by level, the driver in the
+            assert np.allclose(got.params[k][sel], net.params[k][sel], rtol=1e-13, atol=0.0), k      # reference's order (pinned in test_oracle_vs_ref.py)
+        else:
+            assert np.array_equal(got.params[k][sel], net.params[k][sel]), k
     w = got.hruWeight[net.params["BASAREA"][np.repeat(np.arange(net.N), np.diff(net.hruOffset))] > 0]
     assert np.array_equal(w, np.ones_like(w))
 
