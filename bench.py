@@ -116,6 +116,184 @@ def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=
                       f"timed after 24 (lists not yet at steady state: an upper bound for one core)"}
 
 
+FULL = {"c3": 3_000_000, "c4": 5_000_000, "c5": 3_000_000}      # reaches of the 8-GPU configurations (BASELINE.json configs[2..4])
+
+
+def loopback_bench(args, torch, m, uhmod):
+    """The full-size network of an 8-GPU configuration on ONE GPU: cut into sub-basin partitions by the reference's rule
+    (mizuroute_amd/partition.py = domain_decomposition.f90), every partition routed as its own domain one after the other,
+    boundary records of the tributary outlets handed to the mainstem domain through device memory (what RCCL carries between
+    GPUs).  (A) parity: two short windows against the unpartitioned network, bit for bit (interval means, particle counts);
+    (B) timing: windows of the configuration's length, per-domain sweep time, and what eight GPUs would take: every rank its
+    tributary domain, rank 0 also the mainstem one window behind -- max(slowest tributary, rank 0's tributary + mainstem)."""
+    from mizuroute_amd.partition import partition_network
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    cfg = CONFIGS[args.config]
+    methods = [int(c) for c in cfg["methods"]]
+    nparts = args.partitions or 8
+    N = args.reaches or FULL[args.config]
+    frac = uhmod.basin_uh(DT, 2.5, 86400.0)
+    t0 = time.perf_counter()
+    net = m.make_network(N, seed=20240529, floodplain=bool(cfg.get("floodplain")))
+    P = partition_network(net, nparts)
+    t_setup = time.perf_counter() - t0
+    need_uh = any(x != m.KWT for x in methods)
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], DT, 1.5, 5000.0) if need_uh else (None, None)
+
+    def uh_of(spec):
+        if not need_uh:
+            return {}
+        g = spec.reach_global
+        cnt = np.diff(uh_off)[g]
+        off = np.zeros(g.size + 1, np.int32); off[1:] = np.cumsum(cnt)
+        idx = np.repeat(uh_off[g].astype(np.int64), cnt) + (np.arange(int(cnt.sum())) - np.repeat(off[:-1].astype(np.int64), cnt))
+        return dict(uh_offset=off, uh=uhv[idx])
+
+    def make(spec, W, **kw):
+        kw.pop("sweep_share", None)                    # the domains run one after the other here: each may fill the device
+        return m.RoutingDomain(spec.net, DT, methods, frac_future=frac, max_window=W, device=0, **uh_of(spec), **kw)
+
+    def forcing(W, t0s, cols=None, shared=True):
+        """shared: one forcing for the whole network, a domain takes the columns of its HRUs (parity); otherwise a forcing of
+        the domain's own (timing: the whole network's window would not fit beside the domains)"""
+        if not shared:
+            return device_runoff(torch, len(cols), W, t0s, 7 + len(cols) % 97, dev)
+        ro = device_runoff(torch, net.H, W, t0s, 7, dev)
+        return ro if cols is None else ro[:, torch.as_tensor(cols, device=dev, dtype=torch.long)].contiguous()
+
+    def route_partitioned(W, K, timing):
+        """all windows of one domain, then the next; returns per-reach interval means / particle counts and the times"""
+        mean = {mm: np.zeros(net.N) for mm in methods}
+        nw = np.zeros(net.N, np.int64)
+        recs = {}                                      # (partition, window) -> boundary record on the device
+        times = {}
+        for p in range(nparts):
+            sp = P.trib[p]
+            if sp.n_real == 0:
+                continue
+            dom = make(sp, W, export_reaches=sp.export_local)
+            tw = []
+            for k in range(K):
+                ro = forcing(W, k * W, sp.hru_global, shared=not timing)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                dom.run_device(W, k * W * DT, ro.data_ptr()); dom.sync()
+                tw.append(time.perf_counter() - t1)
+                if sp.export_local.size and P.main is not None:
+                    rec = torch.empty(dom.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=dev)
+                    dom.export_boundary(rec.data_ptr()); dom.sync()
+                    recs[(p, k)] = rec
+                del ro
+            times[f"trib{p}"] = dict(reaches=int(sp.n_real), stages=dom.schedule()[0], exports=int(sp.export_local.size), s_per_window=tw)
+            for mm in methods:
+                mean[mm][sp.reach_global[:sp.n_real]] = dom.mean_q(mm)[:sp.n_real]
+            if m.KWT in methods:
+                nw[sp.reach_global[:sp.n_real]] = dom.kwt_state()[0][:sp.n_real]
+            dom.close(); del dom
+        if P.main is not None:
+            ms = P.main
+            dom = make(ms, W, halo_reaches=ms.halo_local, halo_good=ms.halo_good)
+            tw = []
+            for k in range(K):
+                ro = forcing(W, k * W, ms.hru_global, shared=not timing)
+                for p in range(nparts):
+                    base, n = ms.halo_base[p]
+                    if n:
+                        dom.import_boundary(W, recs[(p, k)].data_ptr(), n, base)
+                dom.sync()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                dom.run_device(W, k * W * DT, ro.data_ptr()); dom.sync()
+                tw.append(time.perf_counter() - t1)
+                del ro
+            times["main"] = dict(reaches=int(ms.n_real), halos=int(ms.halo_local.size), stages=dom.schedule()[0], s_per_window=tw,
+                                 record_bytes_per_window=int(sum(r.numel() for (p, k), r in recs.items() if k == 0) * 8))
+            for mm in methods:
+                mean[mm][ms.reach_global[:ms.n_real]] = dom.mean_q(mm)[:ms.n_real]
+            if m.KWT in methods:
+                nw[ms.reach_global[:ms.n_real]] = dom.kwt_state()[0][:ms.n_real]
+            dom.close(); del dom
+        if not timing:
+            recs.clear()
+        torch.cuda.empty_cache()
+        return mean, nw, times, recs
+
+    out = {"metric": "reaches*timesteps/s", "unit": "reaches*timesteps/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"FULL {args.config} network ({net.N} reaches, route_opt {cfg['methods']}) in {nparts} sub-basin partitions (reference decomposition), "
+                                  "all on one GPU, boundary records through device memory", "baseline_config": args.config, "reaches_total": net.N,
+                      "partitions": nparts, "mainstem_reaches": int(P.is_mainstem.sum()), "setup_s": t_setup}}
+    # ---- (A) parity against the unpartitioned network
+    Wa, Ka = 256, 2
+    extra = dict(uh_offset=uh_off, uh=uhv) if need_uh else {}
+    whole = m.RoutingDomain(net, DT, methods, frac_future=frac, max_window=Wa, device=0, **extra)
+    tw = []
+    for k in range(Ka):
+        ro = forcing(Wa, k * Wa)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        whole.run_device(Wa, k * Wa * DT, ro.data_ptr()); whole.sync()
+        tw.append(time.perf_counter() - t1)
+        del ro
+    mean_w = {mm: whole.mean_q(mm) for mm in methods}
+    nw_w = whole.kwt_state()[0] if m.KWT in methods else None
+    out["config"]["whole_network"] = dict(stages=whole.schedule()[0], window_steps=Wa, s_per_window=tw,
+                                          value=float(net.N) * Wa * len(methods) / tw[-1])
+    whole.close(); del whole
+    torch.cuda.empty_cache()
+    mean_p, nw_p, _, _ = route_partitioned(Wa, Ka, False)
+    same = all(np.array_equal(mean_p[mm], mean_w[mm]) for mm in methods) and (nw_w is None or np.array_equal(nw_p, nw_w))
+    out["parity"] = {"partitioned_equals_whole_bit_for_bit": bool(same), "window_steps": Wa, "windows": Ka,
+                     "max_abs_diff": float(max(np.abs(mean_p[mm] - mean_w[mm]).max() for mm in methods))}
+    # ---- (B) timing at the configuration's window length
+    W, K = args.window or cfg["window"], max(2, args.steps)
+    _, _, times, recs = route_partitioned(W, K, True)
+    steady = lambda d: float(np.mean(d["s_per_window"][1:]))
+    trib = {k: steady(v) for k, v in times.items() if k.startswith("trib")}
+    t_main = steady(times["main"]) if "main" in times else 0.0
+    one_gpu = sum(trib.values()) + t_main
+    # rank 0 as it really runs (PartitionedRouter): its tributary window k and the mainstem window k-1 SIDE BY SIDE on one GPU,
+    # each sweep with its share of the wavefront slots; the other partitions' records are the ones measured above
+    t_rank0 = trib.get("trib0", 0.0) + t_main
+    if P.main is not None and P.trib[0].n_real > 0:
+        sp, ms = P.trib[0], P.main
+        d_t = m.RoutingDomain(sp.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.8, export_reaches=sp.export_local, **uh_of(sp))
+        d_m = m.RoutingDomain(ms.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.2, halo_reaches=ms.halo_local,
+                              halo_good=ms.halo_good, **uh_of(ms))
+        ro_t = [forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
+        ro_m = [forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
+        rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=dev) for _ in range(2)]
+        tw = []
+        for k in range(K + 1):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            if k < K:
+                d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
+            if k >= 1:                                   # the mainstem follows one window behind
+                for p in range(nparts):
+                    base, n = ms.halo_base[p]
+                    if n:
+                        d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
+                d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
+            if k < K:
+                d_t.sync()
+                d_t.export_boundary(rec0[k % 2].data_ptr())
+            d_t.sync(); d_m.sync()
+            if 1 <= k < K:
+                tw.append(time.perf_counter() - t1)
+        t_rank0 = float(np.mean(tw[1:] if len(tw) > 1 else tw))
+        times["rank0_side_by_side"] = dict(s_per_window=tw, what="tributary window k and mainstem window k-1 of rank 0 queued together (sweep shares 0.8 / 0.2)")
+        d_t.close(); d_m.close()
+    recs.clear()
+    crit = max(max(trib.values()), t_rank0)
+    out.update({"value": float(net.N) * W * len(methods) / one_gpu, "steps": K, "warmup": 1, "ms_per_step": one_gpu * 1e3, "scaling": "strong",
+                "vs_baseline": None, "error": None if same else "partitioned run differs from the whole network"})
+    out["config"].update({"window_steps": W, "domains": times})
+    out["model_8gpu"] = {"what": "one domain per GPU as measured here; window time = max(slowest tributary rank, rank 0 with its tributary and the mainstem side by side); "
+                                 "the boundary records (bytes above) travel behind the next window's sweep",
+                         "s_per_window": crit, "value": float(net.N) * W * len(methods) / crit,
+                         "slowest_tributary_s": max(trib.values()), "rank0_tributary_plus_mainstem_one_after_the_other_s": trib.get("trib0", 0.0) + t_main,
+                         "rank0_side_by_side_s": t_rank0,
+                         "balance": min(trib.values()) / max(trib.values())}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +310,10 @@ def main():
                     "generated for the whole network and sliced per domain, so that every partitioning routes the same thing")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-forcing leg (value_with_h2d)")
     ap.add_argument("--no-single-step", action="store_true", help="skip the mzr_step leg (single_step)")
+    ap.add_argument("--partitions", type=int, default=0,
+                    help="with --loopback: route the FULL-SIZE network of --config (c3 ~3 M reaches KWT, c4 ~5 M IRF + MC, c5 ~3 M DW) cut into "
+                         "this many sub-basin partitions by the reference's decomposition, all of them on this one GPU")
+    ap.add_argument("--loopback", action="store_true", help="see --partitions: boundary records go through device memory instead of RCCL")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
@@ -139,6 +321,9 @@ def main():
     import torch
     import mizuroute_amd as m
     from mizuroute_amd import uh as uhmod
+
+    if args.loopback:
+        return loopback_bench(args, torch, m, uhmod)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

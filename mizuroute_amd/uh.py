@@ -104,7 +104,9 @@ def basin_uh(dt: float, fshape: float, tscale: float) -> np.ndarray:
 
 
 def make_uh(length: np.ndarray, dt: float, velo: float, diff: float):
-    """Per-reach unit hydrographs at the simulation step; returns (uhOffset[N+1], uh[sum ntdh])."""
+    """Per-reach unit hydrographs at the simulation step; returns (uhOffset[N+1], uh[sum ntdh]).
+    process_param.f90:99-262 (make_uh), all reaches at once: the sums run in the source's order (np.cumsum is sequential
+    along a row), so the result is what the per-reach loop gives, bit for bit."""
     length = np.asarray(length, dtype=np.float64)
     n_seg = length.shape[0]
     dTUH, nHr = 3600.0, 240
@@ -112,45 +114,47 @@ def make_uh(length: np.ndarray, dt: float, velo: float, diff: float):
     fr = np.zeros(nHr)
     fr[:nTsub] = 1.0 / nTsub
     sec = dTUH * np.arange(1, nHr + 1)
-    offs = np.zeros(n_seg + 1, dtype=np.int32)
+    thr5, thr4 = float(np.float32(0.99999)), float(np.float32(0.9999))      # default-real literals in the source (:184,190,222)
+    offs = np.zeros(n_seg + 1, dtype=np.int64)
     chunks = []
-    for i in range(n_seg):
-        L = length[i]
+    hrs = np.arange(1, nHr + 1)
+    for c0 in range(0, n_seg, 65536):
+        L = length[c0:c0 + 65536][:, None]
+        n = L.shape[0]
         if velo > 0.0:
-            pot = ((velo * sec - L) ** 2.0) / (4.0 * diff * sec)
-            H = np.where(pot > 69.0, 0.0, 1.0 / (2.0 * np.sqrt(3.14159265359 * diff * sec)) * L * np.exp(-np.minimum(pot, 700.0)))
+            pot = ((velo * sec[None, :] - L) ** 2.0) / (4.0 * diff * sec[None, :])
+            H = np.where(pot > 69.0, 0.0, 1.0 / (2.0 * np.sqrt(3.14159265359 * diff * sec[None, :])) * L * np.exp(-np.minimum(pot, 700.0)))
         else:
-            H = np.zeros(nHr)
-        inte = float(np.cumsum(H)[-1])
-        UHM = H / inte if inte > 0.0 else H
-        cs = np.cumsum(UHM)
-        # (the thresholds are default-real literals in the source: process_param.f90:184,190,222)
-        idx = np.nonzero(cs > float(np.float32(0.99999)))[0]
-        iHrLast = int(idx[0]) + 1 if idx.size else nHr
-        csr = np.cumsum(UHM[::-1])
-        idx = np.nonzero(csr > float(np.float32(0.99999)))[0]
-        iHrStrt = nHr - int(idx[0]) if idx.size else 1
-        UHQ = np.zeros(nHr)
-        for jHr in range(1, nHr + 1):
-            acc = 0.0
-            for iHr in range(iHrStrt, iHrLast + 1):
-                if jHr - iHr > 0:
-                    if jHr - iHr <= nTsub:
-                        acc += fr[jHr - iHr - 1] * UHM[iHr - 1]
-                else:
-                    break
-            UHQ[jHr - 1] = acc
-        inte = float(np.cumsum(UHQ)[-1])
-        if inte > 0.0:
-            UHQ = UHQ / inte
-        cs = np.cumsum(UHQ)
-        idx = np.nonzero(cs > float(np.float32(0.9999)))[0]
-        iHrLast = int(idx[0]) + 1 if idx.size else nHr
-        UHQ = UHQ / cs[iHrLast - 1]
+            H = np.zeros((n, nHr))
+        inte = np.cumsum(H, axis=1)[:, -1:]
+        UHM = np.where(inte > 0.0, H / np.where(inte > 0.0, inte, 1.0), H)
+        cs = np.cumsum(UHM, axis=1)
+        hit = cs > thr5
+        iHrLast = np.where(hit.any(axis=1), hit.argmax(axis=1) + 1, nHr)
+        csr = np.cumsum(UHM[:, ::-1], axis=1)
+        hit = csr > thr5
+        iHrStrt = np.where(hit.any(axis=1), nHr - hit.argmax(axis=1), 1)
+        inside = (hrs[None, :] >= iHrStrt[:, None]) & (hrs[None, :] <= iHrLast[:, None])
+        UHMm = np.where(inside, UHM, 0.0)
+        # UHQ(jHr) = sum over iHr = iHrStrt..iHrLast (ascending) of fr(jHr-iHr) * UHM(iHr) for 0 < jHr-iHr <= nTsub
+        UHQ = np.zeros((n, nHr))
+        for d in range(min(nTsub, nHr - 1), 0, -1):
+            UHQ[:, d:] = UHQ[:, d:] + fr[d - 1] * UHMm[:, :nHr - d]
+        inte = np.cumsum(UHQ, axis=1)[:, -1:]
+        UHQ = np.where(inte > 0.0, UHQ / np.where(inte > 0.0, inte, 1.0), UHQ)
+        cs = np.cumsum(UHQ, axis=1)
+        hit = cs > thr4
+        iHrLast = np.where(hit.any(axis=1), hit.argmax(axis=1) + 1, nHr)
+        UHQ = UHQ / cs[np.arange(n), iHrLast - 1][:, None]
         ntdh = (iHrLast + nTsub - 1) // nTsub
-        u = np.zeros(ntdh)
-        for jHr in range(1, iHrLast + 1):
-            u[(jHr + nTsub - 1) // nTsub - 1] += UHQ[jHr - 1]
-        chunks.append(u)
-        offs[i + 1] = offs[i] + ntdh
-    return offs, np.concatenate(chunks) if chunks else np.zeros(0)
+        UHQ = np.where(hrs[None, :] <= iHrLast[:, None], UHQ, 0.0)
+        nT = (nHr + nTsub - 1) // nTsub
+        pad = np.zeros((n, nT * nTsub)); pad[:, :nHr] = UHQ
+        grp = pad.reshape(n, nT, nTsub)
+        u = np.zeros((n, nT))
+        for k in range(nTsub):          # hours of a step are added one after the other
+            u = u + grp[:, :, k]
+        keep = np.arange(nT)[None, :] < ntdh[:, None]
+        chunks.append(u[keep])
+        offs[c0 + 1:c0 + n + 1] = offs[c0] + np.cumsum(ntdh)
+    return offs.astype(np.int32), np.concatenate(chunks) if chunks else np.zeros(0)
