@@ -136,7 +136,10 @@ def loopback_bench(args, torch, m, uhmod):
     frac = uhmod.basin_uh(DT, 2.5, 86400.0)
     t0 = time.perf_counter()
     net = m.make_network(N, seed=20240529, floodplain=bool(cfg.get("floodplain")))
-    P = partition_network(net, nparts)
+    from mizuroute_amd.partition import mainstem_cost
+    Wcfg = args.window or cfg["window"]
+    mc = mainstem_cost(net, nparts, Wcfg) if (args.balance and methods == [m.KWT]) else 0.0
+    P = partition_network(net, nparts, main_cost=mc)
     t_setup = time.perf_counter() - t0
     need_uh = any(x != m.KWT for x in methods)
     uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], DT, 1.5, 5000.0) if need_uh else (None, None)
@@ -220,7 +223,8 @@ def loopback_bench(args, torch, m, uhmod):
     out = {"metric": "reaches*timesteps/s", "unit": "reaches*timesteps/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"FULL {args.config} network ({net.N} reaches, route_opt {cfg['methods']}) in {nparts} sub-basin partitions (reference decomposition), "
                                   "all on one GPU, boundary records through device memory", "baseline_config": args.config, "reaches_total": net.N,
-                      "partitions": nparts, "mainstem_reaches": int(P.is_mainstem.sum()), "setup_s": t_setup}}
+                      "partitions": nparts, "mainstem_reaches": int(P.is_mainstem.sum()), "setup_s": t_setup,
+                      "assignment": "reference (assign_node)" if mc == 0.0 else f"rank 0's tributary share cut by the mainstem's cost of {mc:.0f} reaches"}}
     # ---- (A) parity against the unpartitioned network
     Wa, Ka = 256, 2
     extra = dict(uh_offset=uh_off, uh=uhv) if need_uh else {}
@@ -314,6 +318,8 @@ def main():
                     help="with --loopback: route the FULL-SIZE network of --config (c3 ~3 M reaches KWT, c4 ~5 M IRF + MC, c5 ~3 M DW) cut into "
                          "this many sub-basin partitions by the reference's decomposition, all of them on this one GPU")
     ap.add_argument("--loopback", action="store_true", help="see --partitions: boundary records go through device memory instead of RCCL")
+    ap.add_argument("--balance", action="store_true", help="with --loopback or --gpus N: cut rank 0's share of small tributaries by what the mainstem costs it "
+                    "(partition.mainstem_cost; the reference's assignment gives rank 0 an even share plus the mainstem)")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
@@ -378,7 +384,8 @@ def main():
         doms = [(dom, net.H)]
     else:
         from mizuroute_amd.partition import PartitionedRouter, partition_network
-        P = partition_network(net, world, build_for=[rank])
+        from mizuroute_amd.partition import mainstem_cost
+        P = partition_network(net, world, build_for=[rank], main_cost=mainstem_cost(net, world, W) if args.balance else 0.0)
 
         lib_comm = None
         if os.environ.get("MZR_BENCH_TRANSPORT") == "lib" and backend == "nccl":     # the library's own RCCL transport (mzr_comm_*)

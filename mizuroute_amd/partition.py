@@ -123,7 +123,7 @@ def nr_indexx(arr) -> np.ndarray:
     return np.array(idx[1:], dtype=np.int64) - 1
 
 
-def reference_domains(net: RiverNetwork, n_nodes: int):
+def reference_domains(net: RiverNetwork, n_nodes: int, main_cost: float = 0.0):
     """The reference's MPI domains and their nodes (domain_decomposition.f90): `classify_river_basin` / `decomposeDomain`
     (:450-590, :600-720) make, in this order, one tributary domain per basin whose outlet has at most nSeg/nNodes reaches
     upstream (itself counted), the mainstem domain (every reach with more than that), and one tributary domain per reach
@@ -131,7 +131,11 @@ def reference_domains(net: RiverNetwork, n_nodes: int):
     than nTribSeg/nNodes reaches, takes the LAST nNodes-1 domains of the list back out (by position in the list, as the
     source does), and deals what is left, largest first, the mainstem to the root (-1) and every tributary to the node
     of 1..nNodes-1 with the least work so far.  Returns (kind[nDom] 1 tributary / 2 mainstem, outlet reach [nDom] (0-based,
-    -1 for the mainstem), size[nDom], node[nDom], is_mainstem[N], root_of[N])."""
+    -1 for the mainstem), size[nDom], node[nDom], is_mainstem[N], root_of[N]).
+    main_cost (not in the reference; 0 = its rule): what routing the mainstem costs the root, in tributary reaches.  On CPUs
+    the few thousand mainstem reaches are a rounding error of the root's share; on a GPU they are a chain of thousands of
+    dependent stages that costs half a tributary share (`mainstem_cost`), so the root's even share of small tributaries is cut
+    to (nTribSeg - (nNodes-1) main_cost) / nNodes.  The domains themselves and every result stay the same."""
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
     cnt = subtree_sizes(net)
@@ -152,6 +156,8 @@ def reference_domains(net: RiverNetwork, n_nodes: int):
     node = np.full(n_dom, -99, np.int64)
     assigned = np.zeros(n_dom, bool)
     n_even = int(size[kind == 1].sum()) // max(1, n_nodes)
+    if main_cost > 0.0 and n_nodes > 1 and (kind == 2).any():
+        n_even = max(0, int((float(size[kind == 1].sum()) - (n_nodes - 1) * main_cost) / n_nodes))
     small = 0
     for ixx in rank:
         if kind[ixx] == 1:
@@ -216,15 +222,29 @@ def _local_network(net: RiverNetwork, real: np.ndarray, halos: np.ndarray) -> tu
     return sub, loc, np.array(hru_g, np.int64)
 
 
-def partition_network(net: RiverNetwork, n_parts: int, build_for=None) -> Partition:
+def mainstem_cost(net: RiverNetwork, n_parts: int, window: int, level_s: float = 38e-6, reach_steps_per_s: float = 2.9e9) -> float:
+    """What the mainstem domain of an n_parts-way decomposition costs per window, in tributary reaches (KWT on MI355X,
+    profiles/r03_loopback_c3.json): it is a chain of (its stages + window) dependent levels of ~38 us each, while a tributary
+    domain routes ~2.9e9 reach-steps/s."""
+    down0 = net.downIndex.astype(np.int64) - 1
+    is_main = subtree_sizes(net) > (net.N // max(1, n_parts))
+    if not is_main.any():
+        return 0.0
+    dist = hops_to_outlet(down0)
+    depth = int(dist[is_main].max()) + 1
+    return (depth + window) * level_s * reach_steps_per_s / window
+
+
+def partition_network(net: RiverNetwork, n_parts: int, build_for=None, main_cost: float = 0.0) -> Partition:
     """build_for: partitions whose Domain objects (local networks) are materialised; None = all.
-    A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full."""
+    A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full.
+    main_cost: see reference_domains (0 = the reference's assignment)."""
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
     # domains and their nodes exactly as the reference makes them (pinned against the compiled reference routines,
     # the test test_domain_decomposition_matches_the_reference); partition p = node p, the mainstem
     # (node -1, "handled in root proc") goes to partition 0
-    kind, outlet, size, node, is_main, root_of = reference_domains(net, n_parts)
+    kind, outlet, size, node, is_main, root_of = reference_domains(net, n_parts, main_cost)
     roots = np.sort(outlet[kind == 1])
     part_of_root = {int(o): int(max(nd, 0)) for o, nd, k in zip(outlet, node, kind) if k == 1}
     part_of_reach = np.zeros(N, dtype=np.int64)
