@@ -214,13 +214,17 @@ class HistoryWriter:
         tb = self.f.createVariable("time_bounds", "d", ("time", "tbound")); tb.units = time_units; tb.calendar = calendar; tb.long_name = "time interval endpoints"
         _var(self.f, "reachID", "i", ("seg",), np.asarray(reach_id, np.int32), long_name="reach ID", units="-")
         self.vars = {}
-        self.runoff = runoff
-        if runoff:
+        # runoff: True = all three, or the names wanted (the reference's defaults: basRunoff on, instRunoff and dlayRunoff off,
+        # read_control.f90:239-241, popMetadat.f90:238-239)
+        want = ("basRunoff", "instRunoff", "dlayRunoff") if runoff is True else tuple(runoff or ())
+        self.runoff = want
+        if "basRunoff" in want:
             if hru_id is None:
                 raise ValueError("basRunoff needs hru_id")
             self.f.createDimension("hru", len(hru_id))
             _var(self.f, "basinID", "i", ("hru",), np.asarray(hru_id, np.int32), long_name="basin ID", units="-")
-            for name, dims, unit in (("basRunoff", ("time", "hru"), "m/s"), ("instRunoff", ("time", "seg"), "m3/s"), ("dlayRunoff", ("time", "seg"), "m3/s")):
+        for name, dims, unit in (("basRunoff", ("time", "hru"), "m/s"), ("instRunoff", ("time", "seg"), "m3/s"), ("dlayRunoff", ("time", "seg"), "m3/s")):
+            if name in want:
                 v = self.f.createVariable(name, "f", dims); v.units = unit
         for m in self.methods:
             q = self.f.createVariable(HIST_Q[m], "f", ("time", "seg")); q.units = "m3/s"
@@ -266,10 +270,9 @@ class HistoryWriter:
                 var[self.n, :] = dom.mean_q(m, reset=True).astype(np.float32)        # stand-ins in tests
             else:
                 var[self.n, :] = dom.mean(m, which).astype(np.float32)
-        if self.runoff:
-            self.f.variables["basRunoff"][self.n, :] = dom.mean(0, api.M_BAS_RUNOFF).astype(np.float32)
-            self.f.variables["instRunoff"][self.n, :] = dom.mean(0, api.M_INST_RUNOFF).astype(np.float32)
-            self.f.variables["dlayRunoff"][self.n, :] = dom.mean(0, api.M_DLAY_RUNOFF).astype(np.float32)
+        for name, which in (("basRunoff", api.M_BAS_RUNOFF), ("instRunoff", api.M_INST_RUNOFF), ("dlayRunoff", api.M_DLAY_RUNOFF)):
+            if name in self.runoff:
+                self.f.variables[name][self.n, :] = dom.mean(0, which).astype(np.float32)
         if hasattr(dom, "reset_means"):
             dom.reset_means()
         self.n += 1

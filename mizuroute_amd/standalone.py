@@ -412,9 +412,16 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
         time_conv_sol = {"d": 1.0 / 86400.0, "day": 1.0 / 86400.0, "h": 1.0 / 3600.0, "hr": 1.0 / 3600.0, "hour": 1.0 / 3600.0, "s": 1.0, "sec": 1.0, "second": 1.0}[c_time]
     is_lake, is_flux_wm = _truth(ctl.get("is_lake_sim", "F")), _truth(ctl.get("is_flux_wm", "F"))
     is_vol_wm = _truth(ctl.get("is_vol_wm", "F")) and is_lake
+    if is_vol_wm and int(ctl.get("LakeInputOption", 0)) == 1:
+        # the reference reads the target volumes inside its "LakeInputOption 0 or 2" branch only (get_basin_runoff.f90:138-229):
+        # with option 1 its lakes would follow volumes that were never read
+        raise ValueError("<is_vol_wm> T needs <LakeInputOption> 0 or 2: the target volumes are read together with the lake fluxes")
     lakes = read_lakes(ctl, net, n_steps) if is_lake else None
     # history variables beyond discharge and volume (read_control.f90:239-262, histVars_data.f90): basRunoff defaults to T
-    want_runoff = _truth(ctl.get("basRunoff", "T")) or _truth(ctl.get("instRunoff", "F")) or _truth(ctl.get("dlayRunoff", "F"))
+    # (instRunoff is forced off without hillslope routing, read_control.f90:708)
+    runoff_vars = tuple(k for k, dflt in (("basRunoff", "T"), ("instRunoff", "F"), ("dlayRunoff", "F")) if _truth(ctl.get(k, dflt))
+                        and not (k == "instRunoff" and int(ctl.get("doesBasinRoute", 1)) == 0))
+    want_runoff = len(runoff_vars) > 0
     want_inflow, want_height = _truth(ctl.get("outputInflow", "F")), _truth(ctl.get("floodplain", "F"))
     hflags = (api.H_RUNOFF if want_runoff else 0) | (api.H_INFLOW if want_inflow else 0) | (api.H_HEIGHT if want_height else 0)
     dom = api.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=uh_off, uh=uhv, max_window=W, device=device,
@@ -501,7 +508,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
     def hist_open(t):
         return ncfiles.HistoryWriter(hist_name(t), net.reachId, methods, time_units=f"seconds since {t_beg:%Y-%m-%d %H:%M:%S}",
                                      volumes=any(_truth(ctl.get(k, "F")) for k in ncfiles.HIST_VOL.values()), inflow=want_inflow, height=want_height,
-                                     runoff=want_runoff, hru_id=hru_id, solute=tracer)
+                                     runoff=runoff_vars, hru_id=hru_id, solute=tracer)
 
     hfiles = [hist_name(t_beg)]
     hname = hfiles[0]
