@@ -153,9 +153,16 @@ def loopback_bench(args, torch, m, uhmod):
         idx = np.repeat(uh_off[g].astype(np.int64), cnt) + (np.arange(int(cnt.sum())) - np.repeat(off[:-1].astype(np.int64), cnt))
         return dict(uh_offset=off, uh=uhv[idx])
 
+    lakes = None
+    if cfg.get("lakes"):      # c5: 1 % of the reaches are lakes / reservoirs (Doll, Hanasaki, HYPE); one window of lake forcing, reused
+        from mizuroute_amd.synthetic import make_lakes
+        from mizuroute_amd.partition import lakes_for_domain
+        lakes = make_lakes(net, max(Wcfg, 256), DT, seed=9, frac=cfg["lakes"], input_option=1, forcing=False)
+
     def make(spec, W, **kw):
         kw.pop("sweep_share", None)                    # the domains run one after the other here: each may fill the device
-        return m.RoutingDomain(spec.net, DT, methods, frac_future=frac, max_window=W, device=0, **uh_of(spec), **kw)
+        lk = lakes_for_domain(lakes, spec, net.N) if lakes is not None else None
+        return m.RoutingDomain(spec.net, DT, methods, frac_future=frac, max_window=W, device=0, lakes=lk, **uh_of(spec), **kw)
 
     def forcing(W, t0s, cols=None, shared=True):
         """shared: one forcing for the whole network, a domain takes the columns of its HRUs (parity); otherwise a forcing of
@@ -179,6 +186,8 @@ def loopback_bench(args, torch, m, uhmod):
             tw = []
             for k in range(K):
                 ro = forcing(W, k * W, sp.hru_global, shared=not timing)
+                if dom.lakes is not None:
+                    dom.set_lake_forcing(0, W)
                 torch.cuda.synchronize(); t1 = time.perf_counter()
                 dom.run_device(W, k * W * DT, ro.data_ptr()); dom.sync()
                 tw.append(time.perf_counter() - t1)
@@ -204,6 +213,8 @@ def loopback_bench(args, torch, m, uhmod):
                     if n:
                         dom.import_boundary(W, recs[(p, k)].data_ptr(), n, base)
                 dom.sync()
+                if dom.lakes is not None:
+                    dom.set_lake_forcing(0, W)
                 torch.cuda.synchronize(); t1 = time.perf_counter()
                 dom.run_device(W, k * W * DT, ro.data_ptr()); dom.sync()
                 tw.append(time.perf_counter() - t1)
@@ -221,17 +232,19 @@ def loopback_bench(args, torch, m, uhmod):
         return mean, nw, times, recs
 
     out = {"metric": "reaches*timesteps/s", "unit": "reaches*timesteps/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"FULL {args.config} network ({net.N} reaches, route_opt {cfg['methods']}) in {nparts} sub-basin partitions (reference decomposition), "
+           "config": {"workload": f"FULL {args.config} network ({net.N} reaches, route_opt {cfg['methods']}{', ' + str(lakes['reach'].size) + ' lakes' if lakes is not None else ''}) in {nparts} sub-basin partitions (reference decomposition), "
                                   "all on one GPU, boundary records through device memory", "baseline_config": args.config, "reaches_total": net.N,
                       "partitions": nparts, "mainstem_reaches": int(P.is_mainstem.sum()), "setup_s": t_setup,
                       "assignment": "reference (assign_node)" if mc == 0.0 else f"rank 0's tributary share cut by the mainstem's cost of {mc:.0f} reaches"}}
     # ---- (A) parity against the unpartitioned network
     Wa, Ka = 256, 2
     extra = dict(uh_offset=uh_off, uh=uhv) if need_uh else {}
-    whole = m.RoutingDomain(net, DT, methods, frac_future=frac, max_window=Wa, device=0, **extra)
+    whole = m.RoutingDomain(net, DT, methods, frac_future=frac, max_window=Wa, device=0, lakes=lakes, **extra)
     tw = []
     for k in range(Ka):
         ro = forcing(Wa, k * Wa)
+        if lakes is not None:
+            whole.set_lake_forcing(0, Wa)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         whole.run_device(Wa, k * Wa * DT, ro.data_ptr()); whole.sync()
         tw.append(time.perf_counter() - t1)
@@ -258,9 +271,11 @@ def loopback_bench(args, torch, m, uhmod):
     t_rank0 = trib.get("trib0", 0.0) + t_main
     if P.main is not None and P.trib[0].n_real > 0:
         sp, ms = P.trib[0], P.main
-        d_t = m.RoutingDomain(sp.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.8, export_reaches=sp.export_local, **uh_of(sp))
+        lk_t = lakes_for_domain(lakes, sp, net.N) if lakes is not None else None
+        lk_m = lakes_for_domain(lakes, ms, net.N) if lakes is not None else None
+        d_t = m.RoutingDomain(sp.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.8, export_reaches=sp.export_local, lakes=lk_t, **uh_of(sp))
         d_m = m.RoutingDomain(ms.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.2, halo_reaches=ms.halo_local,
-                              halo_good=ms.halo_good, **uh_of(ms))
+                              halo_good=ms.halo_good, lakes=lk_m, **uh_of(ms))
         ro_t = [forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
         ro_m = [forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
         rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=dev) for _ in range(2)]
@@ -268,12 +283,16 @@ def loopback_bench(args, torch, m, uhmod):
         for k in range(K + 1):
             torch.cuda.synchronize(); t1 = time.perf_counter()
             if k < K:
+                if d_t.lakes is not None:
+                    d_t.set_lake_forcing(0, W)
                 d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
             if k >= 1:                                   # the mainstem follows one window behind
                 for p in range(nparts):
                     base, n = ms.halo_base[p]
                     if n:
                         d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
+                if d_m.lakes is not None:
+                    d_m.set_lake_forcing(0, W)
                 d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
             if k < K:
                 d_t.sync()

@@ -235,6 +235,32 @@ def mainstem_cost(net: RiverNetwork, n_parts: int, window: int, level_s: float =
     return (depth + window) * level_s * reach_steps_per_s / window
 
 
+def lakes_for_domain(lakes: dict, spec: "Domain", n_reach_global: int):
+    """The lakes / reservoirs of the whole network (dict of synthetic.make_lakes or standalone.read_lakes: 1-based global
+    reaches, parameters per lake, evaporation / precipitation per HRU, target volumes per reach) as ONE domain sees them: the
+    lakes among the reaches it routes, with the forcing columns of its HRUs.  A lake is routed where it lies; the domain
+    downstream sees its discharge through the boundary record like any other tributary outlet.  None if the domain has none."""
+    if lakes is None:
+        return None
+    g2l = np.full(n_reach_global, -1, dtype=np.int64)
+    g2l[spec.reach_global[:spec.n_real]] = np.arange(spec.n_real)
+    loc = g2l[np.asarray(lakes["reach"], dtype=np.int64) - 1]
+    sel = np.nonzero(loc >= 0)[0]
+    if sel.size == 0:
+        return None
+    sel = sel[np.argsort(loc[sel], kind="stable")]
+    out = dict(input_option=lakes["input_option"], calendar_id=lakes["calendar_id"], ymd=lakes["ymd"],
+               reach=(loc[sel] + 1).astype(np.int32), model_type=np.asarray(lakes["model_type"])[sel].astype(np.int32),
+               par=np.ascontiguousarray(np.asarray(lakes["par"])[:, sel]))
+    for k in ("evap", "precip"):
+        if k in lakes and lakes[k] is not None:
+            out[k] = np.ascontiguousarray(np.asarray(lakes[k])[:, spec.hru_global]) if spec.hru_global.size else np.zeros((len(lakes["ymd"]), 1))
+    if "targ_vol" in lakes:
+        out.update(targ_vol=np.asarray(lakes["targ_vol"])[sel].astype(np.int32), vol_jumpstart=lakes.get("vol_jumpstart", 0),
+                   wm_vol=np.ascontiguousarray(np.asarray(lakes["wm_vol"])[:, spec.reach_global]))
+    return out
+
+
 def partition_network(net: RiverNetwork, n_parts: int, build_for=None, main_cost: float = 0.0) -> Partition:
     """build_for: partitions whose Domain objects (local networks) are materialised; None = all.
     A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full.

@@ -326,7 +326,7 @@ def step_dates(n_steps: int, dt: float, start=(2001, 1, 1), calendar_id: int = 0
 
 def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: float = 0.02, calendar_id: int = 0,
                input_option: int = 0, memory: bool = False, start=(2001, 1, 1), demand_memory: bool = False,
-               target_frac: float = 0.0, vol_jumpstart: bool = False) -> dict:
+               target_frac: float = 0.0, vol_jumpstart: bool = False, forcing: bool = True) -> dict:
     """Synthetic lakes/reservoirs (Doll 70 %, Hanasaki 25 %, HYPE 5 %, plus an
     endorheic one), parameters in the ranges of docs/source/users_guide/lake.rst.  A lake must be
     the only upstream of its outlet reach (kwt_route.f90:551-553)."""
@@ -383,8 +383,10 @@ def make_lakes(net: RiverNetwork, n_steps: int, dt: float, seed: int = 5, frac: 
     par[ix["H06_D_mem_F"]] = 1.0 if demand_memory else 0.0       # the demand is REACH_WM_FLUX: needs is_flux_wm
     par[ix["H06_I_mem_L"]] = 1; par[ix["H06_D_mem_L"]] = 1
     rngf = np.random.default_rng(seed + 77)
-    precip = 3e-8 * (1.0 + rngf.random((n_steps, net.H)))
-    evap = 2e-8 * (1.0 + rngf.random((n_steps, net.H)))
+    precip = evap = None      # (forcing=False: LakeInputOption 1 runs at full size, where [steps][HRU] host arrays are too much)
+    if forcing:
+        precip = 3e-8 * (1.0 + rngf.random((n_steps, net.H)))
+        evap = 2e-8 * (1.0 + rngf.random((n_steps, net.H)))
     out = dict(input_option=input_option, calendar_id=calendar_id, ymd=step_dates(n_steps, dt, start, calendar_id),
                reach=reach, model_type=model, par=par, evap=evap, precip=precip)
     if target_frac > 0:     # is_vol_wm: some lakes follow a prescribed volume (REACH_WM_VOL per step and reach)
