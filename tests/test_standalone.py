@@ -451,7 +451,7 @@ def test_constituent_run_restarted_from_a_file_continues(tmp_path, hip_lib):
     out_2 = standalone.run(second, window=7, log=lambda *_: None)
     fw, f2 = netcdf_file(out_w["restart"], "r", mmap=False), netcdf_file(out_2["restart"], "r", mmap=False)
     for k in fw.variables:
-        a, b = np.asarray(fw.variables[k][:]), np.asarray(f2.variables[k][:])
+        a, b = np.asarray(fw.variables[k].data), np.asarray(f2.variables[k].data)
         assert np.array_equal(a, b), k
     fw.close(); f2.close()
 
