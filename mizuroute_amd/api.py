@@ -243,9 +243,10 @@ class RoutingDomain:
         """One main_route call: TSEC(1:2) = (T0, T1), runoff[nHru] in m/s."""
         self._check(self.L.mzr_step(self.h, float(T0), float(T1), np.ascontiguousarray(runoff, dtype=np.float64)))
 
-    def run(self, runoff, t_start=0.0, wm_flux=None):
+    def run(self, runoff, t_start=0.0, wm_flux=None, first_step=0):
         """runoff[nSteps, nHru] (and wm_flux[nSteps, nRch] if is_flux_wm); returns
-        REACH_Q[nSteps, nRoutes, nRch] (caller's reach order)."""
+        REACH_Q[nSteps, nRoutes, nRch] (caller's reach order).  first_step: position of runoff[0] in the lake forcing of
+        self.lakes (a run handed over in several calls)."""
         runoff = np.ascontiguousarray(runoff, dtype=np.float64)
         n = runoff.shape[0]
         out = np.zeros((n, len(self.methods), self.N))
@@ -253,7 +254,7 @@ class RoutingDomain:
         while done < n:
             w = min(self.max_window, n - done)
             if self.lakes is not None:
-                self.set_lake_forcing(done, w)
+                self.set_lake_forcing(first_step + done, w)
             if self.is_flux_wm:
                 self._check(self.L.mzr_set_wm_flux(self.h, w, np.ascontiguousarray(wm_flux[done:done + w], dtype=np.float64)))
             if getattr(self, "da", None) is not None:

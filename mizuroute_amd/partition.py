@@ -261,6 +261,21 @@ def lakes_for_domain(lakes: dict, spec: "Domain", n_reach_global: int):
     return out
 
 
+def gauges_for_domain(da: dict, spec: "Domain", n_reach_global: int):
+    """Direct insertion of gauge observations (qmodOption 1) as ONE domain sees it: the same gauges and observation columns,
+    every gauge linked to its reach if the domain routes that reach and to none otherwise (what `mzr_set_da` takes for a gauge
+    outside the network).  The corrected discharge of a tributary outlet reaches the mainstem through its boundary record."""
+    if da is None:
+        return None
+    g2l = np.full(n_reach_global, -1, dtype=np.int64)
+    g2l[spec.reach_global[:spec.n_real]] = np.arange(spec.n_real)
+    gr = np.asarray(da["gauge_reach"], dtype=np.int64)
+    loc = np.where(gr >= 1, g2l[np.maximum(gr, 1) - 1], -1)
+    out = dict(da)
+    out["gauge_reach"] = np.where(loc >= 0, loc + 1, -9999).astype(np.int32)
+    return out
+
+
 def partition_network(net: RiverNetwork, n_parts: int, build_for=None, main_cost: float = 0.0) -> Partition:
     """build_for: partitions whose Domain objects (local networks) are materialised; None = all.
     A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full.

@@ -547,6 +547,64 @@ def test_direct_insertion_vs_oracle(trend, hip_lib, oracle_lib, monkeypatch):
     dom.close()
 
 
+def test_lakes_and_direct_insertion_in_partitioned_domains(hip_lib):
+    """Lakes / reservoirs and gauge observations in a network cut into sub-basin partitions: every domain gets the lakes and
+    the gauges among the reaches it routes (partition.lakes_for_domain, gauges_for_domain); the discharge a lake releases or
+    an observation corrects travels to the mainstem in the boundary record.  Bit-identical to the unpartitioned run."""
+    import torch
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.partition import partition_network, lakes_for_domain, gauges_for_domain
+    from mizuroute_amd.synthetic import make_gauges, make_lakes
+    net = m.make_network(6000, seed=18, p3=0.02, floodplain=True)
+    dt, W, steps, nparts = 3600.0, 12, 36, 3
+    ro = m.make_runoff(net.H, steps, seed=19, storm_prob=0.05, storm_amp=3e-6)
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    lakes = make_lakes(net, steps, dt, seed=5, frac=0.02, input_option=0, memory=True)
+    da = make_gauges(net, steps, n_gauge=150, seed=2, every=3, blend=6, trend=2)
+    methods = [m.IRF, m.DW]
+    whole = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=W, lakes=lakes)
+    whole.set_da(da)
+    Qw = whole.run(ro)
+    P = partition_network(net, nparts)
+    assert P.main is not None
+    n_lake = sum(0 if (lk := lakes_for_domain(lakes, d, net.N)) is None else lk["reach"].size for d in P.trib + [P.main])
+    assert n_lake == lakes["reach"].size and lakes_for_domain(lakes, P.main, net.N) is not None      # lakes on the mainstem too
+
+    def build(spec, **kw):
+        g = spec.reach_global
+        cnt = np.diff(uh_off)[g]
+        off = np.zeros(g.size + 1, np.int32); off[1:] = np.cumsum(cnt)
+        u = np.concatenate([uhv[uh_off[x]:uh_off[x + 1]] for x in g])
+        dom = m.RoutingDomain(spec.net, dt, methods, frac_future=ff, uh_offset=off, uh=u, max_window=W,
+                              lakes=lakes_for_domain(lakes, spec, net.N), **kw)
+        dom.set_da(gauges_for_domain(da, spec, net.N))
+        return dom
+
+    Q = np.full((steps, len(methods), net.N), np.nan)
+    recs = {}
+    doms = [(p, sp, build(sp, export_reaches=sp.export_local)) for p, sp in enumerate(P.trib) if sp.n_real > 0]
+    main = build(P.main, halo_reaches=P.main.halo_local, halo_good=P.main.halo_good)
+    for w0 in range(0, steps, W):
+        for p, sp, dom in doms:
+            q = dom.run(ro[w0:w0 + W][:, sp.hru_global], t_start=w0 * dt, first_step=w0)
+            Q[w0:w0 + W][:, :, sp.reach_global[:sp.n_real]] = q[:, :, :sp.n_real]
+            if sp.export_local.size:
+                rec = torch.zeros(dom.boundary_size(W, sp.export_local.size), dtype=torch.float64, device="cuda")
+                dom.export_boundary(rec.data_ptr()); dom.sync()
+                recs[p] = rec
+        for p in range(nparts):
+            base, n = P.main.halo_base[p]
+            if n:
+                main.import_boundary(W, recs[p].data_ptr(), n, base)
+        main.sync()
+        q = main.run(ro[w0:w0 + W][:, P.main.hru_global], t_start=w0 * dt, first_step=w0)
+        Q[w0:w0 + W][:, :, P.main.reach_global[:P.main.n_real]] = q[:, :, :P.main.n_real]
+    assert not np.isnan(Q).any()
+    for ix, meth in enumerate(methods):
+        assert np.array_equal(Q[:, ix], Qw[:, ix]), meth
+
+
 @pytest.mark.parametrize("hw_drain,basin_route,window", [(2, 1, 9), (1, 1, 64), (2, 0, 1)])
 def test_tracer_vs_oracle(hw_drain, basin_route, window, hip_lib, oracle_lib):
     """tracer = T: the constituent through the HRU mapping, the hillslope delay and every routing method, KWT included
