@@ -101,7 +101,8 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
                      const int *haloGood);
 /* number of doubles of a boundary record of nReach reaches over nSteps steps:
    Q[nRoutes][nSteps][nReach] | BASIN_QR[nSteps+1][nReach] | obN[nSteps][nReach] |
-   obQ[nSteps][21][nReach] | obT[nSteps][21][nReach]  (the per-partition wire format) */
+   obQ[nSteps][21][nReach] | obT[nSteps][21][nReach]  (the per-partition wire format); while constituent routing is on
+   (mzr_set_tracer on every domain) reach_solute_flux[nRoutes][nSteps][nReach] follows */
 long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach);
 /* pack the export reaches' records of the last window into rec_dev (device memory) */
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev);
@@ -142,8 +143,8 @@ int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol);
 /* Constituent routing (public_var tracer = T; main_route.f90:161-172,204-236,392-401, basinUH.f90:130-137,
    tracer.f90:43-207): a conservative constituent enters with the runoff as a mass flux per HRU and step
    (x time_conv_solute x mass_conv_solute x basin area), takes the hillslope delay, and is routed with the water of every
-   active method except the runoff accumulation.  mzr_set_tracer after mzr_init_state (on = 0: off; not in partitioned
-   domains); mzr_set_solute hands over solute[nSteps][nHru] (order of the runoff) before every window; after a window
+   active method except the runoff accumulation.  mzr_set_tracer after mzr_init_state (on = 0: off; in partitioned domains the
+   flux of the tributary outlets travels with the boundary record); mzr_set_solute hands over solute[nSteps][nHru] (order of the runoff) before every window; after a window
    mzr_get_solute gives reach_solute_flux of the last step (which = 0) or reach_solute_mass(1) (which = 1) and
    mzr_get_window_solute the flux of every step, out[nSteps][nRch] (method < 0: BASIN_solute, the lateral mass flux into
    the reaches after the hillslope delay). */

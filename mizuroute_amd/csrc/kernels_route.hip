@@ -680,6 +680,7 @@ __global__ void __launch_bounds__(256) k_tracer_stage(MzrDev d, int method, int 
   if (r >= rEnd) return;
   const int t = s - d.sigma[r];
   if (t < 0 || t >= d.W) return;
+  if (d.haloSlot && d.haloSlot[r] >= 0) return;      // a tributary outlet routed in another partition: its flux came with the boundary record
   const int N = d.N;
   const double dt = d.dt;
   const double *Qrow = d.Q + (size_t)t * N, *Frow = d.solFlux + (size_t)t * N;

@@ -149,6 +149,22 @@ __global__ void k_unpack_boundary(const double *rec, int R, int W, int nB, int N
   }
 }
 
+// constituent routing in partitioned domains: reach_solute_flux of the export reaches, [R][W][nB] behind the record proper
+__global__ void k_pack_solute(double *sf, int R, int W, int nB, int N, const int *expInt, QPtrs F) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= nB || t >= W) return;
+  const int r = expInt[b];
+  for (int m = 0; m < R; ++m) sf[((size_t)m * W + t) * nB + b] = F.p[m] ? F.p[m][(size_t)t * N + r] : 0.0;
+}
+__global__ void k_unpack_solute(const double *sf, int R, int W, int nB, int N, int haloBase, const int *haloInt, QPtrsW F) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (b >= nB || t >= W) return;
+  const int r = haloInt[haloBase + b];
+  for (int m = 0; m < R; ++m) if (F.p[m]) F.p[m][(size_t)t * N + r] = sf[((size_t)m * W + t) * nB + b];
+}
+
 }  // namespace
 
 struct mzr_domain {
@@ -975,7 +991,6 @@ static int pullRow(mzr_handle h, const double *src, double *out);
 int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_conv_solute) {
   MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_tracer/state not initialised (call mzr_init_state)") : 1;
-  if (on && (h->nHalo || h->nExp)) return fail(h, 20, "mzr_set_tracer/not available in a partitioned domain");
   (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
   h->tracer = on ? 1 : 0; h->time_conv_solute = time_conv_solute; h->mass_conv_solute = mass_conv_solute; h->solSteps = 0; h->solCur = 0;
@@ -1141,7 +1156,7 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
 long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach) {
   if (!h) return -1;
   const long long R = h->cfg.nRoutes, W = nSteps, B = nReach;
-  return R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B;
+  return R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B + (h->tracer ? R * W * B : 0);      // (+ reach_solute_flux while the tracer is on)
 }
 
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
@@ -1154,6 +1169,11 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
   dim3 block(64), grid((h->nExp + 63) / 64, h->lastW + 1);
   hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, h->lastW, h->nExp, h->N,
                      h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, h->kwN.p ? 1 : 0);
+  if (h->tracer) {
+    QPtrs f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
+    const long long base = (long long)h->cfg.nRoutes * h->lastW * h->nExp + (long long)(h->lastW + 1) * h->nExp + (long long)h->lastW * h->nExp + 2LL * h->lastW * MZR_OB_CAP * h->nExp;
+    hipLaunchKernelGGL(k_pack_solute, dim3((h->nExp + 63) / 64, h->lastW), block, 0, h->stream, rec_dev + base, h->cfg.nRoutes, h->lastW, h->nExp, h->N, h->expInt.p, f);
+  }
   if (!h->exportDone) (void)hipEventCreateWithFlags(&h->exportDone, hipEventDisableTiming);
   (void)hipEventRecord(h->exportDone, h->stream);
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_export_boundary/launch failed");
@@ -1170,6 +1190,11 @@ int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int
   dim3 block(64), grid((nSrc + 63) / 64, nSteps + 1);
   hipLaunchKernelGGL(k_unpack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, nSteps, nSrc, h->N, h->nHalo,
                      haloBase, h->haloInt.p, q, h->qlat.p, h->imN.p, h->imOQ.p, h->imOT.p, h->kwN.p ? 1 : 0);
+  if (h->tracer) {      // the halo reaches' reach_solute_flux goes straight into the window's rows: the constituent pass skips halo reaches
+    QPtrsW f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
+    const long long base = (long long)h->cfg.nRoutes * nSteps * nSrc + (long long)(nSteps + 1) * nSrc + (long long)nSteps * nSrc + 2LL * nSteps * MZR_OB_CAP * nSrc;
+    hipLaunchKernelGGL(k_unpack_solute, dim3((nSrc + 63) / 64, nSteps), block, 0, h->stream, rec_dev + base, h->cfg.nRoutes, nSteps, nSrc, h->N, haloBase, h->haloInt.p, f);
+  }
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_import_boundary/launch failed");
 }
 

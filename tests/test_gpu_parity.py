@@ -547,10 +547,11 @@ def test_direct_insertion_vs_oracle(trend, hip_lib, oracle_lib, monkeypatch):
     dom.close()
 
 
-def test_lakes_and_direct_insertion_in_partitioned_domains(hip_lib):
-    """Lakes / reservoirs and gauge observations in a network cut into sub-basin partitions: every domain gets the lakes and
-    the gauges among the reaches it routes (partition.lakes_for_domain, gauges_for_domain); the discharge a lake releases or
-    an observation corrects travels to the mainstem in the boundary record.  Bit-identical to the unpartitioned run."""
+def test_lakes_direct_insertion_and_constituent_in_partitioned_domains(hip_lib):
+    """Lakes / reservoirs, gauge observations and a constituent in a network cut into sub-basin partitions: every domain gets the
+    lakes and the gauges among the reaches it routes (partition.lakes_for_domain, gauges_for_domain) and the constituent of its
+    HRUs; the discharge a lake releases or an observation corrects, and the constituent flux of the tributary outlets
+    (tracer.f90:43-138), travel to the mainstem in the boundary record.  Bit-identical to the unpartitioned run."""
     import torch
     from mizuroute_amd import uh as uhmod
     from mizuroute_amd.partition import partition_network, lakes_for_domain, gauges_for_domain
@@ -563,9 +564,12 @@ def test_lakes_and_direct_insertion_in_partitioned_domains(hip_lib):
     lakes = make_lakes(net, steps, dt, seed=5, frac=0.02, input_option=0, memory=True)
     da = make_gauges(net, steps, n_gauge=150, seed=2, every=3, blend=6, trend=2)
     methods = [m.IRF, m.DW]
+    sol = np.random.default_rng(20).uniform(0.0, 5.0, (steps, net.H))
     whole = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=W, lakes=lakes)
     whole.set_da(da)
+    whole.set_tracer(sol, time_conv=1.0 / 3600.0, mass_conv=1000.0)
     Qw = whole.run(ro)
+    Fw = whole.solute_flux.copy()
     P = partition_network(net, nparts)
     assert P.main is not None
     n_lake = sum(0 if (lk := lakes_for_domain(lakes, d, net.N)) is None else lk["reach"].size for d in P.trib + [P.main])
@@ -579,9 +583,11 @@ def test_lakes_and_direct_insertion_in_partitioned_domains(hip_lib):
         dom = m.RoutingDomain(spec.net, dt, methods, frac_future=ff, uh_offset=off, uh=u, max_window=W,
                               lakes=lakes_for_domain(lakes, spec, net.N), **kw)
         dom.set_da(gauges_for_domain(da, spec, net.N))
+        dom.set_tracer(sol[:, spec.hru_global] if spec.hru_global.size else np.zeros((steps, 1)), time_conv=1.0 / 3600.0, mass_conv=1000.0)
         return dom
 
     Q = np.full((steps, len(methods), net.N), np.nan)
+    F = np.full((steps, len(methods), net.N), np.nan)
     recs = {}
     doms = [(p, sp, build(sp, export_reaches=sp.export_local)) for p, sp in enumerate(P.trib) if sp.n_real > 0]
     main = build(P.main, halo_reaches=P.main.halo_local, halo_good=P.main.halo_good)
@@ -589,6 +595,7 @@ def test_lakes_and_direct_insertion_in_partitioned_domains(hip_lib):
         for p, sp, dom in doms:
             q = dom.run(ro[w0:w0 + W][:, sp.hru_global], t_start=w0 * dt, first_step=w0)
             Q[w0:w0 + W][:, :, sp.reach_global[:sp.n_real]] = q[:, :, :sp.n_real]
+            F[w0:w0 + W][:, :, sp.reach_global[:sp.n_real]] = dom.solute_flux[:, :, :sp.n_real]
             if sp.export_local.size:
                 rec = torch.zeros(dom.boundary_size(W, sp.export_local.size), dtype=torch.float64, device="cuda")
                 dom.export_boundary(rec.data_ptr()); dom.sync()
@@ -600,9 +607,12 @@ def test_lakes_and_direct_insertion_in_partitioned_domains(hip_lib):
         main.sync()
         q = main.run(ro[w0:w0 + W][:, P.main.hru_global], t_start=w0 * dt, first_step=w0)
         Q[w0:w0 + W][:, :, P.main.reach_global[:P.main.n_real]] = q[:, :, :P.main.n_real]
-    assert not np.isnan(Q).any()
+        F[w0:w0 + W][:, :, P.main.reach_global[:P.main.n_real]] = main.solute_flux[:, :, :P.main.n_real]
+    assert not np.isnan(Q).any() and not np.isnan(F).any()
     for ix, meth in enumerate(methods):
         assert np.array_equal(Q[:, ix], Qw[:, ix]), meth
+        assert np.array_equal(F[:, ix], Fw[:, ix]), ("constituent", meth)
+    assert Fw.max() > 0
 
 
 @pytest.mark.parametrize("hw_drain,basin_route,window", [(2, 1, 9), (1, 1, 64), (2, 0, 1)])
