@@ -247,6 +247,13 @@ __device__ __forceinline__ void mzr_sweep_join_reset(int *head) {
 // Accesses to data that another wavefront of the SAME launch produces or consumes (persistent sweep):
 // relaxed agent-scope atomics = global_load / global_store ... sc1, which bypass the CU's L1 and are
 // coherent across the per-XCD L2s (MI355X_MICROARCH.md, inter-workgroup visibility).  P = false: plain.
+// The hand-off is: sc1 payload stores -> asm volatile "s_waitcnt vmcnt(0)" (with a memory clobber: also a compiler barrier)
+// -> sc1 store of the progress word; and on the other side sc1 poll of the word -> compiler barrier -> sc1 loads of the
+// payload.  That the drained stores are visible before the word relies on gfx9's single vmcnt for loads and stores and on
+// in-order return of loads; it is written for gfx950 and nothing else:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mizuroute_amd device code is written for gfx950 (CDNA4) only"
+#endif
 template <bool P> __device__ __forceinline__ double ldx(const double *p) {
   if (P) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   return *p;
