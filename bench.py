@@ -337,8 +337,10 @@ def main():
                     help="with --loopback: route the FULL-SIZE network of --config (c3 ~3 M reaches KWT, c4 ~5 M IRF + MC, c5 ~3 M DW) cut into "
                          "this many sub-basin partitions by the reference's decomposition, all of them on this one GPU")
     ap.add_argument("--loopback", action="store_true", help="see --partitions: boundary records go through device memory instead of RCCL")
-    ap.add_argument("--balance", action="store_true", help="with --loopback or --gpus N: cut rank 0's share of small tributaries by what the mainstem costs it "
-                    "(partition.mainstem_cost; the reference's assignment gives rank 0 an even share plus the mainstem)")
+    ap.add_argument("--balance", action="store_true", help="with --loopback: cut rank 0's share of small tributaries by what the mainstem costs it "
+                    "(partition.mainstem_cost; the reference's assignment gives rank 0 an even share plus the mainstem).  With --gpus N > 1 "
+                    "this is the default (same domains, same results, rank 0 level with the others)")
+    ap.add_argument("--reference-assignment", action="store_true", help="with --gpus N > 1: the reference's assign_node as it is")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
@@ -404,7 +406,7 @@ def main():
     else:
         from mizuroute_amd.partition import PartitionedRouter, partition_network
         from mizuroute_amd.partition import mainstem_cost
-        P = partition_network(net, world, build_for=[rank], main_cost=mainstem_cost(net, world, W) if args.balance else 0.0)
+        P = partition_network(net, world, build_for=[rank], main_cost=0.0 if args.reference_assignment else mainstem_cost(net, world, W))
 
         lib_comm = None
         if os.environ.get("MZR_BENCH_TRANSPORT") == "lib" and backend == "nccl":     # the library's own RCCL transport (mzr_comm_*)
@@ -713,7 +715,8 @@ def main():
                        "kernel_time_fraction": ktf,
                        "kwt_sweep": dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 and m.KWT in methods else None,
                        "parallelism": ("1 domain" if world == 1 else
-                                       f"{world} sub-basin partitions (reference mainstem rule), mainstem on rank 0, "
+                                       f"{world} sub-basin partitions (the reference's domains; " + ("its node assignment" if args.reference_assignment else
+                                       "rank 0's share of small tributaries cut by the mainstem's cost") + "), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
             "value_with_h2d": value_h2d, "single_step": single,
             "kwt_sweep_arrivals": dict(zip(("arrived_last", "joined_last", "start_delay_hist_log2_10ns"), dom.sweep_arrivals())) if world == 1 and m.KWT in methods else None,
