@@ -24,13 +24,19 @@ done
 python - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+last = collections.defaultdict(dict)      # value of the LAST dispatch of every kernel (the steady window; the sum also holds the census launch and the cold first window)
 for f in glob.glob("$out/g*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0][:60]
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[(k, row["Counter_Name"])] += 1
+        d = int(row.get("Dispatch_Id", 0) or 0)
+        if d >= last[k].get(row["Counter_Name"], (-1, 0.0))[0]:
+            last[k][row["Counter_Name"]] = (d, float(row["Counter_Value"]))
 res = {k: {c: v for c, v in d.items()} for k, d in agg.items()}
-for k in res: res[k]["_dispatches"] = max(cnt[(k, c)] for c in agg[k])
+for k in res:
+    res[k]["_dispatches"] = max(cnt[(k, c)] for c in agg[k])
+    res[k]["_last"] = {c: v[1] for c, v in last[k].items()}
 json.dump(res, open("gpurun_out/${tag}_pmc.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:6]:
     print(k, json.dumps(d))

@@ -25,6 +25,19 @@ def kname(full):
     return re.sub(r"<.*", "", full.split("(")[0].replace("void ", "")).strip()
 
 
+def sweep_launches(size):
+    """durations [ms] of every k_sweep_kwt launch of the --kernel-trace run, in launch order"""
+    sub = "stats" if size == "100k" else "stats_400k"
+    out = []
+    for root, _, files in os.walk(os.path.join(src, sub)):
+        for fn in files:
+            if fn.endswith("kernel_trace.csv"):
+                rows = [r for r in csv.DictReader(open(os.path.join(root, fn))) if "k_sweep_kwt" in r["Kernel_Name"]]
+                rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+                out = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    return out
+
+
 def last_json(path):
     try:
         return json.loads([l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1])
@@ -76,12 +89,16 @@ for size, sfx, cmd in (("100k", "", "--window 16384 --steps 1 --warmup 1"), ("40
         p = pm.get(k, {})
         n = max(1, p.get("_dispatches", 1))
         f, w = p.get("FETCH_SIZE", 0.0) / n, p.get("WRITE_SIZE", 0.0) / n
+        if k == "k_sweep_kwt" and "_last" in p and "FETCH_SIZE" in p["_last"]:      # the steady window: the sum also holds the census launch and the cold first window
+            f, w = p["_last"]["FETCH_SIZE"], p["_last"].get("WRITE_SIZE", w)
         hbm = (RF * f + WF * w) * 1024
         lines.append(f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {f:.0f} | {w:.0f} | {hbm/1e6:.2f} |")
         if k == "k_sweep_kwt" and bench:
             rf = bench.get("roofline") or {}
-            extra = (f"`k_sweep_kwt` at {size}: rocprofv3 average {float(r['AverageNs'])/1e3:.0f} us per launch over all windows of the profiled command "
-                     f"(first, cold window included); the bench line's HIP-event average for a steady window is {rf.get('avg_launch_us', float('nan')):.0f} us; "
+            per = sweep_launches(size)
+            extra = (f"`k_sweep_kwt` at {size}: launches of the profiled command (rocprofv3 kernel trace, ms): {', '.join('%.2f' % x for x in per)} -- the census launch of "
+                     f"mzr_init_state, the cold first window (every reach still in class A), then the steady window(s); the bench line's HIP-event time of a steady window is "
+                     f"{rf.get('avg_launch_us', float('nan'))/1e3:.2f} ms; FETCH / WRITE of the LAST launch; "
                      f"algorithmic {rf.get('algorithmic_bytes_per_launch', 0)/1e6:.0f} MB per launch vs {hbm/1e6:.0f} MB at the memory side "
                      f"({hbm / max(1.0, rf.get('algorithmic_bytes_per_launch', 1.0)):.2f} x).")
             if size == "100k":
