@@ -577,7 +577,7 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
           stx<PERS>(k.Qrow + r, d.imQ[(size_t)t * nH + hs]);
           const int n = d.imN[(size_t)t * nH + hs];
           stx<PERS>(d.obN + (size_t)k.par * N + r, n);
-          double *oq = d.obQ + (size_t)k.par * MZR_OB_CAP * N, *ot = d.obT + (size_t)k.par * MZR_OB_CAP * N;
+          double *oq = d.obQ + (size_t)k.par * MZR_OB_STRIDE * N, *ot = d.obT + (size_t)k.par * MZR_OB_STRIDE * N;
           for (int j = 0; j <= n && n > 0; ++j) {
             stx<PERS>(oq + MZR_OBI(j, r), d.imOQ[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
             stx<PERS>(ot + MZR_OBI(j, r), d.imOT[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
@@ -668,8 +668,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const double *qlat_prev = ks.qlat_prev, *qlat_cur = ks.qlat_cur;
   const int par = ks.par;
   const int *obN = d.obN + (size_t)par * N;
-  const double *obQ = d.obQ + (size_t)par * MZR_OB_CAP * N;
-  const double *obT = d.obT + (size_t)par * MZR_OB_CAP * N;
+  const double *obQ = d.obQ + (size_t)par * MZR_OB_STRIDE * N;
+  const double *obT = d.obT + (size_t)par * MZR_OB_STRIDE * N;
   const int nup = (int)(rcb & 0xff), ng = (int)((rcb >> 8) & 15), u0 = rci[2];
   const unsigned upGood = (rcb >> 16) & 0xff, goodMask = rcb >> 24;
   const bool isOut = (rcb & 0x8000u) != 0;
@@ -1328,7 +1328,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         if (outbox || es >= 0) {
           const int pq = tq & 1;
           int *obNw = d.obN + (size_t)pq * N;
-          double *obQw = d.obQ + (size_t)pq * MZR_OB_CAP * N, *obTw = d.obT + (size_t)pq * MZR_OB_CAP * N;
+          double *obQw = d.obQ + (size_t)pq * MZR_OB_STRIDE * N, *obTw = d.obT + (size_t)pq * MZR_OB_STRIDE * N;
           if (gl == 0 && outbox) stx<PERS>(obNw + r, NR + 2);
           if (gl == 0 && es >= 0) d.exN[(size_t)tq * d.nExp + es] = NR + 2;
 #pragma unroll

@@ -17,8 +17,16 @@
 #define MZR_MAXQPAR_DEV 20 // MAXQPAR, public_var.f90:36
 #define MZR_KW_CAP   20   // at-rest particles per reach (MAXQPAR, public_var.f90:36)
 #define MZR_OB_CAP   21   // outbox entries per reach: KWAVE(0:NR+1) + first non-routed
-#define MZR_KWI(k, r) ((size_t)(r) * MZR_KW_CAP + (k))   // particle k of reach r in kwQ/kwTI/kwTR
-#define MZR_OBI(k, r) ((size_t)(r) * MZR_OB_CAP + (k))   // entry k of reach r in one parity of obQ/obT
+// rows start on 64-byte sectors (24 doubles = 192 bytes per reach): a row of 20 / 21 doubles packed back to back straddles
+// sector boundaries and every partial sector is fetched / written whole (profiles/r03a_summary.md)
+#ifndef MZR_KW_STRIDE
+#define MZR_KW_STRIDE 24
+#endif
+#ifndef MZR_OB_STRIDE
+#define MZR_OB_STRIDE 24
+#endif
+#define MZR_KWI(k, r) ((size_t)(r) * MZR_KW_STRIDE + (k))   // particle k of reach r in kwQ/kwTI/kwTR
+#define MZR_OBI(k, r) ((size_t)(r) * MZR_OB_STRIDE + (k))   // entry k of reach r in one parity of obQ/obT
 #define MZR_MAXUP    8    // immediate upstreams handled by the KWT merge
 #define MZR_NMOL_KW  20   // init_model_data.f90:386-394
 #define MZR_NMOL_MC  2
@@ -109,9 +117,9 @@ struct MzrDev {
   double *mol;                // [nMol][N]
   // ---- KWT
   int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
-  double *kwQ, *kwTI, *kwTR;  // [N][MZR_KW_CAP]
+  double *kwQ, *kwTI, *kwTR;  // [N][MZR_KW_STRIDE]
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
-  double *obQ, *obT;          // [2][N][MZR_OB_CAP]
+  double *obQ, *obT;          // [2][N][MZR_OB_STRIDE]
   const MzrKwtRec *kwtRouted;    // reaches that route particles (at most two upstream reaches), stage-major, class A: 16 lanes each
   const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 20 work-array entries, 8 lanes each (host regroups)
   const MzrKwtRec *kwtRoutedC;   // ... class C: at most 9 entries, 4 lanes each

@@ -1324,10 +1324,10 @@ int mzr_init_state(mzr_handle h) {
           kwt_build_sweep(h);
         }
         h->kwN.alloc(N); h->kwN.zero();
-        h->kwQ.alloc((size_t)MZR_KW_CAP * N); h->kwTI.alloc((size_t)MZR_KW_CAP * N); h->kwTR.alloc((size_t)MZR_KW_CAP * N);
+        h->kwQ.alloc((size_t)MZR_KW_STRIDE * N); h->kwTI.alloc((size_t)MZR_KW_STRIDE * N); h->kwTR.alloc((size_t)MZR_KW_STRIDE * N);
         h->kwQ.zero(); h->kwTI.zero(); h->kwTR.zero();
         h->obN.alloc(2 * N); h->obN.zero();
-        h->obQ.alloc((size_t)2 * MZR_OB_CAP * N); h->obT.alloc((size_t)2 * MZR_OB_CAP * N);
+        h->obQ.alloc((size_t)2 * MZR_OB_STRIDE * N); h->obT.alloc((size_t)2 * MZR_OB_STRIDE * N);
         h->obQ.zero(); h->obT.zero();
         h->kwtStat.alloc(1); h->kwtStat.zero();
         h->dbgCycles.alloc(32 * 1024 + 8 + 65536 * 8); h->dbgCycles.zero();   // counters, then (timing builds) one record per sampled pass
@@ -1991,7 +1991,7 @@ int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
   std::vector<int> n(N);
-  std::vector<double> q((size_t)MZR_KW_CAP * N), ti(q.size()), tr(q.size());
+  std::vector<double> q((size_t)MZR_KW_STRIDE * N), ti(q.size()), tr(q.size());
   MZR_COPY(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
   MZR_COPY(q.data(), h->kwQ.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
   MZR_COPY(ti.data(), h->kwTI.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
@@ -2018,7 +2018,7 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
   std::vector<int> n(N);
-  std::vector<double> q((size_t)MZR_KW_CAP * N, 0.0), ti(q.size(), 0.0), tr(q.size(), 0.0);
+  std::vector<double> q((size_t)MZR_KW_STRIDE * N, 0.0), ti(q.size(), 0.0), tr(q.size(), 0.0);
   for (int e = 0; e < N; ++e) {
     const int i = h->ext2int[e];
     if (numWaves[e] > MZR_KW_CAP) return fail(h, 20, "mzr_set_kwt_state/more than MAXQPAR waves in a reach");
