@@ -734,7 +734,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       n_own_v = ldx<PERS>(d.kwN + r);
       if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
     }
-    const double X0 = ldx<PERS>(d.kwTR + MZR_KWI(0, r));
+    // exit time of the reach's last routed particle = the end of its previous step (the first at-rest element's TR, :1304): inside a
+    // window of the sweep that is T0 + dt of the step before, the same expression that produced it -- one sector read (and, below,
+    // written) per reach-step less; the first step of a window takes it from the state
+    const double X0 = (PERS && t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<PERS>(d.kwTR + MZR_KWI(0, r));
     const double hin = d.hInflow ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
@@ -1320,7 +1323,18 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
         // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
-        if (gl == 0) { stx<PERS>(d.Q + (size_t)tq * N + r, Qout); stx<PERS>(d.kwN + r, NN2 + 1); d.inflow[r] = ctx[2]; if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]); }
+        // The particle count and REACH_INFLOW of a step are single words in sectors of their own: 64 bytes written for 4 / 8.  In
+        // the sweep the count travels in the progress word (the reach reads it back from there, `exact` above), so both are
+        // written where somebody reads them: at the last step of the window (state getters, regrouping, the next window's
+        // first step), and the count every step for the reaches that do not take it from the progress word.
+        const bool lastStep = tq == d.W - 1;
+        const bool countFromWord = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u));
+        if (gl == 0) {
+          stx<PERS>(d.Q + (size_t)tq * N + r, Qout);
+          if (!countFromWord || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
+          if (!PERS || lastStep) d.inflow[r] = ctx[2];
+          if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
+        }
         TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
@@ -1355,7 +1369,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             stx<PERS>(d.kwQ + MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2]);
             stx<PERS>(d.kwTI + MZR_KWI(k2, r), first ? TIMEI : Tw[NR + k2]);
             // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
-            if (first || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
+            if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
           }
         }
         if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
