@@ -376,8 +376,8 @@ __device__ __forceinline__ int kwt_merge_binary_serial(int nup, int ns, int nrA,
 template <bool PERS>
 __device__ __forceinline__ int kwt_merge_generic(int nup, int u0, int NUPS, double RW, double T0, double T1,
                                                  const uint8_t *nGood, const double *width, const double *qlat_prev,
-                                                 const double *qlat_cur, const int *obN, const double *obQ,
-                                                 const double *obT, int N, double *QD, double *TD, int IMAX,
+                                                 const double *qlat_cur, const int *obN, const double *obQT,
+                                                 int N, double *QD, double *TD, int IMAX,
                                                  double *scrD, int *scrI) {
   int *su = scrI, *slen = scrI + 2 * MZR_MAXUP, *snr = scrI + 4 * MZR_MAXUP, *ITIM = scrI + 6 * MZR_MAXUP;
   double *sc = scrD, *CTIME = scrD + 2 * MZR_MAXUP;
@@ -390,11 +390,11 @@ __device__ __forceinline__ int kwt_merge_generic(int nup, int u0, int NUPS, doub
     if (nGood[u] > 0) {
       const int si = nup + IUPR; ++IUPR;
       const int nr = ldx<PERS>(obN + u);
-      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = ldx<PERS>(obT + MZR_OBI(1, u));
+      su[si] = u; snr[si] = nr; slen[si] = nr + 1; sc[si] = width[u] / RW; ITIM[si] = 1; CTIME[si] = ldx<PERS>(obQT + MZR_PT(MZR_OBI(1, u)));
     }
   }
-  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : ldx<PERS>(obQ + MZR_OBI(k, su[i])); };
-  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : ldx<PERS>(obT + MZR_OBI(k, su[i])); };
+  auto sQ = [&](int i, int k) -> double { return i < nup ? (k == 0 ? qlat_prev[su[i]] : qlat_cur[su[i]]) : ldx<PERS>(obQT + MZR_PQ(MZR_OBI(k, su[i]))); };
+  auto sT = [&](int i, int k) -> double { return i < nup ? (k == 0 ? T0 : T1) : ldx<PERS>(obQT + MZR_PT(MZR_OBI(k, su[i]))); };
   unsigned done = 0;
   const unsigned all = (1u << NUPS) - 1u;
   int IPRT = 0, JUPS_OLD = 0x7fffffff, ITIM_OLD = 0x7fffffff;
@@ -577,10 +577,10 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
           stx<PERS>(k.Qrow + r, d.imQ[(size_t)t * nH + hs]);
           const int n = d.imN[(size_t)t * nH + hs];
           stx<PERS>(d.obN + (size_t)k.par * N + r, n);
-          double *oq = d.obQ + (size_t)k.par * MZR_OB_STRIDE * N, *ot = d.obT + (size_t)k.par * MZR_OB_STRIDE * N;
+          double *ob = d.obQT + 2 * (size_t)k.par * MZR_OB_STRIDE * N;
           for (int j = 0; j <= n && n > 0; ++j) {
-            stx<PERS>(oq + MZR_OBI(j, r), d.imOQ[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
-            stx<PERS>(ot + MZR_OBI(j, r), d.imOT[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
+            stx<PERS>(ob + MZR_PQ(MZR_OBI(j, r)), d.imOQ[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
+            stx<PERS>(ob + MZR_PT(MZR_OBI(j, r)), d.imOT[((size_t)t * MZR_OB_CAP + j) * nH + hs]);
           }
         }
       }
@@ -592,14 +592,14 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
           const double Q = mzr_lake::lake_route(d, r, t, ls, k.Qrow, k.qlat_cur[r], vol, vol0, ele, wb, wmAct, PERS);
           stx<PERS>(k.Qrow + r, Q); d.vol[r] = vol; d.vol0[r] = vol0; d.ele[r] = ele; d.wb[r] = wb;
           if (d.trVol0) d.trVol0[(size_t)t * N + r] = vol0;      // REACH_VOL(0) of the step, for the constituent pass (zero for river reaches under KWT)
-          if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
+          if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQT[MZR_PQ(MZR_KWI(0, r))] = -9999.0; d.kwQT[MZR_PT(MZR_KWI(0, r))] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
         }
       }
       if (!done) {   // headwater
         const double qlat_r = k.qlat_cur[r];
         stx<PERS>(k.Qrow + r, qlat_r);
         d.inflow[r] = 0.0;
-        if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
+        if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQT[MZR_PQ(MZR_KWI(0, r))] = -9999.0; d.kwQT[MZR_PT(MZR_KWI(0, r))] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
         if (FULL && d.exportSlot && d.exportSlot[r] >= 0) d.exN[(size_t)t * d.nExp + d.exportSlot[r]] = 0;
         st_head = 1;
       }
@@ -668,8 +668,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const double *qlat_prev = ks.qlat_prev, *qlat_cur = ks.qlat_cur;
   const int par = ks.par;
   const int *obN = d.obN + (size_t)par * N;
-  const double *obQ = d.obQ + (size_t)par * MZR_OB_STRIDE * N;
-  const double *obT = d.obT + (size_t)par * MZR_OB_STRIDE * N;
+  const double *obQT = d.obQT + 2 * (size_t)par * MZR_OB_STRIDE * N;      // this step's parity of the {Q, exit time} rows
+  const __amdgpu_buffer_rsrc_t obRs = mzr_rsrc(obQT), kwRs = mzr_rsrc(d.kwQT);
   const int nup = (int)(rcb & 0xff), ng = (int)((rcb >> 8) & 15), u0 = rci[2];
   const unsigned upGood = (rcb >> 16) & 0xff, goodMask = rcb >> 24;
   const bool isOut = (rcb & 0x8000u) != 0;
@@ -747,14 +747,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
-      if (!exact || k < n_own_v) { q[j] = ldx<PERS>(d.kwQ + MZR_KWI(kk, r)); ti[j] = ldx<PERS>(d.kwTI + MZR_KWI(kk, r)); }
+      if (!exact || k < n_own_v) { const mzr_d2 v = ldq<PERS>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
     }
     if (!GEN && !upLake) {
 #pragma unroll
       for (int j = 0; j < OS; ++j) {
         const int k = gl + j * G, kk = k < MZR_OB_CAP ? k : 0;
-        if (ns > 0 && (!exact || k < nrA_v)) { aq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uA)); at[j] = ldx<PERS>(obT + MZR_OBI(kk, uA)); }
-        if (ns > 1 && (!exact || k < nrB_v)) { bq[j] = ldx<PERS>(obQ + MZR_OBI(kk, uB)); bt[j] = ldx<PERS>(obT + MZR_OBI(kk, uB)); }
+        if (ns > 0 && (!exact || k < nrA_v)) { const mzr_d2 v = ldq<PERS>(obRs, obQT, MZR_OBI(kk, uA)); aq[j] = v.x; at[j] = v.y; }
+        if (ns > 1 && (!exact || k < nrB_v)) { const mzr_d2 v = ldq<PERS>(obRs, obQT, MZR_OBI(kk, uB)); bq[j] = v.x; bt[j] = v.y; }
       }
     }
     // ---- uniform: the work-array need
@@ -931,7 +931,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           }
         } else {
           int nd = -60;
-          if (GEN && gl == 0) nd = kwt_merge_generic<PERS>(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQ, obT, N, QD, TD, IMAX, Xw, (int *)Yw);
+          if (GEN && gl == 0) nd = kwt_merge_generic<PERS>(nup, u0, NUPS, RW, T0, T1, d.nGood, d.width, qlat_prev, qlat_cur, obN, obQT, N, QD, TD, IMAX, Xw, (int *)Yw);
           ND = grp_first<G>(nd);
         }
         TSTAMP(1);
@@ -1342,7 +1342,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         if (outbox || es >= 0) {
           const int pq = tq & 1;
           int *obNw = d.obN + (size_t)pq * N;
-          double *obQw = d.obQ + (size_t)pq * MZR_OB_STRIDE * N, *obTw = d.obT + (size_t)pq * MZR_OB_STRIDE * N;
+          double *obW = d.obQT + 2 * (size_t)pq * MZR_OB_STRIDE * N;
+          const __amdgpu_buffer_rsrc_t obWs = mzr_rsrc(obW);
           if (gl == 0 && outbox) stx<PERS>(obNw + r, NR + 2);
           if (gl == 0 && es >= 0) d.exN[(size_t)tq * d.nExp + es] = NR + 2;
 #pragma unroll
@@ -1351,7 +1352,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             if (k2 <= NR + 2) {
               const double q = k2 <= NR ? Qw[k2] : k2 == NR + 1 ? Q_END : qN1;
               const double x = k2 <= NR ? Xw[k2] : k2 == NR + 1 ? T_END : xN1;
-              if (outbox) { stx<PERS>(obQw + MZR_OBI(k2, r), q); stx<PERS>(obTw + MZR_OBI(k2, r), x); }
+              if (outbox) stq<PERS>(obWs, obW, MZR_OBI(k2, r), q, x);
               if (es >= 0) {   // tributary outlet of a partition: the same record goes to the time-indexed export buffer
                 const size_t nE = d.nExp;
                 d.exOQ[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = q; d.exOT[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = x;
@@ -1366,8 +1367,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           const int k2 = gl + j * G;
           if (k2 <= NN2) {
             const bool first = k2 == 0;
-            stx<PERS>(d.kwQ + MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2]);
-            stx<PERS>(d.kwTI + MZR_KWI(k2, r), first ? TIMEI : Tw[NR + k2]);
+            stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
             // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
             if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
           }
@@ -1642,7 +1642,7 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
   }
   if (first && blockIdx.y == 0) {
     d.inflow[r] = 0.0;
-    if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQ[MZR_KWI(0, r)] = -9999.0; d.kwTI[MZR_KWI(0, r)] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
+    if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQT[MZR_PQ(MZR_KWI(0, r))] = -9999.0; d.kwQT[MZR_PT(MZR_KWI(0, r))] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
   }
 }
 // second, tiny kernel (after the zeroing above has finished): headwaters are complete for the whole window

@@ -25,8 +25,13 @@
 #ifndef MZR_OB_STRIDE
 #define MZR_OB_STRIDE 24
 #endif
-#define MZR_KWI(k, r) ((size_t)(r) * MZR_KW_STRIDE + (k))   // particle k of reach r in kwQ/kwTI/kwTR
-#define MZR_OBI(k, r) ((size_t)(r) * MZR_OB_STRIDE + (k))   // entry k of reach r in one parity of obQ/obT
+#define MZR_KWI(k, r) ((size_t)(r) * MZR_KW_STRIDE + (k))   // particle k of reach r in kwTR, and PAIR index in kwQT
+#define MZR_OBI(k, r) ((size_t)(r) * MZR_OB_STRIDE + (k))   // PAIR index of entry k of reach r in one parity of obQT
+// Flow and time of a particle sit side by side (kwQT / obQT are rows of {Q, T} pairs, 16 bytes each): a lane moves a particle
+// with ONE 16-byte access, and a list of n particles covers n * 16 contiguous bytes instead of two runs of n * 8 in two
+// arrays -- fewer partly used 64-byte sectors, half the memory instructions.  Doubles inside the pair rows:
+#define MZR_PQ(pairIndex) (2 * (size_t)(pairIndex))          // the flow
+#define MZR_PT(pairIndex) (2 * (size_t)(pairIndex) + 1)      // the time (entry time TI in kwQT, exit time in obQT)
 #define MZR_MAXUP    8    // immediate upstreams handled by the KWT merge
 #define MZR_NMOL_KW  20   // init_model_data.f90:386-394
 #define MZR_NMOL_MC  2
@@ -117,9 +122,9 @@ struct MzrDev {
   double *mol;                // [nMol][N]
   // ---- KWT
   int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
-  double *kwQ, *kwTI, *kwTR;  // [N][MZR_KW_STRIDE]
+  double *kwQT, *kwTR;        // [N][MZR_KW_STRIDE][2] {Q, TI} pairs; [N][MZR_KW_STRIDE] expected exit times (state only: written at the last step of a window)
   int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
-  double *obQ, *obT;          // [2][N][MZR_OB_STRIDE]
+  double *obQT;               // [2][N][MZR_OB_STRIDE][2] {Q, exit time} pairs
   const MzrKwtRec *kwtRouted;    // reaches that route particles (at most two upstream reaches), stage-major, class A: 16 lanes each
   const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 20 work-array entries, 8 lanes each (host regroups)
   const MzrKwtRec *kwtRoutedC;   // ... class C: at most 9 entries, 4 lanes each
@@ -273,6 +278,22 @@ template <bool P> __device__ __forceinline__ int ldx(const int *p) {
 template <bool P> __device__ __forceinline__ void stx(double *p, double v) {
   if (P) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
+}
+// 16-byte accesses to the pair rows.  P: other wavefronts of the launch read / wrote them: buffer_load / buffer_store_dwordx4 sc1
+// through a raw buffer descriptor over the whole array (offsets are bytes, 32 bits: arrays of up to 4 GB, i.e. 11 M reaches)
+typedef double mzr_d2 __attribute__((ext_vector_type(2)));
+typedef int mzr_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mzr_rsrc(const void *p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+template <bool P> __device__ __forceinline__ mzr_d2 ldq(__amdgpu_buffer_rsrc_t rs, const double *base, size_t pairIndex) {
+  if (P) return __builtin_bit_cast(mzr_d2, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(unsigned)(pairIndex * 16), 0, 16));
+  return *(const mzr_d2 *)(base + 2 * pairIndex);
+}
+template <bool P> __device__ __forceinline__ void stq(__amdgpu_buffer_rsrc_t rs, double *base, size_t pairIndex, double a, double b) {
+  mzr_d2 v; v.x = a; v.y = b;
+  if (P) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mzr_i4, v), rs, (int)(unsigned)(pairIndex * 16), 0, 16);
+  else *(mzr_d2 *)(base + 2 * pairIndex) = v;
 }
 template <bool P> __device__ __forceinline__ void stx(int *p, int v) {
   if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -232,7 +232,7 @@ struct mzr_domain {
   std::vector<int> kwtStageOff, kwtBOff, kwtCOff;   // [nStages+1] stage offsets in h_kwtRouted / in the class-B and class-C lists (kwtRoutedOff: class A)
   long long kwtWindows = 0, kwtStepsSince = 0; // KWT windows run since mzr_init_state, steps since the last regrouping
   std::vector<int> kwtRoutedOff, kwtGenericOff, kwtLightOff;   // [nStages+1] offsets of each stage in the two lists
-  DBuf<double> kwQ, kwTI, kwTR, obQ, obT;
+  DBuf<double> kwQ, kwTR, obQ;      // kwQ: [N][stride] {Q, TI} pairs; obQ: [2][N][stride] {Q, exit time} pairs
   DBuf<MzrKwtStat> kwtStat;
   DBuf<unsigned long long> dbgCycles;
   // lakes
@@ -297,8 +297,8 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.qi = h->qi.p; d.qlat = h->qlat.p;
   d.basS0 = h->basS[h->basCur].p; d.basS1 = h->basS[h->basCur ^ 1].p;
   d.maxtdh = h->maxtdh; d.ntdh = h->ntdh.p; d.uh = h->uh.p; d.irfQ = h->irfQ.p;
-  d.kwN = h->kwN.p; d.kwQ = h->kwQ.p; d.kwTI = h->kwTI.p; d.kwTR = h->kwTR.p;
-  d.obN = h->obN.p; d.obQ = h->obQ.p; d.obT = h->obT.p;
+  d.kwN = h->kwN.p; d.kwQT = h->kwQ.p; d.kwTR = h->kwTR.p;
+  d.obN = h->obN.p; d.obQT = h->obQ.p;
   d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtRoutedC = h->kwtRoutedC.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
   d.kwDone = h->kwDone.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
   d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p; d.swBeat = h->swBeat.p;
@@ -1324,11 +1324,11 @@ int mzr_init_state(mzr_handle h) {
           kwt_build_sweep(h);
         }
         h->kwN.alloc(N); h->kwN.zero();
-        h->kwQ.alloc((size_t)MZR_KW_STRIDE * N); h->kwTI.alloc((size_t)MZR_KW_STRIDE * N); h->kwTR.alloc((size_t)MZR_KW_STRIDE * N);
-        h->kwQ.zero(); h->kwTI.zero(); h->kwTR.zero();
+        h->kwQ.alloc((size_t)2 * MZR_KW_STRIDE * N); h->kwTR.alloc((size_t)MZR_KW_STRIDE * N);      // kwQ: {Q, TI} pairs
+        h->kwQ.zero(); h->kwTR.zero();
         h->obN.alloc(2 * N); h->obN.zero();
-        h->obQ.alloc((size_t)2 * MZR_OB_STRIDE * N); h->obT.alloc((size_t)2 * MZR_OB_STRIDE * N);
-        h->obQ.zero(); h->obT.zero();
+        h->obQ.alloc((size_t)2 * 2 * MZR_OB_STRIDE * N);      // two parities of {Q, exit time} pairs
+        h->obQ.zero();
         h->kwtStat.alloc(1); h->kwtStat.zero();
         h->dbgCycles.alloc(32 * 1024 + 8 + 65536 * 8); h->dbgCycles.zero();   // counters, then (timing builds) one record per sampled pass
       }
@@ -1991,18 +1991,17 @@ int mzr_get_kwt_state(mzr_handle h, int *numWaves, double *qwave, double *tentry
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
   std::vector<int> n(N);
-  std::vector<double> q((size_t)MZR_KW_STRIDE * N), ti(q.size()), tr(q.size());
+  std::vector<double> q((size_t)2 * MZR_KW_STRIDE * N), tr((size_t)MZR_KW_STRIDE * N);      // q: {Q, TI} pairs
   MZR_COPY(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
   MZR_COPY(q.data(), h->kwQ.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
-  MZR_COPY(ti.data(), h->kwTI.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
-  MZR_COPY(tr.data(), h->kwTR.p, q.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
+  MZR_COPY(tr.data(), h->kwTR.p, tr.size() * sizeof(double), hipMemcpyDeviceToHost, "mzr_get_kwt_state");
   for (int e = 0; e < N; ++e) {
     const int i = h->ext2int[e];
     numWaves[e] = n[i];
     for (int k = 0; k < MZR_WCAP; ++k) {
       const size_t o = (size_t)e * MZR_WCAP + k;
       if (k < n[i]) {
-        qwave[o] = q[MZR_KWI(k, i)]; tentry[o] = ti[MZR_KWI(k, i)]; texit[o] = tr[MZR_KWI(k, i)];
+        qwave[o] = q[MZR_PQ(MZR_KWI(k, i))]; tentry[o] = q[MZR_PT(MZR_KWI(k, i))]; texit[o] = tr[MZR_KWI(k, i)];
         const bool lake = !h->h_lakeSlot.empty() && h->h_lakeSlot[i] >= 0;   // a lake keeps one sentinel particle
         routed[o] = (k == 0 && h->h_nGood[i] > 0 && !lake) ? 1 : 0;          // element 0 = last routed particle
       } else { qwave[o] = tentry[o] = texit[o] = -9999.0; routed[o] = 0; }
@@ -2018,7 +2017,7 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
   int rc = mzr_sync(h); if (rc) return rc;
   const int N = h->N;
   std::vector<int> n(N);
-  std::vector<double> q((size_t)MZR_KW_STRIDE * N, 0.0), ti(q.size(), 0.0), tr(q.size(), 0.0);
+  std::vector<double> q((size_t)2 * MZR_KW_STRIDE * N, 0.0), tr((size_t)MZR_KW_STRIDE * N, 0.0);      // q: {Q, TI} pairs
   for (int e = 0; e < N; ++e) {
     const int i = h->ext2int[e];
     if (numWaves[e] > MZR_KW_CAP) return fail(h, 20, "mzr_set_kwt_state/more than MAXQPAR waves in a reach");
@@ -2026,13 +2025,12 @@ int mzr_set_kwt_state(mzr_handle h, const int *numWaves, const double *qwave, co
     n[i] = numWaves[e];
     for (int k = 0; k < numWaves[e]; ++k) {
       const size_t o = (size_t)e * MZR_WCAP + k;
-      q[MZR_KWI(k, i)] = qwave[o]; ti[MZR_KWI(k, i)] = tentry[o]; tr[MZR_KWI(k, i)] = texit[o];
+      q[MZR_PQ(MZR_KWI(k, i))] = qwave[o]; q[MZR_PT(MZR_KWI(k, i))] = tentry[o]; tr[MZR_KWI(k, i)] = texit[o];
     }
   }
   MZR_COPY(h->kwN.p, n.data(), N * sizeof(int), hipMemcpyHostToDevice, "mzr_set_kwt_state");
   MZR_COPY(h->kwQ.p, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
-  MZR_COPY(h->kwTI.p, ti.data(), q.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
-  MZR_COPY(h->kwTR.p, tr.data(), q.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
+  MZR_COPY(h->kwTR.p, tr.data(), tr.size() * sizeof(double), hipMemcpyHostToDevice, "mzr_set_kwt_state");
   return 0;
 }
 
