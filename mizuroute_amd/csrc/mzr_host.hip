@@ -1261,6 +1261,8 @@ int mzr_init_state(mzr_handle h) {
       }
       if (m == MZR_KWT) {
         if ((size_t)h->h_slope.size() != N || (size_t)h->h_mann.size() != N) return fail(h, 20, "mzr_init_state/R_SLOPE and R_MAN_N must be set before KWT state is initialised");
+        // the particle rows are addressed with 32-bit byte offsets (16-byte buffer accesses): 384 bytes per reach
+        if ((unsigned long long)N * 2ull * MZR_KW_STRIDE * sizeof(double) >= (1ull << 32)) return fail(h, 20, "mzr_init_state/KWT: more than 11 million reaches in one domain (partition the network)");
         std::vector<double> K(N), CW(N);
         {   // kinwav_rch constants, kwt_route.f90:1273-1274,1290: evaluated once, with the host libm
           const double ALFA = 5.0 / 3.0;
