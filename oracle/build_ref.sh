@@ -7,14 +7,14 @@ set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 S=${MZR_REFERENCE_SRC:-/root/reference/route/build/src}
 FC=${FC:-/opt/rocm/lib/llvm/bin/flang}
-OUT="$HERE/_ref"
+OUT="${MZR_REF_OUT:-$HERE/_ref}"      # (MZR_REF_OUT / MZR_REF_FFLAGS: a second build beside it, e.g. -O0 for the drift check of oracle/check_ref_O0.py)
 if [ ! -d "$S" ] || [ ! -x "$FC" ]; then
   echo "build_ref: reference sources or flang not available; skipping (prebuilt $OUT is used if present)"
   exit 0
 fi
 mkdir -p "$OUT/obj"
 cd "$OUT/obj"
-FFLAGS="-O2 -ffp-contract=off -fopenmp"
+FFLAGS="${MZR_REF_FFLAGS:--O2 -ffp-contract=off -fopenmp}"
 H="$HERE/ref_harness"
 SRCS="$S/nrtype.f90 $S/public_var.f90 $S/nr_utils.f90 $S/datetime_data.f90 $S/dataTypes.f90
  $S/base_route.f90 $S/var_lookup.f90 $H/shim_globalData.f90 $H/shim_runtime.f90

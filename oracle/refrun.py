@@ -18,7 +18,7 @@ import numpy as np
 from oracle.casefile import MAGIC_IN, serial_schedule, write_case  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-EXE = os.path.join(HERE, "_ref", "ref_route")
+EXE = os.environ.get("MZR_REF_EXE", os.path.join(HERE, "_ref", "ref_route"))
 MAGIC_OUT = 1297765967
 WCAP = 32
 NMOL = {3: 20, 4: 2, 5: 20}
