@@ -83,7 +83,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=(2,), uh=None, lakes=None):
+def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=(2,), uh=None, lakes=None, one_thread=True):
     """Reference Fortran solvers (oracle/_ref/ref_route) on the host cores, bounded sample of the SAME
     forcing the GPU leg routes: `sample_steps` steps timed after `spinup_steps` untimed ones (particle lists at
     steady state), OpenMP over the reference's own stream-order branches at 16 threads (the best count of the
@@ -103,7 +103,7 @@ def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=
 
     n_all = spinup_steps + sample_steps
     r = refrun.run_case(net, runoff[:n_all], DT, methods, nthreads=nt, schedule=sched, time_from=spinup_steps, **kw, **lk(n_all))
-    one = refrun.run_case(net, runoff[:36], DT, methods, nthreads=1, time_from=24, **kw, **lk(36))
+    one = refrun.run_case(net, runoff[:36], DT, methods, nthreads=1, time_from=24, **kw, **lk(36)) if one_thread else {"ierr": 0, "reach_steps_per_s": None}
     if r["ierr"] or one["ierr"]:
         raise RuntimeError(f"reference harness ierr {r['ierr']} at step {r['ierr_step']}: {r['stdout'][-300:]}")
     # (the harness counts a reach-step per active method, as `value` does)
@@ -308,6 +308,23 @@ def loopback_bench(args, torch, m, uhmod):
     out.update({"value": float(net.N) * W * len(methods) / one_gpu, "steps": K, "warmup": 1, "ms_per_step": one_gpu * 1e3, "scaling": "strong",
                 "vs_baseline": None, "error": None if same else "partitioned run differs from the whole network"})
     out["config"].update({"window_steps": W, "domains": times})
+    # ---- the reference's own solvers on the host cores, a bounded sample of the SAME full-size network (16 OpenMP threads over
+    # its stream-order branches; particle lists far from steady state after a handful of steps: an upper bound for the CPU)
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            n_spin, n_smp = 8, 8
+            ro_cpu = device_runoff(torch, net.H, n_spin + n_smp, 0, 7, dev).cpu().numpy()
+            lk = None
+            if lakes is not None:
+                lk = dict(lakes, evap=np.zeros((n_spin + n_smp, net.H)), precip=np.zeros((n_spin + n_smp, net.H)))
+                lk["ymd"] = lakes["ymd"][:n_spin + n_smp]
+            cpu = cpu_baseline(net, frac, ro_cpu, n_spin, n_smp, methods, (uh_off, uhv) if need_uh else None, lk, one_thread=False)
+            cpu["sample"] = (f"the FULL {net.N}-reach network, route_opt {cfg['methods']}, {n_smp} steps timed after {n_spin} (lists not at steady state: an upper "
+                             f"bound), {cpu['cores']} OpenMP threads over the reference's stream-order branches; unmodified reference solvers, flang -O2")
+        except Exception as e:
+            cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
+    out["cpu_baseline"] = cpu
     out["model_8gpu"] = {"what": "one domain per GPU as measured here; window time = max(slowest tributary rank, rank 0 with its tributary and the mainstem side by side); "
                                  "the boundary records (bytes above) travel behind the next window's sweep",
                          "s_per_window": crit, "value": float(net.N) * W * len(methods) / crit,
