@@ -1636,10 +1636,16 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
   const int per = (tEnd - tBegin + gridDim.y - 1) / gridDim.y;
   const int tB = tBegin + blockIdx.y * per, tE = min(tEnd, tB + per);
   const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
-  for (int t = tB; t < tE; ++t) {
-    d.Q[(size_t)t * N + r] = d.qlat[(size_t)(t + 1) * N + r];
-    if (es >= 0) d.exN[(size_t)t * d.nExp + es] = 0;
+  int t = tB;
+  for (; t + 8 <= tE; t += 8) {      // eight rows in flight per lane
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(d.qlat + (size_t)(t + j + 1) * N + r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d.Q[(size_t)(t + j) * N + r] = v[j];
   }
+  for (; t < tE; ++t) d.Q[(size_t)t * N + r] = d.qlat[(size_t)(t + 1) * N + r];
+  if (es >= 0) for (int t2 = tB; t2 < tE; ++t2) d.exN[(size_t)t2 * d.nExp + es] = 0;
   if (first && blockIdx.y == 0) {
     d.inflow[r] = 0.0;
     if (d.kwN[r] != 1) { d.kwN[r] = 1; d.kwQT[MZR_PQ(MZR_KWI(0, r))] = -9999.0; d.kwQT[MZR_PT(MZR_KWI(0, r))] = -9999.0; d.kwTR[MZR_KWI(0, r)] = -9999.0; }
@@ -1657,7 +1663,15 @@ __global__ void __launch_bounds__(256) k_accum_qsum(const double *Q, double *qsu
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
   double a = qsum[r];
-  for (int t = 0; t < W; ++t) a = a + Q[(size_t)t * N + r];
+  int t = 0;
+  for (; t + 16 <= W; t += 16) {      // sixteen rows in flight per lane (100 k lanes are 1.5 wavefronts per SIMD: latency, not bandwidth); added in step order
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(Q + (size_t)(t + j) * N + r);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a = a + v[j];
+  }
+  for (; t < W; ++t) a = a + Q[(size_t)t * N + r];
   qsum[r] = a;
 }
 
