@@ -10,9 +10,9 @@
 //  * The reference lets the DOWNSTREAM reach strip the routed particles out of its upstream
 //    reach's list (kwt_route.f90:822-848).  The stripped list is a pure function of the upstream
 //    reach's own result -- KWAVE(NR+1:NQ2+1), the same slice an outlet keeps for itself
-//    (:325-344) -- so here every reach stores that at-rest slice itself (kwN/kwQ/kwTI/kwTR,
+//    (:325-344) -- so here every reach stores that at-rest slice itself (kwN/kwQT/kwTR,
 //    <= 20 particles) and publishes what its downstream reach needs, KWAVE(0:NR+1) plus the first
-//    non-routed particle, flow and exit time only, in a per-reach OUTBOX (obN/obQ/obT).  No lane
+//    non-routed particle, flow and exit time only, in a per-reach OUTBOX (obN/obQT).  No lane
 //    ever writes another reach's state, and the outbox is double-buffered on the parity of the
 //    time step so that reach u may already work on step t+1 while its downstream reach consumes
 //    step t in the same launch.
@@ -40,8 +40,8 @@
 // Headwater, lake and halo reaches are O(1) and take one lane each in the trailing blocks of the
 // same launch (the host lists routed and light reaches separately, stage-major).
 //
-// Layout: particle rows are contiguous per reach (kwQ[r][20], obQ[parity][r][21]) so that the G
-// lanes of a group read and write one 160-byte row together; work arrays live in LDS, carved
+// Layout: particle rows are contiguous per reach, {flow, time} pairs of 16 bytes (kwQT[r][24][2], obQT[parity][r][24][2],
+// rows on 64-byte sectors), so that the G lanes of a group move a list with one 16-byte access per lane; work arrays live in LDS, carved
 // among the groups of a wavefront by need.
 // Bound by HBM traffic of the particle rows: see DESIGN.md for the bytes-per-reach-step model.
 #include <float.h>
