@@ -158,3 +158,44 @@ def test_boundary_exchange_over_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def test_nr_indexx_sorts_like_the_reference_routine():
+    """partition.nr_indexx restates nr_utils.f90:114-190 (pinned to the compiled routine through the domain tests of
+    test_oracle_vs_ref.py); here: it IS a sort index, for short arrays (insertion sort) and long ones (quicksort), with ties."""
+    from mizuroute_amd.partition import nr_indexx
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 15, 16, 17, 100, 5000):
+        for hi in (3, 50, 10**6):
+            a = rng.integers(0, hi, n)
+            ix = nr_indexx(a)
+            assert sorted(ix.tolist()) == list(range(n))
+            assert np.all(np.diff(a[ix]) >= 0)
+
+
+def test_lakes_and_gauges_are_dealt_to_the_domains_that_route_them():
+    import mizuroute_amd as m
+    from mizuroute_amd.partition import partition_network, lakes_for_domain, gauges_for_domain, mainstem_cost
+    from mizuroute_amd.synthetic import make_gauges, make_lakes
+    net = m.make_network(8000, seed=4, p3=0.02)
+    lakes = make_lakes(net, 10, 3600.0, seed=5, frac=0.02, input_option=0, target_frac=0.3)
+    da = make_gauges(net, 10, n_gauge=60, seed=2)
+    for main_cost in (0.0, mainstem_cost(net, 4, 64)):
+        P = partition_network(net, 4, main_cost=main_cost)
+        seen_l, seen_g = [], []
+        for d in P.trib + [P.main]:
+            lk = lakes_for_domain(lakes, d, net.N)
+            if lk is not None:
+                g = d.reach_global[lk["reach"] - 1]
+                seen_l += g.tolist()
+                sel = np.searchsorted(lakes["reach"] - 1, g)
+                assert np.array_equal(lk["par"], lakes["par"][:, sel]) and np.array_equal(lk["model_type"], lakes["model_type"][sel])
+                assert lk["evap"].shape == (10, d.hru_global.size) and np.array_equal(lk["evap"], lakes["evap"][:, d.hru_global])
+                assert np.array_equal(lk["wm_vol"], lakes["wm_vol"][:, d.reach_global]) and np.array_equal(lk["targ_vol"], lakes["targ_vol"][sel])
+            gd = gauges_for_domain(da, d, net.N)
+            loc = gd["gauge_reach"]
+            seen_g += d.reach_global[loc[loc > 0] - 1].tolist()
+            assert gd["obs"] is da["obs"] and loc.size == da["gauge_reach"].size
+        assert sorted(seen_l) == sorted((lakes["reach"] - 1).tolist())                      # every lake exactly once
+        assert sorted(seen_g) == sorted((da["gauge_reach"][da["gauge_reach"] > 0] - 1).tolist())
+        assert P.part_of_reach[P.is_mainstem].max() == 0
