@@ -93,17 +93,19 @@ class _Reader:
         self.b, self.p = buf, 0
 
     def i(self, n=1):
+        n = int(n)      # (header fields come back as numpy int32: 8 * n overflowed on the 10 GB dump of a 5 M-reach case)
         v = np.frombuffer(self.b, "<i4", n, self.p); self.p += 4 * n
         return v if n > 1 else int(v[0])
 
     def d(self, n=1):
+        n = int(n)
         v = np.frombuffer(self.b, "<f8", n, self.p); self.p += 8 * n
         return v.copy() if n > 1 else float(v[0])
 
 
 def read_output(path, methods):
     r = _Reader(open(path, "rb").read())
-    magic, N, n_steps, n_routes, ntdh_bas, dump_every = r.i(6)
+    magic, N, n_steps, n_routes, ntdh_bas, dump_every = (int(x) for x in r.i(6))
     assert magic == MAGIC_OUT
     out = dict(N=N, n_steps=n_steps, steps=[], Q=[], VOL=[], QR1=[])
     while True:
