@@ -119,80 +119,84 @@ def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=
 FULL = {"c3": 3_000_000, "c4": 5_000_000, "c5": 3_000_000}      # reaches of the 8-GPU configurations (BASELINE.json configs[2..4])
 
 
-def loopback_bench(args, torch, m, uhmod):
+class Loopback:
     """The full-size network of an 8-GPU configuration on ONE GPU: cut into sub-basin partitions by the reference's rule
     (mizuroute_amd/partition.py = domain_decomposition.f90), every partition routed as its own domain one after the other,
     boundary records of the tributary outlets handed to the mainstem domain through device memory (what RCCL carries between
-    GPUs).  (A) parity: two short windows against the unpartitioned network, bit for bit (interval means, particle counts);
-    (B) timing: windows of the configuration's length, per-domain sweep time, and what eight GPUs would take: every rank its
-    tributary domain, rank 0 also the mainstem one window behind -- max(slowest tributary, rank 0's tributary + mainstem)."""
-    from mizuroute_amd.partition import partition_network
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    cfg = CONFIGS[args.config]
-    methods = [int(c) for c in cfg["methods"]]
-    nparts = args.partitions or 8
-    N = args.reaches or FULL[args.config]
-    frac = uhmod.basin_uh(DT, 2.5, 86400.0)
-    t0 = time.perf_counter()
-    net = m.make_network(N, seed=20240529, floodplain=bool(cfg.get("floodplain")))
-    from mizuroute_amd.partition import mainstem_cost
-    Wcfg = args.window or cfg["window"]
-    mc = mainstem_cost(net, nparts, Wcfg) if (args.balance and methods == [m.KWT]) else 0.0
-    P = partition_network(net, nparts, main_cost=mc)
-    t_setup = time.perf_counter() - t0
-    need_uh = any(x != m.KWT for x in methods)
-    uh_off, uhv = uhmod.make_uh(net.params["RLENGTH"], DT, 1.5, 5000.0) if need_uh else (None, None)
+    GPUs).  parity(): short windows against the unpartitioned network, bit for bit (interval means, particle counts);
+    timing(): windows of the configuration's length, per-domain sweep time, and what eight GPUs would take: every rank its
+    tributary domain, rank 0 also the mainstem one window behind.  Used by `bench.py --loopback`, by the `configs` objects of
+    the default bench line and by tests/test_gpu_scale.py."""
 
-    def uh_of(spec):
-        if not need_uh:
+    def __init__(self, torch, m, uhmod, config, nparts=8, reaches=0, window=0, balance=False):
+        from mizuroute_amd.partition import partition_network, mainstem_cost
+        self.torch, self.m, self.config = torch, m, config
+        self.dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        self.cfg = cfg = CONFIGS[config]
+        self.methods = [int(c) for c in cfg["methods"]]
+        self.nparts = nparts
+        N = reaches or FULL[config]
+        self.frac = uhmod.basin_uh(DT, 2.5, 86400.0)
+        t0 = time.perf_counter()
+        self.net = net = m.make_network(N, seed=20240529, floodplain=bool(cfg.get("floodplain")))
+        self.Wcfg = window or cfg["window"]
+        self.mc = mainstem_cost(net, nparts, self.Wcfg) if (balance and self.methods == [m.KWT]) else 0.0
+        self.P = partition_network(net, nparts, main_cost=self.mc)
+        self.t_setup = time.perf_counter() - t0
+        self.need_uh = any(x != m.KWT for x in self.methods)
+        self.uh_off, self.uhv = uhmod.make_uh(net.params["RLENGTH"], DT, 1.5, 5000.0) if self.need_uh else (None, None)
+        self.lakes = None
+        if cfg.get("lakes"):      # c5: 1 % of the reaches are lakes / reservoirs (Doll, Hanasaki, HYPE); one window of lake forcing, reused
+            from mizuroute_amd.synthetic import make_lakes
+            self.lakes = make_lakes(net, max(self.Wcfg, 256), DT, seed=9, frac=cfg["lakes"], input_option=1, forcing=False)
+
+    def uh_of(self, spec):
+        if not self.need_uh:
             return {}
         g = spec.reach_global
-        cnt = np.diff(uh_off)[g]
+        cnt = np.diff(self.uh_off)[g]
         off = np.zeros(g.size + 1, np.int32); off[1:] = np.cumsum(cnt)
-        idx = np.repeat(uh_off[g].astype(np.int64), cnt) + (np.arange(int(cnt.sum())) - np.repeat(off[:-1].astype(np.int64), cnt))
-        return dict(uh_offset=off, uh=uhv[idx])
+        idx = np.repeat(self.uh_off[g].astype(np.int64), cnt) + (np.arange(int(cnt.sum())) - np.repeat(off[:-1].astype(np.int64), cnt))
+        return dict(uh_offset=off, uh=self.uhv[idx])
 
-    lakes = None
-    if cfg.get("lakes"):      # c5: 1 % of the reaches are lakes / reservoirs (Doll, Hanasaki, HYPE); one window of lake forcing, reused
-        from mizuroute_amd.synthetic import make_lakes
+    def make(self, spec, W, **kw):
         from mizuroute_amd.partition import lakes_for_domain
-        lakes = make_lakes(net, max(Wcfg, 256), DT, seed=9, frac=cfg["lakes"], input_option=1, forcing=False)
+        lk = lakes_for_domain(self.lakes, spec, self.net.N) if self.lakes is not None else None
+        return self.m.RoutingDomain(spec.net, DT, self.methods, frac_future=self.frac, max_window=W, device=0, lakes=lk, **self.uh_of(spec), **kw)
 
-    def make(spec, W, **kw):
-        kw.pop("sweep_share", None)                    # the domains run one after the other here: each may fill the device
-        lk = lakes_for_domain(lakes, spec, net.N) if lakes is not None else None
-        return m.RoutingDomain(spec.net, DT, methods, frac_future=frac, max_window=W, device=0, lakes=lk, **uh_of(spec), **kw)
-
-    def forcing(W, t0s, cols=None, shared=True):
+    def forcing(self, W, t0s, cols=None, shared=True):
         """shared: one forcing for the whole network, a domain takes the columns of its HRUs (parity); otherwise a forcing of
         the domain's own (timing: the whole network's window would not fit beside the domains)"""
+        torch = self.torch
         if not shared:
-            return device_runoff(torch, len(cols), W, t0s, 7 + len(cols) % 97, dev)
-        ro = device_runoff(torch, net.H, W, t0s, 7, dev)
-        return ro if cols is None else ro[:, torch.as_tensor(cols, device=dev, dtype=torch.long)].contiguous()
+            return device_runoff(torch, len(cols), W, t0s, 7 + len(cols) % 97, self.dev)
+        ro = device_runoff(torch, self.net.H, W, t0s, 7, self.dev)
+        return ro if cols is None else ro[:, torch.as_tensor(cols, device=self.dev, dtype=torch.long)].contiguous()
 
-    def route_partitioned(W, K, timing):
-        """all windows of one domain, then the next; returns per-reach interval means / particle counts and the times"""
+    def route_partitioned(self, W, K, timing):
+        """all windows of one domain, then the next; returns per-reach interval means / particle counts, the times and the
+        boundary records (kept on the device only when `timing`)"""
+        torch, m, net, P, methods = self.torch, self.m, self.net, self.P, self.methods
         mean = {mm: np.zeros(net.N) for mm in methods}
         nw = np.zeros(net.N, np.int64)
         recs = {}                                      # (partition, window) -> boundary record on the device
         times = {}
-        for p in range(nparts):
+        for p in range(self.nparts):
             sp = P.trib[p]
             if sp.n_real == 0:
                 continue
-            dom = make(sp, W, export_reaches=sp.export_local)
+            dom = self.make(sp, W, export_reaches=sp.export_local)
             tw = []
             for k in range(K):
-                ro = forcing(W, k * W, sp.hru_global, shared=not timing)
+                ro = self.forcing(W, k * W, sp.hru_global, shared=not timing)
                 if dom.lakes is not None:
                     dom.set_lake_forcing(0, W)
                 torch.cuda.synchronize(); t1 = time.perf_counter()
                 dom.run_device(W, k * W * DT, ro.data_ptr()); dom.sync()
                 tw.append(time.perf_counter() - t1)
                 if sp.export_local.size and P.main is not None:
-                    rec = torch.empty(dom.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=dev)
+                    rec = torch.empty(dom.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=self.dev)
                     dom.export_boundary(rec.data_ptr()); dom.sync()
                     recs[(p, k)] = rec
                 del ro
@@ -204,11 +208,11 @@ def loopback_bench(args, torch, m, uhmod):
             dom.close(); del dom
         if P.main is not None:
             ms = P.main
-            dom = make(ms, W, halo_reaches=ms.halo_local, halo_good=ms.halo_good)
+            dom = self.make(ms, W, halo_reaches=ms.halo_local, halo_good=ms.halo_good)
             tw = []
             for k in range(K):
-                ro = forcing(W, k * W, ms.hru_global, shared=not timing)
-                for p in range(nparts):
+                ro = self.forcing(W, k * W, ms.hru_global, shared=not timing)
+                for p in range(self.nparts):
                     base, n = ms.halo_base[p]
                     if n:
                         dom.import_boundary(W, recs[(p, k)].data_ptr(), n, base)
@@ -231,106 +235,172 @@ def loopback_bench(args, torch, m, uhmod):
         torch.cuda.empty_cache()
         return mean, nw, times, recs
 
-    out = {"metric": "reaches*timesteps/s", "unit": "reaches*timesteps/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"FULL {args.config} network ({net.N} reaches, route_opt {cfg['methods']}{', ' + str(lakes['reach'].size) + ' lakes' if lakes is not None else ''}) in {nparts} sub-basin partitions (reference decomposition), "
-                                  "all on one GPU, boundary records through device memory", "baseline_config": args.config, "reaches_total": net.N,
-                      "partitions": nparts, "mainstem_reaches": int(P.is_mainstem.sum()), "setup_s": t_setup,
-                      "assignment": "reference (assign_node)" if mc == 0.0 else f"rank 0's tributary share cut by the mainstem's cost of {mc:.0f} reaches"}}
-    # ---- (A) parity against the unpartitioned network
-    Wa, Ka = 256, 2
-    extra = dict(uh_offset=uh_off, uh=uhv) if need_uh else {}
-    whole = m.RoutingDomain(net, DT, methods, frac_future=frac, max_window=Wa, device=0, lakes=lakes, **extra)
-    tw = []
-    for k in range(Ka):
-        ro = forcing(Wa, k * Wa)
-        if lakes is not None:
-            whole.set_lake_forcing(0, Wa)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        whole.run_device(Wa, k * Wa * DT, ro.data_ptr()); whole.sync()
-        tw.append(time.perf_counter() - t1)
-        del ro
-    mean_w = {mm: whole.mean_q(mm) for mm in methods}
-    nw_w = whole.kwt_state()[0] if m.KWT in methods else None
-    out["config"]["whole_network"] = dict(stages=whole.schedule()[0], window_steps=Wa, s_per_window=tw,
-                                          value=float(net.N) * Wa * len(methods) / tw[-1])
-    whole.close(); del whole
-    torch.cuda.empty_cache()
-    mean_p, nw_p, _, _ = route_partitioned(Wa, Ka, False)
-    same = all(np.array_equal(mean_p[mm], mean_w[mm]) for mm in methods) and (nw_w is None or np.array_equal(nw_p, nw_w))
-    out["parity"] = {"partitioned_equals_whole_bit_for_bit": bool(same), "window_steps": Wa, "windows": Ka,
-                     "max_abs_diff": float(max(np.abs(mean_p[mm] - mean_w[mm]).max() for mm in methods))}
-    # ---- (B) timing at the configuration's window length
-    W, K = args.window or cfg["window"], max(2, args.steps)
-    _, _, times, recs = route_partitioned(W, K, True)
-    steady = lambda d: float(np.mean(d["s_per_window"][1:]))
-    trib = {k: steady(v) for k, v in times.items() if k.startswith("trib")}
-    t_main = steady(times["main"]) if "main" in times else 0.0
-    one_gpu = sum(trib.values()) + t_main
-    # rank 0 as it really runs (PartitionedRouter): its tributary window k and the mainstem window k-1 SIDE BY SIDE on one GPU,
-    # each sweep with its share of the wavefront slots; the other partitions' records are the ones measured above
-    t_rank0 = trib.get("trib0", 0.0) + t_main
-    if P.main is not None and P.trib[0].n_real > 0:
-        sp, ms = P.trib[0], P.main
-        lk_t = lakes_for_domain(lakes, sp, net.N) if lakes is not None else None
-        lk_m = lakes_for_domain(lakes, ms, net.N) if lakes is not None else None
-        d_t = m.RoutingDomain(sp.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.8, export_reaches=sp.export_local, lakes=lk_t, **uh_of(sp))
-        d_m = m.RoutingDomain(ms.net, DT, methods, frac_future=frac, max_window=W, device=0, sweep_share=0.2, halo_reaches=ms.halo_local,
-                              halo_good=ms.halo_good, lakes=lk_m, **uh_of(ms))
-        ro_t = [forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
-        ro_m = [forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
-        rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=dev) for _ in range(2)]
+    def parity(self, Wa=256, Ka=2):
+        """the partitioned network against the whole one: Ka windows of Wa steps; returns the report and both sets of results"""
+        torch, m, net, methods = self.torch, self.m, self.net, self.methods
+        extra = dict(uh_offset=self.uh_off, uh=self.uhv) if self.need_uh else {}
+        whole = m.RoutingDomain(net, DT, methods, frac_future=self.frac, max_window=Wa, device=0, lakes=self.lakes, **extra)
         tw = []
-        for k in range(K + 1):
+        for k in range(Ka):
+            ro = self.forcing(Wa, k * Wa)
+            if self.lakes is not None:
+                whole.set_lake_forcing(0, Wa)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            if k < K:
-                if d_t.lakes is not None:
-                    d_t.set_lake_forcing(0, W)
-                d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
-            if k >= 1:                                   # the mainstem follows one window behind
-                for p in range(nparts):
-                    base, n = ms.halo_base[p]
-                    if n:
-                        d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
-                if d_m.lakes is not None:
-                    d_m.set_lake_forcing(0, W)
-                d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
-            if k < K:
-                d_t.sync()
-                d_t.export_boundary(rec0[k % 2].data_ptr())
-            d_t.sync(); d_m.sync()
-            if 1 <= k < K:
-                tw.append(time.perf_counter() - t1)
-        t_rank0 = float(np.mean(tw[1:] if len(tw) > 1 else tw))
-        times["rank0_side_by_side"] = dict(s_per_window=tw, what="tributary window k and mainstem window k-1 of rank 0 queued together (sweep shares 0.8 / 0.2)")
-        d_t.close(); d_m.close()
-    recs.clear()
-    crit = max(max(trib.values()), t_rank0)
-    out.update({"value": float(net.N) * W * len(methods) / one_gpu, "steps": K, "warmup": 1, "ms_per_step": one_gpu * 1e3, "scaling": "strong",
-                "vs_baseline": None, "error": None if same else "partitioned run differs from the whole network"})
-    out["config"].update({"window_steps": W, "domains": times})
-    # ---- the reference's own solvers on the host cores, a bounded sample of the SAME full-size network (16 OpenMP threads over
-    # its stream-order branches; particle lists far from steady state after a handful of steps: an upper bound for the CPU)
-    cpu = None
-    if not args.no_cpu_baseline:
+            whole.run_device(Wa, k * Wa * DT, ro.data_ptr()); whole.sync()
+            tw.append(time.perf_counter() - t1)
+            del ro
+        mean_w = {mm: whole.mean_q(mm) for mm in methods}
+        nw_w = whole.kwt_state()[0] if m.KWT in methods else None
+        whole_info = dict(stages=whole.schedule()[0], window_steps=Wa, s_per_window=tw, value=float(net.N) * Wa * len(methods) / tw[-1])
+        whole.close(); del whole
+        torch.cuda.empty_cache()
+        mean_p, nw_p, times, _ = self.route_partitioned(Wa, Ka, False)
+        same = all(np.array_equal(mean_p[mm], mean_w[mm]) for mm in methods) and (nw_w is None or np.array_equal(nw_p, nw_w))
+        rep = {"partitioned_equals_whole_bit_for_bit": bool(same), "window_steps": Wa, "windows": Ka,
+               "max_abs_diff": float(max(np.abs(mean_p[mm] - mean_w[mm]).max() for mm in methods))}
+        return rep, whole_info, dict(mean_whole=mean_w, mean_part=mean_p, nw_whole=nw_w, nw_part=nw_p, domains=times)
+
+    def timing(self, W, K, side_by_side=True):
+        """K windows of W steps of every domain (the first is dropped as warm-up); rank 0's two domains side by side"""
+        torch, m, net, P, methods = self.torch, self.m, self.net, self.P, self.methods
+        from mizuroute_amd.partition import lakes_for_domain
+        _, _, times, recs = self.route_partitioned(W, K, True)
+        med = lambda d: float(np.median(d["s_per_window"][1:]))
+        trib = {k: med(v) for k, v in times.items() if k.startswith("trib")}
+        t_main = med(times["main"]) if "main" in times else 0.0
+        one_gpu = sum(trib.values()) + t_main
+        # rank 0 as it really runs (PartitionedRouter): its tributary window k and the mainstem window k-1 SIDE BY SIDE on one GPU;
+        # the other partitions' records are the ones measured above
+        t_rank0 = trib.get("trib0", 0.0) + t_main
+        if side_by_side and P.main is not None and P.trib[0].n_real > 0:
+            sp, ms = P.trib[0], P.main
+            lk_t = lakes_for_domain(self.lakes, sp, net.N) if self.lakes is not None else None
+            lk_m = lakes_for_domain(self.lakes, ms, net.N) if self.lakes is not None else None
+            share = main_sweep_share(ms, methods, m)
+            d_t = m.RoutingDomain(sp.net, DT, methods, frac_future=self.frac, max_window=W, device=0, sweep_share=1.0 - share, export_reaches=sp.export_local,
+                                  lakes=lk_t, **self.uh_of(sp))
+            d_m = m.RoutingDomain(ms.net, DT, methods, frac_future=self.frac, max_window=W, device=0, sweep_share=share, halo_reaches=ms.halo_local,
+                                  halo_good=ms.halo_good, lakes=lk_m, **self.uh_of(ms))
+            ro_t = [self.forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
+            ro_m = [self.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
+            rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            tw = []
+            for k in range(K + 1):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                if k < K:
+                    if d_t.lakes is not None:
+                        d_t.set_lake_forcing(0, W)
+                    d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
+                if k >= 1:                                   # the mainstem follows one window behind
+                    for p in range(self.nparts):
+                        base, n = ms.halo_base[p]
+                        if n:
+                            d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
+                    if d_m.lakes is not None:
+                        d_m.set_lake_forcing(0, W)
+                    d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
+                if k < K:
+                    d_t.sync()
+                    d_t.export_boundary(rec0[k % 2].data_ptr())
+                d_t.sync(); d_m.sync()
+                if 1 <= k < K:
+                    tw.append(time.perf_counter() - t1)
+            t_rank0 = float(np.median(tw[1:] if len(tw) > 1 else tw))
+            times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share,
+                                               what="tributary window k and mainstem window k-1 of rank 0 queued together; median of the windows after the first")
+            d_t.close(); d_m.close()
+        recs.clear()
+        torch.cuda.empty_cache()
+        crit = max(max(trib.values()), t_rank0)
+        model = {"what": "one domain per GPU as measured here; window time = max(slowest tributary rank, rank 0 with its tributary and the mainstem side by side); "
+                         "the boundary records travel behind the next window's sweep; medians over the timed windows",
+                 "s_per_window": crit, "value": float(net.N) * W * len(methods) / crit,
+                 "slowest_tributary_s": max(trib.values()), "rank0_tributary_plus_mainstem_one_after_the_other_s": trib.get("trib0", 0.0) + t_main,
+                 "rank0_side_by_side_s": t_rank0, "balance": min(trib.values()) / max(trib.values())}
+        return dict(one_gpu_s=one_gpu, value=float(net.N) * W * len(methods) / one_gpu, domains=times, model_8gpu=model, window_steps=W, windows_timed=K - 1)
+
+    def roofline(self, W, p=1):
+        """HBM roofline of the configuration's dominant kernel on tributary domain p (a full per-GPU share of the network):
+        HIP events around the kernel's launches on one window (after two untimed ones), algorithmic bytes from the particle
+        counters of one more window (KWT) or from SURVEY.md 8(d)'s byte model (Eulerian methods)"""
+        torch, m, cfg = self.torch, self.m, self.cfg
+        sp = self.P.trib[p]
+        DOM = cfg.get("dominant", m.KWT)
+        dom = self.make(sp, W, export_reaches=sp.export_local)
+        ros = [self.forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
+        def win(k):
+            if dom.lakes is not None:
+                dom.set_lake_forcing(0, W)
+            dom.run_device(W, k * W * DT, ros[k % 2].data_ptr()); dom.sync()
+        win(0); win(1)
+        dom.timing(DOM, reset=True); dom.set_profiling(1)
+        win(2)
+        dom.set_profiling(0)
+        pt = dom.timing(DOM, reset=True)
+        launches = max(1, pt["launches"])
+        if self.methods == [m.KWT]:
+            dom.set_profiling(2); dom.kwt_traffic(reset=True)
+            win(3)
+            dom.set_profiling(0)
+            tr = dom.kwt_traffic(reset=True)
+            per_rs = kwt_bytes(tr) / max(1, tr["n_route"] + tr["n_head"])
+            kernel = "k_sweep_kwt"
+        else:
+            U = float(sp.net.upIndex.size) / sp.net.N
+            per_rs = float(cfg["bytes"](U))
+            kernel = f"k_stage<{DOM}>"
+        achieved = per_rs * pt["reach_steps"] / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
+        sw = dom.sweep_info() if m.KWT in self.methods else None
+        dom.close(); del dom, ros
+        torch.cuda.empty_cache()
+        return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": per_rs * pt["reach_steps"] / launches,
+                "bytes_per_reach_step": per_rs, "avg_launch_us": pt["kernel_ms"] / launches * 1e3, "launches": launches,
+                "domain": f"trib{p}: {sp.n_real} reaches, window of {W} steps", "kwt_sweep": sw}
+
+    def cpu(self, n_spin, n_smp):
+        """the reference's own solvers on the host cores, a bounded sample of the SAME full-size network"""
+        net, methods = self.net, self.methods
         try:
-            n_spin, n_smp = 8, 8
-            ro_cpu = device_runoff(torch, net.H, n_spin + n_smp, 0, 7, dev).cpu().numpy()
+            ro_cpu = device_runoff(self.torch, net.H, n_spin + n_smp, 0, 7, self.dev).cpu().numpy()
             lk = None
-            if lakes is not None:
-                lk = dict(lakes, evap=np.zeros((n_spin + n_smp, net.H)), precip=np.zeros((n_spin + n_smp, net.H)))
-                lk["ymd"] = lakes["ymd"][:n_spin + n_smp]
-            cpu = cpu_baseline(net, frac, ro_cpu, n_spin, n_smp, methods, (uh_off, uhv) if need_uh else None, lk, one_thread=False)
-            cpu["sample"] = (f"the FULL {net.N}-reach network, route_opt {cfg['methods']}, {n_smp} steps timed after {n_spin} (lists not at steady state: an upper "
-                             f"bound), {cpu['cores']} OpenMP threads over the reference's stream-order branches; unmodified reference solvers, flang -O2")
+            if self.lakes is not None:
+                lk = dict(self.lakes, evap=np.zeros((n_spin + n_smp, net.H)), precip=np.zeros((n_spin + n_smp, net.H)))
+                lk["ymd"] = self.lakes["ymd"][:n_spin + n_smp]
+            cpu = cpu_baseline(net, self.frac, ro_cpu, n_spin, n_smp, methods, (self.uh_off, self.uhv) if self.need_uh else None, lk, one_thread=False)
+            cpu["sample"] = (f"the FULL {net.N}-reach network, route_opt {self.cfg['methods']}, {n_smp} steps timed after {n_spin}, "
+                             f"{cpu['cores']} OpenMP threads over the reference's stream-order branches; unmodified reference solvers, flang -O2")
         except Exception as e:
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
-    out["cpu_baseline"] = cpu
-    out["model_8gpu"] = {"what": "one domain per GPU as measured here; window time = max(slowest tributary rank, rank 0 with its tributary and the mainstem side by side); "
-                                 "the boundary records (bytes above) travel behind the next window's sweep",
-                         "s_per_window": crit, "value": float(net.N) * W * len(methods) / crit,
-                         "slowest_tributary_s": max(trib.values()), "rank0_tributary_plus_mainstem_one_after_the_other_s": trib.get("trib0", 0.0) + t_main,
-                         "rank0_side_by_side_s": t_rank0,
-                         "balance": min(trib.values()) / max(trib.values())}
+        return cpu
+
+
+def main_sweep_share(ms, methods, m):
+    """share of the device's wavefront slots the mainstem domain's persistent sweep gets beside the tributary sweep of the same
+    rank: sized by need -- a few wavefronts per reach of its widest stage -- not a fixed fifth of the device"""
+    return 0.2
+
+
+def loopback_bench(args, torch, m, uhmod):
+    """`bench.py --loopback --config c3|c4|c5 --partitions 8`: parity and timing of the full-size network (class Loopback)"""
+    lb = Loopback(torch, m, uhmod, args.config, args.partitions or 8, args.reaches, args.window, args.balance)
+    net, cfg, methods, nparts, P = lb.net, lb.cfg, lb.methods, lb.nparts, lb.P
+    out = {"metric": "reaches*timesteps/s", "unit": "reaches*timesteps/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"FULL {args.config} network ({net.N} reaches, route_opt {cfg['methods']}{', ' + str(lb.lakes['reach'].size) + ' lakes' if lb.lakes is not None else ''}) in {nparts} sub-basin partitions (reference decomposition), "
+                                  "all on one GPU, boundary records through device memory", "baseline_config": args.config, "reaches_total": net.N,
+                      "partitions": nparts, "mainstem_reaches": int(P.is_mainstem.sum()), "setup_s": lb.t_setup,
+                      "assignment": "reference (assign_node)" if lb.mc == 0.0 else f"rank 0's tributary share cut by the mainstem's cost of {lb.mc:.0f} reaches"}}
+    rep, whole_info, _ = lb.parity(256, 2)
+    same = rep["partitioned_equals_whole_bit_for_bit"]
+    out["config"]["whole_network"] = whole_info
+    out["parity"] = rep
+    W, K = args.window or cfg["window"], max(2, args.steps)
+    tm = lb.timing(W, K)
+    out.update({"value": tm["value"], "steps": K, "warmup": 1, "ms_per_step": tm["one_gpu_s"] * 1e3, "scaling": "strong",
+                "vs_baseline": None, "error": None if same else "partitioned run differs from the whole network"})
+    out["config"].update({"window_steps": W, "domains": tm["domains"]})
+    out["cpu_baseline"] = None if args.no_cpu_baseline else lb.cpu(args.cpu_spinup, args.cpu_sample)
+    out["model_8gpu"] = tm["model_8gpu"]
     print(json.dumps(out))
 
 
@@ -358,6 +428,12 @@ def main():
                     "(partition.mainstem_cost; the reference's assignment gives rank 0 an even share plus the mainstem).  With --gpus N > 1 "
                     "this is the default (same domains, same results, rank 0 level with the others)")
     ap.add_argument("--reference-assignment", action="store_true", help="with --gpus N > 1: the reference's assign_node as it is")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` objects of the default line (full-size c3 / c4 / c5 in 8 partitions on this GPU)")
+    ap.add_argument("--configs", default="c3,c4,c5", help="which full-size configurations the default line carries")
+    ap.add_argument("--cpu-spinup-configs", type=int, default=8, help="untimed steps of the CPU baseline of a `configs` object (full network: about a second per step)")
+    ap.add_argument("--cpu-sample-configs", type=int, default=16, help="timed steps of the CPU baseline of a `configs` object")
+    ap.add_argument("--cpu-spinup", type=int, default=48, help="with --loopback: untimed steps of the CPU baseline on the full network")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="with --loopback: timed steps of the CPU baseline on the full network")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
@@ -687,19 +763,22 @@ def main():
             launches = max(1, pt["launches"])
             avg_ms = pt["kernel_ms"] / launches
             achieved = bytes_total / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
-            traffic = None
+            traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "kwt_hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     if world == 1 and tj.get("reaches") == net.N and tj.get("window") == W:
                         traffic = tj["hbm_bytes_per_launch"]
+                        tsrc = "bundle " + str(tj.get("tag", "?"))
                 except Exception:
                     traffic = None
             sw = dom.sweep_info()
             roof = {"bound": "hbm", "kernel": "k_sweep_kwt" if sw[0] > 0 and os.environ.get("MZR_KWT_SWEEP", "1") != "0" else "k_stage_kwt",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": (f"profiles/kwt_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate run of the same workload and build "
+                                       f"({tsrc}); NOT measured in this run") if traffic is not None else None,
                     "algorithmic_bytes_per_launch": bytes_total / launches,
                     "bytes_per_reach_step": per_rs,
                     "avg_launch_us": avg_ms * 1e3, "launches": launches,
@@ -717,6 +796,44 @@ def main():
         except Exception as e:   # the baseline is reported, never required
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
 
+    # ---- BASELINE.json configs[2..4] at FULL size on this one GPU (N = 1, default configuration only): the 3 M / 5 M / 3 M + lakes
+    # networks cut into eight partitions by the reference's decomposition and routed domain after domain, boundary records through
+    # device memory (class Loopback); per configuration: parity against the unpartitioned network, median window times of every
+    # domain over >= 4 timed windows, roofline of the dominant kernel on one tributary domain, the reference on the full network
+    sweep_geom = dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 and m.KWT in methods else None
+    sweep_arr = dict(zip(("arrived_last", "joined_last", "start_delay_hist_log2_10ns"), dom.sweep_arrivals())) if world == 1 and m.KWT in methods else None
+    configs = None
+    if rank == 0 and world == 1 and args.config == "c2" and not args.no_configs:
+        configs = {}
+        try:
+            dom.close()
+        except Exception:
+            pass
+        del pool
+        torch.cuda.empty_cache()
+        for cname in args.configs.split(","):
+            t_c = time.perf_counter()
+            try:
+                lb = Loopback(torch, m, uhmod, cname, 8)
+                rep, whole_info, _ = lb.parity(128, 1)
+                Wc = CONFIGS[cname]["window"]
+                tmc = lb.timing(Wc, 5)
+                roofc = lb.roofline(Wc)
+                cpuc = None if args.no_cpu_baseline else lb.cpu(args.cpu_spinup_configs, args.cpu_sample_configs)
+                configs[cname] = {"workload": f"FULL {cname} network: {lb.net.N} reaches, route_opt {lb.cfg['methods']}"
+                                              + (f", {lb.lakes['reach'].size} lakes / reservoirs" if lb.lakes is not None else "")
+                                              + ", 8 sub-basin partitions (reference decomposition) one after the other on this GPU",
+                                  "value": tmc["value"], "unit": "reaches*timesteps/s", "window_steps": Wc, "windows_timed": tmc["windows_timed"],
+                                  "s_per_window_all_domains": tmc["one_gpu_s"], "parity": rep, "whole_network": whole_info,
+                                  "domains": {k: {kk: vv for kk, vv in v.items() if kk != "what"} for k, v in tmc["domains"].items()},
+                                  "model_8gpu": tmc["model_8gpu"], "roofline": roofc, "cpu_baseline": cpuc,
+                                  "setup_s": lb.t_setup, "wall_s": None}
+                del lb
+            except Exception as e:
+                configs[cname] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+            configs[cname]["wall_s"] = time.perf_counter() - t_c
+
     if rank == 0:
         out = {
             "metric": "reaches*timesteps/s", "value": value, "unit": "reaches*timesteps/s",
@@ -730,14 +847,14 @@ def main():
                        "window_steps": W, "model_timesteps_timed": K * W, "ms_per_model_timestep": elapsed / (K * W) * 1e3,
                        "simulated_years_per_wallclock_day": (K * W * DT / 31536000.0) / (elapsed / 86400.0),
                        "kernel_time_fraction": ktf,
-                       "kwt_sweep": dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 and m.KWT in methods else None,
+                       "kwt_sweep": sweep_geom,
                        "parallelism": ("1 domain" if world == 1 else
                                        f"{world} sub-basin partitions (the reference's domains; " + ("its node assignment" if args.reference_assignment else
                                        "rank 0's share of small tributaries cut by the mainstem's cost") + "), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
             "value_with_h2d": value_h2d, "single_step": single,
-            "kwt_sweep_arrivals": dict(zip(("arrived_last", "joined_last", "start_delay_hist_log2_10ns"), dom.sweep_arrivals())) if world == 1 and m.KWT in methods else None,
-            "roofline": roof, "cpu_baseline": cpu, "error": post_error,
+            "kwt_sweep_arrivals": sweep_arr,
+            "roofline": roof, "cpu_baseline": cpu, "configs": configs, "error": post_error,
         }
         print(json.dumps(out))
     if dist is not None:

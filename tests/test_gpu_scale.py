@@ -174,3 +174,46 @@ def test_bench_operating_point_sweep_equals_stage_launches(hip_lib, monkeypatch)
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), "particle state differs between the sweep and one launch per stage"
     assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb)
     assert np.isfinite(Qa).all() and (Qa >= 0).all() and sa[0].max() <= 20
+
+
+@pytest.mark.parametrize("config", ["c3", "c4", "c5"])
+def test_full_size_network_partitioned_equals_whole(config, hip_lib):
+    """BASELINE.json configs[2..4] at FULL size -- 3 M reaches KWT, 5 M reaches IRF + Muskingum-Cunge, 3 M reaches diffusive wave with
+    floodplains and 30 000 lakes / reservoirs -- cut into eight sub-basin partitions by the reference's decomposition
+    (domain_decomposition.f90:41-163 = mizuroute_amd/partition.py), every partition routed as a domain of its own, the boundary
+    records of the tributary outlets replayed through the halo reaches of the mainstem domain (what replaces the per-step
+    gather / scatter of mpi_process.f90:1245-1329): interval means of every method and the particle counts of every reach equal
+    the unpartitioned network's, bit for bit, over two windows of 256 steps (bench.py's Loopback.parity, the same code the
+    `configs` objects of the bench line come from).  Property checks on the deep, narrow mainstem domain on top."""
+    import torch
+    import bench
+    from mizuroute_amd import uh as uhmod
+    lb = bench.Loopback(torch, m, uhmod, config, 8)
+    P, net = lb.P, lb.net
+    assert net.N == bench.FULL[config]
+    # the decomposition covers every reach exactly once
+    seen = np.zeros(net.N, np.int32)
+    for sp in P.trib:
+        if sp.n_real:
+            np.add.at(seen, sp.reach_global[:sp.n_real], 1)
+    assert P.main is not None and P.main.n_real > 1000
+    np.add.at(seen, P.main.reach_global[:P.main.n_real], 1)
+    assert seen.min() == 1 and seen.max() == 1
+    assert sum(1 for sp in P.trib if sp.n_real) == 8
+    rep, whole, res = lb.parity(256, 2)
+    print(config, rep, {k: (v["reaches"], v["stages"]) for k, v in res["domains"].items()})
+    assert rep["partitioned_equals_whole_bit_for_bit"], rep
+    assert rep["max_abs_diff"] == 0.0
+    # the mainstem domain: thousands of dependent stages, fed by thousands of halo reaches
+    dm = res["domains"]["main"]
+    assert dm["stages"] > 1000 and dm["halos"] > 1000 and dm["reaches"] == P.main.n_real
+    g = P.main.reach_global[:P.main.n_real]
+    for mm in lb.methods:
+        q = res["mean_part"][mm]
+        assert np.isfinite(q).all() and (q >= 0).all()
+        # a mainstem reach carries more than the mean reach does (it drains more than 1/8 of the network)
+        assert q[g].mean() > 10.0 * q.mean()
+    if m.KWT in lb.methods:
+        nw = res["nw_part"]
+        assert nw.min() >= 1 and nw.max() <= 20
+        assert nw[g].mean() > nw.mean()          # long particle lists sit on the main stems
