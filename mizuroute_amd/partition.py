@@ -62,68 +62,7 @@ def subtree_sizes(net: RiverNetwork) -> np.ndarray:
     return cnt
 
 
-def nr_indexx(arr) -> np.ndarray:
-    """Index array that sorts `arr` ascending, element for element what the reference's `indexx` returns
-    (nr_utils.f90:114-190: quicksort on the index with median of three, insertion sort below 15 elements; NOT stable, and
-    assign_node's treatment of equally large domains follows its order).  0-based result."""
-    a = np.asarray(arr)
-    n = a.size
-    idx = list(range(n + 1))                 # 1-based like the source: idx[1..n] hold 1-based positions
-    A = lambda i: a[i - 1]
-    NN = 15
-    stack = []
-    l, r = 1, n
-    while True:
-        if r - l < NN:
-            for j in range(l + 1, r + 1):
-                indext = idx[j]
-                av = A(indext)
-                i = j - 1
-                while i >= 1:
-                    if A(idx[i]) <= av:
-                        break
-                    idx[i + 1] = idx[i]
-                    i -= 1
-                idx[i + 1] = indext
-            if not stack:
-                break
-            r = stack.pop(); l = stack.pop()
-        else:
-            k = (l + r) // 2
-            if k != l + 1:
-                idx[k], idx[l + 1] = idx[l + 1], idx[k]
-            if A(idx[r]) < A(idx[l]):
-                idx[l], idx[r] = idx[r], idx[l]
-            if A(idx[r]) < A(idx[l + 1]):
-                idx[l + 1], idx[r] = idx[r], idx[l + 1]
-            if A(idx[l + 1]) < A(idx[l]):
-                idx[l], idx[l + 1] = idx[l + 1], idx[l]
-            i, j = l + 1, r
-            indext = idx[l + 1]
-            av = A(indext)
-            while True:
-                i += 1
-                while A(idx[i]) < av:
-                    i += 1
-                j -= 1
-                while A(idx[j]) > av:
-                    j -= 1
-                if j < i:
-                    break
-                if i != j:
-                    idx[i], idx[j] = idx[j], idx[i]
-            idx[l + 1] = idx[j]
-            idx[j] = indext
-            if r - i + 1 >= j - l:
-                stack.append(i); stack.append(r)
-                r = j - 1
-            else:
-                stack.append(l); stack.append(j - 1)
-                l = i
-    return np.array(idx[1:], dtype=np.int64) - 1
-
-
-def reference_domains(net: RiverNetwork, n_nodes: int, main_cost: float = 0.0):
+def reference_domains(net: RiverNetwork, n_nodes: int, main_cost: float = 0.0, sort_index=None):
     """The reference's MPI domains and their nodes (domain_decomposition.f90): `classify_river_basin` / `decomposeDomain`
     (:450-590, :600-720) make, in this order, one tributary domain per basin whose outlet has at most nSeg/nNodes reaches
     upstream (itself counted), the mainstem domain (every reach with more than that), and one tributary domain per reach
@@ -135,7 +74,12 @@ def reference_domains(net: RiverNetwork, n_nodes: int, main_cost: float = 0.0):
     main_cost (not in the reference; 0 = its rule): what routing the mainstem costs the root, in tributary reaches.  On CPUs
     the few thousand mainstem reaches are a rounding error of the root's share; on a GPU they are a chain of thousands of
     dependent stages that costs half a tributary share (`mainstem_cost`), so the root's even share of small tributaries is cut
-    to (nTribSeg - (nNodes-1) main_cost) / nNodes.  The domains themselves and every result stay the same."""
+    to (nTribSeg - (nNodes-1) main_cost) / nNodes.  The domains themselves and every result stay the same.
+    sort_index: the index sort `assign_node` ranks the domains with.  The reference's `indexx` (nr_utils.f90:114-177) is not
+    stable, so WHICH of two equally large domains it serves first is an accident of that routine; here a stable argsort is
+    used (results do not depend on it: same domains, same loads up to the size of a tied domain).  The tests pass the
+    line-for-line restatement kept with the test infrastructure (nr_indexx, beside the C restatement of the solvers) to compare node for node with the
+    compiled reference."""
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
     cnt = subtree_sizes(net)
@@ -152,7 +96,7 @@ def reference_domains(net: RiverNetwork, n_nodes: int, main_cost: float = 0.0):
             kind.append(1); outlet.append(int(r)); size.append(int(cnt[r]))
     kind, outlet, size = np.array(kind, np.int64), np.array(outlet, np.int64), np.array(size, np.int64)
     n_dom = kind.size
-    rank = nr_indexx(size)
+    rank = np.argsort(size, kind="stable") if sort_index is None else np.asarray(sort_index(size))
     node = np.full(n_dom, -99, np.int64)
     assigned = np.zeros(n_dom, bool)
     n_even = int(size[kind == 1].sum()) // max(1, n_nodes)
@@ -276,16 +220,16 @@ def gauges_for_domain(da: dict, spec: "Domain", n_reach_global: int):
     return out
 
 
-def partition_network(net: RiverNetwork, n_parts: int, build_for=None, main_cost: float = 0.0) -> Partition:
+def partition_network(net: RiverNetwork, n_parts: int, build_for=None, main_cost: float = 0.0, sort_index=None) -> Partition:
     """build_for: partitions whose Domain objects (local networks) are materialised; None = all.
     A rank of a multi-GPU job passes [rank]; the assignment itself is always computed in full.
-    main_cost: see reference_domains (0 = the reference's assignment)."""
+    main_cost, sort_index: see reference_domains (0 = the reference's assignment; None = stable argsort)."""
     N = net.N
     down0 = net.downIndex.astype(np.int64) - 1
     # domains and their nodes exactly as the reference makes them (pinned against the compiled reference routines,
     # the test test_domain_decomposition_matches_the_reference); partition p = node p, the mainstem
     # (node -1, "handled in root proc") goes to partition 0
-    kind, outlet, size, node, is_main, root_of = reference_domains(net, n_parts, main_cost)
+    kind, outlet, size, node, is_main, root_of = reference_domains(net, n_parts, main_cost, sort_index)
     roots = np.sort(outlet[kind == 1])
     part_of_root = {int(o): int(max(nd, 0)) for o, nd, k in zip(outlet, node, kind) if k == 1}
     part_of_reach = np.zeros(N, dtype=np.int64)

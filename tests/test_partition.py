@@ -161,9 +161,9 @@ def test_boundary_exchange_over_gloo_world2():
 
 
 def test_nr_indexx_sorts_like_the_reference_routine():
-    """partition.nr_indexx restates nr_utils.f90:114-190 (pinned to the compiled routine through the domain tests of
+    """oracle.nr_indexx restates nr_utils.f90:114-190 (pinned to the compiled routine through the domain tests of
     test_oracle_vs_ref.py); here: it IS a sort index, for short arrays (insertion sort) and long ones (quicksort), with ties."""
-    from mizuroute_amd.partition import nr_indexx
+    from oracle.nr_indexx import nr_indexx
     rng = np.random.default_rng(1)
     for n in (1, 2, 15, 16, 17, 100, 5000):
         for hi in (3, 50, 10**6):
