@@ -643,27 +643,45 @@ def main():
 
     # ---- the same timed region with the forcing handed over in page-locked host memory (N = 1): two host
     # windows, copied by the library on its own stream while the window before is routed
-    value_h2d = None
+    value_h2d, value_h2d_f64, h2d_info = None, None, None
     if world == 1 and not args.no_h2d and lakes is None:
-        try:
-            hosts = [torch.empty((W, net.H), dtype=torch.float64).pin_memory() for _ in range(2)]
-            for hb, ro in zip(hosts, pool):
-                hb.copy_(ro[0])
-            torch.cuda.synchronize()
-            k0 = state["batch"]
-            dom.run_async(W, state["t"], hosts[k0 % 2].data_ptr())      # one untimed window fills the pipeline
-            dom.sync()
-            state["t"] += W * DT
-            t1 = time.perf_counter()
-            for k in range(k0 + 1, k0 + 1 + K):
-                dom.run_async(W, state["t"], hosts[k % 2].data_ptr())
+        # (a) the forcing as the reference's files store it -- single precision, which get_nc widens into real(dp)
+        # (standalone/read_runoff.f90:264-306): mzr_run_async_f32 moves half the bytes and widens on the device; (b) double precision
+        for tag in ("f32", "f64"):
+            try:
+                dt_ = torch.float32 if tag == "f32" else torch.float64
+                hosts = [torch.empty((W, net.H), dtype=dt_).pin_memory() for _ in range(2)]
+                for hb, ro in zip(hosts, pool):
+                    hb.copy_(ro[0])
+                torch.cuda.synchronize()
+                call = dom.run_async_f32 if tag == "f32" else dom.run_async
+                k0 = state["batch"]
+                call(W, state["t"], hosts[k0 % 2].data_ptr())      # one untimed window fills the pipeline
+                dom.sync()
                 state["t"] += W * DT
-            dom.sync()
-            value_h2d = float(net.N) * K * W * len(methods) / (time.perf_counter() - t1)
-            state["batch"] = k0 + 1 + K
-            del hosts
-        except Exception as e:   # reported, never required
-            value_h2d = f"failed: {e}"
+                t1 = time.perf_counter()
+                for k in range(k0 + 1, k0 + 1 + K):
+                    call(W, state["t"], hosts[k % 2].data_ptr())
+                    state["t"] += W * DT
+                dom.sync()
+                el = time.perf_counter() - t1
+                v_ = float(net.N) * K * W * len(methods) / el
+                state["batch"] = k0 + 1 + K
+                nbytes = float(W) * net.H * (4 if tag == "f32" else 8)
+                if tag == "f32":
+                    value_h2d = v_
+                    h2d_info = {"forcing": "float32 in page-locked host memory (as the forcing files store it), widened to f64 on the device behind the copy",
+                                "bytes_per_window": nbytes, "host_to_device_GBps_needed": nbytes * K / el / 1e9}
+                else:
+                    value_h2d_f64 = v_
+                    h2d_info["f64_bytes_per_window"] = nbytes
+                    h2d_info["f64_GBps_achieved_or_needed"] = nbytes * K / el / 1e9
+                del hosts
+            except Exception as e:   # reported, never required
+                if tag == "f32":
+                    value_h2d = f"failed: {e}"
+                else:
+                    value_h2d_f64 = f"failed: {e}"
 
     # ---- one main_route-equivalent call per model time step (mzr_step), the reference driver's loop
     # (standalone/route_runoff.f90:80-108): (a) stepBatch = 1, every call routes its step and synchronises (the
@@ -852,7 +870,7 @@ def main():
                                        f"{world} sub-basin partitions (the reference's domains; " + ("its node assignment" if args.reference_assignment else
                                        "rank 0's share of small tributaries cut by the mainstem's cost") + "), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
-            "value_with_h2d": value_h2d, "single_step": single,
+            "value_resident": value, "value_with_h2d": value_h2d, "value_with_h2d_f64": value_h2d_f64, "h2d": h2d_info, "single_step": single,
             "kwt_sweep_arrivals": sweep_arr,
             "roofline": roof, "cpu_baseline": cpu, "configs": configs, "error": post_error,
         }

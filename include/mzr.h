@@ -185,6 +185,11 @@ int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_d
    standalone/route_runoff.f90:80-108 (read forcing, route) with the read hidden.  The host buffer must stay
    unchanged until the next-but-one mzr_run_async returns, or until mzr_sync. */
 int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff);
+/* same, runoff as the forcing files store it: single precision.  The reference reads its forcing through get_nc into
+   real(dp) (standalone/read_runoff.f90:264-306), i.e. it widens every float of the file; here the widening happens on
+   the device behind the copy, so a window crosses PCIe at half the bytes and the values routed are the same, bit for
+   bit, whenever the file variable is a float. */
+int mzr_run_async_f32(mzr_handle h, int nSteps, double t_start, const float *runoff);
 int mzr_sync(mzr_handle h);
 
 /* Forcing remap in front of basin2reach (get_basin_runoff.f90:86-98 -> process_remap.f90:32-316),
@@ -263,7 +268,7 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
    holds at once, items (blocks of reaches) dealt to them */
 int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems);
 /* KWT persistent sweep, start of its wavefronts: how many of the last launch arrived and how many of them joined (a
-   wavefront that starts more than 10 us after the first one of its launch leaves at once), and since
+   wavefront that starts more than 20 us (MZR_SWEEP_LATE_TICKS = 2000 ticks of the 100 MHz clock) after the first one of its launch leaves at once), and since
    mzr_init_state the number of wavefronts by start delay: hist32[k] counts delays below 2^k ticks of 10 ns */
 int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long long *hist32);
 /* measurement modes (bit mask, default 0):

@@ -56,7 +56,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute", "mzr_get_tracer_state", "mzr_set_tracer_state",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
-           "mzr_get_sweep_info", "mzr_run_async", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
+           "mzr_get_sweep_info", "mzr_run_async", "mzr_run_async_f32", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
            "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync", "mzr_set_history", "mzr_get_mean",
            "mzr_reset_means", "mzr_get_sweep_arrivals"]
 
@@ -101,6 +101,7 @@ def load_library():
     L.mzr_run.argtypes = [vp, ci, cd, dp]
     L.mzr_run_dev.argtypes = [vp, ci, cd, vp]
     L.mzr_run_async.argtypes = [vp, ci, cd, vp]
+    L.mzr_run_async_f32.argtypes = [vp, ci, cd, vp]
     L.mzr_comm_unique_id.argtypes = [C.c_char_p]
     L.mzr_comm_init.argtypes = [ci, ci, C.c_char_p, ci, C.POINTER(vp)]
     L.mzr_comm_send.argtypes = [vp, vp, vp, C.c_longlong, ci]
@@ -370,6 +371,10 @@ class RoutingDomain:
         """Asynchronous window on host-resident (page-locked) runoff [n_steps, nHru]: copy and routing overlap
         with the window before."""
         self._check(self.L.mzr_run_async(self.h, int(n_steps), float(t_start), C.c_void_p(int(runoff_host_ptr))))
+
+    def run_async_f32(self, n_steps, t_start, runoff_host_ptr):
+        """As run_async, forcing in single precision as the files store it (widened on the device behind the copy)."""
+        self._check(self.L.mzr_run_async_f32(self.h, int(n_steps), float(t_start), C.c_void_p(int(runoff_host_ptr))))
 
     def sync(self):
         self._check(self.L.mzr_sync(self.h))

@@ -46,6 +46,7 @@
 // Bound by HBM traffic of the particle rows: see DESIGN.md for the bytes-per-reach-step model.
 #include <float.h>
 #include <algorithm>
+#include <mutex>
 #include "mzr_device.h"
 #include "lake_device.h"
 #include "mzr_math.h"
@@ -950,11 +951,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         if (gl == 0 && (blockIdx.x & 15) == 0) { const int b = size <= 4 ? 0 : size <= 8 ? 1 : size <= 12 ? 2 : size <= 16 ? 3 : size <= 20 ? 4 : size <= 32 ? 5 : size <= 48 ? 6 : 7; atomicAdd(&d.dbgCycles[8 + b], 1ull); }
 #endif
 
-        {   // kwt_rch :163-174
-          double mn = DBL_MAX;
-          for (int k = gl; k < size; k += G) { const double q = Qw[k]; mn = q < mn ? q : mn; }
-          mn = grp_min<G>(mn);
-          if (mn < 0.0) { mzr_raise(d, 20, r, t, 12); break; }
+        {   // kwt_rch :163-174 (minval(Q) < 0: one vote of the group)
+          bool neg = false;
+          for (int k = gl; k < size; k += G) neg = neg || Qw[k] < 0.0;
+          if (grp_any<G>(neg)) { mzr_raise(d, 20, r, t, 12); break; }
         }
         TSTAMP(2);
 
@@ -1119,9 +1119,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           // 10^5 reach-steps on the benchmark forcing): without one the routed list is the list itself, every particle
           // with the exit time RLENGTH/celerity + entry time (:1363-1372, rUpdate :1409-1437), and the group machinery
           // below is skipped.
+          // (The search keeps the smallest crossing point in [0, XMX] and gives up when that is XMX itself, :1301-1322: a wave
+          // breaks iff SOME pair crosses inside [0, XMX) -- one vote of the group instead of an arg-min.)
           bool shock = false;
           if (NI > 1) {
-            double XB = DBL_MAX; int JXB = 0;
+            bool cross = false;
 #pragma unroll
             for (int sl = 0; sl < KS; ++sl) {
               const int jw = gl + sl * G;
@@ -1131,13 +1133,12 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
                   const double WDIFF = rws[sl] - Yw[jw + 1];
                   if (!(WDIFF == 0.0) && !(wci == wcj)) {
                     const double XXB = (ti - tj) / WDIFF;
-                    if (!(XXB < 0.0 || XXB > XMX) && XXB <= XB) { XB = XXB; JXB = jw; }
+                    if (!(XXB < 0.0 || XXB > XMX) && XXB < XMX) cross = true;
                   }
                 }
               }
             }
-            grp_argmin<G, true>(XB, JXB);
-            shock = !(JXB == 0 || XB == XMX);
+            shock = grp_any<G>(cross);
           }
           if (!shock) {
             bool zero = false;
@@ -1712,6 +1713,8 @@ static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exp
 // cnt: two ints of device memory (swHead + 128).  Measured once per process, device and kernel flavour.
 int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream) {
   static int cached[16][2];
+  static std::mutex mu;      // handles of several host threads share the cache; the census itself must not run twice at once either
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0, cus = 0, perCu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev >= 0 && dev < 16 && cached[dev][full]) return cached[dev][full];
@@ -1729,7 +1732,7 @@ int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream) {
   if (hipStreamSynchronize(stream) != hipSuccess) return 0;
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
-  if (dev >= 0 && dev < 16) cached[dev][full] = cap;
+  if (dev >= 0 && dev < 16 && 2 * cap >= api) cached[dev][full] = cap;      // (a census far below the occupancy query ran beside other work: measured again next time)
   return cap;
 }
 

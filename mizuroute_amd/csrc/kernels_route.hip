@@ -14,6 +14,8 @@
 // t (written one launch earlier) is final, and reaches at different depths of the network work
 // on different time steps of the window in the same launch (time-skewed level sweep).
 // These solvers are FP64 transcendental-bound (Newton iterations with pow), not HBM-bound.
+#include <algorithm>
+#include <mutex>
 #include "mzr_device.h"
 #include "lake_device.h"
 #include "mzr_math.h"
@@ -518,6 +520,27 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
   stage_reach<METHOD, false>(d, r, t);
 }
 
+// Two windows in one launch (round 4, "overlapping windows").  The skewed schedule of a window of W steps over S stages is
+// S + W - 1 launches, and the last S - 1 of them (the window drains: only stages > s - W still have steps left) are as
+// empty as the first S - 1 of the next window (it fills: only stages <= s have started).  The two touch complementary
+// stages -- launch j of window k+1 works on stages 0..j, launch W + j of window k on stages j+1..S-1 -- and step 0 of a
+// reach in window k+1 only needs the reach's own last step of window k (one launch earlier) and its upstream reaches' step
+// 0 (same window, one launch earlier).  So the host keeps the drain of a window back until the next window arrives and
+// issues both as ONE launch: blocks [0, nBlocksB) take the new window (p.b), the others the old one (p.a), each with the
+// window's own rows (discharge, lateral flow, lake forcing: double-buffered on the host side).  A window then costs W
+// launches instead of S + W - 1, every one of them over all reaches.  Same arithmetic per reach and step, same order.
+struct MzrDevPair { MzrDev a, b; };
+template <int METHOD>
+__global__ void __launch_bounds__(256) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
+  const bool old = (int)blockIdx.x >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
+  const MzrDev &d = old ? p.a : p.b;
+  const int r = old ? rBeginA + ((int)blockIdx.x - nBlocksB) * (int)blockDim.x + (int)threadIdx.x : rBeginB + (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+  if (r >= (old ? rEndA : rEndB)) return;
+  const int t = (old ? sA : sB) - d.sigma[r];
+  if (t < 0 || t >= d.W) return;
+  stage_reach<METHOD, false>(d, r, t);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Persistent sweep of an Eulerian method over a window: what one launch per stage does (k_stage), without the launches.
 // A window of W steps over S stages is S + W - 1 "launches" of the skewed schedule; with a kernel per launch every one
@@ -618,9 +641,11 @@ __global__ void k_rt_heads(MzrDev d, int sBegin) {
 }
 
 // wavefronts of a method's sweep kernel the device really holds at once (measured: see mzr_sweep_kwt_capacity);
-// d.rtHead must point at 8 * 16 + 2 ints
+// d.rtHead must point at 8 * 16 + 48 ints (eight ticket heads, census / arrival words, histogram of the start delays)
 int mzr_sweep_route_capacity(int method, const MzrDev &d, hipStream_t stream) {
   static int cached[16][6];
+  static std::mutex mu;      // handles of several host threads share the cache; the census itself must not run twice at once either
+  std::lock_guard<std::mutex> lock(mu);
   int dev = 0, cus = 0, perCu = 0;
   if (method < 0 || method > 5 || hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev >= 0 && dev < 16 && cached[dev][method]) return cached[dev][method];
@@ -651,7 +676,7 @@ int mzr_sweep_route_capacity(int method, const MzrDev &d, hipStream_t stream) {
   if (hipStreamSynchronize(stream) != hipSuccess) return 0;
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
-  if (dev >= 0 && dev < 16) cached[dev][method] = cap;
+  if (dev >= 0 && dev < 16 && 2 * cap >= api) cached[dev][method] = cap;      // (a census far below the occupancy query ran beside other work: measured again next time)
   return cap;
 }
 
@@ -723,6 +748,23 @@ void mzr_launch_tracer_stage(int method, const MzrDev &d, int s, int rBegin, int
   const int n = rEnd - rBegin;
   if (n <= 0) return;
   hipLaunchKernelGGL(k_tracer_stage, dim3((n + 255) / 256), dim3(256), 0, stream, d, method, s, rBegin, rEnd);
+}
+
+// old window `a` at launch sA over reaches [rBeginA, rEndA), new window `b` at launch sB over [rBeginB, rEndB)
+void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int rEndA, const MzrDev &b, int sB, int rBeginB, int rEndB, hipStream_t stream) {
+  const int nA = std::max(0, rEndA - rBeginA), nB = std::max(0, rEndB - rBeginB);
+  if (nA + nB <= 0) return;
+  MzrDevPair p; p.a = a; p.b = b;
+  const int nBlocksB = (nB + 255) / 256;
+  dim3 block(256), grid(nBlocksB + (nA + 255) / 256);
+  switch (method) {
+    case 0: hipLaunchKernelGGL(k_stage_pair<0>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 1: hipLaunchKernelGGL(k_stage_pair<1>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 3: hipLaunchKernelGGL(k_stage_pair<3>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 4: hipLaunchKernelGGL(k_stage_pair<4>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 5: hipLaunchKernelGGL(k_stage_pair<5>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    default: break;
+  }
 }
 
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {

@@ -34,6 +34,7 @@ void mzr_launch_sweep_route(int method, const MzrDev &d, int nWaves, int sBegin,
 void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const double *evap, const double *precip,
                              double *lakeEvap, double *lakePrecip, int nSteps, hipStream_t stream);
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream);
+void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int rEndA, const MzrDev &b, int sB, int rBeginB, int rEndB, hipStream_t stream);
 int mzr_remap_ld(int nSteps);
 void mzr_launch_remap(int H, int nSteps, int nSrc, const int *rowStart, const int *rowCnt, const int *srcIdx,
                       const double *weight, const double *src, double *srcT, double *dst, hipStream_t stream);
@@ -59,12 +60,14 @@ template <typename T> struct DBuf {
   void zero(hipStream_t s = 0) { if (p) (void)hipMemsetAsync(p, 0, n * sizeof(T), s); }
   void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); }
   void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void swap(DBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
   ~DBuf() { free(); }
 };
 
 struct RouteBufs {
   int method = -1;
   DBuf<double> Q;                                   // [maxWindow][N]
+  DBuf<double> Qalt;                                // the rows of the window before, while its last launches are kept back (overlapping windows)
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
   DBuf<double> hInflow, hEle, hFlood;               // [N] history sums beyond discharge (mzr_set_history)
   DBuf<double> mol;                                 // [nMol][N]
@@ -90,6 +93,13 @@ __global__ void k_scatter_rows(const double *src, double *dst, const int *ext2in
   if (e < N && t < rows) dst[(size_t)t * N + ext2int[e]] = src[(size_t)t * N + e];
 }
 
+// (overlapping windows: the window before keeps its rows, the new one has its own)
+__global__ void k_carry_qlat2(double *dst, const double *src, int lastW, int N, const int *haloSlot) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  if (haloSlot && haloSlot[r] >= 0) return;
+  dst[r] = src[(size_t)lastW * N + r];
+}
 __global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
@@ -200,15 +210,26 @@ struct mzr_domain {
   std::vector<int> uhOff;
   // window buffers
   DBuf<double> runoffW, runoffW2, qi, qlat, qr0Last, basS[2], scratchOut, wm;
+  DBuf<float> runoffF[2];                        // single-precision forcing windows of mzr_run_async_f32 as they arrive, widened into runoffW / runoffW2
   hipStream_t copyStream = nullptr;             // host -> device forcing windows of mzr_run_async, behind the sweep of the window before
   hipEvent_t rwCopied[2] = {nullptr, nullptr}, rwRead[2] = {nullptr, nullptr};
   hipEvent_t exportDone = nullptr;              // recorded behind the last mzr_export_boundary_dev: what mzr_comm_send waits for
   bool rwUsed[2] = {false, false};
   int rwCur = 0;
+  hipEvent_t rwOther = nullptr; bool rwOtherSet = false;   // a window queued by another entry point (mzr_run_src_dev) still reads runoffW
+
   int wmSteps = 0;
   int basCur = 0;
   int lastW = 0;
   bool havePrevQlat = false;
+  // Overlapping windows of the Eulerian methods (kernels_route.hip, k_stage_pair): the launches in which a window drains
+  // (s >= W) are kept back and issued together with the first launches of the next window, or on their own as soon as
+  // anybody asks for a result (flushTail: every entry point but the run calls).  The window kept back owns its rows
+  // (qlat / qi / Q / lake forcing: the *Alt buffers, swapped in and out); tail.d[ix] are the device views it was launched with.
+  struct { bool pending = false; int W = 0; MzrDev d[6]; } tail;
+  DBuf<double> qiAlt, qlatAlt, lakeEvapAlt, lakePrecipAlt; DBuf<int> calMonthAlt, calDayAlt, calDoyAlt;
+  bool lakeNextInAlt = false;                    // mzr_set_lake_forcing wrote the NEXT window's lake forcing into the *Alt buffers
+  long long pairLaunches = 0, tailFlushes = 0;
   // kwt
   DBuf<int> kwN, obN, kwtLight;
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
@@ -534,7 +555,7 @@ int checkDeviceError(mzr_handle h) {
 // margin below it -- other kernels of the window (hillslope chunks, history sums) come and go beside the sweep, and a
 // sweep with workgroups left waiting for a slot can stall -- times the handle's share of the device.
 int sweepGrid(mzr_handle h, int held) {
-  if (held < 1) return 8;
+  if (held < 1) return 0;      // the capacity could not be measured: the caller decides (the Eulerian methods then keep one launch per stage)
   const double share = (h->cfg.sweepShare > 0.0 && h->cfg.sweepShare <= 1.0) ? h->cfg.sweepShare : 1.0;
   const int g = (int)((held - std::max(64, held / 50)) * share);
   return std::max(8, g & ~7);
@@ -545,6 +566,11 @@ void kwt_build_sweep(mzr_handle h) {
   if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }      // eight ticket heads (one cache line each), census and arrival counters, histogram of the start delays
   int cap = 0;
   { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream)); }
+  if (cap < 1) {      // census failed: a conservative grid (four wavefronts per CU always fit) and a word about it
+    int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+    cap = std::max(8, cus * 4);
+    fprintf(stderr, "mzr: the wavefront capacity of the KWT sweep could not be measured on device %d; sweeping with %d wavefronts\n", h->cfg.device, cap);
+  }
   if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = v; }      // experiments only: any grid, also one the device does not hold
   h->swCap = cap;
   struct It { int code, lo, hi; };
@@ -657,8 +683,12 @@ void kwt_sweep_tables(mzr_handle h, int W) {
 }  // namespace
 
 static int flushSteps(mzr_handle h);
-// steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first
-#define MZR_FLUSH(h) do { if ((h) && (h)->stepN > 0) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
+static void flushTail(mzr_handle h);
+// steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first ...
+#define MZR_FLUSH_STEPS(h) do { if ((h) && (h)->stepN > 0) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
+// ... and so do the launches of the last window that were kept back for the next one (overlapping windows): every entry point
+// that reads or changes anything a window touches takes this one; the run calls themselves take MZR_FLUSH_STEPS
+#define MZR_FLUSH(h) do { MZR_FLUSH_STEPS(h); if ((h) && (h)->tail.pending) flushTail(h); } while (0)
 
 extern "C" {
 
@@ -699,11 +729,21 @@ int mzr_create(const mzr_config *cfg, mzr_handle *out) {
 int mzr_destroy(mzr_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->cfg.device);
+  // Steps put aside by mzr_step (stepBatch > 1) that nobody asked the result of are NOT routed here -- there is nobody left
+  // to read them -- but it is said; launches kept back for a next window are dropped likewise.  Everything queued has to
+  // finish before the buffers it reads (page-locked step rows, forcing windows) are freed.
+  if (h->stepN > 0) fprintf(stderr, "mzr_destroy: %d step(s) handed over with mzr_step (stepBatch %d) were never routed: no result was asked for after them\n", h->stepN, h->cfg.stepBatch);
+  h->tail.pending = false;
+  if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+  for (int ix = 0; ix < 6; ++ix) if (h->routeStream[ix]) (void)hipStreamSynchronize(h->routeStream[ix]);
+  if (h->basinStream) (void)hipStreamSynchronize(h->basinStream);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto &rb : h->route) for (auto &e : rb.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   if (h->exportDone) (void)hipEventDestroy(h->exportDone);
+  if (h->rwOther) (void)hipEventDestroy(h->rwOther);
   for (int i = 0; i < 2; ++i) { if (h->stepHost[i]) (void)hipHostFree(h->stepHost[i]); if (h->stepCopied[i]) (void)hipEventDestroy(h->stepCopied[i]); }
   for (int i = 0; i < 2; ++i) { if (h->rwCopied[i]) (void)hipEventDestroy(h->rwCopied[i]); if (h->rwRead[i]) (void)hipEventDestroy(h->rwRead[i]); }
   for (int ix = 0; ix < 6; ++ix) { if (h->routeStream[ix]) (void)hipStreamDestroy(h->routeStream[ix]); if (h->routeEvent[ix]) (void)hipEventDestroy(h->routeEvent[ix]); }
@@ -922,23 +962,33 @@ static int set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const 
     (void)hipMemcpyAsync(h->lakeFP.p, precip, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, st);
     fe = h->lakeFE.p; fp = h->lakeFP.p;
   }
-  (void)hipMemcpyAsync(h->calMonth.p, month, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(h->calDay.p, day, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
-  (void)hipMemcpyAsync(h->calDoy.p, dayofyear, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
+  // the last window's final launches may still be kept back (overlapping windows) and read ITS forcing: the next window's
+  // goes into the second set of buffers, which run_window swaps in
+  const bool beside = h->tail.pending;
+  if (beside && !h->calMonthAlt.p) {
+    try {
+      h->lakeEvapAlt.alloc(h->lakeEvap.n); h->lakePrecipAlt.alloc(h->lakePrecip.n); h->lakeEvapAlt.zero(st); h->lakePrecipAlt.zero(st);
+      h->calMonthAlt.alloc(h->calMonth.n); h->calDayAlt.alloc(h->calDay.n); h->calDoyAlt.alloc(h->calDoy.n);
+    } catch (const std::string &e) { return fail(h, 91, "mzr_set_lake_forcing/" + e); }
+  }
+  (void)hipMemcpyAsync(beside ? h->calMonthAlt.p : h->calMonth.p, month, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(beside ? h->calDayAlt.p : h->calDay.p, day, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
+  (void)hipMemcpyAsync(beside ? h->calDoyAlt.p : h->calDoy.p, dayofyear, nSteps * sizeof(int), hipMemcpyHostToDevice, st);
   if (fluxes) {
     MzrDev d; fillDev(h, d);
-    mzr_launch_lake_forcing(d, h->lakeReachInt.p, fe, fp, h->lakeEvap.p, h->lakePrecip.p, nSteps, st);
+    mzr_launch_lake_forcing(d, h->lakeReachInt.p, fe, fp, beside ? h->lakeEvapAlt.p : h->lakeEvap.p, beside ? h->lakePrecipAlt.p : h->lakePrecip.p, nSteps, st);
   }
+  h->lakeNextInAlt = beside;
   if (hipStreamSynchronize(st) != hipSuccess) return fail(h, 92, "mzr_set_lake_forcing/device error");
   h->lakeSteps = nSteps;
   return checkDeviceError(h);
 }
 int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, const int *month, const int *day, const int *dayofyear) {
-  MZR_FLUSH(h);
+  MZR_FLUSH_STEPS(h);      // (a window kept back keeps its own lake forcing: set_lake_forcing writes beside it)
   return set_lake_forcing(h, nSteps, evap, precip, false, month, day, dayofyear);
 }
 int mzr_set_lake_forcing_dev(mzr_handle h, int nSteps, const double *evap_dev, const double *precip_dev, const int *month, const int *day, const int *dayofyear) {
-  MZR_FLUSH(h);
+  MZR_FLUSH_STEPS(h);      // (a window kept back keeps its own lake forcing: set_lake_forcing writes beside it)
   return set_lake_forcing(h, nSteps, evap_dev, precip_dev, true, month, day, dayofyear);
 }
 
@@ -1250,7 +1300,8 @@ int mzr_init_state(mzr_handle h) {
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
       if (m != MZR_KWT) {      // persistent sweep of an Eulerian method
         rb.rtDone.alloc(N); rb.rtDone.zero(); rb.rtHead.alloc(8 * 16 + 16 + 32); rb.rtHead.zero();
-        { MzrDev dc; memset(&dc, 0, sizeof dc); dc.rtHead = rb.rtHead.p; dc.err = h->err.p; rb.rtCap = sweepGrid(h, mzr_sweep_route_capacity(m, dc, h->stream)); }
+        { MzrDev dc; memset(&dc, 0, sizeof dc); dc.rtHead = rb.rtHead.p; dc.err = h->err.p; rb.rtCap = sweepGrid(h, mzr_sweep_route_capacity(m, dc, h->stream));
+          if (rb.rtCap < 1) fprintf(stderr, "mzr: the wavefront capacity of the sweep of method %d could not be measured on device %d; one launch per stage instead\n", m, h->cfg.device); }
         if (h->rtTablesW != -2) { rt_build_items(h); h->rtTablesW = -2; }      // once per mzr_init_state (-2: built, tables not yet)
       }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
@@ -1372,6 +1423,12 @@ static void kwt_regroup(mzr_handle h) {
   // (16 lanes): the others.  MZR_KWT_CLASSB_MAX / MZR_KWT_CLASSC_MAX override the
   // thresholds (tests: 0 = nobody, 64 = everybody, through the fall-back).
   int classBMax = 20, classCMax = 9;
+  // Round 4: the cut between B and A depends on what bounds the sweep.  With many more items per launch than wavefronts
+  // (the 375 k-reach shards: 25 k items for 4 000 wavefronts) the sweep is bound by VALU issue, and 8 reaches per pass
+  // cost fewer instructions per reach than 4: class B up to 28 entries (its capacity is 30) measured +13 % there.  With
+  // about as many items as wavefronts (100 k reaches: 6.7 k) the window is bound by its longest chain of passes, which
+  // runs through the reaches that thin every step, and those are faster in 16-lane groups: 28 there measured -8 %.
+  if (h->swCap > 0 && (double)h->h_kwtRouted.size() / 7.0 > 3.0 * h->swCap) classBMax = 28;
   if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
   if (const char *e = getenv("MZR_KWT_CLASSC_MAX")) classCMax = atoi(e);
   const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
@@ -1419,12 +1476,41 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   }
   const int N = h->N;
   hipStream_t st = h->stream;
+  if (h->lakeNextInAlt) {      // this window's lake forcing was written beside the forcing of a window kept back
+    h->lakeEvap.swap(h->lakeEvapAlt); h->lakePrecip.swap(h->lakePrecipAlt);
+    h->calMonth.swap(h->calMonthAlt); h->calDay.swap(h->calDayAlt); h->calDoy.swap(h->calDoyAlt);
+    h->lakeNextInAlt = false;
+  }
+  // Overlapping windows (kernels_route.hip, k_stage_pair): the launches s >= W of this window are kept back and go out with the
+  // first launches of the next one.  Only where a window is nothing but stage launches of the Eulerian methods over rows
+  // of its own: no KWT, constituent, gauge observations, water-management fluxes or imported halo rows, and at least as many
+  // steps as the network has stages (so that never more than two windows are in flight).
+  const int nSt = h->nStages;
+  bool pipe = W >= nSt && nSt >= 2 && idxOf(h, MZR_KWT) < 0 && !h->tracer && !h->qmod && !h->cfg.is_flux_wm && h->nHalo == 0 &&
+              !h->anyLakeTarget && !(W <= 8 && h->rtItems > 0);
+  if (const char *e = getenv("MZR_OVERLAP_WINDOWS")) pipe = pipe && atoi(e) != 0;
+  if (const char *e = getenv("MZR_ROUTE_SWEEP")) pipe = pipe && atoi(e) == 0;      // (a forced persistent sweep routes whole windows)
+  if (h->tail.pending && !pipe) flushTail(h);
+  const double *prevQlat = h->qlat.p;      // rows of the window before (row lastW = its last BASIN_QR(1))
+  if (pipe) {
+    try {
+      if (!h->qlatAlt.p) { h->qlatAlt.alloc(h->qlat.n); h->qlatAlt.zero(st); }
+      if (h->qi.p && !h->qiAlt.p) { h->qiAlt.alloc(h->qi.n); h->qiAlt.zero(st); }
+      for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (!h->route[ix].Qalt.p) { h->route[ix].Qalt.alloc(h->route[ix].Q.n); h->route[ix].Qalt.zero(st); }
+    } catch (const std::string &e) { pipe = false; if (h->tail.pending) flushTail(h); }
+  }
+  if (pipe) {      // this window's rows: the second set (the set of the window before stays as it is until its last launches are out)
+    h->qlat.swap(h->qlatAlt); if (h->qi.p) h->qi.swap(h->qiAlt);
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].Q.swap(h->route[ix].Qalt);
+  }
   MzrDev d; fillDev(h, d);
   d.W = W; d.t_start = t_start; d.T1_single = T1_single; d.runoff = runoff_dev;
   // carry BASIN_QR(1) of the last step of the previous window into row 0 (halo columns already
   // hold the imported row 0 of this window)
-  if (h->lastW > 0)
-    hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot);
+  if (h->lastW > 0) {
+    if (prevQlat != h->qlat.p) hipLaunchKernelGGL(k_carry_qlat2, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, prevQlat, h->lastW, N, d.haloSlot);
+    else hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot);
+  }
   // Which methods go through a persistent sweep (decided here because it decides their stream).  KWT: always (one launch
   // per chunk of the skewed schedule, progress words instead of kernel boundaries; single steps too: 842 dependent stages
   // cost 15 ms per step as hand-offs, 18 ms as launches); MZR_KWT_SWEEP=0 keeps one launch per stage (k_stage_kwt), the
@@ -1532,7 +1618,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
     ++rb.nLaunches;
   }
-  for (int s = 0; s < nS + W - 1; ++s) {
+  const bool withTail = pipe && h->tail.pending;      // the window before drains in this window's first nS - 1 launches
+  for (int s = 0; s < (pipe ? W : nS + W - 1); ++s) {
     if (!anyStage) break;
     if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
     const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
@@ -1543,6 +1630,16 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       hipStream_t sx = rst[ix];
       if (sweep && ix == kwtIx) continue;
       if (rb.method != MZR_KWT && rtSweep && rb.rtCap >= 1) continue;
+      if (withTail && s < nS - 1) {      // launch W' + s of the window before (stages s+1 .. nS-1) and launch s of this one (stages 0 .. s) as one
+        if (prof) {
+          if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+          (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
+        }
+        mzr_launch_stage_pair(rb.method, h->tail.d[ix], h->tail.W + s, h->stageStart[s + 1], N, dr[ix], s, rB, rE, sx);
+        if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+        ++rb.nLaunches; ++h->pairLaunches;
+        continue;
+      }
       if (prof) {
         if (rb.evUsed == rb.events.size()) {
           hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b);
@@ -1563,6 +1660,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       ++rb.nLaunches;
     }
   }
+  if (pipe && anyStage) { h->tail.pending = true; h->tail.W = W; for (int ix = 0; ix < nR; ++ix) h->tail.d[ix] = dr[ix]; }
+  else h->tail.pending = false;
   if (h->tracer) {
     // constituent: lateral mass flux and its hillslope delay for the whole window (after the water's), then, behind every
     // method's routing, the constituent pass over the same skewed schedule
@@ -1636,7 +1735,7 @@ int mzr_sync(mzr_handle h) {
 }
 
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev) {
-  MZR_FLUSH(h);
+  MZR_FLUSH_STEPS(h);
   if (!h) return 1;
   return run_window(h, nSteps, t_start, t_start + h->cfg.dt, runoff_dev);
 }
@@ -1656,7 +1755,11 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
 // The stand-alone driver's loop (standalone/route_runoff.f90:80-108) reads forcing and routes, step after step;
 // here a whole window of forcing is handed over in host memory and the call returns at once: the copy runs on its
 // own stream into one of two device buffers while the window before is still being routed.
-static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_single, const double *runoff, hipEvent_t copied) {
+__global__ void __launch_bounds__(256) k_widen_f32(const float *src, double *dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
+}
+
+static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_single, const double *runoff, hipEvent_t copied, const float *runoff32 = nullptr) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
@@ -1670,6 +1773,14 @@ static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_si
   const int k = h->rwCur;
   double *buf = k == 0 ? h->runoffW.p : h->runoffW2.p;
   if (h->rwUsed[k]) (void)hipStreamWaitEvent(h->copyStream, h->rwRead[k], 0);     // the window that last read this buffer
+  if (k == 0 && h->rwOtherSet) { (void)hipStreamWaitEvent(h->copyStream, h->rwOther, 0); h->rwOtherSet = false; }   // ... also one queued by mzr_run_src_dev
+  if (runoff32) {      // single-precision forcing: half the bytes across PCIe, widened behind the copy on the copy's stream
+    const size_t n = (size_t)nSteps * h->H;
+    try { if (h->runoffF[k].n < (size_t)h->cfg.maxWindow * h->H) h->runoffF[k].alloc((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &e) { return fail(h, 91, "mzr_run_async_f32/" + e); }
+    if (hipMemcpyAsync(h->runoffF[k].p, runoff32, n * sizeof(float), hipMemcpyHostToDevice, h->copyStream) != hipSuccess)
+      return fail(h, 92, "mzr_run_async_f32/hipMemcpyAsync failed");
+    hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, h->copyStream, h->runoffF[k].p, buf, n);
+  } else
   if (hipMemcpyAsync(buf, runoff, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, h->copyStream) != hipSuccess)
     return fail(h, 92, "mzr_run_async/hipMemcpyAsync failed");
   (void)hipEventRecord(h->rwCopied[k], h->copyStream);
@@ -1683,9 +1794,16 @@ static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_si
 }
 
 int mzr_run_async(mzr_handle h, int nSteps, double t_start, const double *runoff) {
-  MZR_FLUSH(h);
+  MZR_FLUSH_STEPS(h);
   if (!h) return 1;
   return run_async_impl(h, nSteps, t_start, t_start + h->cfg.dt, runoff, nullptr);
+}
+
+int mzr_run_async_f32(mzr_handle h, int nSteps, double t_start, const float *runoff) {
+  MZR_FLUSH_STEPS(h);
+  if (!h) return 1;
+  if (!runoff) return fail(h, 20, "mzr_run_async_f32/runoff is null");
+  return run_async_impl(h, nSteps, t_start, t_start + h->cfg.dt, nullptr, nullptr, runoff);
 }
 
 int mzr_set_remap(mzr_handle h, int kind, int nMap, const int *hru_ix, const int *num_qhru, int nOverlap, const int *qhru_ix,
@@ -1773,7 +1891,13 @@ int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   const int rc = mzr_remap_runoff_dev(h, nSteps, src_dev, h->runoffW.p);
   if (rc) return rc;
-  return run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
+  const int rc2 = run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
+  if (rc2) return rc2;
+  // the window is queued, not finished: a later mzr_run_async copies into runoffW on its own stream and has to wait for it
+  if (!h->rwOther) (void)hipEventCreateWithFlags(&h->rwOther, hipEventDisableTiming);
+  (void)hipEventRecord(h->rwOther, h->stream);
+  h->rwOtherSet = true;
+  return 0;
 }
 
 // One time step == one main_route call.  stepBatch = 1 (default): routed and synchronised at once, errors come back with
@@ -1823,6 +1947,35 @@ int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
 }
 
 }  // extern "C"
+
+// The launches s = W .. W + nS - 2 of the last window, kept back for the next one (overlapping windows), on their own: somebody
+// wants a result, or the next window cannot take them along.  Same streams as the window's other launches; the handle's
+// stream then waits for the others, as it does at the end of every window.
+static void flushTail(mzr_handle h) {
+  if (!h->tail.pending) return;
+  h->tail.pending = false;
+  ++h->tailFlushes;
+  (void)hipSetDevice(h->cfg.device);
+  const int nS = h->nStages, N = h->N, nR = h->cfg.nRoutes, W = h->tail.W;
+  const bool prof = h->profiling;
+  for (int j = 0; j < nS - 1; ++j) {
+    const int rB = h->stageStart[j + 1];
+    if (rB >= N) break;
+    for (int ix = 0; ix < nR; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      hipStream_t sx = (nR > 1 && ix > 0 && h->routeStream[ix]) ? h->routeStream[ix] : h->stream;
+      if (prof) {
+        if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
+      }
+      mzr_launch_stage(rb.method, h->tail.d[ix], W + j, rB, N, sx);
+      if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+      ++rb.nLaunches;
+    }
+  }
+  for (int ix = 1; ix < nR; ++ix)
+    if (h->routeStream[ix]) { (void)hipEventRecord(h->routeEvent[ix], h->routeStream[ix]); (void)hipStreamWaitEvent(h->stream, h->routeEvent[ix], 0); }
+}
 
 static int flushSteps(mzr_handle h) {
   const int n = h->stepN;

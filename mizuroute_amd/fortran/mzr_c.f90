@@ -43,7 +43,7 @@ MODULE mzr_c
             mzr_export_boundary_dev, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
-            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, &
+            mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, mzr_run_async_f32, &
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
             mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs, &
             mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute, mzr_get_tracer_state, mzr_set_tracer_state, &
@@ -320,6 +320,14 @@ MODULE mzr_c
       integer(c_int), value :: nSteps
       real(c_double), value :: t_start
       real(c_double), intent(in) :: runoff(*)
+    end function
+    ! the same with the forcing as the files store it (real(sp), what get_nc widens into real(dp): read_runoff.f90:264-306)
+    integer(c_int) function mzr_run_async_f32(h, nSteps, t_start, runoff) bind(C, name='mzr_run_async_f32')
+      import :: c_ptr, c_int, c_double, c_float
+      type(c_ptr), value :: h
+      integer(c_int), value :: nSteps
+      real(c_double), value :: t_start
+      real(c_float), intent(in) :: runoff(*)
     end function
     ! boundary-record transport between partitions (RCCL point-to-point inside the library; replaces the gather / scatter
     ! of mpi_route, mpi_process.f90:1245-1329): id from rank 0 to every rank with the host's MPI_Bcast, then mzr_comm_init

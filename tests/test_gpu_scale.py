@@ -217,3 +217,99 @@ def test_full_size_network_partitioned_equals_whole(config, hip_lib):
         nw = res["nw_part"]
         assert nw.min() >= 1 and nw.max() <= 20
         assert nw[g].mean() > nw.mean()          # long particle lists sit on the main stems
+
+
+@pytest.mark.parametrize("cfg", ["irf_mc", "dw_lakes", "kw_sum"])
+def test_overlapping_windows_equal_windows_one_after_the_other(cfg, hip_lib, monkeypatch):
+    """Overlapping windows of the Eulerian methods (kernels_route.hip k_stage_pair; mc_route.f90:46-416, irf_route.f90:40-264,
+    dfw_route.f90:49-370 stay what they are): the launches in which window k drains are issued together with the launches in
+    which window k+1 fills.  Windows queued back to back -- of different lengths, with a getter in between (which makes the
+    library issue the kept-back launches on their own) and a window shorter than the network is deep (which cannot take
+    them along) -- must leave the same bits as MZR_OVERLAP_WINDOWS=0: discharge, volumes, solver state, interval means,
+    lake state included."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    lakes = None
+    if cfg == "dw_lakes":
+        net = m.make_network(30_000, seed=31, floodplain=True)
+        methods = [m.DW]
+    else:
+        net = m.make_network(30_000, seed=32)
+        methods = [m.IRF, m.MC] if cfg == "irf_mc" else [m.KW, m.SUM]
+    frac, off, v = _uh(net)
+    cuts = [700, 640, 512, 3, 600, 700]
+    total = sum(cuts)
+    if cfg == "dw_lakes":
+        lakes = make_lakes(net, total, DT, seed=9, frac=0.01, input_option=1)
+    ro = bench.device_runoff(torch, net.H, total, 0, 7, dev)
+    torch.cuda.synchronize()
+
+    def route(overlap):
+        monkeypatch.setenv("MZR_OVERLAP_WINDOWS", "1" if overlap else "0")
+        dom = m.RoutingDomain(net, DT, methods, frac_future=frac, uh_offset=off, uh=v, max_window=max(cuts), lakes=lakes)
+        assert dom.schedule()[0] <= 512, dom.schedule()
+        t = 0
+        mid = None
+        for k, w in enumerate(cuts):
+            if lakes is not None:
+                dom.set_lake_forcing(t, w)
+            dom.run_device(w, t * DT, ro[t:t + w].data_ptr())
+            t += w
+            if k == 1:
+                mid = dom.flux(methods[0], m.api.F_Q).copy()      # a getter between two queued windows
+        dom.sync()
+        out = {"mid": mid}
+        for mm in methods:
+            out[("Q", mm)] = dom.flux(mm, m.api.F_Q)
+            out[("mean", mm)] = dom.mean_q(mm)
+            if mm != m.SUM:
+                out[("vol", mm)] = dom.flux(mm, m.api.F_VOL1)
+                out[("wb", mm)] = dom.flux(mm, m.api.F_WB)
+        if m.IRF in methods:
+            out["irf"] = dom.irf_state()
+        for mm in methods:
+            if mm in (m.MC, m.DW, m.KW):
+                out[("mol", mm)] = dom.mol_state(mm)
+        out["qr1"] = dom.flux(methods[0], m.api.F_BASIN_QR1)
+        dom.close()
+        return out
+
+    a, b = route(True), route(False)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.isfinite(a[("Q", methods[0])]).all()
+
+
+def test_host_forcing_windows_f64_and_f32_equal_resident_forcing(hip_lib):
+    """mzr_run_async (the loop of standalone/route_runoff.f90:80-108 with the read hidden) and mzr_run_async_f32 (forcing as the
+    files store it, single precision, widened on the device as get_nc widens it into real(dp), read_runoff.f90:264-306): windows
+    handed over in page-locked host memory, queued without a synchronisation in between, against the same windows resident on
+    the device -- same bits (the forcing here is exactly representable in single precision, as a float file variable is)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    net = m.make_network(20_000, seed=41)
+    frac, off, v = _uh(net)
+    W, K = 96, 5
+    ro32 = (torch.rand((K * W, net.H), dtype=torch.float32) * 2e-7).pin_memory()
+    ro64 = ro32.to(torch.float64).pin_memory()
+    rod = ro64.to(dev)
+    torch.cuda.synchronize()
+    res = []
+    for mode in ("dev", "f64", "f32"):
+        dom = m.RoutingDomain(net, DT, [m.KWT, m.IRF], frac_future=frac, uh_offset=off, uh=v, max_window=W)
+        for k in range(K):
+            if mode == "dev":
+                dom.run_device(W, k * W * DT, rod[k * W:(k + 1) * W].data_ptr())
+            elif mode == "f64":
+                dom.run_async(W, k * W * DT, ro64[k * W:(k + 1) * W].data_ptr())
+            else:
+                dom.run_async_f32(W, k * W * DT, ro32[k * W:(k + 1) * W].data_ptr())
+        dom.sync()
+        res.append((dom.flux(m.KWT, m.api.F_Q), dom.flux(m.IRF, m.api.F_Q), dom.mean_q(m.KWT), dom.kwt_state()[0]))
+        dom.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a, b)
+    assert np.isfinite(res[0][0]).all() and res[0][0].max() > 0
