@@ -116,6 +116,69 @@ def cpu_baseline(net, frac, runoff, spinup_steps=240, sample_steps=240, methods=
                       f"timed after 24 (lists not yet at steady state: an upper bound for one core)"}
 
 
+def cpu_by_threads(net, frac, runoff, methods=(2,), uh=None, lakes=None, counts=(1, 16, 64, 128), spin=48, smp=48):
+    """the OpenMP form of the reference (one process, its stream-order branches dealt to threads) at several thread counts:
+    why cpu_baseline quotes 16"""
+    from oracle import refrun
+    if not refrun.available():
+        return None
+    cores = os.cpu_count() or 1
+    uh_off, uhv = uh if uh is not None else (np.arange(net.N + 1, dtype=np.int32), np.ones(net.N))
+    sched = refrun.streamorder_schedule(net)
+    out = {}
+    for nt in counts:
+        if nt > cores:
+            continue
+        sp, sm = (12, 12) if nt == 1 else (spin, smp)
+        kw = dict(uh=(frac, uh_off, uhv), dump_every=0)
+        if lakes is not None:
+            kw["lakes"] = dict(lakes, evap=lakes["evap"][:sp + sm], precip=lakes["precip"][:sp + sm], ymd=lakes["ymd"][:sp + sm])
+        try:
+            r = refrun.run_case(net, runoff[:sp + sm], DT, list(methods), nthreads=nt, schedule=sched if nt > 1 else None, time_from=sp, **kw)
+            out[str(nt)] = None if r["ierr"] else r["reach_steps_per_s"]
+        except Exception as e:
+            out[str(nt)] = f"failed: {e}"
+    out["sample"] = f"{smp} steps timed after {spin} (1 thread: 12 after 12), same network and forcing"
+    return out
+
+
+def cpu_mpi_like(domains, frac, runoff_of, methods, uh_of=None, lakes_of=None, threads=1, spin=48, smp=48):
+    """The reference's MPI form (mpi_process.f90:1088-1342) as far as it can run here: every tributary domain of the
+    reference's own decomposition in a PROCESS of its own, all at once (that is what its ranks do between two exchanges), each
+    with `threads` OpenMP threads; the mainstem domain (rank 0's extra, serial after the exchange in the reference) is left out,
+    which flatters the CPU.  value = reach-steps of all processes / the slowest process's timed seconds."""
+    from oracle import refrun
+    from concurrent.futures import ThreadPoolExecutor
+    if not refrun.available():
+        return None
+    doms = [d for d in domains if d.n_real > 0]
+
+    def one(dm):
+        net = dm.net
+        uh_off, uhv = uh_of(dm) if uh_of is not None else (np.arange(net.N + 1, dtype=np.int32), np.ones(net.N))
+        kw = dict(uh=(frac, uh_off, uhv), dump_every=0)
+        lk = lakes_of(dm) if lakes_of is not None else None
+        if lk is not None:
+            kw["lakes"] = lk
+        sched = refrun.streamorder_schedule(net) if threads > 1 else None
+        r = refrun.run_case(net, runoff_of(dm), DT, list(methods), nthreads=threads, schedule=sched, time_from=spin, **kw)
+        if r["ierr"]:
+            raise RuntimeError(f"reference harness ierr {r['ierr']}")
+        rs = float(net.N) * smp * len(methods)
+        return rs, rs / r["reach_steps_per_s"]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=len(doms)) as ex:
+        res = list(ex.map(one, doms))
+    wall = time.perf_counter() - t0
+    total = sum(a for a, _ in res)
+    slowest = max(b for _, b in res)
+    return {"value": total / slowest, "unit": "reaches*timesteps/s", "processes": len(doms), "threads_per_process": threads,
+            "cores": len(doms) * threads, "kind": "reference", "timed_s_slowest_process": slowest, "wall_s_with_case_io": wall,
+            "sample": f"{len(doms)} tributary domains of the reference's decomposition, one ref_route process each, side by side, {smp} steps timed after {spin}; "
+                      "mainstem domain and the per-step gather / scatter of mpi_route left out"}
+
+
 FULL = {"c3": 3_000_000, "c4": 5_000_000, "c5": 3_000_000}      # reaches of the 8-GPU configurations (BASELINE.json configs[2..4])
 
 
@@ -279,7 +342,7 @@ class Loopback:
             share = main_sweep_share(ms, methods, m)
             d_t = m.RoutingDomain(sp.net, DT, methods, frac_future=self.frac, max_window=W, device=0, sweep_share=1.0 - share, export_reaches=sp.export_local,
                                   lakes=lk_t, **self.uh_of(sp))
-            d_m = m.RoutingDomain(ms.net, DT, methods, frac_future=self.frac, max_window=W, device=0, sweep_share=share, halo_reaches=ms.halo_local,
+            d_m = m.RoutingDomain(ms.net, DT, methods, frac_future=self.frac, max_window=W, device=0, sweep_share=share, sweep_priority=1, halo_reaches=ms.halo_local,
                                   halo_good=ms.halo_good, lakes=lk_m, **self.uh_of(ms))
             ro_t = [self.forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
             ro_m = [self.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
@@ -370,6 +433,28 @@ class Loopback:
             cpu = cpu_baseline(net, self.frac, ro_cpu, n_spin, n_smp, methods, (self.uh_off, self.uhv) if self.need_uh else None, lk, one_thread=False)
             cpu["sample"] = (f"the FULL {net.N}-reach network, route_opt {self.cfg['methods']}, {n_smp} steps timed after {n_spin}, "
                              f"{cpu['cores']} OpenMP threads over the reference's stream-order branches; unmodified reference solvers, flang -O2")
+            # the MPI shape: the eight tributary domains as eight processes side by side (threads so that the host's cores are used)
+            try:
+                from mizuroute_amd.partition import lakes_for_domain
+                thr = max(1, min(16, (os.cpu_count() or 8) // 8))
+
+                def lk_of(dm):
+                    if self.lakes is None:
+                        return None
+                    l2 = lakes_for_domain(self.lakes, dm, net.N)
+                    if l2 is None:
+                        return None
+                    n_ = n_spin + n_smp
+                    return dict(l2, evap=np.zeros((n_, max(1, dm.hru_global.size))), precip=np.zeros((n_, max(1, dm.hru_global.size))), ymd=self.lakes["ymd"][:n_])
+
+                def uh_pair(dm):
+                    u = self.uh_of(dm)
+                    return (u["uh_offset"], u["uh"]) if u else (np.arange(dm.net.N + 1, dtype=np.int32), np.ones(dm.net.N))
+
+                cpu["mpi_like"] = cpu_mpi_like(self.P.trib, self.frac, lambda dm: ro_cpu[:, dm.hru_global], methods,
+                                               uh_of=uh_pair, lakes_of=lk_of if self.lakes is not None else None, threads=thr, spin=n_spin, smp=n_smp)
+            except Exception as e:
+                cpu["mpi_like"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
         except Exception as e:
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
         return cpu
@@ -377,8 +462,11 @@ class Loopback:
 
 def main_sweep_share(ms, methods, m):
     """share of the device's wavefront slots the mainstem domain's persistent sweep gets beside the tributary sweep of the same
-    rank: sized by need -- a few wavefronts per reach of its widest stage -- not a fixed fifth of the device"""
-    return 0.2
+    rank.  The mainstem is a hundredth of the rank's work but one long chain of dependent passes (its stages + W levels): it needs
+    about as many wavefronts as it has items per level (every reach is active in every level of the skewed schedule, ~7 reaches
+    per item) and, above all, its passes must not queue behind the tributary's on the SIMDs (sweep_priority = 1)."""
+    from mizuroute_amd.partition import MAIN_SWEEP_SHARE
+    return MAIN_SWEEP_SHARE
 
 
 def loopback_bench(args, torch, m, uhmod):
@@ -811,6 +899,15 @@ def main():
             n_spin = 240 if args.config == "c2" else 48                                     # the shards are 4-6 x larger: a bounded sample
             ro_cpu = device_runoff(torch, net.H, 2 * n_spin, 0, 7, dev).cpu().numpy()      # the first steps of the GPU leg's forcing
             cpu = cpu_baseline(net, frac, ro_cpu, n_spin, n_spin, methods, None if kwt_run else (uh_off, uhv), lakes)
+            if cpu is not None and args.config == "c2":
+                cpu["by_threads"] = cpu_by_threads(net, frac, ro_cpu, methods, None if kwt_run else (uh_off, uhv), lakes)
+                try:      # the MPI shape on this network: the reference's decomposition for 8 ranks, one process per tributary domain
+                    from mizuroute_amd.partition import partition_network
+                    P8 = partition_network(net, 8)
+                    thr = max(1, min(16, (os.cpu_count() or 8) // 8))
+                    cpu["mpi_like"] = cpu_mpi_like(P8.trib, frac, lambda dm: ro_cpu[:96, dm.hru_global], methods, threads=thr, spin=48, smp=48)
+                except Exception as e:
+                    cpu["mpi_like"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
         except Exception as e:   # the baseline is reported, never required
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
 

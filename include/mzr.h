@@ -54,7 +54,12 @@ typedef struct mzr_config {
   int    maxWindow;           /* largest number of time steps per mzr_run call             */
   int    device;              /* HIP device ordinal                                        */
   int    is_flux_wm;          /* 1: water-management abstraction/injection fluxes are applied */
-  int    reserved0;           /* (padding, keep 0)                                         */
+  int    lakeMemoryPerMethod; /* Hanasaki reservoirs with inflow / demand memory (lake_route.f90:227-331) keep mutable parameters
+                                 (I_months, D_months, E_rel_ini) that the reference holds ONCE per lake in RPARAM: with several
+                                 active routing methods every method feeds and reads the same memory, once per method and step
+                                 (:258-276,360), so its methods interact.  Here the methods run side by side, each with a copy
+                                 of its own.  0 (default): mzr_set_lakes refuses that combination (ierr 20) instead of silently
+                                 deviating; 1: accept per-method copies knowingly.  One method, or no memory: no difference. */
   double mcTailTol;           /* Muskingum-Cunge: once the outflow of a sub-step (mc_route.f90:246-330) moves by less than
                                  this fraction of itself and the differences contract, the rest of the sub-step sum is
                                  added in closed form.  Default 1e-7 (deviation from iterating on: <= 1.4e-10 of the
@@ -66,7 +71,10 @@ typedef struct mzr_config {
   int    stepBatch;           /* mzr_step: 1 (default) = every call routes its step and returns its ierr; n > 1 = up to n
                                  steps (and at most maxWindow) are put aside and routed as one window when the batch is
                                  full or anything else is asked of the handle; errors then surface at that later call  */
-  int    reserved1;           /* (padding, keep 0)                                         */
+  int    sweepPriority;       /* 0 (default) / 1: the wavefronts of THIS handle's persistent sweeps run at the highest wave
+                                 priority throughout.  For a small, deep domain that sweeps beside a large one on the same GPU
+                                 (rank 0's mainstem beside its tributaries): its window is one long chain of dependent passes
+                                 and a hundredth of the work, so its passes go first wherever they meet the other sweep's  */
   double sweepTimeout;        /* seconds without any progress on the reaches it waits for after which a wavefront of a
                                  persistent sweep gives up with ierr 93 instead of hanging the device (default 8)      */
 } mzr_config;

@@ -41,8 +41,8 @@ class MzrConfig(C.Structure):
                 ("doesBasinRoute", C.c_int), ("hw_drain_point", C.c_int),
                 ("min_length_route", C.c_double), ("runoffMin", C.c_double), ("negRunoffTol", C.c_double),
                 ("time_conv", C.c_double), ("length_conv", C.c_double), ("maxWindow", C.c_int), ("device", C.c_int),
-                ("is_flux_wm", C.c_int), ("reserved0", C.c_int), ("mcTailTol", C.c_double), ("sweepShare", C.c_double),
-                ("stepBatch", C.c_int), ("reserved1", C.c_int), ("sweepTimeout", C.c_double)]
+                ("is_flux_wm", C.c_int), ("lakeMemoryPerMethod", C.c_int), ("mcTailTol", C.c_double), ("sweepShare", C.c_double),
+                ("stepBatch", C.c_int), ("sweepPriority", C.c_int), ("sweepTimeout", C.c_double)]
 
 
 _lib = None
@@ -168,7 +168,7 @@ class RoutingDomain:
     def __init__(self, net, dt, methods, frac_future=None, uh_offset=None, uh=None, does_basin_route=1,
                  hw_drain_point=2, min_length_route=0.0, runoff_min=0.0, max_window=64, device=0,
                  export_reaches=None, halo_reaches=None, halo_good=None, is_flux_wm=0, lakes=None,
-                 time_conv=1.0, length_conv=1.0, history=0, sweep_share=1.0, step_batch=1):
+                 time_conv=1.0, length_conv=1.0, history=0, sweep_share=1.0, step_batch=1, sweep_priority=0, lake_memory_per_method=0):
         L = load_library()
         self.L, self.net, self.N, self.H = L, net, net.N, net.H
         self.methods = list(methods)
@@ -185,6 +185,8 @@ class RoutingDomain:
         cfg.time_conv = float(time_conv); cfg.length_conv = float(length_conv)   # runoff units -> m/s
         cfg.stepBatch = int(step_batch)         # mzr_step: steps put aside and routed together (1 = every call routes its step)
         cfg.sweepShare = float(sweep_share)     # share of the device's wavefront slots this domain's persistent sweeps fill
+        cfg.lakeMemoryPerMethod = int(lake_memory_per_method)   # several methods + Hanasaki memory: accept per-method copies (the reference shares one)
+        cfg.sweepPriority = int(sweep_priority)  # 1: its sweeps' wavefronts go first on every SIMD (a small, deep domain beside a large one)
         self.is_flux_wm = int(is_flux_wm)
         self.max_window = int(max_window)
         self.h = C.c_void_p()

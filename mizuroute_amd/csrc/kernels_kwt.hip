@@ -121,14 +121,19 @@ __device__ __forceinline__ void kwt_beat(const MzrDev &d, int k, int v) {
 #else
 #define MZR_BEAT_ON(d) false
 #endif
-#define MZR_KWD_STEPS(w) ((w) & 0xffff)
-#define MZR_KWD_OUT(w, par) (((w) >> (16 + 5 * (par))) & 31)
-#define MZR_KWD_OWN(w) (((w) >> 26) & 31)
-__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, int wneed, int *word = nullptr, int s = -1, int reach = -1) {
+// (64-bit words: steps in bits 0-15, the at-rest count in 16-20, the counts of the MZR_OB_RING outbox slots in 21-40)
+#define MZR_KWD_STEPS(w) ((int)((w) & 0xffffull))
+#define MZR_KWD_OWN(w) ((int)(((w) >> 16) & 31ull))
+#define MZR_KWD_OUT(w, slot) ((int)(((w) >> (21 + 5 * (slot))) & 31ull))
+#define MZR_KWD_OUTMASK(slot) (31ull << (21 + 5 * (slot)))
+// kwOwn: steps of the window whose at-rest list is in memory (low 16 bits), its particle count above them
+#define MZR_KWO_OWN(w) ((int)(((w) >> 16) & 31ull))
+typedef unsigned long long mzr_word;
+__device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const mzr_word *wp, int wneed, mzr_word *word = nullptr, int s = -1, int reach = -1) {
   long long t0 = 0;
   int spins = 0, vlast = 0;
   for (;;) {
-    int w = wneed;
+    mzr_word w = (mzr_word)(unsigned)wneed;
     if (wp) w = ldx<true>(wp);
     if (word) *word = w;
     const int v = MZR_KWD_STEPS(w);
@@ -164,7 +169,7 @@ __device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const int *wp, in
         const unsigned long long bad = __ballot(v < wneed);
         const int first = __ffsll((long long)bad) - 1;
         if (mzr_lane() == first)
-          mzr_raise_stall(d, 20, reach, s, wp ? (int)(wp - d.kwDone) : -1, w, wneed, -1, first, __popcll(bad), now - t0, d.swHead);
+          mzr_raise_stall(d, 20, reach, s, wp ? (int)((wp >= d.kwOwn && wp < d.kwOwn + d.N) ? wp - d.kwOwn : wp - d.kwDone) : -1, (int)(w & 0xffffffffull), wneed, -1, first, __popcll(bad), now - t0, d.swHead);
         return true;
       }
       vlast = v;
@@ -506,7 +511,7 @@ __device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *
 #define MZR_REC_N 65536
 #define TRECORD(G_, size_, nrem_) do { int _sz = (size_), _nr = (nrem_); for (int _o = 32; _o > 0; _o >>= 1) { _sz = max(_sz, __shfl_xor(_sz, _o, 64)); _nr = max(_nr, __shfl_xor(_nr, _o, 64)); } \
   if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0) { unsigned *_rb = (unsigned *)(d.dbgCycles + 32 * 1024); const unsigned _k = atomicAdd(_rb, 1u) % MZR_REC_N; unsigned *_r = _rb + 16 + (size_t)_k * 16; \
-    _r[0] = (G_); _r[1] = _sz; _r[2] = _nr; _r[3] = _sec[21]; _r[4] = _sec[0]; _r[5] = _sec[1] + _sec[10] + _sec[11] + _sec[12]; _r[6] = _sec[2] + _sec[3]; _r[7] = _sec[4] + _sec[5]; _r[8] = _sec[6]; _r[9] = _sec[16] + _sec[17]; _r[10] = _sec[18] + _sec[19] + _sec[7]; _r[11] = _sec[22]; _r[12] = _sec[10]; _r[13] = _sec[11]; _r[14] = _sec[12]; } } while (0)
+    _r[0] = (G_); _r[1] = _sz; _r[2] = _nr; _r[3] = _sec[21] + _sec[25]; _r[4] = _sec[0]; _r[5] = _sec[1] + _sec[10] + _sec[11] + _sec[12]; _r[6] = _sec[2] + _sec[3]; _r[7] = _sec[4] + _sec[5]; _r[8] = _sec[6]; _r[9] = _sec[16] + _sec[17]; _r[10] = _sec[18] + _sec[19] + _sec[7]; _r[11] = _sec[22]; _r[12] = _sec[10]; _r[13] = _sec[11]; _r[14] = _sec[12]; } } while (0)
 #define TSTAMP_WAVE(i) do { if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], 1ull); } while (0)
 #elif defined(MZR_SWEEP_TRACE)
 // debugging build (make EXTRA=-DMZR_SWEEP_TRACE, run with MZR_SWEEP_DEBUG=1): every wavefront keeps a record of what it is
@@ -534,7 +539,7 @@ struct KwtStep {   // what a lane needs to know about its reach and window step
 __device__ __forceinline__ KwtStep kwt_step(const MzrDev &d, int t) {
   KwtStep k;
   const int tt = t < 0 ? 0 : t;
-  k.t = t; k.par = tt & 1;
+  k.t = t; k.par = tt & (MZR_OB_RING - 1);      // outbox slot of the step
   k.T0 = d.t_start + (double)tt * d.dt;
   k.T1 = (d.W == 1) ? d.T1_single : k.T0 + d.dt;   // mzr_step passes TSEC(2) explicitly
   k.Qrow = d.Q + (size_t)tt * d.N;
@@ -559,9 +564,9 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
   if (PERS) {   // a lake needs the discharge of its upstream reaches, a halo reach overwrites the outbox its downstream reach read two steps ago
     const bool halo = act && FULL && d.haloSlot && d.haloSlot[r] >= 0;
     const int nu = (act && !halo) ? (int)d.nUp[r] : 0, u0 = act ? d.upStart[r] : 0;
-    const int dn = (halo && t >= 2) ? d.down[r] : -1;
+    const int dn = (halo && t >= MZR_OB_RING) ? d.down[r] : -1;
     for (int i = 0; __ballot(i < nu) != 0ull; ++i) if (kwt_wait_deps(d, i < nu ? d.kwDone + u0 + i : nullptr, t + 1, nullptr, s, r)) return true;
-    if (kwt_wait_deps(d, dn >= 0 ? d.kwDone + dn : nullptr, t - 1, nullptr, s, r)) return true;
+    if (kwt_wait_deps(d, dn >= 0 ? d.kwDone + dn : nullptr, t - (MZR_OB_RING - 1), nullptr, s, r)) return true;
     if (kwt_wait_deps(d, (act && t >= 1) ? d.kwDone + r : nullptr, t, nullptr, s, r)) return true;      // its own previous step
     // a lake's own state (volume, Hanasaki memory) was written by whichever wavefront took its last step
     if (__ballot(act && !halo) != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -609,7 +614,7 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
   if (PERS) {
     if (__ballot(act && FULL && d.lakeSlot && d.lakeSlot[r] >= 0) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plain lake state stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (act) stx<true>(d.kwDone + r, t + 1);
+    if (act) stx<true>(d.kwDone + r, (mzr_word)(unsigned)(t + 1));
   }
   if (d.kwtStat) {
     const unsigned long long e = wave_sum(st_head);
@@ -630,6 +635,12 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 5
 #endif
+#ifndef MZR_KWT_POOL
+#define MZR_KWT_POOL 240   // entries of each of the four LDS work arrays of a wavefront: 60 per 16-lane reach, 30 per 8-lane reach
+#endif
+#ifndef MZR_KWT_KTB
+#define MZR_KWT_KTB 4      // entries per lane an 8-lane group can thin (capacity 8 * KTB - 1, and at most its slice of the pool)
+#endif
 // One reach by a group of G adjacent lanes with KS (OS) particle slots per lane for the own row
 // (an outbox row).  `off` = the group's slice of the LDS work arrays, `cap` = how many entries the
 // reach may need: a reach that needs more is left untouched and reported back (true), so that the
@@ -645,6 +656,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   bool ovf = false;
   // The sweep is as fast as its slowest chain of passes, and those are the wide ones (long particle lists, thinning):
   // they go first whenever the SIMD has a choice.
+  const bool boost = PERS && d.sweepPrio;      // the whole sweep of this handle runs at priority 3 (set once in k_sweep_kwt)
 #ifndef MZR_NO_PRIO
   if (G >= 16 && !PERS) __builtin_amdgcn_s_setprio(2);      // (the persistent sweep raises it after its wait: a wavefront that polls has no business in front of one that computes)
 #endif
@@ -682,24 +694,33 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const int uB = u0 + ((upGood & (upGood - 1u)) ? __ffs(upGood & (upGood - 1u)) - 1 : 0);
 #ifdef MZR_KWT_TIMING
   long long _tprev = clock64();
-  unsigned _sec[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned _sec[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int _recSize = 0, _recRem = 0;
 #endif
-  int wword = 0;      // the progress word this lane polled
+  // Round 4, the 16-lane passes of the sweep (SPLIT): the window is as long as its longest chain of passes, and that chain is one
+  // heavy reach taking its W steps one after the other -- each step waiting for the step before.  What a step needs from the
+  // step before is the reach's own at-rest list and nothing else; what it needs from upstream is there long before (upstream
+  // reaches run up to two steps ahead).  So the pass is cut in two at both ends: (1) it waits for its upstream and downstream
+  // reaches only, fetches and MERGES the incoming particles (qexmul_rch), and only then waits for its own step t - 1; (2) it
+  // publishes its at-rest list (kwOwn) as soon as kinwav has decided who stays, and works out the step's discharge and outbox
+  // (interp_rch, the stores its downstream reach waits for: kwDone) after that.  Merge, time-step average and outbox stores
+  // leave the chain; the arithmetic and its order are untouched.
+  constexpr bool SPLIT = PERS && !GEN && G == 16;
+  mzr_word wword = 0;      // the progress word this lane polled
   if (PERS) {
     // step t of this reach needs step t of every upstream reach (their outbox rows and discharge), its own
-    // step t - 1, and overwrites the outbox parity its downstream reach read in step t - 2
+    // step t - 1, and overwrites the outbox slot its downstream reach read in step t - MZR_OB_RING
     const int dn = rci[14];
-    const int *wp = nullptr;
+    const mzr_word *wp = nullptr;
     int wneed = 0;
     if (live) {
       if (gl < nup) { wp = d.kwDone + u0 + gl; wneed = t + 1; }
-      else if (gl == nup && dn >= 0 && t >= 2) { wp = d.kwDone + dn; wneed = t - 1; }
-      else if (gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
+      else if (gl == nup && dn >= 0 && t >= MZR_OB_RING) { wp = d.kwDone + dn; wneed = t - (MZR_OB_RING - 1); }
+      else if (!SPLIT && gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
     if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
 #ifndef MZR_NO_PRIO
-    if (G >= 16) __builtin_amdgcn_s_setprio(2);
+    if (G >= 16 && !boost) __builtin_amdgcn_s_setprio(2);
 #endif
     TSTAMP(21);
   }
@@ -722,33 +743,37 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   // a window on, binary confluence below ordinary reaches): the rows are then read up to their counts only -- about
   // half of them -- and the count loads go away.  Otherwise counts and whole rows are fetched together.
   const bool exact = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u)) && t >= 1;
-  int wSelf = 0;
+  const bool exactNext = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u));      // the next step of the window takes the count from the progress word
+  mzr_word wSelf = 0;
   if (live) {
-    int n_own_v, nrA_v = 0, nrB_v = 0;
+    int n_own_v = 0, nrA_v = 0, nrB_v = 0;
     const int gbase = lane & ~(G - 1);
-    if (PERS && t >= 1) wSelf = __shfl(wword, gbase + nup + 1, 64);      // (also carries the count of the other outbox parity on)
+    if (!SPLIT && PERS && t >= 1) wSelf = (mzr_word)__shfl((long long)wword, gbase + nup + 1, 64);      // (also carries the count of the other outbox parity on)
     if (exact) {
-      n_own_v = MZR_KWD_OWN(wSelf);
-      if (ns > 0) nrA_v = MZR_KWD_OUT(__shfl(wword, gbase + (uA - u0), 64), par);
-      if (ns > 1) nrB_v = MZR_KWD_OUT(__shfl(wword, gbase + (uB - u0), 64), par);
+      if (!SPLIT) n_own_v = MZR_KWD_OWN(wSelf);
+      if (ns > 0) nrA_v = MZR_KWD_OUT((mzr_word)__shfl((long long)wword, gbase + (uA - u0), 64), par);
+      if (ns > 1) nrB_v = MZR_KWD_OUT((mzr_word)__shfl((long long)wword, gbase + (uB - u0), 64), par);
     } else {
-      n_own_v = ldx<PERS>(d.kwN + r);
+      if (!SPLIT) n_own_v = ldx<PERS>(d.kwN + r);
       if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
     }
     // exit time of the reach's last routed particle = the end of its previous step (the first at-rest element's TR, :1304): inside a
     // window of the sweep that is T0 + dt of the step before, the same expression that produced it -- one sector read (and, below,
     // written) per reach-step less; the first step of a window takes it from the state
-    const double X0 = (PERS && t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<PERS>(d.kwTR + MZR_KWI(0, r));
-    const double hin = d.hInflow ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
+    // (SPLIT: everything of the reach's own state -- count, list, X0, the history sum -- is fetched behind the merge, kwt_own below)
+    const double X0 = SPLIT ? 0.0 : (PERS && t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<PERS>(d.kwTR + MZR_KWI(0, r));
+    const double hin = (d.hInflow && !SPLIT) ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
     if (nup > 1) { bs.b1q0 = qlat_prev[u0 + 1]; b1q1 = qlat_cur[u0 + 1]; }
     if (!GEN) { up0 = ldx<PERS>(Qrow + u0); if (nup > 1) up1 = ldx<PERS>(Qrow + u0 + 1); }
+    if (!SPLIT) {
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-      const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
-      if (!exact || k < n_own_v) { const mzr_d2 v = ldq<PERS>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
+      for (int j = 0; j < KS; ++j) {
+        const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
+        if (!exact || k < n_own_v) { const mzr_d2 v = ldq<PERS>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
+      }
     }
     if (!GEN && !upLake) {
 #pragma unroll
@@ -781,6 +806,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     NUPS = nup + NUPR;
     const int NJ0 = n_own == 0 ? 0 : n_own - 1;
     need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
+    if (SPLIT) need = 1;      // (the reach's own count is not known yet: checked in kwt_own; the merge writes behind the 20 entries of a full list)
     if (upLake && nup > 1) need = 0;
     if (empty) { mzr_raise(d, 40, r, t, 11); need = 0; }
     if (need > cap) { ovf = true; need = 0; }
@@ -797,10 +823,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     if (gl == 0) {
       double *c = ctx;
       c[2] = q_up;                     // REACH_INFLOW, stored with the other results at the end
-      c[0] = n_own == 0 ? T0 : X0;     // getusq_rch :587-596: a reach without particles starts at T0
-      c[1] = qlat_r; c[3] = hin;
+      if (!SPLIT) { c[0] = n_own == 0 ? T0 : X0; c[3] = hin; }     // getusq_rch :587-596: a reach without particles starts at T0
+      c[1] = qlat_r;
       if (d.kwtStat && !ovf) {
-        atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own); atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
+        if (!SPLIT) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
+        atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
         atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
       }
     }
@@ -813,11 +840,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     {
       double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
       do {
-        const bool cold = (n_own == 0);
-        const int NJ = cold ? 0 : n_own - 1;
+        bool cold = (n_own == 0);
+        int NJ = cold ? 0 : n_own - 1;
         const bool binary = !GEN && !upLake && NUPS != 1;   // GEN: launch over the confluences of more than two reaches
+        if (!SPLIT) {
 #pragma unroll
-        for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
+          for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
+        }
         if (binary) {
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
@@ -829,9 +858,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         grp_sync();
         TSTAMP(10);
 
-        // ---- qexmul_rch
+        // ---- qexmul_rch (SPLIT: behind the MZR_KW_CAP entries a full own list takes; the own list is put in front of it below)
         int ND;
-        double *QD = Qw + NJ + 1, *TD = Tw + NJ + 1;
+        double *QD = Qw + (SPLIT ? MZR_KW_CAP : NJ + 1), *TD = Tw + (SPLIT ? MZR_KW_CAP : NJ + 1);
         if (upLake) {      // lake outflow enters the river as one particle, getusq_rch :554-559
           if (gl == 0) { QD[0] = ldx<PERS>(Qrow + u0) / RW; TD[0] = T1; }
           ND = 1;
@@ -938,6 +967,41 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         TSTAMP(1);
         if (ND < 0) { mzr_raise(d, -ND, r, t, 11); break; }
         grp_sync();
+        if (SPLIT) {
+          // ---- the reach's own step t - 1 (another wavefront's work; the only dependency on the window's longest chain): its
+          // at-rest list, fetched up to its count, goes in front of the merged particles
+          const int gbase = lane & ~(G - 1);
+          mzr_word wOwn = 0;
+#ifndef MZR_NO_PRIO
+          if (!boost) __builtin_amdgcn_s_setprio(0);
+#endif
+          if (kwt_wait_deps(d, (live && t >= 1 && gl == 0) ? d.kwOwn + r : nullptr, t, &wOwn, s, r)) return 2;
+#ifndef MZR_NO_PRIO
+          if (!boost) __builtin_amdgcn_s_setprio(2);
+#endif
+          TSTAMP(25);
+          wOwn = (mzr_word)__shfl((long long)wOwn, gbase, 64);
+          const int n_own_v = exact ? MZR_KWO_OWN(wOwn) : ldx<true>(d.kwN + r);
+          const double X0 = (t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<true>(d.kwTR + MZR_KWI(0, r));
+          const double hin = d.hInflow ? ldx<true>(d.hInflow + r) : 0.0;
+#pragma unroll
+          for (int j = 0; j < KS; ++j) {
+            const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
+            if (!exact || k < n_own_v) { const mzr_d2 v = ldq<true>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
+          }
+          n_own = uni<G>(n_own_v);
+          cold = (n_own == 0);
+          NJ = cold ? 0 : n_own - 1;
+          if (NJ + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX) > cap || n_own > MZR_KW_CAP) { ovf = true; break; }      // (nothing of the step has been written yet)
+          Qw += MZR_KW_CAP - 1 - NJ; Tw += MZR_KW_CAP - 1 - NJ;      // entry NJ + 1 = the first merged particle
+#pragma unroll
+          for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
+          if (gl == 0) {
+            ctx[0] = n_own == 0 ? T0 : X0; ctx[3] = hin;
+            if (d.kwtStat) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
+          }
+          grp_sync();
+        }
         if (cold) {   // getusq_rch :587-596
           const double DT = T1 - T0;
           if (gl == 0) { Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; }
@@ -967,7 +1031,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           // a pass that has to thin is the slowest kind, and the sweep is as fast as its slowest chain of passes:
           // it goes first whenever the SIMD has a choice
 #ifndef MZR_NO_PRIO
-          __builtin_amdgcn_s_setprio(3);
+          if (!boost) __builtin_amdgcn_s_setprio(3);
 #endif
           const int NPRT = size - 1;
           const bool big = GEN && NPRT > 63;      // beyond the alive bit-mask: neighbours found by walking the error array
@@ -977,7 +1041,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // The interpolation errors stay in registers (lane gl holds particles gl, gl+G, ...): one removal = local
             // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
             // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
-            constexpr int KT = G >= 16 ? 64 / G : 32 / G;      // entries before thinning: at most 60 (16 lanes), 30 (8 lanes)
+            constexpr int KT = G >= 16 ? 64 / G : MZR_KWT_KTB;      // entries before thinning: at most 60 (16 lanes), 8 * KTB - 1 (8 lanes)
             double e[KT];
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
@@ -1310,10 +1374,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         TSTAMP(16);
-        double QNEW;
-        if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
-        TSTAMP(17);
-        const double Qout = QNEW * rc[2] + ctx[1];
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
         const double dTx = xN1 - xN;
         const double Q_END = qN + ((qN1 - qN) / dTx) * (T_END - xN);
@@ -1323,25 +1383,52 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         // registers since the loads at the top
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
+        if (SPLIT) {
+          // ---- the at-rest state KWAVE(NR+1:NQ2+1) and what else the reach's own next step reads, written through, drained and
+          // published (kwOwn) BEFORE the time-step average and the outbox: the next step of this reach starts here
+          const bool lastS = tq == d.W - 1;
+#pragma unroll
+          for (int j = 0; j < KS; ++j) {
+            const int k2 = gl + j * G;
+            if (k2 <= NN2) {
+              const bool first = k2 == 0;
+              stq<true>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
+              if ((first && !(d.W > 1)) || lastS) stx<true>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
+            }
+          }
+          if (gl == 0) {
+            if (lastS || !exactNext) stx<true>(d.kwN + r, NN2 + 1);
+            if (lastS) d.inflow[r] = ctx[2];
+            if (d.hInflow) stx<true>(d.hInflow + r, ctx[3] + ctx[2]);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (gl == 0) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));
+          TSTAMP(26);
+        }
+        double QNEW;
+        if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
+        TSTAMP(17);
+        const double Qout = QNEW * rc[2] + ctx[1];
         // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
         // The particle count and REACH_INFLOW of a step are single words in sectors of their own: 64 bytes written for 4 / 8.  In
         // the sweep the count travels in the progress word (the reach reads it back from there, `exact` above), so both are
         // written where somebody reads them: at the last step of the window (state getters, regrouping, the next window's
         // first step), and the count every step for the reaches that do not take it from the progress word.
         const bool lastStep = tq == d.W - 1;
-        const bool countFromWord = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u));
         if (gl == 0) {
           stx<PERS>(d.Q + (size_t)tq * N + r, Qout);
-          if (!countFromWord || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
-          if (!PERS || lastStep) d.inflow[r] = ctx[2];
-          if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
+          if (!SPLIT) {
+            if (!exactNext || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
+            if (!PERS || lastStep) d.inflow[r] = ctx[2];
+            if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
+          }
         }
         TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         const bool outbox = !isOut;
         if (outbox || es >= 0) {
-          const int pq = tq & 1;
+          const int pq = tq & (MZR_OB_RING - 1);
           int *obNw = d.obN + (size_t)pq * N;
           double *obW = d.obQT + 2 * (size_t)pq * MZR_OB_STRIDE * N;
           const __amdgpu_buffer_rsrc_t obWs = mzr_rsrc(obW);
@@ -1366,7 +1453,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           const int k2 = gl + j * G;
-          if (k2 <= NN2) {
+          if (!SPLIT && k2 <= NN2) {
             const bool first = k2 == 0;
             stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
             // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
@@ -1376,11 +1463,18 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
         TSTAMP(7); TSTAMP_WAVE(20);
         if (PERS) {   // results written through (sc1) and drained, then the step is published
+          if (SPLIT) {      // the word of this reach's step t - 1 (its outbox count of the other parity stays): published long ago by now
+            mzr_word wk = 0;
+            if (kwt_wait_deps(d, (live && tq >= 1 && gl == 0) ? d.kwDone + r : nullptr, tq, &wk, s, r)) return 2;
+            wSelf = wk;
+          }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (gl == 0) {
-            const int pq = tq & 1, keep = MZR_KWD_OUT(wSelf, pq ^ 1);      // the other parity's count stays (0 in the first step)
+            const int pq = tq & (MZR_OB_RING - 1);
+            const mzr_word keep = wSelf & (MZR_KWD_OUTMASK(0) | MZR_KWD_OUTMASK(1) | MZR_KWD_OUTMASK(2) | MZR_KWD_OUTMASK(3)) & ~MZR_KWD_OUTMASK(pq);      // the other slots' counts stay (0 in the first step)
             const int nOut = isOut ? 0 : NR + 2;
-            stx<true>(d.kwDone + r, (tq + 1) | (nOut << (16 + 5 * pq)) | (keep << (16 + 5 * (pq ^ 1))) | ((NN2 + 1) << 26));
+            if (!SPLIT) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));
+            stx<true>(d.kwDone + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)) | ((mzr_word)(unsigned)nOut << (21 + 5 * pq)) | keep);
           }
           TSTAMP(22);
           kwt_beat(d, 3, 4);
@@ -1402,7 +1496,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #ifdef MZR_KWT_TIMING
   if (PERS) TRECORD(G, _recSize, _recRem);
 #endif
-  if (CAN_THIN || G >= 16) __builtin_amdgcn_s_setprio(0);
+  if ((CAN_THIN || G >= 16) && !boost) __builtin_amdgcn_s_setprio(0);
   return ovf ? 1 : 0;
 }
 
@@ -1439,7 +1533,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   constexpr int GB = KwtCls::GB, RB = KwtCls::RB, KB = KwtCls::KB, GC = KwtCls::GC, RC = KwtCls::RC, KC = KwtCls::KC;
   constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
   // entries 0..G*K-1 (the outbox write reaches index NR+2 <= size) within the group's slice of the pool
-  constexpr int CAPB = GB * 4 - 1 < GPB ? GB * 4 - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
+  constexpr int CAPB = GB * MZR_KWT_KTB - 1 < GPB ? GB * MZR_KWT_KTB - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
   __shared__ double sCtx[RC][MZR_CTX];
   const int b = blockIdx.x, lane = threadIdx.x & 63;
@@ -1520,7 +1614,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   constexpr int GA = KwtCls::GA, RA = KwtCls::RA, KA = KwtCls::KA, OA = KwtCls::OA;
   constexpr int GB = KwtCls::GB, RB = KwtCls::RB, KB = KwtCls::KB, GC = KwtCls::GC, RC = KwtCls::RC, KC = KwtCls::KC;
   constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
-  constexpr int CAPB = GB * 4 - 1 < GPB ? GB * 4 - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
+  constexpr int CAPB = GB * MZR_KWT_KTB - 1 < GPB ? GB * MZR_KWT_KTB - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
   __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
   __shared__ double sCtx[RC][MZR_CTX];
 #ifdef MZR_LDS_PAD      // experiment: more LDS per workgroup, so that fewer of them fit a CU
@@ -1531,6 +1625,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
   const int arr = mzr_sweep_join(d0.swHead);      // (a wavefront that starts behind time does not join)
   if (arr < 0) return;
+  if (d0.sweepPrio) __builtin_amdgcn_s_setprio(3);      // mzr_config.sweepPriority: a small, deep domain sweeping beside a large one
   const int Wm1 = d0.W - 1;
   const int q0 = arr < 64 ? (arr & 7) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7);     // HW_REG_XCC_ID: a speed hint only
   kwt_beat(d0, 5, q0); kwt_beat(d0, 3, 1); kwt_beat(d0, 4, 0);
@@ -1629,7 +1724,7 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
   if (d.err->code != 0) return;      // a window that failed stays as it is
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (first && blockIdx.y == 0) {   // first slab of the first chunk of steps: also the per-reach bookkeeping
-    for (int r = i; r < d.N; r += gridDim.x * blockDim.x) d.kwDone[r] = 0;
+    for (int r = i; r < d.N; r += gridDim.x * blockDim.x) { d.kwDone[r] = 0; d.kwOwn[r] = 0; }
   }
   if (i >= d.nHead) return;
   const int r = d.kwtHead[i];
@@ -1656,7 +1751,7 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
 __global__ void __launch_bounds__(256) k_kwt_head_done(MzrDev d) {
   if (d.err->code != 0) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < d.nHead) d.kwDone[d.kwtHead[i]] = d.W;
+  if (i < d.nHead) d.kwDone[d.kwtHead[i]] = (unsigned long long)(unsigned)d.W;
 }
 
 // History sum of REACH_Q (histVars_data.f90:229-231 accumulates step by step): the window's rows added in step order.
@@ -1682,7 +1777,7 @@ void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStrea
 
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int hcBegin, int hcEnd, int gnBegin, int gnEnd,
                           int ltBegin, int ltEnd, hipStream_t stream) {
-  constexpr int POOL = 240, POOLG = 1024;   // binary confluence: 20 + 2 + 2 * 19 = 60 entries per reach at most, 4 reaches
+  constexpr int POOL = MZR_KWT_POOL, POOLG = 1024;   // binary confluence: 20 + 2 + 2 * 19 = 60 entries per reach at most, 4 reaches
   const int nA = haEnd - haBegin, nB = hbEnd - hbBegin, nC = hcEnd - hcBegin, nLt = ltEnd - ltBegin, nGn = gnEnd - gnBegin;
   const bool full = d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm);
   dim3 block(64);
@@ -1719,16 +1814,16 @@ int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream) {
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev >= 0 && dev < 16 && cached[dev][full]) return cached[dev][full];
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  const hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<true, 240>, 64, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<false, 240>, 64, 0);
+  const hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<true, MZR_KWT_POOL>, 64, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<false, MZR_KWT_POOL>, 64, 0);
   if (e != hipSuccess) return 0;
   const int api = cus * perCu;
   int peak[2] = {0, 0};
   int *cnt = d.swHead + 8 * 16;
   if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) return 0;
   const int grid = api + api / 4;
-  if (full) hipLaunchKernelGGL((k_sweep_kwt<true, 240>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
-  else hipLaunchKernelGGL((k_sweep_kwt<false, 240>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
+  if (full) hipLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
+  else hipLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
   if (hipStreamSynchronize(stream) != hipSuccess) return 0;
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
@@ -1757,6 +1852,6 @@ __global__ void k_sweep_heads(MzrDev d, int sBegin) {
 void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {
   if (nWaves < 1 || sEnd <= sBegin) return;
   hipLaunchKernelGGL(k_sweep_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
-  if (kwt_full(d)) hipLaunchKernelGGL((k_sweep_kwt<true, 240>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
-  else hipLaunchKernelGGL((k_sweep_kwt<false, 240>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
+  if (kwt_full(d)) hipLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
+  else hipLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
 }

@@ -17,6 +17,11 @@
 #define MZR_MAXQPAR_DEV 20 // MAXQPAR, public_var.f90:36
 #define MZR_KW_CAP   20   // at-rest particles per reach (MAXQPAR, public_var.f90:36)
 #define MZR_OB_CAP   21   // outbox entries per reach: KWAVE(0:NR+1) + first non-routed
+// The outbox of a reach is a ring over the time steps (slot = step mod MZR_OB_RING): step t of a reach overwrites what its
+// downstream reach read in step t - MZR_OB_RING.  With two slots (rounds 1-3) a heavy reach r and its heavy downstream reach
+// d were chained both ways -- d(t) needs r(t), r(t+2) needs d(t) -- so that two steps of r cost a pass of r AND a pass of d
+// however fast r's own steps follow each other; with four, r runs up to four steps ahead and the loop no longer binds.
+#define MZR_OB_RING  4
 // rows start on 64-byte sectors (24 doubles = 192 bytes per reach): a row of 20 / 21 doubles packed back to back straddles
 // sector boundaries and every partial sector is fetched / written whole (profiles/r03a_summary.md)
 #ifndef MZR_KW_STRIDE
@@ -120,11 +125,17 @@ struct MzrDev {
   double *irfQ;               // [maxtdh][N]
   // ---- KW / MC / DW molecules
   double *mol;                // [nMol][N]
+  // Muskingum-Cunge: reaches that keep asking for many Courant sub-steps (short, flat reaches: 50-200 every step) go first, in
+  // blocks of their own, so that a launch does not end on the one wavefront that drew such a lane late
+  unsigned short *mcSub;      // [N] sub-steps the reach executed in its last step (written by the kernel, read by the host now and then)
+  const int *mcSlow;          // [nMcSlow] the reaches served by the leading blocks, heaviest first
+  const uint8_t *mcIsSlow;    // [N] 1 = served by a leading block
+  int nMcSlow;
   // ---- KWT
   int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
   double *kwQT, *kwTR;        // [N][MZR_KW_STRIDE][2] {Q, TI} pairs; [N][MZR_KW_STRIDE] expected exit times (state only: written at the last step of a window)
-  int    *obN;                // [2][N] routed-flag count of the outbox (NR+2)
-  double *obQT;               // [2][N][MZR_OB_STRIDE][2] {Q, exit time} pairs
+  int    *obN;                // [MZR_OB_RING][N] routed-flag count of the outbox (NR+2)
+  double *obQT;               // [MZR_OB_RING][N][MZR_OB_STRIDE][2] {Q, exit time} pairs
   const MzrKwtRec *kwtRouted;    // reaches that route particles (at most two upstream reaches), stage-major, class A: 16 lanes each
   const MzrKwtRec *kwtRoutedB;   // ... class B: reaches that lately needed at most 20 work-array entries, 8 lanes each (host regroups)
   const MzrKwtRec *kwtRoutedC;   // ... class C: at most 9 entries, 4 lanes each
@@ -132,7 +143,10 @@ struct MzrDev {
   const int *kwtLight;        // headwater, lake and halo reaches, stage-major (one lane each)
   // ---- KWT persistent sweep (k_sweep_kwt): wavefronts draw items (blocks of reaches) of the skewed schedule in
   // launch order from per-XCD ticket counters and hand results on through kwDone
-  int *kwDone;                // [N] steps of the current window a reach has completed (headwaters: W from the start)
+  unsigned long long *kwDone; // [N] steps of the current window a reach has completed (headwaters: W from the start), particle counts above them (kernels_kwt.hip, MZR_KWD_*)
+  unsigned long long *kwOwn;                // [N] steps of the current window whose AT-REST particle list is in memory (low 16 bits; above them its count): what the
+                              // reach's own next step waits for.  A 16-lane pass publishes it before it works out the step's discharge and outbox,
+                              // the other passes together with kwDone.
   const int *down;            // [N] downstream reach (internal index), -1 = outlet
   const int *swItem;          // [nItems] stage-ordered; item = class << 28 | block index in the class list (0 A, 1 B, 2 generic, 3 lake / halo)
   const int *swLo, *swHi;     // [nItems] smallest / largest stage among the item's reaches
@@ -192,6 +206,7 @@ struct MzrDev {
   const int *rtRA, *rtP;      // per launch: first active item, ticket prefix per queue (as swRA / swP)
   int *rtHead;                // [8][16] ticket counters
   int *swBeat;                // [wavefronts][8] what every wavefront of a persistent sweep is doing (launch, item, queue, phase, items done): only with MZR_SWEEP_DEBUG=1
+  int sweepPrio;              // 1: wavefronts of this handle's persistent sweeps keep the highest wave priority (mzr_config.sweepPriority)
   long long stallTicks;       // a polling wavefront gives up (code 93) when nothing it polls has changed for this many ticks of the 100 MHz clock
   MzrKwtStat *kwtStat;
   unsigned long long *dbgCycles;   // [32] per-section wave cycles (only with -DMZR_KWT_TIMING)
@@ -274,6 +289,14 @@ template <bool P> __device__ __forceinline__ double ldx(const double *p) {
 template <bool P> __device__ __forceinline__ int ldx(const int *p) {
   if (P) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
+}
+template <bool P> __device__ __forceinline__ unsigned long long ldx(const unsigned long long *p) {
+  if (P) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template <bool P> __device__ __forceinline__ void stx(unsigned long long *p, unsigned long long v) {
+  if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
 }
 template <bool P> __device__ __forceinline__ void stx(double *p, double v) {
   if (P) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -71,6 +71,7 @@ struct RouteBufs {
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
   DBuf<double> hInflow, hEle, hFlood;               // [N] history sums beyond discharge (mzr_set_history)
   DBuf<double> mol;                                 // [nMol][N]
+  DBuf<unsigned short> mcSub; DBuf<int> mcSlow; DBuf<uint8_t> mcIsSlow; int nMcSlow = 0; long long mcWindows = 0;   // Muskingum-Cunge: sub-steps per reach, the reaches that go first
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
   DBuf<int> rtDone, rtHead;                         // persistent sweep of an Eulerian method: progress per reach, ticket counters
@@ -236,7 +237,7 @@ struct mzr_domain {
   DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll, kwtRoutedCAll;   // classes A / B / C over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
-  DBuf<int> kwDone, down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
+  DBuf<unsigned long long> kwOwn, kwDone; DBuf<int> down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
   DBuf<int> swBeat;                                // [swCap][8] per-wavefront record of the sweep (MZR_SWEEP_DEBUG=1)
   DBuf<int> rtItemR, rtItemInfo, rtRA, rtP;        // items of the Eulerian sweeps (k_sweep_route) and their per-launch tables
   int tracer = 0, solSteps = 0, solCur = 0; double time_conv_solute = 1.0, mass_conv_solute = 1.0;      // constituent routing (mzr_set_tracer / mzr_set_solute)
@@ -310,6 +311,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwK = h->kwK.p; d.kwCW = h->kwCW.p;
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
   d.mcTailTol = h->cfg.mcTailTol >= 0.0 ? h->cfg.mcTailTol : 0.0;
+  d.sweepPrio = h->cfg.sweepPriority != 0;
   d.stallTicks = (long long)((h->cfg.sweepTimeout > 0.0 ? h->cfg.sweepTimeout : 8.0) * 1.e8);      // wall_clock64: 100 MHz
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;
@@ -321,7 +323,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwN = h->kwN.p; d.kwQT = h->kwQ.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQT = h->obQ.p;
   d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtRoutedC = h->kwtRoutedC.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
-  d.kwDone = h->kwDone.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
+  d.kwDone = h->kwDone.p; d.kwOwn = h->kwOwn.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
   d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p; d.swBeat = h->swBeat.p;
   d.kwtHead = h->kwtHead.p; d.nHead = (int)h->h_kwtHead.size(); d.nDepLight = (int)h->h_kwtDepLight.size();
   d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nC = (int)h->h_swC.size(); d.nG = (int)h->h_kwtGeneric.size();
@@ -350,6 +352,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
   d.rtDone = rb.rtDone.p; d.rtHead = rb.rtHead.p;
+  d.mcSub = rb.mcSub.p; d.mcSlow = rb.mcSlow.p; d.mcIsSlow = rb.mcIsSlow.p; d.nMcSlow = rb.nMcSlow;
   d.qobs = rb.qobs.p; d.qerr = rb.qerr.p; d.qelapsed = rb.qelapsed.p;
   d.solFlux = rb.solFlux.p; d.solMass = rb.solMass.p; d.trVol0 = h->tracer ? rb.trVol0.p : nullptr;
 }
@@ -363,11 +366,11 @@ std::string stallReportKwt(mzr_handle h, const MzrErr &e) {
   char b[512];
   std::string out;
   const int N = h->N;
-  std::vector<int> done(N, 0), heads(8 * 16 + 16, 0);
-  if (h->kwDone.p) (void)hipMemcpy(done.data(), h->kwDone.p, (size_t)N * sizeof(int), hipMemcpyDeviceToHost);
+  std::vector<unsigned long long> done(N, 0); std::vector<int> heads(8 * 16 + 16, 0);
+  if (h->kwDone.p) (void)hipMemcpy(done.data(), h->kwDone.p, (size_t)N * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   if (h->swHead.p) (void)hipMemcpy(heads.data(), h->swHead.p, heads.size() * sizeof(int), hipMemcpyDeviceToHost);
   const int W = h->swTablesW;
-  auto steps = [&](int r) { return (r >= 0 && r < N) ? (done[r] & 0xffff) : -1; };
+  auto steps = [&](int r) { return (r >= 0 && r < N) ? (int)(done[r] & 0xffffull) : -1; };
   auto sig = [&](int r) { return (r >= 0 && r < N && !h->h_sigma.empty()) ? h->h_sigma[r] : -1; };
   // reach -> item of the sweep
   std::vector<int> itemOf(N, -1);
@@ -926,6 +929,10 @@ int mzr_set_lakes(mzr_handle h, int LakeInputOption, int calendarId, int nLake, 
     if (e < 0 || e >= N) return fail(h, 20, "mzr_set_lakes/lake reach index out of range");
     if (modelType[l] < 0 || modelType[l] > 3) return fail(h, 20, "lake_route/unable to identify the parametric lake model type");
     slot[h->ext2int[e]] = l; lri[l] = h->ext2int[e];
+    if (modelType[l] == 2 && h->cfg.nRoutes > 1 && !h->cfg.lakeMemoryPerMethod && (par[(size_t)52 * nLake + l] != 0.0 || par[(size_t)53 * nLake + l] != 0.0))
+      return fail(h, 20, "mzr_set_lakes/Hanasaki reservoirs with inflow or demand memory and more than one routing method: the reference's methods share "
+                         "one set of mutable parameters per lake (lake_route.f90:258-276,360), this library keeps one per method; set "
+                         "mzr_config.lakeMemoryPerMethod = 1 to accept that, or route one method per handle");
     if (modelType[l] == 2 && par[(size_t)52 * nLake + l] != 0.0)
       L = std::max(L, (int)std::floor(par[(size_t)54 * nLake + l] * 31 * 86400.0 / h->cfg.dt));
     if (modelType[l] == 2 && par[(size_t)53 * nLake + l] != 0.0)
@@ -1305,7 +1312,7 @@ int mzr_init_state(mzr_handle h) {
         if (h->rtTablesW != -2) { rt_build_items(h); h->rtTablesW = -2; }      // once per mzr_init_state (-2: built, tables not yet)
       }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
-      if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); }
+      if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); rb.mcSub.alloc(N); rb.mcSub.zero(); rb.mcIsSlow.alloc(N); rb.mcIsSlow.zero(); rb.nMcSlow = 0; }
       if (m == MZR_IRF) {
         if (h->maxtdh < 1) return fail(h, 20, "mzr_init_state/reach unit hydrographs not set (IRF)");
         h->irfQ.alloc((size_t)h->maxtdh * N); h->irfQ.zero();
@@ -1372,15 +1379,15 @@ int mzr_init_state(mzr_handle h) {
           if (head.empty()) head.push_back(0);
           if (depLight.empty()) depLight.push_back(0);
           h->kwtHead.upload(head); h->kwtDepLight.upload(depLight);
-          h->kwDone.alloc(N); h->kwDone.zero();
+          h->kwDone.alloc(N); h->kwDone.zero(); h->kwOwn.alloc(N); h->kwOwn.zero();
           h->kwtHeadSteps = 0;
           kwt_build_sweep(h);
         }
         h->kwN.alloc(N); h->kwN.zero();
         h->kwQ.alloc((size_t)2 * MZR_KW_STRIDE * N); h->kwTR.alloc((size_t)MZR_KW_STRIDE * N);      // kwQ: {Q, TI} pairs
         h->kwQ.zero(); h->kwTR.zero();
-        h->obN.alloc(2 * N); h->obN.zero();
-        h->obQ.alloc((size_t)2 * 2 * MZR_OB_STRIDE * N);      // two parities of {Q, exit time} pairs
+        h->obN.alloc((size_t)MZR_OB_RING * N); h->obN.zero();
+        h->obQ.alloc((size_t)MZR_OB_RING * 2 * MZR_OB_STRIDE * N);      // a ring of MZR_OB_RING steps of {Q, exit time} pairs
         h->obQ.zero();
         h->kwtStat.alloc(1); h->kwtStat.zero();
         h->dbgCycles.alloc(32 * 1024 + 8 + 65536 * 8); h->dbgCycles.zero();   // counters, then (timing builds) one record per sampled pass
@@ -1405,17 +1412,50 @@ int mzr_init_state(mzr_handle h) {
 // reach holds changes slowly, so every now and then the routed list of each stage is regrouped by
 // the particle counts of the last step: saturated reaches share wavefronts, light ones do too, and
 // reaches that hold only a few particles go to the class that gives them 8 lanes instead of 16.
+// Muskingum-Cunge: which reaches keep taking many Courant sub-steps (mc_route.f90:283-330: ntSub = ceil(dt / L * celerity) --
+// short reaches with a fast wave, the same ones step after step).  One lane per reach, so a launch lasts as long as its
+// slowest lane, and a hundred such lanes scattered over the wavefronts of a launch decide how long ALL of them take.  They
+// are listed here (from the sub-step counts the kernel leaves behind), heaviest first, and served by the leading blocks of
+// every launch (kernels_route.hip, stage_lane_reach): dispatched first, slow lanes with slow lanes.  Which reach is served
+// by which block changes nothing in the results.
+static void mc_regroup(mzr_handle h, int ix) {
+  RouteBufs &rb = h->route[ix];
+  if (!rb.mcSub.p) return;
+  const int N = h->N;
+  (void)hipStreamSynchronize(h->stream);
+  if (h->routeStream[ix]) (void)hipStreamSynchronize(h->routeStream[ix]);
+  std::vector<unsigned short> sub(N);
+  if (hipMemcpy(sub.data(), rb.mcSub.p, (size_t)N * sizeof(unsigned short), hipMemcpyDeviceToHost) != hipSuccess) return;
+  int thr = 6;
+  if (const char *e = getenv("MZR_MC_SLOW_MIN")) thr = atoi(e);
+  std::vector<std::pair<int, int>> key;
+  if (thr > 0) for (int r = 0; r < N; ++r) if (sub[r] >= thr) key.emplace_back(-(int)sub[r], r);
+  if ((int)key.size() > N / 8) key.clear();      // (most reaches are slow: nothing to single out)
+  std::sort(key.begin(), key.end());
+  std::vector<int> list; std::vector<uint8_t> flag(N, 0);
+  for (const auto &k : key) { list.push_back(k.second); flag[k.second] = 1; }
+  try {
+    if (list.empty()) { rb.nMcSlow = 0; }
+    else { rb.mcSlow.upload(list); rb.nMcSlow = (int)list.size(); }
+    (void)hipMemcpy(rb.mcIsSlow.p, flag.data(), (size_t)N, hipMemcpyHostToDevice);
+  } catch (const std::string &) { rb.nMcSlow = 0; }
+}
+
 static void kwt_regroup(mzr_handle h) {
   if (h->h_kwtRouted.size() < 2 || !h->kwN.p) return;
   (void)hipStreamSynchronize(h->stream);
   const int N = h->N;
-  std::vector<int> n(N), ob((size_t)2 * N);
+  std::vector<int> n(N), ob((size_t)MZR_OB_RING * N);
   (void)hipMemcpy(n.data(), h->kwN.p, N * sizeof(int), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(ob.data(), h->obN.p, (size_t)2 * N * sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipMemcpy(ob.data(), h->obN.p, (size_t)MZR_OB_RING * N * sizeof(int), hipMemcpyDeviceToHost);
   // work-array entries the reach needed in the last step (the kernel's `need`), from the larger outbox parity
   auto need = [&](const MzrKwtRec &rc) {
     int l = std::max(n[rc.r], 1) + rc.nup;
-    for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) l += std::max(std::max(ob[rc.u0 + k], ob[(size_t)N + rc.u0 + k]) - 1, 0);
+    for (int k = 0; k < rc.nup; ++k) if ((rc.upGood >> k) & 1) {
+      int m = 0;
+      for (int sl = 0; sl < MZR_OB_RING; ++sl) m = std::max(m, ob[(size_t)sl * N + rc.u0 + k]);
+      l += std::max(m - 1, 0);
+    }
     return l;
   };
   // class C (4 lanes, capacity 11 entries): reaches that needed at most 9 entries in the last step; class B (8 lanes,
@@ -1473,6 +1513,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     const bool early = W > 1 && (h->kwtWindows == 1 || h->kwtWindows == 2);
     if (h->kwtWindows > 0 && (early || h->kwtStepsSince >= std::max(512LL, 8LL * W))) { kwt_regroup(h); h->kwtStepsSince = 0; }
     ++h->kwtWindows; h->kwtStepsSince += W;
+  }
+  for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {      // Muskingum-Cunge: the slow reaches are listed after the first two windows, then every 8 windows
+    RouteBufs &rb = h->route[ix];
+    if (rb.method != MZR_MC || W < 2) continue;
+    const long long k = rb.mcWindows++;
+    if (k == 1 || k == 2 || (k > 2 && k % 8 == 0)) mc_regroup(h, ix);
   }
   const int N = h->N;
   hipStream_t st = h->stream;

@@ -28,11 +28,11 @@ MODULE mzr_c
     integer(c_int)  :: maxWindow
     integer(c_int)  :: device
     integer(c_int)  :: is_flux_wm
-    integer(c_int)  :: reserved0
+    integer(c_int)  :: lakeMemoryPerMethod   ! 1: several methods with Hanasaki memory lakes keep per-method copies (refused otherwise)
     real(c_double)  :: mcTailTol       ! Muskingum-Cunge closed-form tail of the sub-step sum (0 = iterate every sub-step)
     real(c_double)  :: sweepShare      ! share of the device's wavefront slots this handle's persistent sweeps fill (1 = all)
     integer(c_int)  :: stepBatch       ! mzr_step: steps put aside and routed as one window (1 = every call routes its step)
-    integer(c_int)  :: reserved1
+    integer(c_int)  :: sweepPriority   ! 1: this handle's persistent sweeps run at the highest wave priority (rank 0's mainstem beside its tributaries)
     real(c_double)  :: sweepTimeout    ! seconds without progress before a persistent sweep gives up (ierr 93)
   end type mzr_config
 

@@ -28,6 +28,12 @@ import numpy as np
 from .synthetic import RiverNetwork, hops_to_outlet
 
 
+# Rank 0 sweeps its tributary domain and the mainstem domain side by side on one GPU.  The mainstem is a hundredth of the work
+# and one long chain of dependent passes: it gets the wavefronts its items per level ask for (a few hundred of 4 000) and the
+# highest wave priority (mzr_config.sweepPriority), the tributary sweep everything else.
+MAIN_SWEEP_SHARE = 0.12
+
+
 @dataclass
 class Domain:
     part: int                       # owning partition (rank)
@@ -291,11 +297,12 @@ class PartitionedRouter:
         # rank 0 routes its tributary window k and the mainstem window k-1 side by side on one GPU: the two persistent
         # sweeps share the device's wavefront slots out (a sweep whose grid does not fit the device can stall)
         both = td.n_real > 0 and self.main_spec is not None
-        self.trib = make_domain(td, export_reaches=td.export_local, sweep_share=0.8 if both else 1.0) if td.n_real > 0 else None
+        self.trib = make_domain(td, export_reaches=td.export_local, sweep_share=(1.0 - MAIN_SWEEP_SHARE) if both else 1.0) if td.n_real > 0 else None
         self.main = None
         if self.main_spec is not None:
             ms = self.main_spec
-            self.main = make_domain(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good, sweep_share=0.2 if both else 1.0)
+            self.main = make_domain(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good, sweep_share=MAIN_SWEEP_SHARE if both else 1.0,
+                                    sweep_priority=1 if both else 0)
         self.n_routes = None
         self._pending = None            # (w, t_start, runoff_main_ptr, record, keep) of the window whose exchange is still due
 

@@ -565,7 +565,9 @@ def test_lakes_direct_insertion_and_constituent_in_partitioned_domains(hip_lib):
     da = make_gauges(net, steps, n_gauge=150, seed=2, every=3, blend=6, trend=2)
     methods = [m.IRF, m.DW]
     sol = np.random.default_rng(20).uniform(0.0, 5.0, (steps, net.H))
-    whole = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=W, lakes=lakes)
+    # (two methods and Hanasaki reservoirs with memory: per-method copies of the mutable parameters, accepted knowingly --
+    # test_hanasaki_memory_with_several_methods_is_refused)
+    whole = m.RoutingDomain(net, dt, methods, frac_future=ff, uh_offset=uh_off, uh=uhv, max_window=W, lakes=lakes, lake_memory_per_method=1)
     whole.set_da(da)
     whole.set_tracer(sol, time_conv=1.0 / 3600.0, mass_conv=1000.0)
     Qw = whole.run(ro)
@@ -581,7 +583,7 @@ def test_lakes_direct_insertion_and_constituent_in_partitioned_domains(hip_lib):
         off = np.zeros(g.size + 1, np.int32); off[1:] = np.cumsum(cnt)
         u = np.concatenate([uhv[uh_off[x]:uh_off[x + 1]] for x in g])
         dom = m.RoutingDomain(spec.net, dt, methods, frac_future=ff, uh_offset=off, uh=u, max_window=W,
-                              lakes=lakes_for_domain(lakes, spec, net.N), **kw)
+                              lakes=lakes_for_domain(lakes, spec, net.N), lake_memory_per_method=1, **kw)
         dom.set_da(gauges_for_domain(da, spec, net.N))
         dom.set_tracer(sol[:, spec.hru_global] if spec.hru_global.size else np.zeros((steps, 1)), time_conv=1.0 / 3600.0, mass_conv=1000.0)
         return dom
@@ -1012,3 +1014,23 @@ def test_history_means_vs_oracle(tmp_path, hip_lib, oracle_lib):
         assert name in f.variables and f.variables[name][:].shape[0] == 2 and f.variables[name][:].dtype.itemsize == 4, name
     assert f.variables["basRunoff"].dimensions == ("time", "hru")
     f.close()
+
+
+def test_hanasaki_memory_with_several_methods_is_refused(hip_lib):
+    """lake_route.f90:258-276,360: the reference keeps the mutable Hanasaki parameters (I_months, D_months, E_rel_ini) once per lake
+    in RPARAM, so with several active methods every method feeds and reads the same memory.  This library routes the methods side
+    by side with a copy each: it says so (ierr 20) instead of deviating silently, unless the caller accepts it
+    (mzr_config.lakeMemoryPerMethod); one method, or reservoirs without memory, are not affected."""
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(800, seed=3)
+    ff = np.array([0.6, 0.4])
+    off, v = np.arange(net.N + 1, dtype=np.int32), np.ones(net.N)
+    mem = make_lakes(net, 4, 3600.0, seed=5, frac=0.05, input_option=1, memory=True)
+    assert (mem["model_type"] == 2).any()
+    with pytest.raises(m.MzrError) as e:
+        m.RoutingDomain(net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=off, uh=v, max_window=4, lakes=mem)
+    assert e.value.ierr == 20 and "lakeMemoryPerMethod" in e.value.message
+    m.RoutingDomain(net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=off, uh=v, max_window=4, lakes=mem, lake_memory_per_method=1).close()
+    m.RoutingDomain(net, 3600.0, [m.DW], frac_future=ff, uh_offset=off, uh=v, max_window=4, lakes=mem).close()
+    plain = make_lakes(net, 4, 3600.0, seed=5, frac=0.05, input_option=1, memory=False)
+    m.RoutingDomain(net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=off, uh=v, max_window=4, lakes=plain).close()

@@ -65,7 +65,7 @@ class RecordingDomain:
     """Stand-in for RoutingDomain on CPU: fabricates a deterministic boundary record per export
     reach and remembers what it is asked to import."""
 
-    def __init__(self, spec, export_reaches=None, halo_reaches=None, halo_good=None, sweep_share=1.0):
+    def __init__(self, spec, export_reaches=None, halo_reaches=None, halo_good=None, sweep_share=1.0, sweep_priority=0):
         import torch
         self.torch, self.spec = torch, spec
         self.exp = np.asarray(export_reaches if export_reaches is not None else [], dtype=np.int64)

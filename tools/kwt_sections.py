@@ -21,10 +21,10 @@ ro = bench.device_runoff(torch, net.H, W, W, 7, dev); torch.cuda.synchronize()
 dom.run_device(W, W * 3600.0, ro.data_ptr()); dom.sync()
 dom.L.mzr_debug_cycles(dom.h, buf, 1)
 names = ["0 setup/need", "1 load own + merge", "2 min/inflow", "3 remove", "4 celerity pow", "5 shock search", "6 routing loop", "7 interp + stores"]
-tot = max(1, sum(buf[i] for i in range(8)) + sum(buf[i] for i in range(16, 20)) + buf[21] + buf[22])
+tot = max(1, sum(buf[i] for i in range(8)) + sum(buf[i] for i in range(16, 20)) + buf[21] + buf[22] + buf[25] + buf[26])
 for i, n in enumerate(names):
     print(f"{n:22s} {buf[i]:16d}  {100.0*buf[i]/tot:5.1f}%")
-for i, n in zip(list(range(16, 20)) + [21, 22], ["7a count routed", "7b interp", "7c Q_END + scalar stores", "7d outbox stores", "P1 wait for dependencies", "P2 drain + publish"]):
+for i, n in zip(list(range(16, 20)) + [21, 25, 26, 22], ["7a count routed", "7b interp", "7c Q_END + scalar stores", "7d outbox stores", "P1 wait for up / downstream (all, narrow passes)", "P1b wait for the own step (16 lanes)", "P2a at-rest stores, drain, publish own (16 lanes)", "P2 drain + publish"]):
     print(f"{n:22s} {buf[i]:16d}  {100.0*buf[i]/tot:5.1f}%")
 print("(7 = at-rest stores only when the 7a-7d stamps are present)")
 print("dependency polls that had to wait", buf[23], "spin iterations", buf[24])
