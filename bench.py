@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CONFIGS = {
     "c2": dict(reaches=100_000, methods="2", window=16384, workload="synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
     "c3": dict(reaches=375_000, methods="2", window=4096, workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
-    "c4": dict(reaches=625_000, methods="14", window=2048, dominant=4, bytes=lambda U: 152 + 12 * U,
+    "c4": dict(reaches=625_000, methods="14", window=3072, dominant=4, bytes=lambda U: 152 + 12 * U,
                workload="one of 8 shards of a ~5 M-reach MERIT-like network, IRF-UH + Muskingum-Cunge (route_opt 14), dt 3600 s, hillslope UH on"),
     "c5": dict(reaches=375_000, methods="5", window=2048, dominant=5, bytes=lambda U: 440 + 12 * U, lakes=0.01, floodplain=True,
                workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, diffusive wave (route_opt 5), 1 % lakes (Doll / Hanasaki / HYPE), "
@@ -368,9 +368,9 @@ class Loopback:
                 d_t.sync(); d_m.sync()
                 if 1 <= k < K:
                     tw.append(time.perf_counter() - t1)
-            t_rank0 = float(np.median(tw[1:] if len(tw) > 1 else tw))
-            times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share,
-                                               what="tributary window k and mainstem window k-1 of rank 0 queued together; median of the windows after the first")
+            t_rank0 = float(np.median(tw[len(tw) // 2:]))      # (the first windows of two fresh domains hold their regroupings and table builds)
+            times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share, sweep_priority_mainstem=1,
+                                               what="tributary window k and mainstem window k-1 of rank 0 queued together; median of the later half of the windows")
             d_t.close(); d_m.close()
         recs.clear()
         torch.cuda.empty_cache()
@@ -932,7 +932,7 @@ def main():
                 lb = Loopback(torch, m, uhmod, cname, 8)
                 rep, whole_info, _ = lb.parity(128, 1)
                 Wc = CONFIGS[cname]["window"]
-                tmc = lb.timing(Wc, 5)
+                tmc = lb.timing(Wc, 7)
                 roofc = lb.roofline(Wc)
                 cpuc = None if args.no_cpu_baseline else lb.cpu(args.cpu_spinup_configs, args.cpu_sample_configs)
                 configs[cname] = {"workload": f"FULL {cname} network: {lb.net.N} reaches, route_opt {lb.cfg['methods']}"

@@ -102,15 +102,20 @@ int mzr_set_frac_future(mzr_handle h, int n, const double *frac);
 /* Sub-basin partitioning (replaces the MPI domain decomposition, mpi_process.f90:473-606,1245-1329):
    exportReach[] = reaches of THIS domain (tributary outlets) whose per-step boundary records are
    shipped to the domain that owns their downstream reach; haloReach[] = reaches of this domain that
-   stand for tributary outlets computed elsewhere (no upstreams, no HRUs here; haloGood = their
-   count(goodBas) > 0 in the full network).  Indices are 1-based, caller's reach order.  Call
+   stand for tributary outlets computed elsewhere (no upstreams, no HRUs here; haloGood bit 0 = their
+   count(goodBas) > 0 in the full network, bit 1 (value 2) = the reach is a lake where it is routed: the reach below
+   it then takes the lake's outflow as one particle and must have no other upstream reach, kwt_route.f90:540-559).  Indices are 1-based, caller's reach order.  Call
    after mzr_set_network, before mzr_init_state. */
 int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach,
                      const int *haloGood);
 /* number of doubles of a boundary record of nReach reaches over nSteps steps:
-   Q[nRoutes][nSteps][nReach] | BASIN_QR[nSteps+1][nReach] | obN[nSteps][nReach] |
+   header[4] | Q[nRoutes][nSteps][nReach] | BASIN_QR[nSteps+1][nReach] | obN[nSteps][nReach] |
    obQ[nSteps][21][nReach] | obT[nSteps][21][nReach]  (the per-partition wire format); while constituent routing is on
-   (mzr_set_tracer on every domain) reach_solute_flux[nRoutes][nSteps][nReach] follows */
+   (mzr_set_tracer: the same on EVERY domain, before the first mzr_boundary_size) reach_solute_flux[nRoutes][nSteps][nReach]
+   follows.  header = {format tag, nRoutes, nSteps, nReach (+ 2^30 with the constituent)}: written by
+   mzr_export_boundary_dev, checked by mzr_import_boundary_dev -- a record that is not what the importing domain expects
+   (other methods, window length, reach count, constituent on one side only) raises ierr 20 at the next synchronisation
+   and nothing of it is used */
 long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach);
 /* pack the export reaches' records of the last window into rec_dev (device memory) */
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev);

@@ -108,11 +108,16 @@ __global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot
   qlat[r] = qlat[(size_t)lastW * N + r];
 }
 
-// boundary record (include/mzr.h): Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB]
+// boundary record (include/mzr.h): header[4] | Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB] [| solute flux[R][W][nB]]
+// header = {magic, nRoutes, steps, reaches + 2^30 while the constituent is on}: what the sender packed, checked by the receiver
+// (a sender and a receiver that disagree on any of them -- e.g. mzr_set_tracer on one side only -- would otherwise read each
+// other's records at the wrong offsets without a word)
+#define MZR_REC_HDR 4
+#define MZR_REC_MAGIC 20260929.0
 struct RecView { double *Q, *ql, *n, *oq, *ot; };
 __host__ __device__ inline RecView recView(double *rec, int R, int W, int nB) {
   RecView v;
-  v.Q = rec; v.ql = v.Q + (size_t)R * W * nB; v.n = v.ql + (size_t)(W + 1) * nB;
+  v.Q = rec + MZR_REC_HDR; v.ql = v.Q + (size_t)R * W * nB; v.n = v.ql + (size_t)(W + 1) * nB;
   v.oq = v.n + (size_t)W * nB; v.ot = v.oq + (size_t)W * MZR_OB_CAP * nB;
   return v;
 }
@@ -121,10 +126,11 @@ struct QPtrsW { double *p[6]; };
 
 // grid: x over export slots, y over steps 0..W (row W only carries the last BASIN_QR row)
 __global__ void k_pack_boundary(double *rec, int R, int W, int nB, int N, const int *expInt, QPtrs Q, const double *qlat,
-                                const int *exN, const double *exOQ, const double *exOT, int hasKwt) {
+                                const int *exN, const double *exOQ, const double *exOT, int hasKwt, int tracer) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (b >= nB) return;
+  if (b == 0 && t == 0) { rec[0] = MZR_REC_MAGIC; rec[1] = (double)R; rec[2] = (double)W; rec[3] = (double)nB + (tracer ? 1073741824.0 : 0.0); }
   const RecView v = recView(rec, R, W, nB);
   const int r = expInt[b];
   v.ql[(size_t)t * nB + b] = qlat[(size_t)t * N + r];
@@ -141,10 +147,15 @@ __global__ void k_pack_boundary(double *rec, int R, int W, int nB, int N, const 
 }
 
 __global__ void k_unpack_boundary(const double *rec, int R, int W, int nB, int N, int nHalo, int haloBase, const int *haloInt,
-                                  QPtrsW imQ, double *qlat, int *imN, double *imOQ, double *imOT, int hasKwt) {
+                                  QPtrsW imQ, double *qlat, int *imN, double *imOQ, double *imOT, int hasKwt, int tracer, MzrErr *err) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (b >= nB) return;
+  // the record must be what this domain expects (ierr 20 at the next synchronisation; nothing of it is used)
+  if (!(rec[0] == MZR_REC_MAGIC && rec[1] == (double)R && rec[2] == (double)W && rec[3] == (double)nB + (tracer ? 1073741824.0 : 0.0))) {
+    if (b == 0 && t == 0 && atomicCAS(&err->code, 0, 20) == 0) { err->reach = -1; err->step = (int)rec[2]; err->where = 30; }
+    return;
+  }
   const RecView v = recView(const_cast<double *>(rec), R, W, nB);
   const int hs = haloBase + b;
   const int r = haloInt[hs];
@@ -510,6 +521,7 @@ int checkDeviceError(mzr_handle h) {
     case 18: what = "kwt_rch/getusq_rch/lake outlet reach should have one upstream lake"; break;
     case 20: what = "persistent KWT sweep gave up waiting for a reach it depends on"; break;
     case 21: what = "persistent sweep of an Eulerian method gave up waiting for a reach it depends on"; break;
+    case 30: what = "mzr_import_boundary_dev/the record is not what this domain expects (routing methods, window length, reach count, or the constituent on one side only; 'window step' = the steps the record holds)"; break;
   }
   char buf[768];
   snprintf(buf, sizeof buf, "main_routing/route_network/%s [where %d, reach index %d id %d, window step %d]", what, e.where, ext + 1, id, e.step);
@@ -1182,8 +1194,8 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
     if (e < 0 || e >= N) return fail(h, 20, "mzr_set_boundary/halo reach index out of range");
     const int i = h->ext2int[e];
     if (h->h_nUp[i] != 0) return fail(h, 20, "mzr_set_boundary/a halo reach must not have upstream reaches in this domain");
-    hs[i] = b; h->h_haloInt[b] = i; h->h_haloGood[b] = haloGood[b] != 0;
-    ng[i] = haloGood[b] ? 1 : 0;      // what its downstream reach sees: count(goodBas) of the full network
+    hs[i] = b; h->h_haloInt[b] = i; h->h_haloGood[b] = (haloGood[b] & 1) | (haloGood[b] & 2);      // bit 0: good; bit 1: a lake where it is routed
+    ng[i] = (haloGood[b] & 1) ? 1 : 0;      // what its downstream reach sees: count(goodBas) of the full network
   }
   if (nHalo > 0 && !h->highPriority) {
     // a domain that consumes halo records is the mainstem of a partitioned network: few reaches, many
@@ -1213,7 +1225,7 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
 long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach) {
   if (!h) return -1;
   const long long R = h->cfg.nRoutes, W = nSteps, B = nReach;
-  return R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B + (h->tracer ? R * W * B : 0);      // (+ reach_solute_flux while the tracer is on)
+  return MZR_REC_HDR + R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B + (h->tracer ? R * W * B : 0);      // (header; + reach_solute_flux while the tracer is on)
 }
 
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
@@ -1225,10 +1237,10 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
   QPtrs q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].Q.p : nullptr;
   dim3 block(64), grid((h->nExp + 63) / 64, h->lastW + 1);
   hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, h->lastW, h->nExp, h->N,
-                     h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, h->kwN.p ? 1 : 0);
+                     h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, h->kwN.p ? 1 : 0, h->tracer ? 1 : 0);
   if (h->tracer) {
     QPtrs f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
-    const long long base = (long long)h->cfg.nRoutes * h->lastW * h->nExp + (long long)(h->lastW + 1) * h->nExp + (long long)h->lastW * h->nExp + 2LL * h->lastW * MZR_OB_CAP * h->nExp;
+    const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * h->lastW * h->nExp + (long long)(h->lastW + 1) * h->nExp + (long long)h->lastW * h->nExp + 2LL * h->lastW * MZR_OB_CAP * h->nExp;
     hipLaunchKernelGGL(k_pack_solute, dim3((h->nExp + 63) / 64, h->lastW), block, 0, h->stream, rec_dev + base, h->cfg.nRoutes, h->lastW, h->nExp, h->N, h->expInt.p, f);
   }
   if (!h->exportDone) (void)hipEventCreateWithFlags(&h->exportDone, hipEventDisableTiming);
@@ -1246,10 +1258,10 @@ int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int
   QPtrsW q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].imQ.p : nullptr;
   dim3 block(64), grid((nSrc + 63) / 64, nSteps + 1);
   hipLaunchKernelGGL(k_unpack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, nSteps, nSrc, h->N, h->nHalo,
-                     haloBase, h->haloInt.p, q, h->qlat.p, h->imN.p, h->imOQ.p, h->imOT.p, h->kwN.p ? 1 : 0);
+                     haloBase, h->haloInt.p, q, h->qlat.p, h->imN.p, h->imOQ.p, h->imOT.p, h->kwN.p ? 1 : 0, h->tracer ? 1 : 0, h->err.p);
   if (h->tracer) {      // the halo reaches' reach_solute_flux goes straight into the window's rows: the constituent pass skips halo reaches
     QPtrsW f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
-    const long long base = (long long)h->cfg.nRoutes * nSteps * nSrc + (long long)(nSteps + 1) * nSrc + (long long)nSteps * nSrc + 2LL * nSteps * MZR_OB_CAP * nSrc;
+    const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * nSteps * nSrc + (long long)(nSteps + 1) * nSrc + (long long)nSteps * nSrc + 2LL * nSteps * MZR_OB_CAP * nSrc;
     hipLaunchKernelGGL(k_unpack_solute, dim3((nSrc + 63) / 64, nSteps), block, 0, h->stream, rec_dev + base, h->cfg.nRoutes, nSteps, nSrc, h->N, haloBase, h->haloInt.p, f);
   }
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_import_boundary/launch failed");
@@ -1351,7 +1363,12 @@ int mzr_init_state(mzr_handle h) {
               for (int k = 0; k < rc.nup; ++k) {
                 const int u = rc.u0 + k;
                 if (!h->h_lakeSlot.empty() && h->h_lakeSlot[u] >= 0) rc.flags |= 0x40;
-                if (h->nHalo && !h->h_haloSlot.empty() && h->h_haloSlot[u] >= 0) rc.flags |= 0x20;   // its progress word carries no particle counts
+                if (h->nHalo && !h->h_haloSlot.empty() && h->h_haloSlot[u] >= 0) {
+                  rc.flags |= 0x20;   // its progress word carries no particle counts
+                  // a tributary outlet that is a LAKE where it is routed: its outflow enters this reach as one particle, and it
+                  // has to be this reach's only upstream reach (getusq_rch, kwt_route.f90:540-559), exactly as if the lake were here
+                  if (h->h_haloGood[h->h_haloSlot[u]] & 2) rc.flags |= 0x40;
+                }
                 if (h->h_nGood[u] > 0) {
                   rc.upGood |= (uint8_t)(1u << k);
                   if (nsr == 0) rc.scA = width[u] / width[i]; else if (nsr == 1) rc.scB = width[u] / width[i];
@@ -1468,7 +1485,9 @@ static void kwt_regroup(mzr_handle h) {
   // cost fewer instructions per reach than 4: class B up to 28 entries (its capacity is 30) measured +13 % there.  With
   // about as many items as wavefronts (100 k reaches: 6.7 k) the window is bound by its longest chain of passes, which
   // runs through the reaches that thin every step, and those are faster in 16-lane groups: 28 there measured -8 %.
-  if (h->swCap > 0 && (double)h->h_kwtRouted.size() / 7.0 > 3.0 * h->swCap) classBMax = 28;
+  // (round 4, with the outbox ring of four steps and the split 16-lane pass the chain no longer punishes the narrower groups:
+  // 24 there measured +4.6 %, 28 +-0)
+  classBMax = (h->swCap > 0 && (double)h->h_kwtRouted.size() / 7.0 > 3.0 * h->swCap) ? 28 : 24;
   if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
   if (const char *e = getenv("MZR_KWT_CLASSC_MAX")) classCMax = atoi(e);
   const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
@@ -1543,7 +1562,11 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       if (!h->qlatAlt.p) { h->qlatAlt.alloc(h->qlat.n); h->qlatAlt.zero(st); }
       if (h->qi.p && !h->qiAlt.p) { h->qiAlt.alloc(h->qi.n); h->qiAlt.zero(st); }
       for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (!h->route[ix].Qalt.p) { h->route[ix].Qalt.alloc(h->route[ix].Q.n); h->route[ix].Qalt.zero(st); }
-    } catch (const std::string &e) { pipe = false; if (h->tail.pending) flushTail(h); }
+    } catch (const std::string &e) {      // no room for the second set of rows: windows one after the other, as before
+      pipe = false; (void)hipGetLastError();
+      h->qlatAlt.free(); h->qiAlt.free(); for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].Qalt.free();
+      if (h->tail.pending) flushTail(h);
+    }
   }
   if (pipe) {      // this window's rows: the second set (the set of the window before stays as it is until its last launches are out)
     h->qlat.swap(h->qlatAlt); if (h->qi.p) h->qi.swap(h->qiAlt);

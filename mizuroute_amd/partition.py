@@ -185,6 +185,18 @@ def mainstem_cost(net: RiverNetwork, n_parts: int, window: int, level_s: float =
     return (depth + window) * level_s * reach_steps_per_s / window
 
 
+def halo_flags(lakes: dict, spec: "Domain") -> np.ndarray:
+    """halo_good of a mainstem domain with the lakes of the whole network marked (bit 1): a tributary outlet that is a lake where
+    it is routed reaches the mainstem reach below it as a lake does (kwt_route.f90:540-559; mzr_set_boundary)."""
+    hg = np.asarray(spec.halo_good, dtype=np.int32).copy()
+    if lakes is None or hg.size == 0:
+        return hg
+    is_lake = np.zeros(int(max(spec.reach_global.max(), np.asarray(lakes["reach"]).max())) + 1, bool)
+    is_lake[np.asarray(lakes["reach"], dtype=np.int64) - 1] = True
+    halo_global = spec.reach_global[spec.n_real:]
+    return hg | (2 * is_lake[halo_global]).astype(np.int32)
+
+
 def lakes_for_domain(lakes: dict, spec: "Domain", n_reach_global: int):
     """The lakes / reservoirs of the whole network (dict of synthetic.make_lakes or standalone.read_lakes: 1-based global
     reaches, parameters per lake, evaporation / precipitation per HRU, target volumes per reach) as ONE domain sees them: the

@@ -1034,3 +1034,76 @@ def test_hanasaki_memory_with_several_methods_is_refused(hip_lib):
     m.RoutingDomain(net, 3600.0, [m.DW], frac_future=ff, uh_offset=off, uh=v, max_window=4, lakes=mem).close()
     plain = make_lakes(net, 4, 3600.0, seed=5, frac=0.05, input_option=1, memory=False)
     m.RoutingDomain(net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=off, uh=v, max_window=4, lakes=plain).close()
+
+
+def test_kwt_lake_at_a_tributary_outlet_reaches_the_mainstem_as_a_lake(hip_lib):
+    """kwt_route.f90:540-559 (getusq_rch): the reach below a lake takes the lake's outflow as ONE particle, and the lake must be its
+    only upstream reach ("lake outlet reach should have one upstream lake", ierr 10 otherwise).  In a partitioned network the
+    lake may be the outlet of a tributary domain and the reach below it a mainstem reach that only sees a halo: the halo carries
+    the flag (mzr_set_boundary haloGood bit 1, partition.halo_flags), so the mainstem domain does what the whole network does --
+    here the refusal, since a tributary joins the mainstem at a confluence."""
+    from mizuroute_amd.partition import partition_network, halo_flags, lakes_for_domain
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(3000, seed=61)
+    P = partition_network(net, 2)
+    assert P.main is not None
+    tmpl = make_lakes(net, 8, 3600.0, seed=5, frac=0.01, input_option=1)
+    src = next(sp for sp in P.trib if sp.n_real and sp.export_local.size)
+    lake_g = int(src.reach_global[src.export_local[0] - 1])                     # a tributary outlet, global 0-based
+    lakes = dict(tmpl, reach=np.array([lake_g + 1], np.int32), model_type=np.array([1], np.int32), par=np.ascontiguousarray(tmpl["par"][:, :1]))
+    ro = m.make_runoff(net.H, 8, seed=3, storm_prob=0.05, storm_amp=2e-6)
+    ff = np.array([0.6, 0.4])
+    # the whole network refuses: the reach below the lake is a confluence
+    whole = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=8, lakes=lakes)
+    with pytest.raises(m.MzrError) as e:
+        whole.run(ro)
+    assert e.value.ierr == 10
+    # so does the mainstem domain, which only sees the lake as a halo reach
+    hf = halo_flags(lakes, P.main)
+    assert (hf & 2).sum() == 1 and ((hf & 1) == (P.main.halo_good != 0)).all()
+    main = m.RoutingDomain(P.main.net, 3600.0, [m.KWT], frac_future=ff, max_window=8, halo_reaches=P.main.halo_local, halo_good=hf,
+                           lakes=lakes_for_domain(lakes, P.main, net.N))
+    with pytest.raises(m.MzrError) as e2:      # (the halo rows hold zeros: nothing was imported; the refusal does not depend on them)
+        main.run(ro[:, P.main.hru_global])
+    assert e2.value.ierr == 10
+
+
+def test_boundary_record_that_does_not_fit_is_refused(hip_lib):
+    """The boundary record carries what the sender packed (routing methods, steps, reaches, constituent on / off): a receiver that
+    expects something else -- here the constituent switched on on one side only, and a record of another window length -- raises
+    ierr 20 instead of reading the record at the wrong offsets (what replaces mpi_process.f90:1245-1329 has no MPI datatype to
+    catch it)."""
+    import torch
+    from mizuroute_amd.partition import partition_network
+    net = m.make_network(3000, seed=62)
+    P = partition_network(net, 2)
+    src = next(sp for sp in P.trib if sp.n_real and sp.export_local.size)
+    ff = np.array([0.6, 0.4])
+    W = 6
+    ro = m.make_runoff(net.H, W, seed=3, storm_prob=0.05, storm_amp=2e-6)
+    trib = m.RoutingDomain(src.net, 3600.0, [m.KWT], frac_future=ff, max_window=W, export_reaches=src.export_local)
+    trib.run(ro[:, src.hru_global])
+    n = src.export_local.size
+    rec = torch.zeros(trib.boundary_size(W, n), dtype=torch.float64, device="cuda")
+    trib.export_boundary(rec.data_ptr()); trib.sync()
+    base, cnt = P.main.halo_base[src.part]
+    assert cnt == n
+
+    def mainstem(tracer):
+        d = m.RoutingDomain(P.main.net, 3600.0, [m.KWT], frac_future=ff, max_window=W, halo_reaches=P.main.halo_local, halo_good=P.main.halo_good)
+        if tracer:
+            d.set_tracer(np.zeros((W, max(1, P.main.hru_global.size))), time_conv=1.0, mass_conv=1.0)
+        return d
+
+    ok = mainstem(False)
+    ok.import_boundary(W, rec.data_ptr(), n, base); ok.sync()              # the record fits
+    bad = mainstem(True)                                                      # constituent on one side only
+    bad.import_boundary(W, rec.data_ptr(), n, base)
+    with pytest.raises(m.MzrError) as e:
+        bad.sync()
+    assert e.value.ierr == 20 and "record" in e.value.message
+    bad2 = mainstem(False)                                                    # another window length
+    bad2.import_boundary(W - 1, rec.data_ptr(), n, base)
+    with pytest.raises(m.MzrError) as e:
+        bad2.sync()
+    assert e.value.ierr == 20
