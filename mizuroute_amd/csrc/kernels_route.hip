@@ -514,27 +514,17 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
   if (d.hEle) { stx<COH>(d.hEle + r, ldx<COH>(d.hEle + r) + ldx<COH>(d.ele + r)); stx<COH>(d.hFlood + r, ldx<COH>(d.hFlood + r) + ldx<COH>(d.floodvol + r)); }
 }
 
-// Reach of a lane: the leading nLead blocks serve the method's list of slow reaches (Muskingum-Cunge: mcSlow), the others the
-// range [rBegin, rEnd) without them.  -1 = nothing to do.
-template <int METHOD>
-__device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int block, int nLead, int rBegin, int rEnd) {
-  if (METHOD == 4 && nLead > 0) {
-    if (block < nLead) {
-      const int i = block * (int)blockDim.x + (int)threadIdx.x;
-      if (i >= d.nMcSlow) return -1;
-      const int r = d.mcSlow[i];
-      return (r >= rBegin && r < rEnd) ? r : -1;
-    }
-    const int r = rBegin + (block - nLead) * (int)blockDim.x + (int)threadIdx.x;
-    return (r < rEnd && !d.mcIsSlow[r]) ? r : -1;
-  }
-  const int r = rBegin + block * (int)blockDim.x + (int)threadIdx.x;
-  return r < rEnd ? r : -1;
+// Reach of a lane position p (block-aligned: launches start at a multiple of 256): through the method's lane permutation
+// when there is one (mzr_device.h, lanePerm).  -1 = nothing to do.
+__device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int p, int rBegin, int rEnd) {
+  if (p >= ((rEnd + 255) & ~255)) return -1;
+  const int r = d.lanePerm ? d.lanePerm[p] : p;
+  return (r >= rBegin && r < rEnd) ? r : -1;
 }
 
 template <int METHOD>
-__global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int rEnd, int nLead) {
-  const int r = stage_lane_reach<METHOD>(d, (int)blockIdx.x, nLead, rBegin, rEnd);
+__global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
+  const int r = stage_lane_reach(d, (rBegin & ~255) + (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, rBegin, rEnd);
   if (r < 0) return;
   const int t = s - d.sigma[r];
   if (t < 0 || t >= d.W) return;
@@ -552,13 +542,11 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
 // launches instead of S + W - 1, every one of them over all reaches.  Same arithmetic per reach and step, same order.
 struct MzrDevPair { MzrDev a, b; };
 template <int METHOD>
-__global__ void __launch_bounds__(256) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB, int nLead) {
-  // blocks: [0, nLead) slow reaches of the new window, [nLead, 2 nLead) of the old one, then the new window's range, then the old one's
-  const int b = (int)blockIdx.x;
-  const bool old = b < 2 * nLead ? b >= nLead : b - 2 * nLead >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
+__global__ void __launch_bounds__(256) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
+  const bool old = (int)blockIdx.x >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
   const MzrDev &d = old ? p.a : p.b;
-  const int blk = b < 2 * nLead ? (old ? b - nLead : b) : nLead + (old ? b - 2 * nLead - nBlocksB : b - 2 * nLead);
-  const int r = stage_lane_reach<METHOD>(d, blk, nLead, old ? rBeginA : rBeginB, old ? rEndA : rEndB);
+  const int rB = old ? rBeginA : rBeginB, rE = old ? rEndA : rEndB;
+  const int r = stage_lane_reach(d, (rB & ~255) + ((int)blockIdx.x - (old ? nBlocksB : 0)) * (int)blockDim.x + (int)threadIdx.x, rB, rE);
   if (r < 0) return;
   const int t = (old ? sA : sB) - d.sigma[r];
   if (t < 0 || t >= d.W) return;
@@ -779,16 +767,15 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
   const int nA = std::max(0, rEndA - rBeginA), nB = std::max(0, rEndB - rBeginB);
   if (nA + nB <= 0) return;
   MzrDevPair p; p.a = a; p.b = b;
-  const int nBlocksB = (nB + 255) / 256;
-  const int nLead = (method == 4 && b.nMcSlow > 0 && b.mcSlow == a.mcSlow) ? (b.nMcSlow + 255) / 256 : 0;
-  if (nLead == 0) { p.a.nMcSlow = 0; p.b.nMcSlow = 0; }
-  dim3 block(256), grid(2 * nLead + nBlocksB + (nA + 255) / 256);
+  auto blocks = [](int rB, int rE) { return rE > rB ? (rE - (rB & ~255) + 255) / 256 : 0; };
+  const int nBlocksB = blocks(rBeginB, rEndB);
+  dim3 block(256), grid(nBlocksB + blocks(rBeginA, rEndA));
   switch (method) {
-    case 0: hipLaunchKernelGGL(k_stage_pair<0>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB, 0); break;
-    case 1: hipLaunchKernelGGL(k_stage_pair<1>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB, 0); break;
-    case 3: hipLaunchKernelGGL(k_stage_pair<3>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB, 0); break;
-    case 4: hipLaunchKernelGGL(k_stage_pair<4>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB, nLead); break;
-    case 5: hipLaunchKernelGGL(k_stage_pair<5>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB, 0); break;
+    case 0: hipLaunchKernelGGL(k_stage_pair<0>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 1: hipLaunchKernelGGL(k_stage_pair<1>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 3: hipLaunchKernelGGL(k_stage_pair<3>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 4: hipLaunchKernelGGL(k_stage_pair<4>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 5: hipLaunchKernelGGL(k_stage_pair<5>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
     default: break;
   }
 }
@@ -796,14 +783,13 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {
   const int n = rEnd - rBegin;
   if (n <= 0) return;
-  const int nLead = (method == 4 && d.nMcSlow > 0) ? (d.nMcSlow + 255) / 256 : 0;
-  dim3 block(256), grid(nLead + (n + 255) / 256);
+  dim3 block(256), grid((rEnd - (rBegin & ~255) + 255) / 256);
   switch (method) {
-    case 0: hipLaunchKernelGGL(k_stage<0>, grid, block, 0, stream, d, s, rBegin, rEnd, 0); break;
-    case 1: hipLaunchKernelGGL(k_stage<1>, grid, block, 0, stream, d, s, rBegin, rEnd, 0); break;
-    case 3: hipLaunchKernelGGL(k_stage<3>, grid, block, 0, stream, d, s, rBegin, rEnd, 0); break;
-    case 4: hipLaunchKernelGGL(k_stage<4>, grid, block, 0, stream, d, s, rBegin, rEnd, nLead); break;
-    case 5: hipLaunchKernelGGL(k_stage<5>, grid, block, 0, stream, d, s, rBegin, rEnd, 0); break;
+    case 0: hipLaunchKernelGGL(k_stage<0>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 1: hipLaunchKernelGGL(k_stage<1>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 3: hipLaunchKernelGGL(k_stage<3>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 4: hipLaunchKernelGGL(k_stage<4>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 5: hipLaunchKernelGGL(k_stage<5>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
     default: break;
   }
 }

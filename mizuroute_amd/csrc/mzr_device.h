@@ -125,12 +125,12 @@ struct MzrDev {
   double *irfQ;               // [maxtdh][N]
   // ---- KW / MC / DW molecules
   double *mol;                // [nMol][N]
-  // Muskingum-Cunge: reaches that keep asking for many Courant sub-steps (short, flat reaches: 50-200 every step) go first, in
-  // blocks of their own, so that a launch does not end on the one wavefront that drew such a lane late
-  unsigned short *mcSub;      // [N] sub-steps the reach executed in its last step (written by the kernel, read by the host now and then)
-  const int *mcSlow;          // [nMcSlow] the reaches served by the leading blocks, heaviest first
-  const uint8_t *mcIsSlow;    // [N] 1 = served by a leading block
-  int nMcSlow;
+  // One lane per reach, and a wavefront lasts as long as its slowest lane: Muskingum-Cunge reaches take 2 to 200 Courant sub-steps
+  // (the same reaches step after step), the IRF convolution runs over 1 to maxtdh taps.  The reaches of every aligned block of
+  // 256 are therefore dealt to the block's four wavefronts by that count (lanePerm: position -> reach, a permutation inside
+  // each block, so every reach is still served exactly once and the block still touches the same 256-reach span of every array)
+  unsigned short *mcSub;      // [N] Muskingum-Cunge sub-steps the reach executed in its last step (written by the kernel, read by the host now and then)
+  const int *lanePerm;        // [ceil(N / 256) * 256] or null: reach served by a lane position (-1 = none)
   // ---- KWT
   int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
   double *kwQT, *kwTR;        // [N][MZR_KW_STRIDE][2] {Q, TI} pairs; [N][MZR_KW_STRIDE] expected exit times (state only: written at the last step of a window)

@@ -71,7 +71,8 @@ struct RouteBufs {
   DBuf<double> vol, vol0, inflow, ele, floodvol, wb, qsum, wmact;   // [N]
   DBuf<double> hInflow, hEle, hFlood;               // [N] history sums beyond discharge (mzr_set_history)
   DBuf<double> mol;                                 // [nMol][N]
-  DBuf<unsigned short> mcSub; DBuf<int> mcSlow; DBuf<uint8_t> mcIsSlow; int nMcSlow = 0; long long mcWindows = 0;   // Muskingum-Cunge: sub-steps per reach, the reaches that go first
+  DBuf<unsigned short> mcSub; long long mcWindows = 0;   // Muskingum-Cunge: sub-steps per reach as the kernel leaves them
+  DBuf<int> lanePerm; bool havePerm = false;           // reaches of every aligned block of 256 dealt to its wavefronts by loop trip count (mzr_device.h)
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
   DBuf<int> rtDone, rtHead;                         // persistent sweep of an Eulerian method: progress per reach, ticket counters
@@ -363,7 +364,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
   d.rtDone = rb.rtDone.p; d.rtHead = rb.rtHead.p;
-  d.mcSub = rb.mcSub.p; d.mcSlow = rb.mcSlow.p; d.mcIsSlow = rb.mcIsSlow.p; d.nMcSlow = rb.nMcSlow;
+  d.mcSub = rb.mcSub.p; d.lanePerm = rb.havePerm ? rb.lanePerm.p : nullptr;
   d.qobs = rb.qobs.p; d.qerr = rb.qerr.p; d.qelapsed = rb.qelapsed.p;
   d.solFlux = rb.solFlux.p; d.solMass = rb.solMass.p; d.trVol0 = h->tracer ? rb.trVol0.p : nullptr;
 }
@@ -699,6 +700,7 @@ void kwt_sweep_tables(mzr_handle h, int W) {
 
 static int flushSteps(mzr_handle h);
 static void flushTail(mzr_handle h);
+static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key);
 // steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first ...
 #define MZR_FLUSH_STEPS(h) do { if ((h) && (h)->stepN > 0) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
 // ... and so do the launches of the last window that were kept back for the next one (overlapping windows): every entry point
@@ -1324,10 +1326,15 @@ int mzr_init_state(mzr_handle h) {
         if (h->rtTablesW != -2) { rt_build_items(h); h->rtTablesW = -2; }      // once per mzr_init_state (-2: built, tables not yet)
       }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
-      if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); rb.mcSub.alloc(N); rb.mcSub.zero(); rb.mcIsSlow.alloc(N); rb.mcIsSlow.zero(); rb.nMcSlow = 0; }
+      if (m == MZR_MC) { rb.mol.alloc((size_t)MZR_NMOL_MC * N); rb.mol.zero(); rb.mcSub.alloc(N); rb.mcSub.zero(); rb.havePerm = false; }
       if (m == MZR_IRF) {
         if (h->maxtdh < 1) return fail(h, 20, "mzr_init_state/reach unit hydrographs not set (IRF)");
         h->irfQ.alloc((size_t)h->maxtdh * N); h->irfQ.zero();
+        {      // the convolution runs over ntdh taps of the reach: wavefronts of like reaches (build_lane_perm)
+          std::vector<uint16_t> nt(N);
+          (void)hipMemcpy(nt.data(), h->ntdh.p, N * sizeof(uint16_t), hipMemcpyDeviceToHost);
+          build_lane_perm(h, ix, std::vector<int>(nt.begin(), nt.end()));
+        }
       }
       if (m == MZR_KWT) {
         if ((size_t)h->h_slope.size() != N || (size_t)h->h_mann.size() != N) return fail(h, 20, "mzr_init_state/R_SLOPE and R_MAN_N must be set before KWT state is initialised");
@@ -1429,12 +1436,32 @@ int mzr_init_state(mzr_handle h) {
 // reach holds changes slowly, so every now and then the routed list of each stage is regrouped by
 // the particle counts of the last step: saturated reaches share wavefronts, light ones do too, and
 // reaches that hold only a few particles go to the class that gives them 8 lanes instead of 16.
-// Muskingum-Cunge: which reaches keep taking many Courant sub-steps (mc_route.f90:283-330: ntSub = ceil(dt / L * celerity) --
-// short reaches with a fast wave, the same ones step after step).  One lane per reach, so a launch lasts as long as its
-// slowest lane, and a hundred such lanes scattered over the wavefronts of a launch decide how long ALL of them take.  They
-// are listed here (from the sub-step counts the kernel leaves behind), heaviest first, and served by the leading blocks of
-// every launch (kernels_route.hip, stage_lane_reach): dispatched first, slow lanes with slow lanes.  Which reach is served
-// by which block changes nothing in the results.
+// One lane per reach in the Eulerian stage kernels: a wavefront lasts as long as its slowest lane.  Muskingum-Cunge reaches take
+// 2 to 200 Courant sub-steps (mc_route.f90:283-330: ntSub = ceil(dt / L * celerity) -- short reaches with a fast wave, the same
+// ones step after step), the IRF convolution 1 to maxtdh taps (irf_route.f90:210-264).  The reaches of every aligned block of 256
+// lane positions are dealt to the block's four wavefronts by that count, largest first (lanePerm): slow lanes sit with slow
+// lanes.  A permutation inside each block: every reach is served exactly once, by whichever lane -- results cannot change.
+static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key) {
+  RouteBufs &rb = h->route[ix];
+  const int N = h->N, Np = (N + 255) & ~255;
+  std::vector<int> perm(Np, -1);
+  std::vector<std::pair<int, int>> blk;
+  bool any = false;
+  for (int b0 = 0; b0 < N; b0 += 256) {
+    blk.clear();
+    for (int r = b0; r < std::min(N, b0 + 256); ++r) blk.emplace_back(-key[r], r);
+    std::stable_sort(blk.begin(), blk.end());
+    if (blk.front().first != blk.back().first) any = true;
+    for (size_t k = 0; k < blk.size(); ++k) perm[b0 + k] = blk[k].second;
+  }
+  if (const char *e = getenv("MZR_LANE_PERM")) if (atoi(e) == 0) any = false;
+  try {
+    if (!rb.lanePerm.p) rb.lanePerm.alloc(Np);      // allocated once: a window kept back may still point at it
+    if (any) (void)hipMemcpy(rb.lanePerm.p, perm.data(), (size_t)Np * sizeof(int), hipMemcpyHostToDevice);
+    rb.havePerm = any;
+  } catch (const std::string &) { rb.havePerm = false; }
+}
+
 static void mc_regroup(mzr_handle h, int ix) {
   RouteBufs &rb = h->route[ix];
   if (!rb.mcSub.p) return;
@@ -1443,19 +1470,8 @@ static void mc_regroup(mzr_handle h, int ix) {
   if (h->routeStream[ix]) (void)hipStreamSynchronize(h->routeStream[ix]);
   std::vector<unsigned short> sub(N);
   if (hipMemcpy(sub.data(), rb.mcSub.p, (size_t)N * sizeof(unsigned short), hipMemcpyDeviceToHost) != hipSuccess) return;
-  int thr = 6;
-  if (const char *e = getenv("MZR_MC_SLOW_MIN")) thr = atoi(e);
-  std::vector<std::pair<int, int>> key;
-  if (thr > 0) for (int r = 0; r < N; ++r) if (sub[r] >= thr) key.emplace_back(-(int)sub[r], r);
-  if ((int)key.size() > N / 8) key.clear();      // (most reaches are slow: nothing to single out)
-  std::sort(key.begin(), key.end());
-  std::vector<int> list; std::vector<uint8_t> flag(N, 0);
-  for (const auto &k : key) { list.push_back(k.second); flag[k.second] = 1; }
-  try {
-    if (list.empty()) { rb.nMcSlow = 0; }
-    else { rb.mcSlow.upload(list); rb.nMcSlow = (int)list.size(); }
-    (void)hipMemcpy(rb.mcIsSlow.p, flag.data(), (size_t)N, hipMemcpyHostToDevice);
-  } catch (const std::string &) { rb.nMcSlow = 0; }
+  std::vector<int> key(sub.begin(), sub.end());
+  build_lane_perm(h, ix, key);
 }
 
 static void kwt_regroup(mzr_handle h) {

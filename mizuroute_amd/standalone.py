@@ -167,20 +167,28 @@ def augment_topology(seg_id, down_id, length, slope, hru_id, hru_seg, hru_area, 
     hruOffset = np.zeros(N + 1, dtype=np.int32); hruOffset[1:] = np.cumsum(cnt)
     hruIndex = (order + 1).astype(np.int32)
     # the reference sums a reach's HRU areas one after the other in file order (network_topo.f90:160-190)
+    # (position by position over the ragged lists: the j-th HRU of every reach at once -- the same left-to-right additions)
     basarea = np.zeros(N)
-    for h in order:
-        basarea[seg_of_hru[h]] = basarea[seg_of_hru[h]] + hru_area[h]
+    for j in range(int(cnt.max()) if cnt.size else 0):
+        has = np.nonzero(cnt > j)[0]
+        basarea[has] = basarea[has] + hru_area[order[hruOffset[has] + j]]
     w = np.where(basarea[seg_of_hru[order]] > 0, hru_area[order] / np.where(basarea[seg_of_hru[order]] > 0, basarea[seg_of_hru[order]], 1.0), 0.0)
     down0 = downIndex.astype(np.int64) - 1
     dist = hops_to_outlet(down0)
     # area above a reach: its upstream reaches' total areas added in upstream-list order, headwaters first (reachOrder)
+    # (level by level from the headwaters, and within a level the j-th upstream reach of every reach at once: the same additions in
+    # the same order as the reference's loop over the upstream list)
     totarea = basarea.copy()
-    for dlev in range(int(dist.max()), -1, -1):
-        for r in np.nonzero(dist == dlev)[0]:
-            ups = 0.0
-            for e in range(upOffset[r], upOffset[r + 1]):
-                ups = ups + totarea[upIndex[e] - 1]
-            totarea[r] = basarea[r] + ups
+    nup = np.diff(upOffset).astype(np.int64)
+    by_level = np.argsort(-dist, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(np.bincount(int(dist.max()) - dist, minlength=int(dist.max()) + 1))]) if N else np.zeros(1, np.int64)
+    for lv in range(bounds.size - 1):
+        rs = by_level[bounds[lv]:bounds[lv + 1]]
+        ups = np.zeros(rs.size)
+        for j in range(int(nup[rs].max()) if rs.size else 0):
+            has = np.nonzero(nup[rs] > j)[0]
+            ups[has] = ups[has] + totarea[upIndex[upOffset[rs[has]] + j] - 1]
+        totarea[rs] = basarea[rs] + ups
     width = nml["wscale"] * np.sqrt(totarea)
     rdepth = np.full(N, HIGH_DEPTH)
     side = np.zeros(N)

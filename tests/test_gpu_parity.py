@@ -1060,10 +1060,22 @@ def test_kwt_lake_at_a_tributary_outlet_reaches_the_mainstem_as_a_lake(hip_lib):
     assert e.value.ierr == 10
     # so does the mainstem domain, which only sees the lake as a halo reach
     hf = halo_flags(lakes, P.main)
-    assert (hf & 2).sum() == 1 and ((hf & 1) == (P.main.halo_good != 0)).all()
+    assert ((hf & 2) != 0).sum() == 1 and ((hf & 1) == (P.main.halo_good != 0)).all()
     main = m.RoutingDomain(P.main.net, 3600.0, [m.KWT], frac_future=ff, max_window=8, halo_reaches=P.main.halo_local, halo_good=hf,
                            lakes=lakes_for_domain(lakes, P.main, net.N))
-    with pytest.raises(m.MzrError) as e2:      # (the halo rows hold zeros: nothing was imported; the refusal does not depend on them)
+    import torch
+    for sp in P.trib:                                   # the tributaries' records of the window, as the exchange would deliver them
+        if not (sp.n_real and sp.export_local.size):
+            continue
+        td = m.RoutingDomain(sp.net, 3600.0, [m.KWT], frac_future=ff, max_window=8, export_reaches=sp.export_local,
+                             lakes=lakes_for_domain(lakes, sp, net.N))
+        td.run(ro[:, sp.hru_global])
+        rec = torch.zeros(td.boundary_size(8, sp.export_local.size), dtype=torch.float64, device="cuda")
+        td.export_boundary(rec.data_ptr()); td.sync()
+        base, n = P.main.halo_base[sp.part]
+        main.import_boundary(8, rec.data_ptr(), n, base); main.sync()
+        td.close()
+    with pytest.raises(m.MzrError) as e2:
         main.run(ro[:, P.main.hru_global])
     assert e2.value.ierr == 10
 

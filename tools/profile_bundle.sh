@@ -5,13 +5,13 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 o=gpurun_out/$tag; rm -rf $o; mkdir -p $o
-python bench.py > $o/bench.json 2> $o/bench.err
+python bench.py --no-configs > $o/bench.json 2> $o/bench.err
 tail -c 600 $o/bench.json
-ARGS="--no-cpu-baseline --no-roofline --no-h2d --no-single-step --window 16384 --steps 2 --warmup 3"      # (two regroupings behind it: the last windows are steady)
+ARGS="--no-cpu-baseline --no-roofline --no-h2d --no-single-step --no-configs --window 16384 --steps 2 --warmup 3"      # (two regroupings behind it: the last windows are steady)
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -o k -- python bench.py $ARGS > $o/stats.log 2>&1
 bash tools/pmc.sh ${tag}_100k "python bench.py $ARGS" > $o/pmc_100k.log 2>&1
 # 400 k reaches: rows no longer fit the 256 MiB Infinity Cache
-ARGS4="--no-cpu-baseline --no-h2d --no-single-step --reaches 400000 --window 2048 --steps 2 --warmup 2"
+ARGS4="--no-cpu-baseline --no-h2d --no-single-step --no-configs --reaches 400000 --window 2048 --steps 2 --warmup 2"
 python bench.py $ARGS4 > $o/bench_400k.json 2> $o/bench_400k.err
 tail -c 400 $o/bench_400k.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_400k -o k -- python bench.py $ARGS4 --no-roofline > $o/stats_400k.log 2>&1
