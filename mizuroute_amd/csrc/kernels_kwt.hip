@@ -638,6 +638,23 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_POOL
 #define MZR_KWT_POOL 240   // entries of each of the four LDS work arrays of a wavefront: 60 per 16-lane reach, 30 per 8-lane reach
 #endif
+// Instruction accounting (tools/kwt_dup.sh): a section executed MZR_DUP_x times leaves the same results and, under
+// rocprofv3 --pmc SQ_INSTS_VALU, its instruction count as the difference to the plain build
+#ifndef MZR_DUP_MERGE
+#define MZR_DUP_MERGE 1
+#endif
+#ifndef MZR_DUP_THIN
+#define MZR_DUP_THIN 1
+#endif
+#ifndef MZR_DUP_KINWAV
+#define MZR_DUP_KINWAV 1
+#endif
+#ifndef MZR_DUP_INTERP
+#define MZR_DUP_INTERP 1
+#endif
+#ifndef MZR_THIN_LDS
+#define MZR_THIN_LDS 1     // remove_rch with the errors and the alive list in LDS (0: in registers and a bit mask, rounds 2-3)
+#endif
 #ifndef MZR_KWT_KTB
 #define MZR_KWT_KTB 4      // entries per lane an 8-lane group can thin (capacity 8 * KTB - 1, and at most its slice of the pool)
 #endif
@@ -877,26 +894,33 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           const int nA = ns > 0 ? nrA - 2 : 0, nB = ns > 1 ? nrB - 2 : 0;
           ND = nA + nB + 1;
           bool slow = false;
-          for (int m = gl; m < ND; m += G) {
+#pragma unroll 1
+          for (int _rep = 0; _rep < MZR_DUP_MERGE; ++_rep) {
+          if (MZR_DUP_MERGE > 1) asm volatile("" ::: "memory");
+          {   // the particle at T1, led by the first basin series: once per reach (every lane of the group the same; it used to sit
+              // in the loop below, where one lane of one group makes the whole wavefront issue it in every turn)
+            const double CT = T1;
+            double Q_AGG = 0.0;
+            Q_AGG = Q_AGG + bs.b0q1 * bs.bsc;
+            if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
+            if (ns > 0) {
+              const double tb = SAt[nA], te = SAt[nA + 1], qb = SAq[nA], qe = SAq[nA + 1];
+              if (te < CT || tb > CT) slow = true;
+              const double SLOPE = (qe - qb) / (te - tb);
+              Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scA;
+            }
+            if (ns > 1) {
+              const double tb = SBt[nB], te = SBt[nB + 1], qb = SBq[nB], qe = SBq[nB + 1];
+              if (te < CT || tb > CT) slow = true;
+              const double SLOPE = (qe - qb) / (te - tb);
+              Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scB;
+            }
+            if (gl == 0) { QD[nA + nB] = Q_AGG; TD[nA + nB] = CT; }
+          }
+          for (int m = gl; m < nA + nB; m += G) {
             double CT, Q_AGG = 0.0;
             int pos = m;
-            if (m == nA + nB) {   // the particle at T1, led by the first basin series
-              CT = T1;
-              Q_AGG = Q_AGG + bs.b0q1 * bs.bsc;
-              if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
-              if (ns > 0) {
-                const double tb = SAt[nA], te = SAt[nA + 1], qb = SAq[nA], qe = SAq[nA + 1];
-                if (te < CT || tb > CT) slow = true;
-                const double SLOPE = (qe - qb) / (te - tb);
-                Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scA;
-              }
-              if (ns > 1) {
-                const double tb = SBt[nB], te = SBt[nB + 1], qb = SBq[nB], qe = SBq[nB + 1];
-                if (te < CT || tb > CT) slow = true;
-                const double SLOPE = (qe - qb) / (te - tb);
-                Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scB;
-              }
-            } else {
+            {
               const bool isA = m < nA;
               const int i = isA ? m + 1 : m - nA + 1;                 // index in the own series
               const double *St = isA ? SAt : SBt, *Sq = isA ? SAq : SBq;
@@ -921,17 +945,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
                   slow = slow || tu == CT;
                 }
               } else {
-                int lo = 0, hi = nO;                       // cnt in [lo, hi]
-                const int nbis = 32 - __clz(nA > nB ? nA : nB);
-#pragma unroll 1
-                for (int it = 0; it < nbis; ++it) {        // nO <= 19 < 32
-                  const int mid = (lo + hi) >> 1;
-                  const double tm = Ot[mid + 1 <= nO ? mid + 1 : (nO > 0 ? nO : 1)];
-                  const bool less = lo < hi && tm < CT;
-                  lo = less ? mid + 1 : lo;
-                  hi = (lo < hi && !less) ? mid : hi;
+                // cnt = how many of Ot[1..nO] (ascending) are earlier than CT: five probes at 16, 8, 4, 2, 1 (nO <= 19 < 32)
+#pragma unroll
+                for (int st = 16; st >= 1; st >>= 1) {
+                  const int pr = cnt + st;
+                  const double tm = Ot[pr <= nO ? pr : 0];
+                  cnt = (pr <= nO && tm < CT) ? pr : cnt;
                 }
-                cnt = lo;
                 if (cnt < nO && Ot[cnt + 1] == CT) slow = true;
               }
               pos = (i - 1) + cnt;
@@ -951,6 +971,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             }
             QD[pos] = Q_AGG; TD[pos] = CT;
             TSTAMP(12);
+          }
           }
           if (grp_any<G>(slow)) {
             KCOUNT(8, 1);
@@ -1042,7 +1063,67 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
             // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
             constexpr int KT = G >= 16 ? 64 / G : MZR_KWT_KTB;      // entries before thinning: at most 60 (16 lanes), 8 * KTB - 1 (8 lanes)
+#if MZR_THIN_LDS
+            // Round 4: the errors and the alive list live in LDS -- Xw[i] = error of particle i, Yw[i] = {previous, next alive
+            // particle} -- instead of four registers per lane and a 64-bit mask per lane: a removal costs one broadcast read of
+            // the removed particle's links, one read of the neighbour's links (even lanes the lower, odd lanes the upper
+            // neighbour), the six values of the re-evaluation, and three small writes; what it no longer costs is the patch of
+            // the register copies (three compares and six selects per slot) and the 64-bit mask arithmetic that found the
+            // neighbours (VALU issue is what bounds the sweep).  Same errors, same MINLOC order, same survivors.
+            const bool side = gl & 1;
+            double *E = Xw;
+            int2 *L = (int2 *)Yw;
+#pragma unroll 1
+            for (int _rep = 0; _rep < MZR_DUP_THIN; ++_rep) {
+            if (MZR_DUP_THIN > 1) { asm volatile("" ::: "memory"); MPRT = NPRT; }
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+              const int i = gl + j * G;
+              if (i <= NPRT) {
+                double ei = DBL_MAX;
+                if (i >= 1 && i < NPRT) ei = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
+                E[i] = ei; L[i] = make_int2(i - 1, i + 1);
+              }
+            }
+            grp_sync();
+            int ISEL = 0;
+            while (MPRT >= MZR_MAXQPAR_DEV) {
+              double ev[KT];
+#pragma unroll
+              for (int j = 0; j < KT; ++j) { const int i = gl + j * G; ev[j] = i <= NPRT ? E[i] : DBL_MAX; }
+              double emin = DBL_MAX; ISEL = 0;
+#pragma unroll
+              for (int j = 0; j < KT; ++j) if (ev[j] < emin) { emin = ev[j]; ISEL = gl + j * G; }
+              ISEL = grp_argmin_pos<G>(emin, ISEL);         // first minimum of ABSERR (removed entries hold +Inf)
+              if (ISEL == 0 || ISEL == 0x7fffffff) { ISEL = 0; break; }   // no finite interpolation error left (NaN/Inf input)
+              const int2 ls = L[ISEL];                     // INDEX1(ISEL - 1), INDEX1(ISEL + 1)
+              const int c = side ? ls.y : ls.x;
+              const int2 lc = L[c];
+              const bool valid = side ? c < NPRT : c > 0;
+              const int a = !valid ? c : side ? ls.x : lc.x, b = !valid ? c : side ? lc.y : ls.y;
+              const double en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
+              grp_sync();
+              if (gl < 2) { L[c] = make_int2(side ? ls.x : lc.x, side ? lc.y : ls.y); if (valid) E[c] = en; }
+              if (gl == 2) E[ISEL] = INFINITY;              // removed: never the minimum again
+              grp_sync();
+              --MPRT;
+            }
+            }
+            {   // who is left
+              mask = 0ull;
+#pragma unroll
+              for (int j = 0; j < KT; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && E[i <= NPRT ? i : 0] != INFINITY) << (j * G); }
+              grp_sync();
+            }
+#else
             double e[KT];
+            const unsigned long long mask0 = mask;
+            unsigned long long x = 0;
+            const bool side = gl & 1;
+            int ISEL = 0;
+#pragma unroll 1
+            for (int _rep = 0; _rep < MZR_DUP_THIN; ++_rep) {
+            if (MZR_DUP_THIN > 1) { asm volatile("" ::: "memory"); MPRT = NPRT; }
 #pragma unroll
             for (int j = 0; j < KT; ++j) {
               const int i = gl + j * G;
@@ -1053,9 +1134,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // removed particle; odd lanes hold it bit-reversed (bit 63-i) and re-evaluate the neighbour above, so that
             // both sides run the same "nearest alive bit below" twice; the first neighbour of the other side comes
             // through the lane pair.
-            const bool side = gl & 1;
-            unsigned long long x = side ? __brevll(mask) : mask;
-            int ISEL = 0;
+            x = side ? __brevll(mask0) : mask0;
+            ISEL = 0;
             while (MPRT >= MZR_MAXQPAR_DEV) {
               double emin = DBL_MAX; ISEL = 0;
 #pragma unroll
@@ -1088,7 +1168,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               }
               --MPRT;
             }
+            }
             mask = side ? __brevll(x) : x;
+#endif
           } else {
           for (int i = gl; i <= NPRT; i += G) {
             double e = DBL_MAX;
@@ -1170,6 +1252,12 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           // cw = ALFA*K**(1/ALFA) with K = sqrt(R_SLOPE)/R_MAN_N and ALFA = 5/3, XMX = RLENGTH: from the record (host, once)
           const double cw = rc[3], XMX = rc[4];
           double wcs[KS], rws[KS];     // celerity of the lane's own particles and its reciprocal
+          bool shock = false;
+          double tes[KS];
+          bool zero = false;
+#pragma unroll 1
+          for (int _rep = 0; _rep < MZR_DUP_KINWAV; ++_rep) {
+          if (MZR_DUP_KINWAV > 1) asm volatile("" ::: "memory");
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
@@ -1185,7 +1273,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           // below is skipped.
           // (The search keeps the smallest crossing point in [0, XMX] and gives up when that is XMX itself, :1301-1322: a wave
           // breaks iff SOME pair crosses inside [0, XMX) -- one vote of the group instead of an arg-min.)
-          bool shock = false;
+          shock = false;
           if (NI > 1) {
             bool cross = false;
 #pragma unroll
@@ -1195,8 +1283,12 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
                 const double wcj = wcs[sl], wci = Xw[jw + 1], tj = Tw[jw], ti = Tw[jw + 1];
                 if (!(wci == 0.0 || wcj == 0.0) && !(wcj > wci && ti > tj)) {
                   const double WDIFF = rws[sl] - Yw[jw + 1];
-                  if (!(WDIFF == 0.0) && !(wci == wcj)) {
-                    const double XXB = (ti - tj) / WDIFF;
+                  // (a later, faster wave always catches up somewhere; nearly always far beyond the end of the reach.  The quotient
+                  // is only formed where the product cannot rule that out: (ti - tj) > XMX * WDIFF * (1 + 1e-9) with both
+                  // positive means (ti - tj) / WDIFF > XMX whatever the two roundings do)
+                  const double dtt = ti - tj;
+                  if (!(WDIFF == 0.0) && !(wci == wcj) && !(WDIFF > 0.0 && dtt > (XMX * WDIFF) * (1.0 + 1.e-9))) {
+                    const double XXB = dtt / WDIFF;
                     if (!(XXB < 0.0 || XXB > XMX) && XXB < XMX) cross = true;
                   }
                 }
@@ -1204,9 +1296,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             }
             shock = grp_any<G>(cross);
           }
+          zero = false;
           if (!shock) {
-            bool zero = false;
-            double tes[KS];
 #pragma unroll
             for (int sl = 0; sl < KS; ++sl) {
               const int h = gl + sl * G;
@@ -1220,6 +1311,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
                 }
               }
             }
+          }
+          }      // (MZR_DUP_KINWAV)
+          if (!shock) {
             if (grp_any<G>(zero)) { mzr_raise(d, 20, r, t, 13); break; }
             grp_sync();          // the neighbours have read the celerities this overwrites
 #pragma unroll
@@ -1406,7 +1500,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           TSTAMP(26);
         }
         double QNEW;
-        if (grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW)) { mzr_raise(d, 1, r, t, 15); break; }
+        int _ibad = 0;
+#pragma unroll 1
+        for (int _rep = 0; _rep < MZR_DUP_INTERP; ++_rep) {
+          if (MZR_DUP_INTERP > 1) asm volatile("" ::: "memory");
+          _ibad = grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW);
+        }
+        if (_ibad) { mzr_raise(d, 1, r, t, 15); break; }
         TSTAMP(17);
         const double Qout = QNEW * rc[2] + ctx[1];
         // (the history sum of REACH_Q is taken from the Q rows once per window, k_accum_qsum)
