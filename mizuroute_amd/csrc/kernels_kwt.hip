@@ -504,6 +504,54 @@ __device__ __forceinline__ int grp_interp_rch(const double *TOLD, const double *
   return 0;
 }
 
+// interp_rch as kwt_rch calls it for the time-step average (:257-311): the exit times X(0:NR+1) of the particles routed in this
+// step with the last one routed before (X(0) <= T0 < X(1): the +1 s fix of kinwav) and the first one still waiting
+// (X(NR) < T1 <= X(NR+1): that is what NR counts), strictly increasing.  Then the two index searches of interp_rch are known
+// beforehand -- IBEG = 2, IEND = NOLD -- and are only VERIFIED here (four broadcast reads, one vote of the wavefront; anything
+// else goes through the general routine above).  The leading and the trailing partial trapezoid are one instruction sequence
+// on even / odd lanes, the interior trapezoids one per lane, and the running sum -- the reference's order -- takes its terms
+// from LDS with constant offsets, six at a time.  Same operations on the same operands as interp_rch, term for term.
+template <int G, int KS>
+__device__ __forceinline__ int grp_interp_step(const double *X, const double *Q, double *TERM, int NOLD, double T0, double T1, int gl, double *QNEW) {
+  const double x0 = X[0], x1 = X[1], xl = X[NOLD - 1], xp = X[NOLD - 2];
+  const bool ok = NOLD >= 2 && x0 <= T0 && T0 <= x1 && T1 <= xl && (NOLD == 2 || xp < T1);
+  if (__ballot(!ok) != 0ull) return grp_interp_rch<G, KS>(X, Q, TERM, NOLD, T0, T1, gl, QNEW);
+  // ---- partial trapezoids: even lanes the one that starts at T0 (between points 1 and 2), odd lanes the one that ends at T1
+  // (between points NOLD-1 and NOLD); with NOLD = 2 they are the same segment and QNEW is the mean of the two estimates
+  const bool side = gl & 1;
+  const int ia = side ? NOLD - 2 : 0, ib = ia + 1;              // 0-based
+  const double tA = X[ia], tB = X[ib], qA = Q[ia], qB = Q[ib];
+  const double Tq = side ? T1 : T0;
+  const double SLOPE = (qB - qA) / (tB - tA);
+  const double QEST = SLOPE * (Tq - tA) + qA;
+  const double part = side ? (T1 - tA) * 0.5 * (qA + QEST) : (tB - T0) * 0.5 * (QEST + qB);
+  const double estO = dpp_d<0xF5>(QEST), estE = dpp_d<0xA0>(QEST);        // quad_perm [1,1,3,3] / [0,0,2,2]: the odd / even lane of the pair
+  if (NOLD == 2 || T1 < x1) {      // T1 < T(IBEG): both ends of the interval on one segment (:1545-1552)
+    *QNEW = 0.5 * (estE + estO);
+    // (uniform per group, but not per wavefront: the other groups go on)
+  }
+  double AREAB = dpp_d<0xA0>(part), AREAE = dpp_d<0xF5>(part);
+  if (!(T0 < x1)) AREAB = 0.0;
+  if (!(T1 < xl)) AREAE = 0.0;
+  // ---- interior trapezoids between points i-1 and i (1-based i = 3 .. NOLD-1, and NOLD when T1 sits on the last point)
+#pragma unroll
+  for (int sl = 0; sl < KS; ++sl) {
+    const int i = gl + sl * G + 1;
+    if (i >= 3 && i <= NOLD) TERM[i - 1] = (X[i - 1] - X[i - 2]) * 0.5 * (Q[i - 2] + Q[i - 1]);
+  }
+  grp_sync();
+  double AREAM = 0.0;
+  const int cnt = NOLD - 3 + ((T1 == xl && T0 < xp) ? 1 : 0);      // terms 3 .. NOLD-1 (+ NOLD)
+  const double *tp = TERM + 2;
+#pragma unroll 1
+  for (int k0 = 0; __ballot(k0 < cnt) != 0ull; k0 += 6) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double v = tp[k0 + k]; if (k0 + k < cnt) AREAM = AREAM + v; }
+  }
+  if (!(NOLD == 2 || T1 < x1)) *QNEW = (AREAB + AREAE + AREAM) / (T1 - T0);
+  return 0;
+}
+
 #ifdef MZR_KWT_TIMING
 #define KCOUNT(i, v) do { if (gl == 0) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(v)); } while (0)
 #define TSTAMP(i) do { const long long _n = clock64(); _sec[i] += (unsigned)(_n - _tprev); if ((blockIdx.x & 15) == 0 && (threadIdx.x & 63) == __ffsll(__ballot(1)) - 1) atomicAdd(&d.dbgCycles[(((blockIdx.x >> 4) & 1023) << 5) + (i)], (unsigned long long)(_n - _tprev)); _tprev = _n; } while (0)
@@ -652,6 +700,18 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_DUP_INTERP
 #define MZR_DUP_INTERP 1
 #endif
+#ifndef MZR_DUP_COUNT
+#define MZR_DUP_COUNT 1
+#endif
+#ifndef MZR_DUP_STORES
+#define MZR_DUP_STORES 1
+#endif
+#ifndef MZR_DUP_WAIT
+#define MZR_DUP_WAIT 1
+#endif
+#ifndef MZR_DUP_STAGE
+#define MZR_DUP_STAGE 1
+#endif
 #ifndef MZR_THIN_LDS
 #define MZR_THIN_LDS 1     // remove_rch with the errors and the alive list in LDS (0: in registers and a bit mask, rounds 2-3)
 #endif
@@ -736,6 +796,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
       else if (!SPLIT && gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
     if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
+    for (int _rep = 1; _rep < MZR_DUP_WAIT; ++_rep) { asm volatile("" ::: "memory"); if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2; }
 #ifndef MZR_NO_PRIO
     if (G >= 16 && !boost) __builtin_amdgcn_s_setprio(2);
 #endif
@@ -864,7 +925,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
           for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
         }
+#pragma unroll 1
+        for (int _rep = 0; _rep < MZR_DUP_STAGE; ++_rep)
         if (binary) {
+          if (MZR_DUP_STAGE > 1) asm volatile("" ::: "memory");
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
             const int k = gl + j * G;
@@ -1073,27 +1137,38 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             const bool side = gl & 1;
             double *E = Xw;
             int2 *L = (int2 *)Yw;
+            // (most lists that thin hold fewer than 2 G particles: the slots beyond the second are only looked at when some
+            // group of the wavefront needs them)
+            constexpr int KN = KT < 2 ? KT : 2;
+            const bool wide = KT > KN && __ballot(NPRT >= KN * G) != 0ull;
 #pragma unroll 1
             for (int _rep = 0; _rep < MZR_DUP_THIN; ++_rep) {
             if (MZR_DUP_THIN > 1) { asm volatile("" ::: "memory"); MPRT = NPRT; }
-#pragma unroll
-            for (int j = 0; j < KT; ++j) {
+            auto err0 = [&](int j) {
               const int i = gl + j * G;
               if (i <= NPRT) {
                 double ei = DBL_MAX;
                 if (i >= 1 && i < NPRT) ei = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
                 E[i] = ei; L[i] = make_int2(i - 1, i + 1);
               }
+            };
+#pragma unroll
+            for (int j = 0; j < KN; ++j) err0(j);
+            if (wide) {
+#pragma unroll
+              for (int j = KN; j < KT; ++j) err0(j);
             }
             grp_sync();
             int ISEL = 0;
             while (MPRT >= MZR_MAXQPAR_DEV) {
-              double ev[KT];
-#pragma unroll
-              for (int j = 0; j < KT; ++j) { const int i = gl + j * G; ev[j] = i <= NPRT ? E[i] : DBL_MAX; }
               double emin = DBL_MAX; ISEL = 0;
+              auto take = [&](int j) { const int i = gl + j * G; const double ev = i <= NPRT ? E[i] : DBL_MAX; if (ev < emin) { emin = ev; ISEL = i; } };
 #pragma unroll
-              for (int j = 0; j < KT; ++j) if (ev[j] < emin) { emin = ev[j]; ISEL = gl + j * G; }
+              for (int j = 0; j < KN; ++j) take(j);
+              if (wide) {
+#pragma unroll
+                for (int j = KN; j < KT; ++j) take(j);
+              }
               ISEL = grp_argmin_pos<G>(emin, ISEL);         // first minimum of ABSERR (removed entries hold +Inf)
               if (ISEL == 0 || ISEL == 0x7fffffff) { ISEL = 0; break; }   // no finite interpolation error left (NaN/Inf input)
               const int2 ls = L[ISEL];                     // INDEX1(ISEL - 1), INDEX1(ISEL + 1)
@@ -1112,7 +1187,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             {   // who is left
               mask = 0ull;
 #pragma unroll
-              for (int j = 0; j < KT; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && E[i <= NPRT ? i : 0] != INFINITY) << (j * G); }
+              for (int j = 0; j < KN; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && E[i <= NPRT ? i : 0] != INFINITY) << (j * G); }
+              if (wide) {
+#pragma unroll
+                for (int j = KN; j < KT; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && E[i <= NPRT ? i : 0] != INFINITY) << (j * G); }
+              }
               grp_sync();
             }
 #else
@@ -1464,8 +1543,12 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 
         // ---- time-step average and housekeeping, kwt_rch :257-311
         int NR = 0;
+#pragma unroll 1
+        for (int _rep = 0; _rep < MZR_DUP_COUNT; ++_rep) {
+        if (MZR_DUP_COUNT > 1) { asm volatile("" ::: "memory"); NR = 0; }
 #pragma unroll
         for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
+        }
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         TSTAMP(16);
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
@@ -1504,7 +1587,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll 1
         for (int _rep = 0; _rep < MZR_DUP_INTERP; ++_rep) {
           if (MZR_DUP_INTERP > 1) asm volatile("" ::: "memory");
-          _ibad = grp_interp_rch<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW);
+          _ibad = grp_interp_step<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW);
         }
         if (_ibad) { mzr_raise(d, 1, r, t, 15); break; }
         TSTAMP(17);
@@ -1527,7 +1610,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         const bool outbox = !isOut;
+#pragma unroll 1
+        for (int _rep = 0; _rep < MZR_DUP_STORES; ++_rep)
         if (outbox || es >= 0) {
+          if (MZR_DUP_STORES > 1) asm volatile("" ::: "memory");
           const int pq = tq & (MZR_OB_RING - 1);
           int *obNw = d.obN + (size_t)pq * N;
           double *obW = d.obQT + 2 * (size_t)pq * MZR_OB_STRIDE * N;

@@ -303,6 +303,19 @@ struct mzr_domain {
 namespace {
 
 int fail(mzr_handle h, int code, const std::string &m) { h->msg = m; return code; }
+// Window-sized staging buffers that only some entry points need are made on first use (a 625 k-reach domain with windows of
+// 3072 steps would otherwise carry 30 GB it never touches): the library's own forcing window (mzr_run, mzr_run_async,
+// mzr_run_src_dev, mzr_step) and the row-reordering scratch of the host getters / setters.  false = out of memory.
+bool ensureRunoffW(mzr_handle h) {
+  if (h->runoffW.p) return true;
+  try { h->runoffW.alloc((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &) { (void)hipGetLastError(); return false; }
+  return true;
+}
+bool ensureScratch(mzr_handle h) {
+  if (h->scratchOut.p) return true;
+  try { h->scratchOut.alloc((size_t)h->cfg.maxWindow * h->N); } catch (const std::string &) { (void)hipGetLastError(); return false; }
+  return true;
+}
 // checked copies of the state getters / setters: a failed copy is an error, not silently wrong state
 #define MZR_COPY(dst, src, bytes, kind, who) do { if (hipMemcpy((dst), (src), (bytes), (kind)) != hipSuccess) return fail(h, 92, std::string(who) + "/hipMemcpy failed"); } while (0)
 
@@ -1040,6 +1053,7 @@ int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol) {
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_wm_vol/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
+  if (!ensureScratch(h)) return fail(h, 91, "mzr/out of device memory (row scratch)");
   (void)hipMemcpyAsync(h->scratchOut.p, vol, (size_t)nSteps * N * sizeof(double), hipMemcpyHostToDevice, h->stream);
   // scratchOut is in the caller's order: row t, reach e -> the lake's external index
   std::vector<int> ext(h->nLake);
@@ -1121,6 +1135,7 @@ int mzr_get_window_solute(mzr_handle h, int method, double *out) {
   if (W < 1) return fail(h, 20, "mzr_get_window_solute/no window has been run");
   dim3 block(256), grid((N + 255) / 256, W);
   const double *src = method < 0 ? h->basSol.p + N : h->route[ix].solFlux.p;      // method < 0: BASIN_solute (rows 1..W)
+  if (!ensureScratch(h)) return fail(h, 91, "mzr/out of device memory (row scratch)");
   hipLaunchKernelGGL(k_gather_rows, grid, block, 0, h->stream, src, h->scratchOut.p, h->d_ext2int.p, N, W);
   if (hipMemcpyAsync(out, h->scratchOut.p, (size_t)W * N * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
     return fail(h, 92, "mzr_get_window_solute/hipMemcpy failed");
@@ -1277,7 +1292,7 @@ int mzr_init_state(mzr_handle h) {
   const size_t N = h->N, W = h->cfg.maxWindow;
   if (h->cfg.doesBasinRoute == 1 && h->ntdhBas < 1) return fail(h, 20, "mzr_init_state/FRAC_FUTURE not set");
   try {
-    h->runoffW.alloc(W * h->H);
+    h->runoffW.free();      // (made on first use: ensureRunoffW)
     if (h->cfg.doesBasinRoute == 1) {
       h->qi.alloc(W * N); h->qi.zero();      // halo reaches have no HRUs of their own: their rows stay zero (basin state getters)
       h->basS[0].alloc((size_t)h->ntdhBas * N); h->basS[1].alloc((size_t)h->ntdhBas * N);
@@ -1286,7 +1301,7 @@ int mzr_init_state(mzr_handle h) {
     h->basCur = 0;
     h->qlat.alloc((W + 1) * N); h->qlat.zero();
     h->qr0Last.alloc(N); h->qr0Last.zero();
-    h->scratchOut.alloc(W * N);
+    h->scratchOut.free();   // (made on first use: ensureScratch)
     if (h->cfg.is_flux_wm) { h->wm.alloc(W * N); h->wm.zero(); h->wmSteps = 0; }
     h->err.alloc(1); h->err.zero();
     if (h->nLake) {
@@ -1795,6 +1810,7 @@ int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_set_wm_flux/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N;
+  if (!ensureScratch(h)) return fail(h, 91, "mzr/out of device memory (row scratch)");
   (void)hipMemcpyAsync(h->scratchOut.p, flux, (size_t)nSteps * N * sizeof(double), hipMemcpyHostToDevice, h->stream);
   dim3 block(256), grid((N + 255) / 256, nSteps);
   hipLaunchKernelGGL(k_scatter_rows, grid, block, 0, h->stream, h->scratchOut.p, h->wm.p, h->d_ext2int.p, N, nSteps);
@@ -1831,6 +1847,7 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
+  if (!ensureRunoffW(h)) return fail(h, 91, "mzr/out of device memory (forcing window)");
   (void)hipMemcpyAsync(h->runoffW.p, runoff, (size_t)nSteps * h->H * sizeof(double), hipMemcpyHostToDevice, h->stream);
   const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
   if (rc) return rc;
@@ -1856,6 +1873,7 @@ static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_si
     for (int i = 0; i < 2; ++i) { (void)hipEventCreateWithFlags(&h->rwCopied[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->rwRead[i], hipEventDisableTiming); }
   }
   const int k = h->rwCur;
+  if (!ensureRunoffW(h)) return fail(h, 91, "mzr/out of device memory (forcing window)");
   double *buf = k == 0 ? h->runoffW.p : h->runoffW2.p;
   if (h->rwUsed[k]) (void)hipStreamWaitEvent(h->copyStream, h->rwRead[k], 0);     // the window that last read this buffer
   if (k == 0 && h->rwOtherSet) { (void)hipStreamWaitEvent(h->copyStream, h->rwOther, 0); h->rwOtherSet = false; }   // ... also one queued by mzr_run_src_dev
@@ -1974,6 +1992,7 @@ int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_
   if (!h) return 1;
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
+  if (!ensureRunoffW(h)) return fail(h, 91, "mzr/out of device memory (forcing window)");
   const int rc = mzr_remap_runoff_dev(h, nSteps, src_dev, h->runoffW.p);
   if (rc) return rc;
   const int rc2 = run_window(h, nSteps, t_start, t_start + h->cfg.dt, h->runoffW.p);
@@ -2001,6 +2020,7 @@ int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
   if (h->cfg.is_flux_wm || h->nLake || h->qmod || h->tracer) cap = 1;
   if (cap <= 1) {
     MZR_FLUSH(h);
+    if (!ensureRunoffW(h)) return fail(h, 91, "mzr/out of device memory (forcing window)");
     (void)hipMemcpyAsync(h->runoffW.p, runoff, (size_t)h->H * sizeof(double), hipMemcpyHostToDevice, h->stream);
     const int rc = run_window(h, 1, T0, T1, h->runoffW.p);
     if (rc) return rc;
@@ -2155,6 +2175,7 @@ int mzr_get_window_q(mzr_handle h, int method, double *out) {
   const int N = h->N, W = h->lastW;
   if (W < 1) return fail(h, 20, "mzr_get_window_q/no window has been run");
   dim3 block(256), grid((N + 255) / 256, W);
+  if (!ensureScratch(h)) return fail(h, 91, "mzr/out of device memory (row scratch)");
   hipLaunchKernelGGL(k_gather_rows, grid, block, 0, h->stream, h->route[ix].Q.p, h->scratchOut.p, h->d_ext2int.p, N, W);
   if (hipMemcpyAsync(out, h->scratchOut.p, (size_t)W * N * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess)
     return fail(h, 92, "mzr_get_window_q/hipMemcpy failed");

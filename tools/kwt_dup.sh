@@ -17,7 +17,7 @@ print("$lab", " ".join(f"{k}={v:.4g}" for k, v in sorted(agg.items())))
 PY
   rm -rf $o/$lab
 }
-for v in "" "-DMZR_DUP_MERGE=2" "-DMZR_DUP_THIN=2" "-DMZR_DUP_KINWAV=2" "-DMZR_DUP_INTERP=2"; do
+for v in ${VARIANTS:-"" "-DMZR_DUP_MERGE=2" "-DMZR_DUP_THIN=2" "-DMZR_DUP_KINWAV=2" "-DMZR_DUP_INTERP=2" "-DMZR_DUP_COUNT=2" "-DMZR_DUP_STORES=2" "-DMZR_DUP_WAIT=2" "-DMZR_DUP_STAGE=2" "-DMZR_THIN_LDS=0"}; do
   make -C mizuroute_amd/csrc clean >/dev/null; make -C mizuroute_amd/csrc all EXTRA="$v" -j8 > $o/build.log 2>&1 || { echo "BUILD FAILED [$v]"; tail -5 $o/build.log; }
   l=$(echo "base$v" | tr -d ' =-' )
   count ${l}_c2 --window 4096 --steps 2 --warmup 3
