@@ -759,8 +759,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   const int par = ks.par;
   const int *obN = d.obN + (size_t)par * N;
   const double *obQT = d.obQT + 2 * (size_t)par * MZR_OB_STRIDE * N;      // this step's parity of the {Q, exit time} rows
-  const __amdgpu_buffer_rsrc_t kwRs = mzr_rsrc(d.kwQT);
-  const size_t obSlot = 2 * (size_t)MZR_OB_STRIDE * N;      // doubles per slot of the outbox ring
+  const __amdgpu_buffer_rsrc_t obRs = mzr_rsrc(obQT), kwRs = mzr_rsrc(d.kwQT);
   const int nup = (int)(rcb & 0xff), ng = (int)((rcb >> 8) & 15), u0 = rci[2];
   const unsigned upGood = (rcb >> 16) & 0xff, goodMask = rcb >> 24;
   const bool isOut = (rcb & 0x8000u) != 0;
@@ -858,8 +857,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #pragma unroll
       for (int j = 0; j < OS; ++j) {
         const int k = gl + j * G, kk = k < MZR_OB_CAP ? k : 0;
-        if (ns > 0 && (!exact || k < nrA_v)) { const mzr_d2 v = ldq_ring<PERS>(d.obQT, obSlot, par, MZR_OBI(kk, uA)); aq[j] = v.x; at[j] = v.y; }
-        if (ns > 1 && (!exact || k < nrB_v)) { const mzr_d2 v = ldq_ring<PERS>(d.obQT, obSlot, par, MZR_OBI(kk, uB)); bq[j] = v.x; bt[j] = v.y; }
+        if (ns > 0 && (!exact || k < nrA_v)) { const mzr_d2 v = ldq<PERS>(obRs, obQT, MZR_OBI(kk, uA)); aq[j] = v.x; at[j] = v.y; }
+        if (ns > 1 && (!exact || k < nrB_v)) { const mzr_d2 v = ldq<PERS>(obRs, obQT, MZR_OBI(kk, uB)); bq[j] = v.x; bt[j] = v.y; }
       }
     }
     // ---- uniform: the work-array need
@@ -1617,6 +1616,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           if (MZR_DUP_STORES > 1) asm volatile("" ::: "memory");
           const int pq = tq & (MZR_OB_RING - 1);
           int *obNw = d.obN + (size_t)pq * N;
+          double *obW = d.obQT + 2 * (size_t)pq * MZR_OB_STRIDE * N;
+          const __amdgpu_buffer_rsrc_t obWs = mzr_rsrc(obW);
           if (gl == 0 && outbox) stx<PERS>(obNw + r, NR + 2);
           if (gl == 0 && es >= 0) d.exN[(size_t)tq * d.nExp + es] = NR + 2;
 #pragma unroll
@@ -1625,7 +1626,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             if (k2 <= NR + 2) {
               const double q = k2 <= NR ? Qw[k2] : k2 == NR + 1 ? Q_END : qN1;
               const double x = k2 <= NR ? Xw[k2] : k2 == NR + 1 ? T_END : xN1;
-              if (outbox) stq_ring<PERS>(d.obQT, obSlot, pq, MZR_OBI(k2, r), q, x);
+              if (outbox) stq<PERS>(obWs, obW, MZR_OBI(k2, r), q, x);
               if (es >= 0) {   // tributary outlet of a partition: the same record goes to the time-indexed export buffer
                 const size_t nE = d.nExp;
                 d.exOQ[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = q; d.exOT[((size_t)tq * MZR_OB_CAP + k2) * nE + es] = x;

@@ -318,25 +318,6 @@ template <bool P> __device__ __forceinline__ void stq(__amdgpu_buffer_rsrc_t rs,
   if (P) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mzr_i4, v), rs, (int)(unsigned)(pairIndex * 16), 0, 16);
   else *(mzr_d2 *)(base + 2 * pairIndex) = v;
 }
-// 16-byte accesses to the outbox ring.  Which slot a lane uses follows the lane's time step (groups of one wavefront may be on
-// different steps), and a buffer descriptor must be wave-uniform: the access is issued once per slot, under the lanes of that
-// slot, with the slot's own (scalar) descriptor -- instead of the waterfall loop (v_readfirstlane x 4, two 64-bit compares per
-// turn) the compiler wraps around an access whose descriptor differs between lanes.
-template <bool P> __device__ __forceinline__ mzr_d2 ldq_ring(const double *ring, size_t slotDoubles, int slot, size_t pairIndex) {
-  if (!P) return *(const mzr_d2 *)(ring + (size_t)slot * slotDoubles + 2 * pairIndex);
-  mzr_d2 v; v.x = 0.0; v.y = 0.0;
-#pragma unroll
-  for (int sl = 0; sl < MZR_OB_RING; ++sl)
-    if (slot == sl) v = __builtin_bit_cast(mzr_d2, __builtin_amdgcn_raw_buffer_load_b128(mzr_rsrc(ring + (size_t)sl * slotDoubles), (int)(unsigned)(pairIndex * 16), 0, 16));
-  return v;
-}
-template <bool P> __device__ __forceinline__ void stq_ring(double *ring, size_t slotDoubles, int slot, size_t pairIndex, double a, double b) {
-  mzr_d2 v; v.x = a; v.y = b;
-  if (!P) { *(mzr_d2 *)(ring + (size_t)slot * slotDoubles + 2 * pairIndex) = v; return; }
-#pragma unroll
-  for (int sl = 0; sl < MZR_OB_RING; ++sl)
-    if (slot == sl) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mzr_i4, v), mzr_rsrc(ring + (size_t)sl * slotDoubles), (int)(unsigned)(pairIndex * 16), 0, 16);
-}
 template <bool P> __device__ __forceinline__ void stx(int *p, int v) {
   if (P) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
