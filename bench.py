@@ -943,6 +943,7 @@ def main():
     # domain over >= 4 timed windows, roofline of the dominant kernel on one tributary domain, the reference on the full network
     sweep_geom = dict(zip(("wavefronts", "device_wavefront_slots", "items_per_launch"), dom.sweep_info())) if world == 1 and m.KWT in methods else None
     sweep_arr = dict(zip(("arrived_last", "joined_last", "start_delay_hist_log2_10ns"), dom.sweep_arrivals())) if world == 1 and m.KWT in methods else None
+    sweep_retries = dom.sweep_retries() if m.KWT in methods else None      # windows routed again after an ierr 93 (none in a healthy run)
     configs = None
     if rank == 0 and world == 1 and args.config == "c2" and not args.no_configs:
         configs = {}
@@ -997,7 +998,7 @@ def main():
                                        "rank 0's share of small tributaries cut by the mainstem's cost") + "), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
             "value_resident": value, "value_with_h2d": value_h2d, "value_with_h2d_f64": value_h2d_f64, "h2d": h2d_info, "single_step": single,
-            "kwt_sweep_arrivals": sweep_arr,
+            "kwt_sweep_arrivals": sweep_arr, "kwt_sweep_retries": sweep_retries,
             "roofline": roof, "cpu_baseline": cpu, "configs": configs, "error": post_error,
         }
         print(json.dumps(out))

@@ -280,6 +280,11 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
 /* KWT persistent sweep: wavefronts the sweep kernel is launched with (0 = not in use), wavefronts the device
    holds at once, items (blocks of reaches) dealt to them */
 int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems);
+/* Windows whose persistent KWT sweep gave up waiting (ierr 93) and that were routed again through one launch per stage, since
+   mzr_create.  That happens at mzr_sync / any getter when the failed window is the only one queued since the last
+   synchronisation (its starting state is kept until then); the caller sees no error, only a slow window and a line on stderr.
+   With several windows queued the error is reported as before (later windows have built on nothing). */
+int mzr_get_sweep_retries(mzr_handle h, long long *nRetries);
 /* KWT persistent sweep, start of its wavefronts: how many of the last launch arrived and how many of them joined (a
    wavefront that starts more than 20 us (MZR_SWEEP_LATE_TICKS = 2000 ticks of the 100 MHz clock) after the first one of its launch leaves at once), and since
    mzr_init_state the number of wavefronts by start delay: hist32[k] counts delays below 2^k ticks of 10 ns */

@@ -58,7 +58,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_run_async_f32", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
            "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync", "mzr_set_history", "mzr_get_mean",
-           "mzr_reset_means", "mzr_get_sweep_arrivals"]
+           "mzr_reset_means", "mzr_get_sweep_arrivals", "mzr_get_sweep_retries"]
 
 
 def load_library():
@@ -477,6 +477,12 @@ class RoutingDomain:
         hist = (C.c_longlong * 32)()
         self._check(self.L.mzr_get_sweep_arrivals(self.h, C.byref(a), C.byref(j), hist))
         return a.value, j.value, [int(x) for x in hist]
+
+    def sweep_retries(self):
+        """windows whose persistent KWT sweep gave up (ierr 93) and that were routed again through one launch per stage"""
+        n = C.c_longlong(0)
+        self._check(self.L.mzr_get_sweep_retries(self.h, C.byref(n)))
+        return n.value
 
     def sweep_info(self):
         """(wavefronts of the persistent KWT sweep, wavefronts the device holds at once, items dealt to them)"""

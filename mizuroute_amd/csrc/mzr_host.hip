@@ -243,6 +243,13 @@ struct mzr_domain {
   DBuf<double> qiAlt, qlatAlt, lakeEvapAlt, lakePrecipAlt; DBuf<int> calMonthAlt, calDayAlt, calDoyAlt;
   bool lakeNextInAlt = false;                    // mzr_set_lake_forcing wrote the NEXT window's lake forcing into the *Alt buffers
   long long pairLaunches = 0, tailFlushes = 0;
+  // A KWT window that ended with ierr 93 (the persistent sweep gave up waiting: DESIGN.md 2.4) is routed again through one launch
+  // per stage -- when the state it started from is still known: the at-rest particles are copied aside before every sweep
+  // (580 bytes per reach), and the failed window must be the only one queued since the last synchronisation (later windows
+  // see the error, skip their sweeps, and their hillslope pre-pass has moved on: nothing to go back to).
+  struct { bool valid = false; int W = 0, queued = 0; double t_start = 0.0, T1_single = 0.0; } retry;
+  DBuf<int> snapN; DBuf<double> snapQ, snapTR, snapQsum, snapHIn;
+  long long sweepRetries = 0;
   // kwt
   DBuf<int> kwN, obN, kwtLight;
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
@@ -1672,7 +1679,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     dr[ix] = d;
     setRoute(h, dr[ix], ix);
-    if (h->profiling) h->route[ix].evUsed = 0;
+    // (event pairs of windows queued without a synchronisation in between pile up; mzr_sync reads and releases them)
   }
   if (multi) {
     if (!h->routeEvent[0]) (void)hipEventCreateWithFlags(&h->routeEvent[0], hipEventDisableTiming);
@@ -1688,6 +1695,22 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     dk.swRA = h->swRA.p; dk.swP = h->swP.p;
     dk.kwtLight = h->kwtDepLight.p;
     const int nLaunch = nS + W - 1;
+    {      // the state this window starts from, kept until the window is known to have finished (retry above)
+      const bool can = !h->nLake && !h->tracer && !h->cfg.is_flux_wm;
+      ++h->retry.queued;
+      h->retry.valid = false;
+      if (can && h->retry.queued == 1) {
+        try {
+          if (!h->snapN.p) { h->snapN.alloc(h->kwN.n); h->snapQ.alloc(h->kwQ.n); h->snapTR.alloc(h->kwTR.n); h->snapQsum.alloc(N); if (rb.hInflow.p) h->snapHIn.alloc(N); }
+          (void)hipMemcpyAsync(h->snapN.p, h->kwN.p, h->kwN.n * sizeof(int), hipMemcpyDeviceToDevice, sx);
+          (void)hipMemcpyAsync(h->snapQ.p, h->kwQ.p, h->kwQ.n * sizeof(double), hipMemcpyDeviceToDevice, sx);
+          (void)hipMemcpyAsync(h->snapTR.p, h->kwTR.p, h->kwTR.n * sizeof(double), hipMemcpyDeviceToDevice, sx);
+          (void)hipMemcpyAsync(h->snapQsum.p, rb.qsum.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, sx);
+          if (rb.hInflow.p && h->snapHIn.p) (void)hipMemcpyAsync(h->snapHIn.p, rb.hInflow.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, sx);
+          h->retry.valid = true; h->retry.W = W; h->retry.t_start = t_start; h->retry.T1_single = T1_single;
+        } catch (const std::string &) { (void)hipGetLastError(); }
+      }
+    }
     mzr_launch_kwt_window_init(dk, 0, W, sx);
     if (prof) {
       if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
@@ -1819,12 +1842,52 @@ int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
   return 0;
 }
 
+// The window just synchronised ended with ierr 93 and its starting state was kept (mzr_domain::retry): back to that state, and the
+// window's KWT routing once more through one launch per stage (k_stage_kwt: no progress words, no waiting -- the form the sweep
+// is tested against, bit for bit).  The hillslope series of the window (qlat) are untouched by the sweep and still there.
+static int retryKwtWindow(mzr_handle h) {
+  const int kwtIx = idxOf(h, MZR_KWT);
+  if (kwtIx < 0 || !h->retry.valid || !h->snapN.p) return 1;
+  RouteBufs &rb = h->route[kwtIx];
+  const int N = h->N, W = h->retry.W, nS = h->nStages;
+  hipStream_t st = h->stream;
+  (void)hipMemset(h->err.p, 0, sizeof(MzrErr));
+  (void)hipMemcpyAsync(h->kwN.p, h->snapN.p, h->kwN.n * sizeof(int), hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(h->kwQ.p, h->snapQ.p, h->kwQ.n * sizeof(double), hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(h->kwTR.p, h->snapTR.p, h->kwTR.n * sizeof(double), hipMemcpyDeviceToDevice, st);
+  (void)hipMemcpyAsync(rb.qsum.p, h->snapQsum.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st);
+  if (rb.hInflow.p && h->snapHIn.p) (void)hipMemcpyAsync(rb.hInflow.p, h->snapHIn.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st);
+  MzrDev d; fillDev(h, d);
+  d.W = W; d.t_start = h->retry.t_start; d.T1_single = h->retry.T1_single; d.runoff = nullptr;
+  setRoute(h, d, kwtIx);
+  for (int s = 0; s < nS + W - 1; ++s) {
+    const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
+    mzr_launch_stage_kwt(d, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1], h->kwtCOff[sLo], h->kwtCOff[sHi + 1],
+                         h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
+  }
+  mzr_launch_accum_qsum(rb.Q.p, rb.qsum.p, N, W, st);
+  if (hipStreamSynchronize(st) != hipSuccess) return 1;
+  ++h->sweepRetries;
+  return 0;
+}
+
 int mzr_sync(mzr_handle h) {
   MZR_FLUSH(h);
   if (!h) return 1;
   (void)hipSetDevice(h->cfg.device);
   const hipError_t e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) return fail(h, 92, std::string("mzr_sync/") + hipGetErrorString(e));
+  if (h->retry.valid && h->retry.queued == 1) {      // exactly one KWT window since the last synchronisation: did its sweep give up?
+    int code = 0;
+    if (hipMemcpy(&code, h->err.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && code == 93) {
+      MzrErr e93;
+      (void)hipMemcpy(&e93, h->err.p, sizeof e93, hipMemcpyDeviceToHost);
+      fprintf(stderr, "mzr: the persistent KWT sweep of a window of %d steps gave up waiting (ierr 93, reach index %d, schedule step %d); the window is routed "
+                      "again with one launch per stage\n", h->retry.W, e93.reach, e93.s);
+      if (retryKwtWindow(h) != 0) return fail(h, 93, "mzr_sync/the persistent KWT sweep gave up waiting and the window could not be routed again");
+    }
+  }
+  h->retry.queued = 0; h->retry.valid = false;
   if (h->profiling) {
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
       RouteBufs &rb = h->route[ix];
@@ -2478,6 +2541,12 @@ int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems) {
   return 0;
 }
 
+int mzr_get_sweep_retries(mzr_handle h, long long *nRetries) {
+  if (!h || !nRetries) return 1;
+  *nRetries = h->sweepRetries;
+  return 0;
+}
+
 int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long long *hist32) {
   MZR_FLUSH(h);
   if (!h || !h->swHead.p) return 1;
@@ -2489,7 +2558,13 @@ int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long
   return 0;
 }
 
-int mzr_set_profiling(mzr_handle h, int mode) { if (!h) return 1; h->profiling = (mode & 1) != 0; h->countTraffic = (mode & 2) != 0; return 0; }
+int mzr_set_profiling(mzr_handle h, int mode) {
+  if (!h) return 1;
+  const bool on = (mode & 1) != 0;
+  if (on != h->profiling) for (auto &rb : h->route) rb.evUsed = 0;      // (event pairs recorded but never read belong to nobody)
+  h->profiling = on; h->countTraffic = (mode & 2) != 0;
+  return 0;
+}
 
 int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset) {
   MZR_FLUSH(h);

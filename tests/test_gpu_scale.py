@@ -313,3 +313,35 @@ def test_host_forcing_windows_f64_and_f32_equal_resident_forcing(hip_lib):
         for a, b in zip(res[0], other):
             assert np.array_equal(a, b)
     assert np.isfinite(res[0][0]).all() and res[0][0].max() > 0
+
+
+def test_window_whose_sweep_gave_up_is_routed_again(hip_lib, monkeypatch):
+    """ierr 93 (a wavefront of the persistent KWT sweep sees no progress on what it waits for and gives up instead of hanging the
+    device) is provoked here with a watchdog of one clock tick.  A caller that synchronises every window does
+    not see it: the library goes back to the state the window started from and routes it through one launch per stage
+    (k_stage_kwt), and the results are those of a run that never used the sweep -- bit for bit."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    net = m.make_network(30_000, seed=51)
+    frac, _, _ = _uh(net)
+    W, K = 96, 3
+    ro = bench.device_runoff(torch, net.H, K * W, 0, 7, dev)
+    torch.cuda.synchronize()
+
+    def route(sweep, timeout):
+        monkeypatch.setenv("MZR_KWT_SWEEP", "1" if sweep else "0")
+        monkeypatch.setenv("MZR_SWEEP_TIMEOUT_S", timeout)
+        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W)
+        for k in range(K):
+            dom.run_device(W, k * W * DT, ro[k * W:(k + 1) * W].data_ptr())
+            dom.sync()
+        out = dom.kwt_state(), dom.flux(m.KWT, m.api.F_Q), dom.mean_q(m.KWT), dom.sweep_retries()
+        dom.close()
+        return out
+
+    sa, Qa, Ma, ra = route(True, "1e-8")
+    sb, Qb, Mb, rb = route(False, "8")
+    assert ra >= 1 and rb == 0, (ra, rb)
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb)
