@@ -8,7 +8,7 @@ from mizuroute_amd import uh as uhmod
 sys.argv = sys.argv[:1]
 import bench
 
-N, W, NWIN = 100000, 1024, 3
+N, W, NWIN = int(os.environ.get('NR', '100000')), int(os.environ.get('WW', '1024')), 3
 net = m.make_network(N, seed=20240529)
 frac = uhmod.basin_uh(3600.0, 2.5, 86400.0)
 uh_off, uh = uhmod.make_uh(net.params["RLENGTH"], 3600.0, 1.5, 5000.0)

@@ -9,19 +9,26 @@ pm = json.load(open(f"{src}/{tag}_methods_pmc.json"))
 stats = {re.sub(r"\(.*", "", r["Name"]).replace("void ", "").strip(): r for r in csv.DictReader(open(f"{src}/stats/k_kernel_stats.csv"))}
 names = {"k_stage<0>": "SUM", "k_stage<1>": "IRF", "k_stage<3>": "KW", "k_stage<4>": "MC", "k_stage<5>": "DW"}
 N = 100000
-L = [f"# Eulerian methods, {tag}", "", "`tools/profile_methods.sh` on one MI355X: 100 000 reaches, windows of 1024 steps, one launch per stage (`k_stage<M>`), one method per domain;",
+L = [f"# Eulerian methods, {tag}", "", "`tools/profile_methods.sh` on one MI355X: 100 000 reaches, windows of 1024 steps, one launch per stage (`k_stage<M>`; from round 4 on also `k_stage_pair<M>`, the launches that serve two overlapping windows at once: both are summed here), one method per domain;",
      "kernel times from `rocprofv3 --kernel-trace --stats`, counters from separate `--pmc` passes summed over all launches.  FP64 peak used: 78.6 TFLOP/s vector",
      "(MI355X_MICROARCH.md) = 39.3 x 10^12 FP64 lane-instructions/s with an FMA counted once; HBM 8 TB/s.", "",
      "| method | reach-steps/s | avg launch us | VALU insts / reach-step (lanes) | FP64 share of VALU | FP64 lane-inst/s (share of peak) | VALU util | waves/SIMD | algorithmic GB/s (share of HBM peak) |",
      "|---|---|---|---|---|---|---|---|---|"]
 BYTES = {"SUM": 16 + 8 * 1, "IRF": 24 * 12 + 12 + 56, "KW": 440 + 12, "MC": 152 + 12, "DW": 440 + 12}
 for k, nm in names.items():
-    p = next((v for kk, v in pm.items() if kk.replace("void ", "").startswith(k)), None)
-    st = stats.get(k)
-    if not p or not st or nm not in bm:
+    # one launch per stage (k_stage<M>) and, since round 4, the launches that serve two overlapping windows (k_stage_pair<M>)
+    kp = k.replace("k_stage<", "k_stage_pair<")
+    ps = [v for kk, v in pm.items() if kk.replace("void ", "").startswith(k) or kk.replace("void ", "").startswith(kp)]
+    sts = [stats[x] for x in (k, kp) if x in stats]
+    if not ps or not sts or nm not in bm:
         continue
+    p = {}
+    for q in ps:
+        for c, v in q.items():
+            if isinstance(v, (int, float)):
+                p[c] = p.get(c, 0) + v
     rs = bm[nm]["reach_steps_per_s"]
-    calls, tot_ns = int(st["Calls"]), float(st["TotalDurationNs"])
+    calls, tot_ns = sum(int(x["Calls"]) for x in sts), sum(float(x["TotalDurationNs"]) for x in sts)
     fp64 = sum(p.get(c, 0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
     lanes = p.get("SQ_THREAD_CYCLES_VALU", 0) / max(1, p.get("SQ_ACTIVE_INST_VALU", 1))
     den = p["GRBM_GUI_ACTIVE"] / 8 * 1024
