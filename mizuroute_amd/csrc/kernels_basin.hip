@@ -15,11 +15,20 @@
 // fold for the virtual output times W..W+n-2.
 #include "mzr_device.h"
 
-// grid: x over reaches, y over tiles of BT steps of the window (the HRU list of a reach is read once per tile)
-#define BT 8
-__global__ void __launch_bounds__(256) k_basin2reach(MzrDev d, int tBegin, int tEnd) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t0 = tBegin + blockIdx.y * BT;
+// A block = 256 reaches x a tile of BT steps of the window (the HRU list of a reach is read once per tile).  The lanes GATHER
+// from the tile's runoff rows (HRUs in the caller's order), so every row of a tile is needed whole by every block of the tile:
+// round 4 maps the blocks so that ALL blocks of a tile run on ONE XCD (workgroups go to the XCDs round robin by their linear
+// index: block L sits on XCD L mod 8) and the tile's rows (BT x 8 H bytes: 3.2 MB at 100 k HRUs) stay in that XCD's 4 MB L2.
+// With x = reach block, y = tile as the launch grid, the blocks of a tile were dealt to all eight XCDs and each L2 fetched
+// every row again: 62.7 GB fetched for 13 GB of forcing (profiles/r04b_summary.md).
+// grid: 1-D, 8 * ceil(tiles / 8) * nReachBlocks blocks.
+#define BT 4
+__global__ void __launch_bounds__(256) k_basin2reach(MzrDev d, int tBegin, int tEnd, int nRB) {
+  const int L = blockIdx.x, xcd = L & 7, m = L >> 3;
+  const int tile = (m / nRB) * 8 + xcd, rb = m % nRB;
+  const int r = rb * blockDim.x + threadIdx.x;
+  const int t0 = tBegin + tile * BT;
+  if (t0 >= tEnd) return;
   if (r >= d.N) return;
   if (d.haloSlot && d.haloSlot[r] >= 0) return;     // lateral inflow of a halo reach is imported
   const int e0 = d.hruOff[r], e1 = d.hruOff[r + 1];
@@ -200,8 +209,9 @@ void mzr_launch_lake_forcing(const MzrDev &d, const int *lakeReachInt, const dou
 void mzr_launch_basin_chunk(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream) {
   const int n = tEnd - tBegin;
   if (n <= 0) return;
-  dim3 block(256), grid((d.N + 255) / 256, (n + BT - 1) / BT);
-  hipLaunchKernelGGL(k_basin2reach, grid, block, 0, stream, d, tBegin, tEnd);
+  dim3 block(256);
+  const int nRB = (d.N + 255) / 256, tiles = (n + BT - 1) / BT;
+  hipLaunchKernelGGL(k_basin2reach, dim3((unsigned)(8 * ((tiles + 7) / 8) * nRB)), block, 0, stream, d, tBegin, tEnd, nRB);
   if (d.doesBasinRoute == 1) {
     dim3 gridO((d.N + 255) / 256, (n + HT - 1) / HT);
     hipLaunchKernelGGL(k_hillslope_out, gridO, block, 0, stream, d, tBegin, tEnd);

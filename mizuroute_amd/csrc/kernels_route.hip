@@ -251,7 +251,10 @@ __device__ __forceinline__ double d_direct_insertion(const MzrDev &d, int r, int
 // One reach, one step of the window.  COH: the persistent sweep -- discharge rows and the reach's own state are produced and
 // consumed by different wavefronts of the SAME launch, so they go through sc1 accesses (ldx / stx, mzr_device.h);
 // COH = false is the launch-per-stage form with plain accesses.
-template <int METHOD, bool COH>
+// FULL = false compiles the rarely used branches out -- lakes, water-management fluxes, gauge observations, the constituent's
+// REACH_VOL(0) rows -- and with them a third of the registers (Muskingum-Cunge 167 -> see DESIGN.md 4): these kernels are chains
+// of dependent FP64 operations, and how many wavefronts a SIMD holds is what hides them.
+template <int METHOD, bool COH, bool FULL = true>
 __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
   const int N = d.N;
   double *Qrow = d.Q + (size_t)t * N;
@@ -262,7 +265,7 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
   const double qlat = d.qlat[(size_t)(t + 1) * N + r];
   const double dt = d.dt;
 
-  if (METHOD != 0 && d.lakeSlot) {   // lake reach: lake_route replaces the reach solver (main_route.f90:375-381)
+  if (FULL && METHOD != 0 && d.lakeSlot) {   // lake reach: lake_route replaces the reach solver (main_route.f90:375-381)
     const int ls = d.lakeSlot[r];
     if (ls >= 0) {
       double vol = ldx<COH>(d.vol + r), vol0 = vol, ele = ldx<COH>(d.ele + r), wb = 0.0, wmAct = 0.0;
@@ -298,9 +301,9 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
   double vol0 = vol_prev;
   // water management: abstraction from storage, then upstream inflow, then lateral flow; injection
   // into the lateral flow (irf_route.f90:118-142, identical in mc/dfw/kwe)
-  const double wmflux = (d.is_flux_wm && d.wm) ? d.wm[(size_t)t * N + r] : 0.0;
+  const double wmflux = (FULL && d.is_flux_wm && d.wm) ? d.wm[(size_t)t * N + r] : 0.0;
   double wmAct = wmflux;
-  if (d.is_flux_wm && wmflux != -9999.0) {
+  if (FULL && d.is_flux_wm && wmflux != -9999.0) {
     double Qabs = wmflux;
     if (Qabs > 0) {
       if (vol / dt > Qabs) {
@@ -338,9 +341,28 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
       q0 = fmin(lim, q0);
       vol = vol - (q0 - qu) * dt;
       Qout = q0 + p.Qlat;
-      for (int j = 1; j < nt; ++j) {
+      // eoshift(shift=1) of the convolution window, eight taps at a time: the loads of a batch are all in flight before its first
+      // store (taken one by one, a tap's store -- which may alias the next tap's load as far as the compiler knows -- keeps the next
+      // load waiting: one memory round trip per tap, and this kernel is nothing but memory round trips)
+      int j = 1;
+      for (; j + 8 <= nt; j += 8) {
+        double a[8], u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a[k] = ldx<COH>(d.irfQ + (size_t)(j + k) * N + r); u[k] = d.uh[(size_t)(j + k) * N + r]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stx<COH>(d.irfQ + (size_t)(j + k - 1) * N + r, a[k] + u[k] * qu);
+      }
+      if (j + 4 <= nt) {
+        double a[4], u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = ldx<COH>(d.irfQ + (size_t)(j + k) * N + r); u[k] = d.uh[(size_t)(j + k) * N + r]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) stx<COH>(d.irfQ + (size_t)(j + k - 1) * N + r, a[k] + u[k] * qu);
+        j += 4;
+      }
+      for (; j < nt; ++j) {
         const double v = ldx<COH>(d.irfQ + (size_t)j * N + r) + d.uh[(size_t)j * N + r] * qu;
-        stx<COH>(d.irfQ + (size_t)(j - 1) * N + r, v);                             // eoshift(shift=1)
+        stx<COH>(d.irfQ + (size_t)(j - 1) * N + r, v);
       }
       stx<COH>(d.irfQ + (size_t)(nt - 1) * N + r, 0.0);
     } else {
@@ -502,12 +524,12 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
     }
     stx<COH>(d.floodvol + r, flood); stx<COH>(d.ele + r, ele);
   }
-  if (d.qmod) Qout = d_direct_insertion<COH>(d, r, t, Qout);      // irf_route.f90:188-198 and alike: after the solver, before anybody reads REACH_Q
+  if (FULL && d.qmod) Qout = d_direct_insertion<COH>(d, r, t, Qout);      // irf_route.f90:188-198 and alike: after the solver, before anybody reads REACH_Q
   stx<COH>(Qrow + r, Qout);
   stx<COH>(d.vol + r, vol); stx<COH>(d.vol0 + r, vol0);
-  if (d.trVol0) d.trVol0[(size_t)t * N + r] = vol0;      // REACH_VOL(0) of the step, for the constituent pass
-  if (!d.qmod) stx<COH>(d.wb + r, d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt));      // the water balance only without data assimilation (:200-202)
-  if (d.wmact) stx<COH>(d.wmact + r, wmAct);
+  if (FULL && d.trVol0) d.trVol0[(size_t)t * N + r] = vol0;      // REACH_VOL(0) of the step, for the constituent pass
+  if (!(FULL && d.qmod)) stx<COH>(d.wb + r, d_wb(vol, vol0, p.q_up, p.Qlat, Qout, wmAct, dt));      // the water balance only without data assimilation (:200-202)
+  if (FULL && d.wmact) stx<COH>(d.wmact + r, wmAct);
   stx<COH>(d.qsum + r, ldx<COH>(d.qsum + r) + Qout);
   // history sums of the other per-method fluxes (histVars_data.f90:229-246), when asked for
   if (d.hInflow) stx<COH>(d.hInflow + r, ldx<COH>(d.hInflow + r) + p.q_up);
@@ -522,13 +544,23 @@ __device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int p, int rBeg
   return (r >= rBegin && r < rEnd) ? r : -1;
 }
 
-template <int METHOD>
-__global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
+// Muskingum-Cunge without the rare branches needs 155 VGPRs (3 wavefronts per SIMD); MZR_MC_WAVES asks the compiler for more
+// wavefronts (fewer registers, spills if it must): measured, see DESIGN.md 6
+#ifndef MZR_MC_WAVES
+#define MZR_MC_WAVES 0
+#endif
+#if MZR_MC_WAVES
+#define MZR_STAGE_OCC(M, F) __attribute__((amdgpu_waves_per_eu(((M) == 4 && !(F)) ? MZR_MC_WAVES : 1, ((M) == 4 && !(F)) ? MZR_MC_WAVES : 8)))
+#else
+#define MZR_STAGE_OCC(M, F)
+#endif
+template <int METHOD, bool FULL>
+__global__ void __launch_bounds__(256) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
   const int r = stage_lane_reach(d, (rBegin & ~255) + (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, rBegin, rEnd);
   if (r < 0) return;
   const int t = s - d.sigma[r];
   if (t < 0 || t >= d.W) return;
-  stage_reach<METHOD, false>(d, r, t);
+  stage_reach<METHOD, false, FULL>(d, r, t);
 }
 
 // Two windows in one launch (round 4, "overlapping windows").  The skewed schedule of a window of W steps over S stages is
@@ -541,8 +573,8 @@ __global__ void __launch_bounds__(256) k_stage(MzrDev d, int s, int rBegin, int 
 // window's own rows (discharge, lateral flow, lake forcing: double-buffered on the host side).  A window then costs W
 // launches instead of S + W - 1, every one of them over all reaches.  Same arithmetic per reach and step, same order.
 struct MzrDevPair { MzrDev a, b; };
-template <int METHOD>
-__global__ void __launch_bounds__(256) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
+template <int METHOD, bool FULL>
+__global__ void __launch_bounds__(256) MZR_STAGE_OCC(METHOD, FULL) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
   const bool old = (int)blockIdx.x >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
   const MzrDev &d = old ? p.a : p.b;
   const int rB = old ? rBeginA : rBeginB, rE = old ? rEndA : rEndB;
@@ -550,7 +582,7 @@ __global__ void __launch_bounds__(256) k_stage_pair(MzrDevPair p, int sA, int rB
   if (r < 0) return;
   const int t = (old ? sA : sB) - d.sigma[r];
   if (t < 0 || t >= d.W) return;
-  stage_reach<METHOD, false>(d, r, t);
+  stage_reach<METHOD, false, FULL>(d, r, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -770,12 +802,13 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
   auto blocks = [](int rB, int rE) { return rE > rB ? (rE - (rB & ~255) + 255) / 256 : 0; };
   const int nBlocksB = blocks(rBeginB, rEndB);
   dim3 block(256), grid(nBlocksB + blocks(rBeginA, rEndA));
+  const bool full = (a.lakeSlot || (a.is_flux_wm && a.wm) || a.qmod || a.trVol0 || a.wmact) || (b.lakeSlot || (b.is_flux_wm && b.wm) || b.qmod || b.trVol0 || b.wmact);
   switch (method) {
-    case 0: hipLaunchKernelGGL(k_stage_pair<0>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 1: hipLaunchKernelGGL(k_stage_pair<1>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 3: hipLaunchKernelGGL(k_stage_pair<3>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 4: hipLaunchKernelGGL(k_stage_pair<4>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 5: hipLaunchKernelGGL(k_stage_pair<5>, grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 0: if (full) hipLaunchKernelGGL((k_stage_pair<0, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<0, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 1: if (full) hipLaunchKernelGGL((k_stage_pair<1, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<1, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 3: if (full) hipLaunchKernelGGL((k_stage_pair<3, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<3, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 4: if (full) hipLaunchKernelGGL((k_stage_pair<4, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<4, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    case 5: if (full) hipLaunchKernelGGL((k_stage_pair<5, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<5, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
     default: break;
   }
 }
@@ -784,12 +817,13 @@ void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, 
   const int n = rEnd - rBegin;
   if (n <= 0) return;
   dim3 block(256), grid((rEnd - (rBegin & ~255) + 255) / 256);
+  const bool full = (d.lakeSlot || (d.is_flux_wm && d.wm) || d.qmod || d.trVol0 || d.wmact);
   switch (method) {
-    case 0: hipLaunchKernelGGL(k_stage<0>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 1: hipLaunchKernelGGL(k_stage<1>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 3: hipLaunchKernelGGL(k_stage<3>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 4: hipLaunchKernelGGL(k_stage<4>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 5: hipLaunchKernelGGL(k_stage<5>, grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 0: if (full) hipLaunchKernelGGL((k_stage<0, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<0, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 1: if (full) hipLaunchKernelGGL((k_stage<1, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<1, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 3: if (full) hipLaunchKernelGGL((k_stage<3, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<3, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 4: if (full) hipLaunchKernelGGL((k_stage<4, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<4, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    case 5: if (full) hipLaunchKernelGGL((k_stage<5, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<5, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
     default: break;
   }
 }
