@@ -538,6 +538,13 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
 
 // Reach of a lane position p (block-aligned: launches start at a multiple of 256): through the method's lane permutation
 // when there is one (mzr_device.h, lanePerm).  -1 = nothing to do.
+// Lanes per workgroup of the stage kernels, measured per method (profiles/r04_experiments.md, reach-steps/s at 100 k / 625 k
+// reaches): one wavefront for IRF (5.3 / 6.6 x 10^9 against 4.6 / 6.0 with four: a workgroup keeps its slots until its
+// last wavefront is done, and the tap counts differ) and for KW / DW (4.7 against 4.4-4.7 x 10^9 at 100 k); four for
+// Muskingum-Cunge, whose lanes are dealt to the wavefronts of a 256-position block by sub-step count (5.2 against 4.3-4.5 x 10^9
+// on the shard: the block's wavefronts share what they fetch of the block's span through their CU).
+__host__ __device__ constexpr int stage_wg(int method) { return (method == 4 || method == 0) ? 256 : 64; }
+__device__ __forceinline__ int stage_lane_pos(int L, int base) { return base + L * (int)blockDim.x + (int)threadIdx.x; }
 __device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int p, int rBegin, int rEnd) {
   if (p >= ((rEnd + 255) & ~255)) return -1;
   const int r = d.lanePerm ? d.lanePerm[p] : p;
@@ -555,8 +562,8 @@ __device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int p, int rBeg
 #define MZR_STAGE_OCC(M, F)
 #endif
 template <int METHOD, bool FULL>
-__global__ void __launch_bounds__(256) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
-  const int r = stage_lane_reach(d, (rBegin & ~255) + (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, rBegin, rEnd);
+__global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
+  const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x, rBegin & ~255), rBegin, rEnd);
   if (r < 0) return;
   const int t = s - d.sigma[r];
   if (t < 0 || t >= d.W) return;
@@ -574,11 +581,11 @@ __global__ void __launch_bounds__(256) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDe
 // launches instead of S + W - 1, every one of them over all reaches.  Same arithmetic per reach and step, same order.
 struct MzrDevPair { MzrDev a, b; };
 template <int METHOD, bool FULL>
-__global__ void __launch_bounds__(256) MZR_STAGE_OCC(METHOD, FULL) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
+__global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
   const bool old = (int)blockIdx.x >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
   const MzrDev &d = old ? p.a : p.b;
   const int rB = old ? rBeginA : rBeginB, rE = old ? rEndA : rEndB;
-  const int r = stage_lane_reach(d, (rB & ~255) + ((int)blockIdx.x - (old ? nBlocksB : 0)) * (int)blockDim.x + (int)threadIdx.x, rB, rE);
+  const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x - (old ? nBlocksB : 0), rB & ~255), rB, rE);
   if (r < 0) return;
   const int t = (old ? sA : sB) - d.sigma[r];
   if (t < 0 || t >= d.W) return;
@@ -799,10 +806,11 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
   const int nA = std::max(0, rEndA - rBeginA), nB = std::max(0, rEndB - rBeginB);
   if (nA + nB <= 0) return;
   MzrDevPair p; p.a = a; p.b = b;
-  auto blocks = [](int rB, int rE) { return rE > rB ? (rE - (rB & ~255) + 255) / 256 : 0; };
+  const int wg = stage_wg(method);
+  auto blocks = [wg](int rB, int rE) { return rE > rB ? (rE - (rB & ~255) + wg - 1) / wg : 0; };
   const int nBlocksB = blocks(rBeginB, rEndB);
-  dim3 block(256), grid(nBlocksB + blocks(rBeginA, rEndA));
-  const bool full = (a.lakeSlot || (a.is_flux_wm && a.wm) || a.qmod || a.trVol0 || a.wmact) || (b.lakeSlot || (b.is_flux_wm && b.wm) || b.qmod || b.trVol0 || b.wmact);
+  dim3 block(wg), grid(nBlocksB + blocks(rBeginA, rEndA));
+  const bool full = (a.lakeSlot || a.is_flux_wm || a.qmod || a.trVol0) || (b.lakeSlot || b.is_flux_wm || b.qmod || b.trVol0);
   switch (method) {
     case 0: if (full) hipLaunchKernelGGL((k_stage_pair<0, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<0, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
     case 1: if (full) hipLaunchKernelGGL((k_stage_pair<1, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<1, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
@@ -816,8 +824,9 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
 void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, hipStream_t stream) {
   const int n = rEnd - rBegin;
   if (n <= 0) return;
-  dim3 block(256), grid((rEnd - (rBegin & ~255) + 255) / 256);
-  const bool full = (d.lakeSlot || (d.is_flux_wm && d.wm) || d.qmod || d.trVol0 || d.wmact);
+  const int wg = stage_wg(method);
+  dim3 block(wg), grid((rEnd - (rBegin & ~255) + wg - 1) / wg);
+  const bool full = (d.lakeSlot || d.is_flux_wm || d.qmod || d.trVol0);
   switch (method) {
     case 0: if (full) hipLaunchKernelGGL((k_stage<0, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<0, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
     case 1: if (full) hipLaunchKernelGGL((k_stage<1, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<1, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;

@@ -1352,7 +1352,10 @@ int mzr_init_state(mzr_handle h) {
       if (m == MZR_IRF) {
         if (h->maxtdh < 1) return fail(h, 20, "mzr_init_state/reach unit hydrographs not set (IRF)");
         h->irfQ.alloc((size_t)h->maxtdh * N); h->irfQ.zero();
-        {      // the convolution runs over ntdh taps of the reach: wavefronts of like reaches (build_lane_perm)
+        // (dealing the lanes to wavefronts by tap count -- build_lane_perm with ntdh as the key -- was measured slower for IRF once its
+        // loads were batched: 5.3 against 6.0 x 10^9 reach-steps/s on the 625 k shard; the kernel is bound by what it fetches, and
+        // a wavefront of scattered reaches fetches four times the sectors it uses.  MZR_IRF_PERM=1 switches it on.)
+        if (const char *e = getenv("MZR_IRF_PERM")) if (atoi(e) != 0) {
           std::vector<uint16_t> nt(N);
           (void)hipMemcpy(nt.data(), h->ntdh.p, N * sizeof(uint16_t), hipMemcpyDeviceToHost);
           build_lane_perm(h, ix, std::vector<int>(nt.begin(), nt.end()));
