@@ -245,7 +245,7 @@ class Loopback:
         ro = device_runoff(torch, self.net.H, W, t0s, 7, self.dev)
         return ro if cols is None else ro[:, torch.as_tensor(cols, device=self.dev, dtype=torch.long)].contiguous()
 
-    def route_partitioned(self, W, K, timing):
+    def route_partitioned(self, W, K, timing, extra=0):
         """all windows of one domain, then the next; returns per-reach interval means / particle counts, the times and the
         boundary records (kept on the device only when `timing`)"""
         torch, m, net, P, methods = self.torch, self.m, self.net, self.P, self.methods
@@ -259,7 +259,9 @@ class Loopback:
                 continue
             dom = self.make(sp, W, export_reaches=sp.export_local)
             tw = []
-            for k in range(K):
+            # (`extra` more windows of the partitions 1..: their records -- a few outlets each -- feed the mainstem in the longer
+            # side-by-side run of rank 0, whose own partition 0 produces its record live)
+            for k in range(K + (extra if p > 0 else 0)):
                 ro = self.forcing(W, k * W, sp.hru_global, shared=not timing)
                 if dom.lakes is not None:
                     dom.set_lake_forcing(0, W)
@@ -336,7 +338,8 @@ class Loopback:
         """K windows of W steps of every domain (the first is dropped as warm-up); rank 0's two domains side by side"""
         torch, m, net, P, methods = self.torch, self.m, self.net, self.P, self.methods
         from mizuroute_amd.partition import lakes_for_domain
-        _, _, times, recs = self.route_partitioned(W, K, True)
+        EXTRA = 4 if side_by_side else 0
+        _, _, times, recs = self.route_partitioned(W, K, True, extra=EXTRA)
         med = lambda d: float(np.median(d["s_per_window"][1:]))
         trib = {k: med(v) for k, v in times.items() if k.startswith("trib")}
         t_main = med(times["main"]) if "main" in times else 0.0
@@ -357,8 +360,7 @@ class Loopback:
             ro_m = [self.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
             rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=self.dev) for _ in range(2)]
             tw = []
-            KS = K + 4      # (two fresh domains: their first windows hold the regroupings and table builds; the records of the other
-                            # partitions are taken round and round, their content does not matter for the time)
+            KS = K + EXTRA      # (two fresh domains: their first windows hold the regroupings and table builds)
             for k in range(KS + 1):
                 torch.cuda.synchronize(); t1 = time.perf_counter()
                 if k < KS:
@@ -369,7 +371,7 @@ class Loopback:
                     for p in range(self.nparts):
                         base, n = ms.halo_base[p]
                         if n:
-                            d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, (k - 1) % K)]).data_ptr(), n, base)
+                            d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
                     if d_m.lakes is not None:
                         d_m.set_lake_forcing(0, W)
                     d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())

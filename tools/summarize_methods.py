@@ -7,6 +7,7 @@ src, dst = f"gpurun_out/{tag}_methods", "profiles"
 bm = json.loads([l for l in open(f"{src}/bench_methods.json") if l.startswith("{")][-1])
 pm = json.load(open(f"{src}/{tag}_methods_pmc.json"))
 stats = {re.sub(r"\(.*", "", r["Name"]).replace("void ", "").strip(): r for r in csv.DictReader(open(f"{src}/stats/k_kernel_stats.csv"))}
+stats_full = dict(stats)
 names = {"k_stage<0>": "SUM", "k_stage<1>": "IRF", "k_stage<3>": "KW", "k_stage<4>": "MC", "k_stage<5>": "DW"}
 N = 100000
 L = [f"# Eulerian methods, {tag}", "", "`tools/profile_methods.sh` on one MI355X: 100 000 reaches, windows of 1024 steps, one launch per stage (`k_stage<M>`; from round 4 on also `k_stage_pair<M>`, the launches that serve two overlapping windows at once: both are summed here), one method per domain;",
@@ -18,8 +19,10 @@ BYTES = {"SUM": 16 + 8 * 1, "IRF": 24 * 12 + 12 + 56, "KW": 440 + 12, "MC": 152 
 for k, nm in names.items():
     # one launch per stage (k_stage<M>) and, since round 4, the launches that serve two overlapping windows (k_stage_pair<M>)
     kp = k.replace("k_stage<", "k_stage_pair<")
-    ps = [v for kk, v in pm.items() if kk.replace("void ", "").startswith(k) or kk.replace("void ", "").startswith(kp)]
-    sts = [stats[x] for x in (k, kp) if x in stats]
+    pre = (k[:-1], kp[:-1])      # "k_stage<4" matches k_stage<4> and k_stage<4, false> (round 4: instantiations with / without the rare branches)
+    hit = lambda name: any(name.replace("void ", "").startswith(x + ">") or name.replace("void ", "").startswith(x + ",") for x in pre)
+    ps = [v for kk, v in pm.items() if hit(kk)]
+    sts = [v for kk, v in stats_full.items() if hit(kk)]
     if not ps or not sts or nm not in bm:
         continue
     p = {}
