@@ -70,7 +70,9 @@ typedef struct mzr_config {
                                  fit the device together                                               */
   int    stepBatch;           /* mzr_step: 1 (default) = every call routes its step and returns its ierr; n > 1 = up to n
                                  steps (and at most maxWindow) are put aside and routed as one window when the batch is
-                                 full or anything else is asked of the handle; errors then surface at that later call  */
+                                 full or anything else is asked of the handle; errors then surface at that later call.
+                                 One-step calls (nSteps = 1, host pointers) of mzr_set_lake_forcing, mzr_set_wm_flux,
+                                 mzr_set_wm_vol, mzr_set_obs, mzr_set_solute made before a mzr_step travel with that step */
   int    sweepPriority;       /* 0 (default) / 1: the wavefronts of THIS handle's persistent sweeps run at the highest wave
                                  priority throughout.  For a small, deep domain that sweeps beside a large one on the same GPU
                                  (rank 0's mainstem beside its tributaries): its window is one long chain of dependent passes

@@ -135,7 +135,7 @@ def load_library():
     L.mzr_set_lakes.argtypes = [vp, ci, ci, ci, ip, ip, dp]
     L.mzr_set_lake_target.argtypes = [vp, ip, ci]
     L.mzr_set_wm_vol.argtypes = [vp, ci, dp]
-    L.mzr_set_lake_forcing.argtypes = [vp, ci, dp, dp, ip, ip, ip]
+    L.mzr_set_lake_forcing.argtypes = [vp, ci, vp, vp, ip, ip, ip]
     L.mzr_set_lake_forcing_dev.argtypes = [vp, ci, vp, vp, ip, ip, ip]
     L.mzr_get_flux.argtypes = [vp, ci, ci, dp]
     L.mzr_get_window_q.argtypes = [vp, ci, dp]
@@ -339,6 +339,10 @@ class RoutingDomain:
         self._check(self.L.mzr_set_obs(self.h, int(w), np.ascontiguousarray(self.da["have"][first:first + w], dtype=np.int32),
                                        np.ascontiguousarray(self.da["obs"][first:first + w], dtype=np.float64)))
 
+    def set_solute(self, w, solute):
+        """basin constituent mass flux [w, nHru] of the next window (constituent routing on: enable_tracer)"""
+        self._check(self.L.mzr_set_solute(self.h, int(w), np.ascontiguousarray(solute, dtype=np.float64)))
+
     def set_wm_flux(self, w, wm_flux):
         """REACH_WM_FLUX [w, nRch] of the next window (is_flux_wm; -9999 = no data for the reach)."""
         self._check(self.L.mzr_set_wm_flux(self.h, int(w), np.ascontiguousarray(wm_flux, dtype=np.float64)))
@@ -358,10 +362,10 @@ class RoutingDomain:
         if evap_dev_ptr is not None:
             self._check(self.L.mzr_set_lake_forcing_dev(self.h, int(w), C.c_void_p(int(evap_dev_ptr)), C.c_void_p(int(precip_dev_ptr)), *cal))
         elif int(lk["input_option"]) == 1:
-            self._check(self.L.mzr_set_lake_forcing_dev(self.h, int(w), None, None, *cal))
+            self._check(self.L.mzr_set_lake_forcing(self.h, int(w), None, None, *cal))
         else:
-            self._check(self.L.mzr_set_lake_forcing(self.h, int(w), c(lk["evap"][first:first + w], np.float64),
-                                                    c(lk["precip"][first:first + w], np.float64), *cal))
+            ev, pr = c(lk["evap"][first:first + w], np.float64), c(lk["precip"][first:first + w], np.float64)
+            self._check(self.L.mzr_set_lake_forcing(self.h, int(w), ev.ctypes.data, pr.ctypes.data, *cal))
         if "targ_vol" in lk:      # REACH_WM_VOL of the window
             self._check(self.L.mzr_set_wm_vol(self.h, int(w), c(lk["wm_vol"][first:first + w], np.float64)))
 

@@ -724,9 +724,15 @@ int mzr_sweep_route_capacity(int method, const MzrDev &d, hipStream_t stream) {
     case 5: hipLaunchKernelGGL(k_sweep_route<5>, grid, block, 0, stream, d, 0, -1); break;
     default: break;
   }
-  if (hipStreamSynchronize(stream) != hipSuccess) return 0;
+  const hipError_t eLaunch = hipGetLastError();
+  const hipError_t eSync = hipStreamSynchronize(stream);
+  if (eLaunch != hipSuccess || eSync != hipSuccess) {
+    fprintf(stderr, "mzr: census of the sweep of method %d: launch of %d wavefronts: %s, synchronize: %s\n", method, api + api / 4, hipGetErrorString(eLaunch), hipGetErrorString(eSync));
+    return 0;
+  }
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
+  if (cap < 1) fprintf(stderr, "mzr: census of the sweep of method %d: %d wavefronts launched (%d per CU by the occupancy query), %d counted, peak %d\n", method, api + api / 4, perCu, peak[0], peak[1]);
   if (dev >= 0 && dev < 16 && 2 * cap >= api) cached[dev][method] = cap;      // (a census far below the occupancy query ran beside other work: measured again next time)
   return cap;
 }

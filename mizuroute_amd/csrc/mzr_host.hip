@@ -79,6 +79,7 @@ struct RouteBufs {
   DBuf<double> solFlux, solMass, trVol0;            // constituent routing (mzr_set_tracer): [maxWindow][N], [N], [maxWindow][N]
   DBuf<double> qobs, qerr; DBuf<int> qelapsed;      // [N] direct insertion (mzr_set_da): RCHFLX%Qobs, ROUTE%Qerror, RCHFLX%Qelapsed
   int rtCap = 0;                                    // wavefronts the device holds of this method's sweep kernel
+  bool rtCapTried = false;
   long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
@@ -302,6 +303,16 @@ struct mzr_domain {
   // alternately) until the batch is full or somebody asks for a result, and are then routed as one window
   double *stepHost[2] = {nullptr, nullptr}; hipEvent_t stepCopied[2] = {nullptr, nullptr}; bool stepInFlight[2] = {false, false};
   int stepCur = 0, stepN = 0, stepCap = 0; double stepT0 = 0.0, stepT1 = 0.0;
+  // ... and so do the per-step rows of the per-window inputs handed over beside them (one-step calls of mzr_set_lake_forcing,
+  // mzr_set_wm_flux, mzr_set_wm_vol, mzr_set_solute, mzr_set_obs): the row for the COMING step waits in `next`, mzr_step
+  // moves it behind the rows of the pending steps, flushSteps hands them to the window setters in one piece.  A row whose
+  // step never comes as mzr_step is handed to its setter as it is the next time anything is asked of the handle.
+  struct StepRows { bool staged = false; std::vector<double> next[2], rows[2]; std::vector<int> nextI[3], rowsI[3]; };
+  enum { SR_LAKE = 0, SR_WMFLUX, SR_WMVOL, SR_SOLUTE, SR_OBS, SR_KINDS };
+  StepRows sr[SR_KINDS];
+  unsigned srMask = 0;            // kinds whose rows the pending steps carry
+  bool srAny = false;             // a row is staged for the coming step
+  bool srApplying = false;        // flushSteps is handing rows to the setters (they neither stage nor flush then)
   int histFlags = 0;                            // MZR_H_*: which history sums beyond discharge are kept
   long long histSteps = 0;                      // steps in the runoff sums since the last reset
   DBuf<double> hInst, hDlay, hBas;              // [N], [N], [H] sums of BASIN_QI, BASIN_QR(1), basin runoff
@@ -718,11 +729,23 @@ void kwt_sweep_tables(mzr_handle h, int W) {
 
 }  // namespace
 
-static int flushSteps(mzr_handle h);
+static int flushSteps(mzr_handle h, bool keepStaged = false);
 static void flushTail(mzr_handle h);
+// the row of one kind for the coming step (a later call for the same step replaces it, as a second call of the setter would)
+static int stageRow(mzr_handle h, int kind, const double *a, size_t na, const double *b, size_t nb, const int *i0, const int *i1, const int *i2) {
+  mzr_domain::StepRows &r = h->sr[kind];
+  r.next[0].assign(a ? a : nullptr, a ? a + na : nullptr);
+  r.next[1].assign(b ? b : nullptr, b ? b + nb : nullptr);
+  const int *ip[3] = {i0, i1, i2};
+  for (int k = 0; k < 3; ++k) { r.nextI[k].clear(); if (ip[k]) r.nextI[k].push_back(*ip[k]); }
+  r.staged = true; h->srAny = true;
+  return 0;
+}
 static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key);
 // steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first ...
-#define MZR_FLUSH_STEPS(h) do { if ((h) && (h)->stepN > 0) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
+#define MZR_FLUSH_STEPS(h) do { if ((h) && ((h)->stepN > 0 || (h)->srAny) && !(h)->srApplying) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
+// a one-step call of a per-window setter on a handle that batches its steps: the row is put aside for the coming mzr_step
+#define MZR_STAGES(h, nSteps) ((h) && (h)->cfg.stepBatch > 1 && (nSteps) == 1 && !(h)->srApplying && (h)->haveState)
 // ... and so do the launches of the last window that were kept back for the next one (overlapping windows): every entry point
 // that reads or changes anything a window touches takes this one; the run calls themselves take MZR_FLUSH_STEPS
 #define MZR_FLUSH(h) do { MZR_FLUSH_STEPS(h); if ((h) && (h)->tail.pending) flushTail(h); } while (0)
@@ -1025,6 +1048,10 @@ static int set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const 
   return checkDeviceError(h);
 }
 int mzr_set_lake_forcing(mzr_handle h, int nSteps, const double *evap, const double *precip, const int *month, const int *day, const int *dayofyear) {
+  if (MZR_STAGES(h, nSteps) && h->nLake && month && day && dayofyear && (h->LakeInputOption == 1 || (evap && precip))) {
+    const bool fluxes = h->LakeInputOption != 1;
+    return stageRow(h, mzr_domain::SR_LAKE, fluxes ? evap : nullptr, h->H, fluxes ? precip : nullptr, h->H, month, day, dayofyear);
+  }
   MZR_FLUSH_STEPS(h);      // (a window kept back keeps its own lake forcing: set_lake_forcing writes beside it)
   return set_lake_forcing(h, nSteps, evap, precip, false, month, day, dayofyear);
 }
@@ -1054,6 +1081,7 @@ __global__ void k_gather_lake_rows(const double *src, double *dst, const int *la
 
 // REACH_WM_VOL of the next window: vol[nSteps][nRch] in the caller's reach order (main_route.f90:115-122); only lake reaches are read
 int mzr_set_wm_vol(mzr_handle h, int nSteps, const double *vol) {
+  if (MZR_STAGES(h, nSteps) && h->nLake && vol) return stageRow(h, mzr_domain::SR_WMVOL, vol, h->N, nullptr, 0, nullptr, nullptr, nullptr);
   MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_wm_vol/state not initialised") : 1;
   if (!h->nLake) return fail(h, 20, "mzr_set_wm_vol/no lakes in this domain");
@@ -1106,6 +1134,7 @@ int mzr_set_tracer(mzr_handle h, int on, double time_conv_solute, double mass_co
 
 // basin constituent mass flux of the next window, solute[nSteps][nHru] in the order of the runoff
 int mzr_set_solute(mzr_handle h, int nSteps, const double *solute) {
+  if (MZR_STAGES(h, nSteps) && h->tracer && solute) return stageRow(h, mzr_domain::SR_SOLUTE, solute, h->H, nullptr, 0, nullptr, nullptr, nullptr);
   MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_solute/state not initialised") : 1;
   if (!h->tracer) return fail(h, 20, "mzr_set_solute/constituent routing is off (mzr_set_tracer)");
@@ -1186,6 +1215,7 @@ int mzr_set_da(mzr_handle h, int qBlendPeriod, int QerrTrend, int nGauge, const 
 // gauge observations of the next window: have[nSteps] (1 = there is an observation time at this step), obs[nSteps][nGauge]
 // (NaN or negative = no value at this gauge)
 int mzr_set_obs(mzr_handle h, int nSteps, const int *have, const double *obs) {
+  if (MZR_STAGES(h, nSteps) && h->qmod && have && obs) return stageRow(h, mzr_domain::SR_OBS, obs, h->nGauge, nullptr, 0, have, nullptr, nullptr);
   MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_obs/state not initialised") : 1;
   if (!h->qmod) return fail(h, 20, "mzr_set_obs/direct insertion is off (mzr_set_da)");
@@ -1343,8 +1373,7 @@ int mzr_init_state(mzr_handle h) {
       for (DBuf<double> *b : {&rb.vol, &rb.vol0, &rb.inflow, &rb.ele, &rb.floodvol, &rb.wb, &rb.qsum, &rb.wmact}) { b->alloc(N); b->zero(); }
       if (m != MZR_KWT) {      // persistent sweep of an Eulerian method
         rb.rtDone.alloc(N); rb.rtDone.zero(); rb.rtHead.alloc(8 * 16 + 16 + 32); rb.rtHead.zero();
-        { MzrDev dc; memset(&dc, 0, sizeof dc); dc.rtHead = rb.rtHead.p; dc.err = h->err.p; rb.rtCap = sweepGrid(h, mzr_sweep_route_capacity(m, dc, h->stream));
-          if (rb.rtCap < 1) fprintf(stderr, "mzr: the wavefront capacity of the sweep of method %d could not be measured on device %d; one launch per stage instead\n", m, h->cfg.device); }
+        rb.rtCap = 0; rb.rtCapTried = false;      // (measured by the first window short enough to be swept: run_window)
         if (h->rtTablesW != -2) { rt_build_items(h); h->rtTablesW = -2; }      // once per mzr_init_state (-2: built, tables not yet)
       }
       if (m == MZR_KW || m == MZR_DW) { rb.mol.alloc((size_t)MZR_NMOL_KW * N); rb.mol.zero(); }
@@ -1636,6 +1665,15 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   bool rtSweep = W <= 8;
   if (const char *e = getenv("MZR_ROUTE_SWEEP")) rtSweep = atoi(e) != 0;
   if (h->rtItems < 1) rtSweep = false;
+  if (rtSweep)
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      if (rb.method == MZR_KWT || rb.rtCapTried) continue;
+      rb.rtCapTried = true;
+      MzrDev dc; memset(&dc, 0, sizeof dc); dc.rtHead = rb.rtHead.p; dc.err = h->err.p;
+      rb.rtCap = sweepGrid(h, mzr_sweep_route_capacity(rb.method, dc, h->stream));
+      if (rb.rtCap < 1) fprintf(stderr, "mzr: the wavefront capacity of the sweep of method %d could not be measured on device %d; one launch per stage instead\n", rb.method, h->cfg.device);
+    }
   bool anyPersistent = sweep;
   for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (h->route[ix].method != MZR_KWT && rtSweep && h->route[ix].rtCap >= 1) anyPersistent = true;
   // hillslope pre-pass.  The fold is causal and launch s of the sweep only touches steps <= s, so only the
@@ -1830,6 +1868,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
 }
 
 int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
+  if (MZR_STAGES(h, nSteps) && h->cfg.is_flux_wm && flux) return stageRow(h, mzr_domain::SR_WMFLUX, flux, h->N, nullptr, 0, nullptr, nullptr, nullptr);
   MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_set_wm_flux/state not initialised") : 1;
   if (!h->cfg.is_flux_wm) return fail(h, 20, "mzr_set_wm_flux/is_flux_wm is off in the configuration");
@@ -2076,14 +2115,14 @@ int mzr_run_src_dev(mzr_handle h, int nSteps, double t_start, const double *src_
 // stages) when stepBatch of them have come together, or as soon as anything is asked of the handle (a getter,
 // mzr_sync, a setter) -- a host that keeps its time loop and fetches results at output frequency then runs at the speed
 // of the windows.  Results are bit-identical either way.  A step whose (T0, T1) does not continue the pending ones by
-// exactly dt, and any configuration with per-window inputs (lakes, water management, observations, constituents),
-// is routed as before.
+// exactly dt starts a window of its own; the per-step inputs beside the runoff (lake forcing, abstraction / injection,
+// target volumes, observations, constituent) handed over by one-step setter calls before the step travel with it
+// (mzr_domain::StepRows) -- pending steps that carry other kinds of rows than this one are routed first.
 int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
   if (!h) return 1;
   if (!h->haveState) return fail(h, 20, "mzr_step/state not initialised (call mzr_init_state)");
   (void)hipSetDevice(h->cfg.device);
-  int cap = std::min(h->cfg.stepBatch, h->cfg.maxWindow);
-  if (h->cfg.is_flux_wm || h->nLake || h->qmod || h->tracer) cap = 1;
+  const int cap = std::min(h->cfg.stepBatch, h->cfg.maxWindow);
   if (cap <= 1) {
     MZR_FLUSH(h);
     if (!ensureRunoffW(h)) return fail(h, 91, "mzr/out of device memory (forcing window)");
@@ -2095,9 +2134,13 @@ int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
   const double dt = h->cfg.dt;
   // not the continuation of what is pending, or a step of another length (a window of its own: the kernels take TSEC(2) of a
   // single step as given and T0 + dt otherwise)
-  if (h->stepN > 0 && (!(T0 == h->stepT0 + (double)h->stepN * dt) || !(T1 == T0 + dt))) MZR_FLUSH(h);
+  // the rows handed over for this step (lake forcing, abstraction / injection, ...): the pending steps must carry the same kinds
+  unsigned mask = 0;
+  for (int k = 0; k < mzr_domain::SR_KINDS; ++k) if (h->sr[k].staged) mask |= 1u << k;
+  if (h->stepN > 0 && (!(T0 == h->stepT0 + (double)h->stepN * dt) || !(T1 == T0 + dt) || mask != h->srMask)) { const int rc = flushSteps(h, true); if (rc) return rc; }
   if (!h->stepHost[0] || h->stepCap != cap) {
-    MZR_FLUSH(h);
+    { const int rc = flushSteps(h, true); if (rc) return rc; }
+    if (h->tail.pending) flushTail(h);
     for (int i = 0; i < 2; ++i) {
       if (h->stepInFlight[i]) { (void)hipEventSynchronize(h->stepCopied[i]); h->stepInFlight[i] = false; }
       if (h->stepHost[i]) { (void)hipHostFree(h->stepHost[i]); h->stepHost[i] = nullptr; }
@@ -2111,6 +2154,18 @@ int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
     if (h->stepInFlight[h->stepCur]) { (void)hipEventSynchronize(h->stepCopied[h->stepCur]); h->stepInFlight[h->stepCur] = false; }      // its last copy has left
   }
   memcpy(h->stepHost[h->stepCur] + (size_t)h->stepN * h->H, runoff, (size_t)h->H * sizeof(double));
+  if (h->stepN == 0) {
+    h->srMask = mask;
+    for (int k = 0; k < mzr_domain::SR_KINDS; ++k) { for (auto &v : h->sr[k].rows) v.clear(); for (auto &v : h->sr[k].rowsI) v.clear(); }
+  }
+  for (int k = 0; k < mzr_domain::SR_KINDS; ++k) {
+    mzr_domain::StepRows &r = h->sr[k];
+    if (!r.staged) continue;
+    for (int j = 0; j < 2; ++j) r.rows[j].insert(r.rows[j].end(), r.next[j].begin(), r.next[j].end());
+    for (int j = 0; j < 3; ++j) r.rowsI[j].insert(r.rowsI[j].end(), r.nextI[j].begin(), r.nextI[j].end());
+    r.staged = false;
+  }
+  h->srAny = false;
   h->stepT1 = T1;
   ++h->stepN;
   if (h->stepN == cap || !(T1 == T0 + dt)) return flushSteps(h);
@@ -2148,15 +2203,47 @@ static void flushTail(mzr_handle h) {
     if (h->routeStream[ix]) { (void)hipEventRecord(h->routeEvent[ix], h->routeStream[ix]); (void)hipStreamWaitEvent(h->stream, h->routeEvent[ix], 0); }
 }
 
-static int flushSteps(mzr_handle h) {
+// n rows of one kind to its window setter (srApplying: the setter neither stages them again nor flushes)
+static int applyRows(mzr_handle h, int kind, int n, std::vector<double> *a, std::vector<int> *ai) {
+  h->srApplying = true;
+  int rc = 0;
+  switch (kind) {
+    case mzr_domain::SR_LAKE:   rc = mzr_set_lake_forcing(h, n, a[0].empty() ? nullptr : a[0].data(), a[1].empty() ? nullptr : a[1].data(), ai[0].data(), ai[1].data(), ai[2].data()); break;
+    case mzr_domain::SR_WMFLUX: rc = mzr_set_wm_flux(h, n, a[0].data()); break;
+    case mzr_domain::SR_WMVOL:  rc = mzr_set_wm_vol(h, n, a[0].data()); break;
+    case mzr_domain::SR_SOLUTE: rc = mzr_set_solute(h, n, a[0].data()); break;
+    case mzr_domain::SR_OBS:    rc = mzr_set_obs(h, n, ai[0].data(), a[0].data()); break;
+    default: break;
+  }
+  h->srApplying = false;
+  return rc;
+}
+
+static int flushSteps(mzr_handle h, bool keepStaged) {
   const int n = h->stepN;
-  if (n < 1) return 0;
-  h->stepN = 0;
-  const int k = h->stepCur;
-  h->stepCur ^= 1;
-  h->stepInFlight[k] = true;
-  const double T1_single = n == 1 ? h->stepT1 : h->stepT0 + h->cfg.dt;
-  return run_async_impl(h, n, h->stepT0, T1_single, h->stepHost[k], h->stepCopied[k]);
+  if (n >= 1) {
+    h->stepN = 0;
+    const int k = h->stepCur;
+    h->stepCur ^= 1;
+    h->stepInFlight[k] = true;
+    for (int kind = 0; kind < mzr_domain::SR_KINDS; ++kind)
+      if (h->srMask >> kind & 1) { const int rc = applyRows(h, kind, n, h->sr[kind].rows, h->sr[kind].rowsI); if (rc) return rc; }
+    h->srMask = 0;
+    const double T1_single = n == 1 ? h->stepT1 : h->stepT0 + h->cfg.dt;
+    const int rc = run_async_impl(h, n, h->stepT0, T1_single, h->stepHost[k], h->stepCopied[k]);
+    if (rc) return rc;
+  }
+  if (!keepStaged && h->srAny) {      // rows whose step has not come as mzr_step: to their setters as they are
+    h->srAny = false;
+    for (int kind = 0; kind < mzr_domain::SR_KINDS; ++kind) {
+      mzr_domain::StepRows &r = h->sr[kind];
+      if (!r.staged) continue;
+      r.staged = false;
+      const int rc = applyRows(h, kind, 1, r.next, r.nextI);
+      if (rc) return rc;
+    }
+  }
+  return 0;
 }
 
 extern "C" {

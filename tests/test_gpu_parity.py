@@ -118,6 +118,82 @@ def test_pipelined_steps_equal_a_window(hip_lib):
     assert all(np.array_equal(x, y) for x, y in zip(d1.kwt_state(), d2.kwt_state()))
 
 
+@pytest.mark.parametrize("case", ["irf_target_volume_lakes", "kw_mc_lakes"])
+def test_pipelined_steps_carry_their_lake_forcing_abstractions_observations_and_constituent(case, hip_lib):
+    """stepBatch > 1 in a configuration with per-step inputs beside the runoff: the host's loop stays as the reference's driver
+    has it (per step: lake evaporation / precipitation and calendar, REACH_WM_FLUX, REACH_WM_VOL, gauge observations, basin
+    constituent -- main_route.f90:115-148,161-172 --, then the step); the one-step calls of the setters put their rows aside
+    with the step, and the batch is routed as one window.  Same bits as one step per call, and as windows handed over whole;
+    a getter in the middle of a batch, and a one-step setter followed by a window call instead of mzr_step, change nothing."""
+    from mizuroute_amd import uh as uhmod
+    from mizuroute_amd.synthetic import make_gauges, make_lakes
+    net = m.make_network(1200, seed=71, n_outlets=5, floodplain=True)
+    steps, dt = 45, 21600.0
+    ro = m.make_runoff(net.H, steps, seed=72, storm_prob=0.05, storm_amp=3e-6)
+    frac = uhmod.basin_uh(dt, 2.5, 86400.0)
+    off, v = uhmod.make_uh(net.params["RLENGTH"], dt, 1.5, 5000.0)
+    sol = np.random.default_rng(73).uniform(0.0, 5.0, (steps, net.H))
+    da = make_gauges(net, steps, n_gauge=60, seed=74, every=3, blend=6, trend=2)
+    if case == "irf_target_volume_lakes":
+        methods, wm_on = [m.IRF], 1
+        lakes = make_lakes(net, steps, dt, seed=7, frac=0.03, memory=True, input_option=2, calendar_id=1, start=(2004, 2, 10),
+                           demand_memory=True, target_frac=0.4, vol_jumpstart=1)
+        lr = lakes["reach"] - 1
+        wm = np.full((steps, net.N), -9999.0)
+        wm[:, lr] = 0.3e-8 * net.params["TOTAREA"][lr][None, :] * (1.0 + np.sin(np.arange(steps) / 9.0))[:, None] * (np.random.default_rng(8).random((steps, lr.size)) - 0.15)
+    else:
+        methods, wm_on, wm = [m.KW, m.MC], 0, None
+        lakes = make_lakes(net, steps, dt, seed=7, frac=0.03, input_option=0)
+
+    def build(**kw):
+        dom = m.RoutingDomain(net, dt, methods, frac_future=frac, uh_offset=off, uh=v, max_window=16, lakes=lakes, is_flux_wm=wm_on, **kw)
+        dom.set_da(da)
+        return dom
+
+    def hand_over(dom, it):      # what the reference's driver reads per step, one-step calls
+        dom.set_lake_forcing(it, 1)
+        if wm_on:
+            dom.set_wm_flux(1, wm[it:it + 1])
+        dom.set_obs(it, 1)
+        dom.set_solute(1, sol[it:it + 1])
+
+    def results(dom):
+        out = []
+        for meth in methods:
+            out += [dom.flux(meth), dom.flux(meth, m.api.F_VOL1), dom.solute_state(meth, 0), dom.solute_state(meth, 1), dom.mean_q(meth, reset=False)]
+        return out
+
+    a = build(); a.set_tracer(sol, time_conv=1.0 / 3600.0, mass_conv=1000.0)      # whole windows
+    one, bat = build(step_batch=1), build(step_batch=16)
+    for d in (one, bat):
+        d.enable_tracer(time_conv=1.0 / 3600.0, mass_conv=1000.0)
+    mid = None
+    for it in range(steps):
+        for d in (one, bat):
+            hand_over(d, it)
+            d.step(it * dt, (it + 1) * dt, ro[it])
+        if it == 20:      # a getter in the middle of the second batch routes what is pending
+            mid = [results(one), results(bat)]
+    assert all(np.array_equal(x, y) for x, y in zip(*mid))
+    Qa = a.run(ro, wm_flux=wm)
+    ra, r1, rb = results(a), results(one), results(bat)
+    assert all(np.array_equal(x, y) for x, y in zip(r1, rb)), "batched steps against one step per call"
+    assert all(np.array_equal(x, y) for x, y in zip(ra, rb)), "batched steps against whole windows"
+    assert max(np.abs(x).max() for x in rb) > 0
+    # rows put aside for a step that then arrives as a window call: handed to their setters as they are
+    it = steps - 1
+    w1, w2 = build(step_batch=16), build(step_batch=1)
+    for d in (w1, w2):
+        d.enable_tracer(time_conv=1.0 / 3600.0, mass_conv=1000.0)
+        for k in range(3):
+            hand_over(d, k)
+            if k < 2:
+                d.step(k * dt, (k + 1) * dt, ro[k])
+            else:
+                d._check(d.L.mzr_run(d.h, 1, k * dt, np.ascontiguousarray(ro[k:k + 1])))
+    assert all(np.array_equal(x, y) for x, y in zip(results(w1), results(w2)))
+
+
 @pytest.mark.parametrize("N,seed,dt,kw", [
     (3000, 21, 3600.0, dict(p3=0.03)),
     (20000, 22, 3600.0, dict()),
