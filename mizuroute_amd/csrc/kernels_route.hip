@@ -561,13 +561,27 @@ __device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int p, int rBeg
 #else
 #define MZR_STAGE_OCC(M, F)
 #endif
+// Block tb of a reach's steps: with d.stepBlock = KB > 1 the time skew of the schedule is counted in blocks of KB steps -- launch s
+// takes every reach of stage j through the steps [KB (s - j), KB (s - j) + KB) -- so the reach's state (the IRF convolution window,
+// the 20 nodes of KW / DW) is still in the caches when its next step reads it, and a window is S + W / KB - 1 launches.  The
+// upstream rows of the block were written by the launch before (stage j - 1: the same block) or earlier.  Same arithmetic per
+// reach and step, same order.
+template <int METHOD, bool FULL>
+__device__ __forceinline__ void stage_reach_block(const MzrDev &d, int r, int tb) {
+  if (tb < 0) return;
+  const int KB = d.stepBlock;
+  const int t0 = tb * KB;
+  if (t0 >= d.W) return;
+  const int t1 = min(d.W, t0 + KB);
+#pragma unroll 1
+  for (int t = t0; t < t1; ++t) stage_reach<METHOD, false, FULL>(d, r, t);
+}
+
 template <int METHOD, bool FULL>
 __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
   const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x, rBegin & ~255), rBegin, rEnd);
   if (r < 0) return;
-  const int t = s - d.sigma[r];
-  if (t < 0 || t >= d.W) return;
-  stage_reach<METHOD, false, FULL>(d, r, t);
+  stage_reach_block<METHOD, FULL>(d, r, s - d.sigma[r]);
 }
 
 // Two windows in one launch (round 4, "overlapping windows").  The skewed schedule of a window of W steps over S stages is
@@ -587,9 +601,7 @@ __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) 
   const int rB = old ? rBeginA : rBeginB, rE = old ? rEndA : rEndB;
   const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x - (old ? nBlocksB : 0), rB & ~255), rB, rE);
   if (r < 0) return;
-  const int t = (old ? sA : sB) - d.sigma[r];
-  if (t < 0 || t >= d.W) return;
-  stage_reach<METHOD, false, FULL>(d, r, t);
+  stage_reach_block<METHOD, FULL>(d, r, (old ? sA : sB) - d.sigma[r]);
 }
 
 // ------------------------------------------------------------------------------------------------

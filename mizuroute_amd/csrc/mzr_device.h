@@ -83,6 +83,8 @@ struct MzrKwtStat { unsigned long long w_in, w_up, w_out, n_head, n_route, n_edg
 struct MzrDev {
   int N, H;
   int W;                  // steps in the current window
+  int stepBlock;          // steps a reach takes per launch of the Eulerian stage kernels (blocked time skew: launch s works on the
+                          // steps [KB (s - stage), KB (s - stage + 1)) of every reach); 1 = one step per launch
   int nStages;            // longest path (reaches) in the domain
   // ---- topology (internal order)
   const int      *sigma;      // [N] stage of each reach (0 = farthest from the outlet)

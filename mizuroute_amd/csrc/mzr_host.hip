@@ -240,7 +240,7 @@ struct mzr_domain {
   // (s >= W) are kept back and issued together with the first launches of the next window, or on their own as soon as
   // anybody asks for a result (flushTail: every entry point but the run calls).  The window kept back owns its rows
   // (qlat / qi / Q / lake forcing: the *Alt buffers, swapped in and out); tail.d[ix] are the device views it was launched with.
-  struct { bool pending = false; int W = 0; MzrDev d[6]; } tail;
+  struct { bool pending = false; int W = 0; MzrDev d[6]; } tail;      // (W: launches of the window = its steps in blocks of d.stepBlock)
   DBuf<double> qiAlt, qlatAlt, lakeEvapAlt, lakePrecipAlt; DBuf<int> calMonthAlt, calDayAlt, calDoyAlt;
   bool lakeNextInAlt = false;                    // mzr_set_lake_forcing wrote the NEXT window's lake forcing into the *Alt buffers
   long long pairLaunches = 0, tailFlushes = 0;
@@ -344,6 +344,7 @@ int idxOf(mzr_handle h, int method) {
 
 void fillDev(mzr_handle h, MzrDev &d) {
   memset(&d, 0, sizeof d);
+  d.stepBlock = 1;
   d.N = h->N; d.H = h->H; d.nStages = h->nStages;
   d.sigma = h->sigma.p; d.upStart = h->upStart.p; d.nUp = h->nUp.p; d.nGood = h->nGood.p;
   d.goodMask = h->goodMask.p; d.isOutlet = h->isOutlet.p;
@@ -743,6 +744,9 @@ static int stageRow(mzr_handle h, int kind, const double *a, size_t na, const do
 }
 static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key);
 // steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first ...
+#ifndef MZR_STEP_BLOCK_DEFAULT
+#define MZR_STEP_BLOCK_DEFAULT 4
+#endif
 #define MZR_FLUSH_STEPS(h) do { if ((h) && ((h)->stepN > 0 || (h)->srAny) && !(h)->srApplying) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
 // a one-step call of a per-window setter on a handle that batches its steps: the row is put aside for the coming mzr_step
 #define MZR_STAGES(h, nSteps) ((h) && (h)->cfg.stepBatch > 1 && (nSteps) == 1 && !(h)->srApplying && (h)->haveState)
@@ -1589,6 +1593,21 @@ static void kwt_regroup(mzr_handle h) {
   kwt_build_sweep(h);
 }
 
+// Steps a reach takes per launch of the Eulerian stage kernels.  More than one keeps a reach's state in the caches from one step to
+// the next and divides the launches of a long window; it also makes the schedule's fill and drain (S - 1 launches each, part of
+// the stages idle) KB times longer, which overlapping windows hide and windows that cannot overlap (partitioned domains) pay.
+// MZR_STEP_BLOCK forces it (tests run several); one step per launch wherever KWT's launches share the loop, and in short windows.
+// Measured (profiles/r04_experiments.md, reach-steps/s with 1 / 4 steps per launch, windows overlapping): 100 k reaches, windows of
+// 4096: IRF 6.2 / 7.35, KW 4.6 / 5.65, DW 4.5 / 5.5 x 10^9; 625 k reaches, windows of 2048: IRF 6.5 / 6.7, DW 5.1 / 5.6; Muskingum-
+// Cunge loses (2.15 / 2.08, 4.0 / 2.8 x 10^9: a launch waits for its slowest reach, now through four steps of sub-steps).  So:
+// four where the windows can overlap with it (at least as many blocks as stages) and no method is Muskingum-Cunge; else one.
+static int stepBlockFor(mzr_handle h, int W, bool canOverlap) {
+  int kb = (canOverlap && idxOf(h, MZR_MC) < 0 && W / MZR_STEP_BLOCK_DEFAULT >= h->nStages) ? MZR_STEP_BLOCK_DEFAULT : 1;
+  if (const char *e = getenv("MZR_STEP_BLOCK")) kb = atoi(e);
+  if (idxOf(h, MZR_KWT) >= 0 || W <= 8) kb = 1;
+  return std::max(1, std::min(kb, W));
+}
+
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
@@ -1621,10 +1640,14 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // of its own: no KWT, constituent, gauge observations, water-management fluxes or imported halo rows, and at least as many
   // steps as the network has stages (so that never more than two windows are in flight).
   const int nSt = h->nStages;
-  bool pipe = W >= nSt && nSt >= 2 && idxOf(h, MZR_KWT) < 0 && !h->tracer && !h->qmod && !h->cfg.is_flux_wm && h->nHalo == 0 &&
+  // Steps per launch of the Eulerian stage kernels (kernels_route.hip, stage_reach_block): see stepBlockFor
+  bool pipe = nSt >= 2 && idxOf(h, MZR_KWT) < 0 && !h->tracer && !h->qmod && !h->cfg.is_flux_wm && h->nHalo == 0 &&
               !h->anyLakeTarget && !(W <= 8 && h->rtItems > 0);
   if (const char *e = getenv("MZR_OVERLAP_WINDOWS")) pipe = pipe && atoi(e) != 0;
   if (const char *e = getenv("MZR_ROUTE_SWEEP")) pipe = pipe && atoi(e) == 0;      // (a forced persistent sweep routes whole windows)
+  const int KB = stepBlockFor(h, W, pipe && h->nExp == 0);      // (an export asks for the window's last launches at once: no overlap)
+  const int WB = (W + KB - 1) / KB;      // the window in blocks = launches in which a stage is active
+  pipe = pipe && WB >= nSt;
   if (h->tail.pending && !pipe) flushTail(h);
   const double *prevQlat = h->qlat.p;      // rows of the window before (row lastW = its last BASIN_QR(1))
   if (pipe) {
@@ -1643,7 +1666,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].Q.swap(h->route[ix].Qalt);
   }
   MzrDev d; fillDev(h, d);
-  d.W = W; d.t_start = t_start; d.T1_single = T1_single; d.runoff = runoff_dev;
+  d.W = W; d.t_start = t_start; d.T1_single = T1_single; d.runoff = runoff_dev; d.stepBlock = KB;
   // carry BASIN_QR(1) of the last step of the previous window into row 0 (halo columns already
   // hold the imported row 0 of this window)
   if (h->lastW > 0) {
@@ -1715,7 +1738,13 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     // device, and a sweep whose grid does not fit beside another one can stall
     const bool persistent = h->route[ix].method == MZR_KWT ? sweep : (rtSweep && h->route[ix].rtCap >= 1);
     if (multi && ix > 0 && !persistent) {
-      if (!h->routeStream[ix]) { (void)hipStreamCreateWithFlags(&h->routeStream[ix], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&h->routeEvent[ix], hipEventDisableTiming); }
+      if (!h->routeStream[ix]) {      // (the other methods of a mainstem domain go to high-priority streams like its first: mzr_set_boundary)
+        int lo = 0, hi = 0;
+        if (!(h->highPriority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+              hipStreamCreateWithPriority(&h->routeStream[ix], hipStreamNonBlocking, hi) == hipSuccess))
+          (void)hipStreamCreateWithFlags(&h->routeStream[ix], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&h->routeEvent[ix], hipEventDisableTiming);
+      }
       rst[ix] = h->routeStream[ix];
     }
     dr[ix] = d;
@@ -1783,10 +1812,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     ++rb.nLaunches;
   }
   const bool withTail = pipe && h->tail.pending;      // the window before drains in this window's first nS - 1 launches
-  for (int s = 0; s < (pipe ? W : nS + W - 1); ++s) {
+  int nextChunk = 1;
+  for (int s = 0; s < (pipe ? WB : nS + WB - 1); ++s) {
     if (!anyStage) break;
-    if (chunked && s > 0 && s % CH == 0 && s / CH < nChunks) (void)hipStreamWaitEvent(st, h->basinEvents[s / CH], 0);
-    const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
+    // (launch s reads the hillslope series up to step KB (s + 1) - 1)
+    while (chunked && nextChunk < nChunks && (long long)nextChunk * CH <= (long long)KB * (s + 1) - 1) { (void)hipStreamWaitEvent(st, h->basinEvents[nextChunk], 0); ++nextChunk; }
+    const int sLo = std::max(0, s - (WB - 1)), sHi = std::min(s, nS - 1);
     const int rB = h->stageStart[sLo], rE = h->stageStart[sHi + 1];
     if (rE <= rB) continue;
     for (int ix = 0; ix < nR; ++ix) {
@@ -1824,7 +1855,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       ++rb.nLaunches;
     }
   }
-  if (pipe && anyStage) { h->tail.pending = true; h->tail.W = W; for (int ix = 0; ix < nR; ++ix) h->tail.d[ix] = dr[ix]; }
+  if (pipe && anyStage) { h->tail.pending = true; h->tail.W = WB; for (int ix = 0; ix < nR; ++ix) h->tail.d[ix] = dr[ix]; }
   else h->tail.pending = false;
   if (h->tracer) {
     // constituent: lateral mass flux and its hillslope delay for the whole window (after the water's), then, behind every

@@ -226,7 +226,7 @@ def test_overlapping_windows_equal_windows_one_after_the_other(cfg, hip_lib, mon
     which window k+1 fills.  Windows queued back to back -- of different lengths, with a getter in between (which makes the
     library issue the kept-back launches on their own) and a window shorter than the network is deep (which cannot take
     them along) -- must leave the same bits as MZR_OVERLAP_WINDOWS=0: discharge, volumes, solver state, interval means,
-    lake state included."""
+    lake state included.  The same for several steps per launch (MZR_STEP_BLOCK; default 4 where the windows are long enough)."""
     import torch
     import bench
     dev = torch.device("cuda", 0)
@@ -245,8 +245,12 @@ def test_overlapping_windows_equal_windows_one_after_the_other(cfg, hip_lib, mon
     ro = bench.device_runoff(torch, net.H, total, 0, 7, dev)
     torch.cuda.synchronize()
 
-    def route(overlap):
+    def route(overlap, block=None):
         monkeypatch.setenv("MZR_OVERLAP_WINDOWS", "1" if overlap else "0")
+        if block is None:
+            monkeypatch.delenv("MZR_STEP_BLOCK", raising=False)
+        else:
+            monkeypatch.setenv("MZR_STEP_BLOCK", str(block))
         dom = m.RoutingDomain(net, DT, methods, frac_future=frac, uh_offset=off, uh=v, max_window=max(cuts), lakes=lakes)
         assert dom.schedule()[0] <= 512, dom.schedule()
         t = 0
@@ -280,6 +284,12 @@ def test_overlapping_windows_equal_windows_one_after_the_other(cfg, hip_lib, mon
     for k in a:
         assert np.array_equal(a[k], b[k]), k
     assert np.isfinite(a[("Q", methods[0])]).all()
+    # several steps of a reach per launch (stage_reach_block: the skew of the schedule counted in blocks of steps), with block
+    # lengths that divide no window, overlapping and not: the same bits again
+    for overlap, block in ((True, 2), (True, 5), (False, 7)):
+        c = route(overlap, block)
+        for k in a:
+            assert np.array_equal(c[k], b[k]), (k, overlap, block)
 
 
 def test_host_forcing_windows_f64_and_f32_equal_resident_forcing(hip_lib):
