@@ -745,7 +745,7 @@ static int stageRow(mzr_handle h, int kind, const double *a, size_t na, const do
 static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key);
 // steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first ...
 #ifndef MZR_STEP_BLOCK_DEFAULT
-#define MZR_STEP_BLOCK_DEFAULT 4
+#define MZR_STEP_BLOCK_DEFAULT 8
 #endif
 #define MZR_FLUSH_STEPS(h) do { if ((h) && ((h)->stepN > 0 || (h)->srAny) && !(h)->srApplying) { const int _rc = flushSteps(h); if (_rc) return _rc; } } while (0)
 // a one-step call of a per-window setter on a handle that batches its steps: the row is put aside for the coming mzr_step
@@ -1600,9 +1600,14 @@ static void kwt_regroup(mzr_handle h) {
 // Measured (profiles/r04_experiments.md, reach-steps/s with 1 / 4 steps per launch, windows overlapping): 100 k reaches, windows of
 // 4096: IRF 6.2 / 7.35, KW 4.6 / 5.65, DW 4.5 / 5.5 x 10^9; 625 k reaches, windows of 2048: IRF 6.5 / 6.7, DW 5.1 / 5.6; Muskingum-
 // Cunge loses (2.15 / 2.08, 4.0 / 2.8 x 10^9: a launch waits for its slowest reach, now through four steps of sub-steps).  So:
-// four where the windows can overlap with it (at least as many blocks as stages) and no method is Muskingum-Cunge; else one.
+// Windows of 16 384 at 100 k reaches, 1 / 4 / 8 / 16 steps: IRF 6.5 / 8.0 / 8.3 / 8.5, KW 4.9 / 6.1 / 6.45 / 6.4, DW 4.7 / 5.9 / 6.2 / 6.2;
+// at 625 k DW is best with 2-4 (5.6; 4.7 with 8).  So: where the windows can overlap with it (at least as many blocks as stages)
+// and no method is Muskingum-Cunge, the largest of 8 (4 from 300 k reaches on), 4, 2 that leaves as many blocks as stages; else one.
 static int stepBlockFor(mzr_handle h, int W, bool canOverlap) {
-  int kb = (canOverlap && idxOf(h, MZR_MC) < 0 && W / MZR_STEP_BLOCK_DEFAULT >= h->nStages) ? MZR_STEP_BLOCK_DEFAULT : 1;
+  int kb = 1;
+  if (canOverlap && idxOf(h, MZR_MC) < 0)
+    for (int k = (h->N >= 300000 ? std::min(4, MZR_STEP_BLOCK_DEFAULT) : MZR_STEP_BLOCK_DEFAULT); k >= 2; k /= 2)
+      if (W / k >= h->nStages) { kb = k; break; }
   if (const char *e = getenv("MZR_STEP_BLOCK")) kb = atoi(e);
   if (idxOf(h, MZR_KWT) >= 0 || W <= 8) kb = 1;
   return std::max(1, std::min(kb, W));
