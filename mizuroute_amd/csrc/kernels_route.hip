@@ -577,11 +577,16 @@ __device__ __forceinline__ void stage_reach_block(const MzrDev &d, int r, int tb
   for (int t = t0; t < t1; ++t) stage_reach<METHOD, false, FULL>(d, r, t);
 }
 
-template <int METHOD, bool FULL>
+// BLK = false is the one-step-per-launch form as it always was: the loop of the blocked form costs registers even when it
+// runs once (DW 208 -> 260 VGPRs, Muskingum-Cunge 153 -> 202, IRF 74 -> 112), so the two are separate instantiations.
+template <int METHOD, bool FULL, bool BLK>
 __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
   const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x, rBegin & ~255), rBegin, rEnd);
   if (r < 0) return;
-  stage_reach_block<METHOD, FULL>(d, r, s - d.sigma[r]);
+  if (BLK) { stage_reach_block<METHOD, FULL>(d, r, s - d.sigma[r]); return; }
+  const int t = s - d.sigma[r];
+  if (t < 0 || t >= d.W) return;
+  stage_reach<METHOD, false, FULL>(d, r, t);
 }
 
 // Two windows in one launch (round 4, "overlapping windows").  The skewed schedule of a window of W steps over S stages is
@@ -594,14 +599,17 @@ __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) 
 // window's own rows (discharge, lateral flow, lake forcing: double-buffered on the host side).  A window then costs W
 // launches instead of S + W - 1, every one of them over all reaches.  Same arithmetic per reach and step, same order.
 struct MzrDevPair { MzrDev a, b; };
-template <int METHOD, bool FULL>
+template <int METHOD, bool FULL, bool BLK>
 __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
   const bool old = (int)blockIdx.x >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
   const MzrDev &d = old ? p.a : p.b;
   const int rB = old ? rBeginA : rBeginB, rE = old ? rEndA : rEndB;
   const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x - (old ? nBlocksB : 0), rB & ~255), rB, rE);
   if (r < 0) return;
-  stage_reach_block<METHOD, FULL>(d, r, (old ? sA : sB) - d.sigma[r]);
+  if (BLK) { stage_reach_block<METHOD, FULL>(d, r, (old ? sA : sB) - d.sigma[r]); return; }
+  const int t = (old ? sA : sB) - d.sigma[r];
+  if (t < 0 || t >= d.W) return;
+  stage_reach<METHOD, false, FULL>(d, r, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -829,12 +837,15 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
   const int nBlocksB = blocks(rBeginB, rEndB);
   dim3 block(wg), grid(nBlocksB + blocks(rBeginA, rEndA));
   const bool full = (a.lakeSlot || a.is_flux_wm || a.qmod || a.trVol0) || (b.lakeSlot || b.is_flux_wm || b.qmod || b.trVol0);
+  const bool blk = a.stepBlock > 1 || b.stepBlock > 1;
+#define MZR_PAIR(M) case M: \
+    if (full) { if (blk) hipLaunchKernelGGL((k_stage_pair<M, true, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); \
+                else hipLaunchKernelGGL((k_stage_pair<M, true, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); } \
+    else { if (blk) hipLaunchKernelGGL((k_stage_pair<M, false, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); \
+           else hipLaunchKernelGGL((k_stage_pair<M, false, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); } \
+    break;
   switch (method) {
-    case 0: if (full) hipLaunchKernelGGL((k_stage_pair<0, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<0, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 1: if (full) hipLaunchKernelGGL((k_stage_pair<1, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<1, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 3: if (full) hipLaunchKernelGGL((k_stage_pair<3, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<3, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 4: if (full) hipLaunchKernelGGL((k_stage_pair<4, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<4, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
-    case 5: if (full) hipLaunchKernelGGL((k_stage_pair<5, true>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); else hipLaunchKernelGGL((k_stage_pair<5, false>), grid, block, 0, stream, p, sA, rBeginA, rEndA, sB, rBeginB, rEndB, nBlocksB); break;
+    MZR_PAIR(0) MZR_PAIR(1) MZR_PAIR(3) MZR_PAIR(4) MZR_PAIR(5)
     default: break;
   }
 }
@@ -845,12 +856,13 @@ void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, 
   const int wg = stage_wg(method);
   dim3 block(wg), grid((rEnd - (rBegin & ~255) + wg - 1) / wg);
   const bool full = (d.lakeSlot || d.is_flux_wm || d.qmod || d.trVol0);
+  const bool blk = d.stepBlock > 1;
+#define MZR_STAGE(M) case M: \
+    if (full) { if (blk) hipLaunchKernelGGL((k_stage<M, true, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<M, true, false>), grid, block, 0, stream, d, s, rBegin, rEnd); } \
+    else { if (blk) hipLaunchKernelGGL((k_stage<M, false, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<M, false, false>), grid, block, 0, stream, d, s, rBegin, rEnd); } \
+    break;
   switch (method) {
-    case 0: if (full) hipLaunchKernelGGL((k_stage<0, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<0, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 1: if (full) hipLaunchKernelGGL((k_stage<1, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<1, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 3: if (full) hipLaunchKernelGGL((k_stage<3, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<3, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 4: if (full) hipLaunchKernelGGL((k_stage<4, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<4, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
-    case 5: if (full) hipLaunchKernelGGL((k_stage<5, true>), grid, block, 0, stream, d, s, rBegin, rEnd); else hipLaunchKernelGGL((k_stage<5, false>), grid, block, 0, stream, d, s, rBegin, rEnd); break;
+    MZR_STAGE(0) MZR_STAGE(1) MZR_STAGE(3) MZR_STAGE(4) MZR_STAGE(5)
     default: break;
   }
 }

@@ -1605,7 +1605,10 @@ static void kwt_regroup(mzr_handle h) {
 // and no method is Muskingum-Cunge, the largest of 8 (4 from 300 k reaches on), 4, 2 that leaves as many blocks as stages; else one.
 static int stepBlockFor(mzr_handle h, int W, bool canOverlap) {
   int kb = 1;
-  if (canOverlap && idxOf(h, MZR_MC) < 0)
+  // (the blocked kernels are instantiations of their own and need more registers -- the loop costs them even when it runs once: DW 208 ->
+  // 262 VGPRs, with the lake / water-management / observation branches 217 -> 358: those configurations keep one step per launch)
+  const bool full = h->nLake || h->cfg.is_flux_wm || h->qmod || h->tracer;
+  if (canOverlap && !full && idxOf(h, MZR_MC) < 0)
     for (int k = (h->N >= 300000 ? std::min(4, MZR_STEP_BLOCK_DEFAULT) : MZR_STEP_BLOCK_DEFAULT); k >= 2; k /= 2)
       if (W / k >= h->nStages) { kb = k; break; }
   if (const char *e = getenv("MZR_STEP_BLOCK")) kb = atoi(e);
