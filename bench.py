@@ -704,6 +704,7 @@ def main():
     error = None
     elapsed, value, tm = None, None, None
     events_in_timed = False
+    events_behind = False
     try:
         torch.cuda.synchronize()
         run_batches(KW)
@@ -711,9 +712,12 @@ def main():
         dom.timing(DOM, reset=True)
         # KWT on one GPU: the sweep is ONE launch per window, so the HIP events around it (two per window, on the library's
         # stream) ride in the timed region itself: roofline.achieved is the average over exactly the K timed launches
-        events_in_timed = world == 1 and kwt_run and not args.no_roofline
-        if events_in_timed:
-            dom.set_profiling(1)
+        # ... but NOT while `value` is timed: timing-enabled events on the sweep's stream slow some windows by up to a quarter (447 ->
+        # 510-600 ms, in a pattern with a period of eight windows whose strength differs from process to process; six processes
+        # without events: 3.28-3.30 x 10^9 every one; with events, as markers or attached to the dispatch: 2.77-3.30;
+        # profiles/r04_experiments.md).  So the K timed windows run without them and K more windows right behind carry the events.
+        events_in_timed = False
+        events_behind = world == 1 and kwt_run and not args.no_roofline
 
         if dist is not None:
             dist.barrier()
@@ -726,8 +730,6 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         tm = dom.timing(DOM, reset=True)
-        if events_in_timed:
-            dom.set_profiling(0)
         if dist is not None:
             tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -843,6 +845,7 @@ def main():
     # every stage launch on the library's stream, on the window that follows the timed region
     roof, ktf = None, None
     post_error = None
+    value_events = None
     try:
         if args.no_roofline:
             pass
@@ -851,9 +854,19 @@ def main():
                 dist.barrier()
                 run_batches(1)
                 sync_all()
-        if rank == 0 and not args.no_roofline and events_in_timed:
-            pt = tm
-            ktf = pt["kernel_ms"] * 1e-3 / elapsed if elapsed > 0 else None
+        if rank == 0 and not args.no_roofline and events_behind:      # the same K windows once more, HIP events on every sweep launch
+            dom.timing(DOM, reset=True)
+            dom.set_profiling(1)
+            torch.cuda.synchronize()
+            t_prof = time.perf_counter()
+            run_batches(K)
+            sync_all()
+            torch.cuda.synchronize()
+            t_prof = time.perf_counter() - t_prof
+            dom.set_profiling(0)
+            pt = dom.timing(DOM, reset=True)
+            ktf = pt["kernel_ms"] * 1e-3 / t_prof if t_prof > 0 else None
+            value_events = float(net.N) * K * W * len(methods) / t_prof
         elif rank == 0 and not args.no_roofline:
             dom.timing(DOM, reset=True)
             dom.set_profiling(1)
@@ -918,7 +931,11 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_total / launches,
                     "bytes_per_reach_step": per_rs,
                     "avg_launch_us": avg_ms * 1e3, "launches": launches,
-                    "timed_over": "the K timed windows (HIP events around every sweep launch on the library's stream)" if events_in_timed else "one window behind the timed region",
+                    "min_launch_us": pt.get("min_ms", 0.0) * 1e3, "max_launch_us": pt.get("max_ms", 0.0) * 1e3,
+                    "frac_of_shortest_launch": (bytes_total / launches / (pt["min_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if pt.get("min_ms") else None,
+                    "timed_over": (f"{K} windows right behind the K timed ones, HIP events attached to every sweep launch on the library's stream; the events themselves slow "
+                                   "some windows (see value_with_events against value), so `value` is timed without them") if events_behind else "one window behind the timed region",
+                    "value_with_events": value_events if events_behind else None,
                     "particles_per_routed_reach": (tr["w_in"] + tr["w_up"] + tr["w_out"]) / max(1, tr["n_route"])}
 
 

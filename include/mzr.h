@@ -298,6 +298,9 @@ int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long
       read with mzr_get_kwt_traffic */
 int mzr_set_profiling(mzr_handle h, int mode);
 int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kernel_ms, long long *reachSteps, int reset);
+/* shortest and longest event-timed launch [ms] since the last reset (mode 1; 0 = none).  Timing-enabled events on the stream of a
+   persistent sweep slow some of its windows (profiles/r04_experiments.md): the shortest launch is the undisturbed kernel */
+int mzr_get_timing_range(mzr_handle h, int method, double *min_ms, double *max_ms, int reset);
 /* particle traffic counters of the KWT sweep since the last reset (for the roofline model);
    counted only while profiling mode 2 is on */
 int mzr_get_kwt_traffic(mzr_handle h, long long *w_in, long long *w_up, long long *w_out,

@@ -51,7 +51,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_set_param", "mzr_set_uh", "mzr_set_frac_future", "mzr_init_state", "mzr_step", "mzr_run",
            "mzr_run_dev", "mzr_sync", "mzr_get_flux", "mzr_get_window_q", "mzr_get_mean_q",
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
-           "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing",
+           "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing", "mzr_get_timing_range",
            "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute", "mzr_get_tracer_state", "mzr_set_tracer_state",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
@@ -151,6 +151,7 @@ def load_library():
     L.mzr_set_profiling.argtypes = [vp, ci]
     LL = C.POINTER(C.c_longlong)
     L.mzr_get_timing.argtypes = [vp, ci, LL, C.POINTER(cd), LL, ci]
+    L.mzr_get_timing_range.argtypes = [vp, ci, C.POINTER(cd), C.POINTER(cd), ci]
     L.mzr_get_kwt_traffic.argtypes = [vp, LL, LL, LL, LL, LL, LL, ci]
     _lib = L
     return L
@@ -526,7 +527,9 @@ class RoutingDomain:
     def timing(self, method, reset=False):
         n, ms, rs = C.c_longlong(0), C.c_double(0), C.c_longlong(0)
         self._check(self.L.mzr_get_timing(self.h, method, C.byref(n), C.byref(ms), C.byref(rs), int(reset)))
-        return dict(launches=n.value, kernel_ms=ms.value, reach_steps=rs.value)
+        lo, hi = C.c_double(0), C.c_double(0)
+        self._check(self.L.mzr_get_timing_range(self.h, method, C.byref(lo), C.byref(hi), int(reset)))
+        return dict(launches=n.value, kernel_ms=ms.value, reach_steps=rs.value, min_ms=lo.value, max_ms=hi.value)
 
     def kwt_traffic(self, reset=False):
         v = [C.c_longlong(0) for _ in range(6)]

@@ -47,6 +47,7 @@
 #include <float.h>
 #include <algorithm>
 #include <mutex>
+#include <hip/hip_ext.h>
 #include "mzr_device.h"
 #include "lake_device.h"
 #include "mzr_math.h"
@@ -2035,9 +2036,18 @@ __global__ void k_sweep_heads(MzrDev d, int sBegin) {
   mzr_sweep_join_reset(d.swHead);
 }
 
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream) {
+// evStart / evStop (profiling): attached to the sweep's own dispatch (hipExtLaunchKernelGGL), not recorded as markers around it --
+// marker packets in front of and behind a persistent launch were measured to slow some windows by a quarter (446 -> 560 ms, a
+// pattern with a period of eight windows; without events, and with events attached to the dispatch, every window takes 447 ms:
+// profiles/r04_experiments.md)
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
   if (nWaves < 1 || sEnd <= sBegin) return;
   hipLaunchKernelGGL(k_sweep_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
+  if (evStart && evStop) {
+    if (kwt_full(d)) hipExtLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
+    else hipExtLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
+    return;
+  }
   if (kwt_full(d)) hipLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
   else hipLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
 }

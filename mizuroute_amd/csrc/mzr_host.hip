@@ -46,7 +46,7 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream);
 int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream);
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
 
 namespace {
 
@@ -80,7 +80,7 @@ struct RouteBufs {
   DBuf<double> qobs, qerr; DBuf<int> qelapsed;      // [N] direct insertion (mzr_set_da): RCHFLX%Qobs, ROUTE%Qerror, RCHFLX%Qelapsed
   int rtCap = 0;                                    // wavefronts the device holds of this method's sweep kernel
   bool rtCapTried = false;
-  long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0;   // meanSteps: steps summed into qsum since its last reset
+  long long nLaunches = 0, reachSteps = 0, meanSteps = 0; double kernel_ms = 0.0, kernel_ms_min = 0.0, kernel_ms_max = 0.0;   // meanSteps: steps summed into qsum since its last reset
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t evUsed = 0;
 };
 
@@ -297,6 +297,7 @@ struct mzr_domain {
   DBuf<MzrErr> err;
   RouteBufs route[6];
   bool profiling = false;       // HIP events around every stage launch
+  hipStream_t timerStream = nullptr; hipEvent_t timerGate[2] = {nullptr, nullptr};      // the KWT sweep's timing events live here (run_window)
   bool countTraffic = false;    // KWT particle-traffic counters (atomics: not for timed runs)
   long long stepsDone = 0, totalSteps = 0;
   // steps handed over one at a time (mzr_step with stepBatch > 1): rows wait in page-locked host memory (two buffers, filled
@@ -799,6 +800,7 @@ int mzr_destroy(mzr_handle h) {
   if (h->stepN > 0) fprintf(stderr, "mzr_destroy: %d step(s) handed over with mzr_step (stepBatch %d) were never routed: no result was asked for after them\n", h->stepN, h->cfg.stepBatch);
   h->tail.pending = false;
   if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
+  if (h->timerStream) (void)hipStreamSynchronize(h->timerStream);
   for (int ix = 0; ix < 6; ++ix) if (h->routeStream[ix]) (void)hipStreamSynchronize(h->routeStream[ix]);
   if (h->basinStream) (void)hipStreamSynchronize(h->basinStream);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1790,12 +1792,30 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       }
     }
     mzr_launch_kwt_window_init(dk, 0, W, sx);
-    if (prof) {
+    if (prof) {      // the event pair rides on the sweep's own dispatch (see mzr_launch_sweep_kwt)
       if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
-      (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
-    }
-    mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
-    if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
+      // Timing-enabled events on the sweep's own stream -- as markers around the launch or attached to its dispatch -- slow some
+      // windows by up to a quarter (profiles/r04_experiments.md).  So the timing events go to a stream of their own, chained to the
+      // sweep's stream by events without timing: start = everything in front of the sweep has finished, stop = the sweep has.
+      static const int how = getenv("MZR_EVENT_MARKERS") ? atoi(getenv("MZR_EVENT_MARKERS")) : 0;      // debugging aid: 1 markers, 2 attached
+      if (how == 1) {
+        (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
+        (void)hipEventRecord(rb.events[rb.evUsed].second, sx);
+      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second);
+      else {
+        if (!h->timerStream) {
+          (void)hipStreamCreateWithFlags(&h->timerStream, hipStreamNonBlocking);
+          (void)hipEventCreateWithFlags(&h->timerGate[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&h->timerGate[1], hipEventDisableTiming);
+        }
+        (void)hipEventRecord(h->timerGate[0], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[0], 0);
+        (void)hipEventRecord(rb.events[rb.evUsed].first, h->timerStream);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
+        (void)hipEventRecord(h->timerGate[1], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[1], 0);
+        (void)hipEventRecord(rb.events[rb.evUsed].second, h->timerStream);
+      }
+      ++rb.evUsed;
+    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
     ++rb.nLaunches;
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
   }
@@ -1970,9 +1990,16 @@ int mzr_sync(mzr_handle h) {
   }
   h->retry.queued = 0; h->retry.valid = false;
   if (h->profiling) {
+    if (h->timerStream) (void)hipStreamSynchronize(h->timerStream);
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
       RouteBufs &rb = h->route[ix];
-      for (size_t k = 0; k < rb.evUsed; ++k) { float ms = 0; (void)hipEventElapsedTime(&ms, rb.events[k].first, rb.events[k].second); rb.kernel_ms += ms; }
+      const bool logEach = getenv("MZR_LAUNCH_LOG") != nullptr;      // debugging aid: every event-timed launch on stderr
+      for (size_t k = 0; k < rb.evUsed; ++k) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, rb.events[k].first, rb.events[k].second); rb.kernel_ms += ms;
+        if (rb.kernel_ms_min == 0.0 || ms < rb.kernel_ms_min) rb.kernel_ms_min = ms;
+        if (ms > rb.kernel_ms_max) rb.kernel_ms_max = ms;
+        if (logEach) fprintf(stderr, "mzr launch method %d #%zu %.3f ms\n", rb.method, k, ms);
+      }
       rb.evUsed = 0;
     }
   }
@@ -2692,6 +2719,13 @@ int mzr_set_profiling(mzr_handle h, int mode) {
   const bool on = (mode & 1) != 0;
   if (on != h->profiling) for (auto &rb : h->route) rb.evUsed = 0;      // (event pairs recorded but never read belong to nobody)
   h->profiling = on; h->countTraffic = (mode & 2) != 0;
+  if (on)      // event pairs made ahead: none is created inside a window (the KWT sweep takes one pair per window)
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
+      RouteBufs &rb = h->route[ix];
+      if (rb.method != MZR_KWT) continue;
+      (void)hipSetDevice(h->cfg.device);
+      while (rb.events.size() < 64) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
+    }
   return 0;
 }
 
@@ -2703,6 +2737,19 @@ int mzr_get_timing(mzr_handle h, int method, long long *nLaunches, double *kerne
   RouteBufs &rb = h->route[ix];
   *nLaunches = rb.nLaunches; *kernel_ms = rb.kernel_ms; *reachSteps = rb.reachSteps;
   if (reset) { rb.nLaunches = 0; rb.kernel_ms = 0; rb.reachSteps = 0; }
+  return 0;
+}
+
+// shortest and longest event-timed launch since the last reset (mode 1); 0 = none
+int mzr_get_timing_range(mzr_handle h, int method, double *min_ms, double *max_ms, int reset) {
+  MZR_FLUSH(h);
+  if (!h) return 1;
+  const int ix = idxOf(h, method);
+  if (ix < 0) return fail(h, 81, "mzr_get_timing_range/method not active");
+  RouteBufs &rb = h->route[ix];
+  if (min_ms) *min_ms = rb.kernel_ms_min;
+  if (max_ms) *max_ms = rb.kernel_ms_max;
+  if (reset) { rb.kernel_ms_min = 0.0; rb.kernel_ms_max = 0.0; }
   return 0;
 }
 
