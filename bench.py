@@ -519,8 +519,10 @@ def main():
     ap.add_argument("--window", type=int, default=0,
                     help="model time steps per batch; 0 = what --config says (16384 for c2), fewer when --steps is large (about 2M model steps in total)")
     ap.add_argument("--reaches", type=int, default=0, help="reaches per GPU (default: what --config says)")
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
-                    help="BASELINE.json configuration: c2 (default, the metric's headline) or the per-GPU shard of c3 / c4 / c5 (N = 1 only)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration.  --gpus 1: c2 (default, the metric's headline: 100 k reaches KWT) or the per-GPU shard of c3 / c4 / c5.  "
+                         "--gpus N > 1: c3 (default: ONE network of N x 375 k reaches -- the ~3 M-reach north-star network at N = 8 -- cut into N sub-basin "
+                         "partitions by the reference's decomposition, windows of 4096) or c2 (N x 100 k reaches, windows of 16 384)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default="", help="write <DUMP>.rank<r>.npz with the per-reach interval mean of REACH_Q and the particle "
                     "counts of the reaches this rank routes (tests: a partitioned run must equal the one-rank run); forcing is then "
@@ -534,7 +536,8 @@ def main():
     ap.add_argument("--balance", action="store_true", help="with --loopback: cut rank 0's share of small tributaries by what the mainstem costs it "
                     "(partition.mainstem_cost; the reference's assignment gives rank 0 an even share plus the mainstem).  With --gpus N > 1 "
                     "this is the default (same domains, same results, rank 0 level with the others)")
-    ap.add_argument("--reference-assignment", action="store_true", help="with --gpus N > 1: the reference's assign_node as it is")
+    ap.add_argument("--reference-assignment", action="store_true", help="with --gpus N > 1: the reference's assign_node as it is (the default since round 5; "
+                    "--balance cuts rank 0's share of small tributaries by the mainstem's cost instead)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` objects of the default line (full-size c3 / c4 / c5 in 8 partitions on this GPU)")
     ap.add_argument("--configs", default="c3,c4,c5", help="which full-size configurations the default line carries")
     ap.add_argument("--cpu-spinup-configs", type=int, default=8, help="untimed steps of the CPU baseline of a `configs` object (full network: about a second per step)")
@@ -577,9 +580,13 @@ def main():
     # the mainstem owner (rank 0) once per window over RCCL point-to-point.
     frac = uhmod.basin_uh(DT, 2.5, 86400.0)
     K, KW = max(1, args.steps), max(0, args.warmup)
+    # N = 1: BASELINE.json configs[1] (c2).  N > 1: configs[2] (c3), the north-star network -- N x 375 k reaches, i.e. the ~3 M-reach
+    # CONUS-scale network at N = 8 -- partitioned as the reference partitions it (domain_decomposition.f90:41-163)
+    if args.config is None:
+        args.config = "c2" if world == 1 else "c3"
     cfg = CONFIGS[args.config]
-    if world > 1 and args.config != "c2":
-        raise SystemExit("--config c3/c4/c5 are per-GPU shards: run them with --gpus 1")
+    if world > 1 and args.config not in ("c2", "c3"):
+        raise SystemExit("--gpus N > 1 routes a KWT network (c3, or c2's reaches per GPU); the c4 / c5 shards run with --gpus 1, their full networks with --loopback")
     methods = [int(c) for c in cfg["methods"]]
     kwt_run = methods == [m.KWT]
     DOM = cfg.get("dominant", m.KWT)          # the method the roofline object describes
@@ -590,6 +597,12 @@ def main():
             W //= 2
     n_reach = args.reaches or cfg["reaches"]
     net = m.make_network(n_reach * world, seed=20240529, floodplain=bool(cfg.get("floodplain")))
+    workload = cfg["workload"]
+    if world > 1:
+        workload = (f"ONE synthetic HDMA-CONUS-like network of {net.N} reaches ({n_reach} per GPU"
+                    + ("; BASELINE.json configs[2]: the ~3 M-reach network at 8 GPUs" if args.config == "c3" else "; BASELINE.json configs[1]'s reaches per GPU")
+                    + f"), KWT (route_opt 2), dt 3600 s, hillslope UH on, cut into {world} sub-basin partitions by the reference's domain decomposition "
+                      "(domain_decomposition.f90:41-163), one partition per GPU, mainstem on rank 0, one boundary-record message per partition and window over RCCL p2p")
     router = None
     lakes = None
     if world == 1:
@@ -606,7 +619,7 @@ def main():
     else:
         from mizuroute_amd.partition import PartitionedRouter, partition_network
         from mizuroute_amd.partition import mainstem_cost
-        P = partition_network(net, world, build_for=[rank], main_cost=0.0 if args.reference_assignment else mainstem_cost(net, world, W))
+        P = partition_network(net, world, build_for=[rank], main_cost=mainstem_cost(net, world, W) if (args.balance and not args.reference_assignment) else 0.0)
 
         lib_comm = None
         if os.environ.get("MZR_BENCH_TRANSPORT") == "lib" and backend == "nccl":     # the library's own RCCL transport (mzr_comm_*)
@@ -742,7 +755,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "reaches*timesteps/s", "value": None, "unit": "reaches*timesteps/s", "n_gpus": world, "steps": K, "warmup": KW,
                               "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": cfg["workload"], "baseline_config": args.config, "window_steps": W}, "roofline": None,
+                              "config": {"workload": workload, "baseline_config": args.config, "window_steps": W}, "roofline": None,
                               "cpu_baseline": None, "error": error}))
         sys.stdout.flush()
         os._exit(1)
@@ -1007,7 +1020,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": KW,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "baseline_config": args.config, "route_opt": cfg["methods"],
+            "config": {"workload": workload, "baseline_config": args.config, "route_opt": cfg["methods"],
                        "reaches_per_gpu": net.N // world, "reaches_total": net.N, "stages": n_stages,
                        "max_stage_width": max_width,
                        "step": "one forcing window (batch) of window_steps model time steps",
@@ -1016,7 +1029,7 @@ def main():
                        "kernel_time_fraction": ktf,
                        "kwt_sweep": sweep_geom,
                        "parallelism": ("1 domain" if world == 1 else
-                                       f"{world} sub-basin partitions (the reference's domains; " + ("its node assignment" if args.reference_assignment else
+                                       f"{world} sub-basin partitions (the reference's domains; " + ("its node assignment" if (args.reference_assignment or not args.balance) else
                                        "rank 0's share of small tributaries cut by the mainstem's cost") + "), mainstem on rank 0, "
                                        "one boundary-record message per partition per window over RCCL p2p")},
             "value_resident": value, "value_with_h2d": value_h2d, "value_with_h2d_f64": value_h2d_f64, "h2d": h2d_info, "single_step": single,

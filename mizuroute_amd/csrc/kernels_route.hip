@@ -833,9 +833,10 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
   if (nA + nB <= 0) return;
   MzrDevPair p; p.a = a; p.b = b;
   const int wg = stage_wg(method);
-  auto blocks = [wg](int rB, int rE) { return rE > rB ? (rE - (rB & ~255) + wg - 1) / wg : 0; };
-  const int nBlocksB = blocks(rBeginB, rEndB);
-  dim3 block(wg), grid(nBlocksB + blocks(rBeginA, rEndA));
+  // (with a lane permutation the reaches of a 256-position block may sit anywhere in it: the covered range ends on a block boundary)
+  auto blocks = [wg](const MzrDev &v, int rB, int rE) { const int e = v.lanePerm ? ((rE + 255) & ~255) : rE; return rE > rB ? (e - (rB & ~255) + wg - 1) / wg : 0; };
+  const int nBlocksB = blocks(b, rBeginB, rEndB);
+  dim3 block(wg), grid(nBlocksB + blocks(a, rBeginA, rEndA));
   const bool full = (a.lakeSlot || a.is_flux_wm || a.qmod || a.trVol0) || (b.lakeSlot || b.is_flux_wm || b.qmod || b.trVol0);
   const bool blk = a.stepBlock > 1 || b.stepBlock > 1;
 #define MZR_PAIR(M) case M: \
@@ -854,7 +855,8 @@ void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, 
   const int n = rEnd - rBegin;
   if (n <= 0) return;
   const int wg = stage_wg(method);
-  dim3 block(wg), grid((rEnd - (rBegin & ~255) + wg - 1) / wg);
+  const int rCover = d.lanePerm ? ((rEnd + 255) & ~255) : rEnd;      // a lane permutation moves reaches anywhere inside their 256-position block
+  dim3 block(wg), grid((rCover - (rBegin & ~255) + wg - 1) / wg);
   const bool full = (d.lakeSlot || d.is_flux_wm || d.qmod || d.trVol0);
   const bool blk = d.stepBlock > 1;
 #define MZR_STAGE(M) case M: \

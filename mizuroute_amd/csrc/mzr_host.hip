@@ -181,10 +181,12 @@ __global__ void k_pack_solute(double *sf, int R, int W, int nB, int N, const int
   const int r = expInt[b];
   for (int m = 0; m < R; ++m) sf[((size_t)m * W + t) * nB + b] = F.p[m] ? F.p[m][(size_t)t * N + r] : 0.0;
 }
-__global__ void k_unpack_solute(const double *sf, int R, int W, int nB, int N, int haloBase, const int *haloInt, QPtrsW F) {
+__global__ void k_unpack_solute(const double *rec, const double *sf, int R, int W, int nB, int N, int haloBase, const int *haloInt, QPtrsW F) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (b >= nB || t >= W) return;
+  // (a record this domain does not expect: k_unpack_boundary has raised ierr 20; nothing of it is used here either)
+  if (!(rec[0] == MZR_REC_MAGIC && rec[1] == (double)R && rec[2] == (double)W && rec[3] == (double)nB + 1073741824.0)) return;
   const int r = haloInt[haloBase + b];
   for (int m = 0; m < R; ++m) if (F.p[m]) F.p[m][(size_t)t * N + r] = sf[((size_t)m * W + t) * nB + b];
 }
@@ -1322,7 +1324,7 @@ int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int
   if (h->tracer) {      // the halo reaches' reach_solute_flux goes straight into the window's rows: the constituent pass skips halo reaches
     QPtrsW f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
     const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * nSteps * nSrc + (long long)(nSteps + 1) * nSrc + (long long)nSteps * nSrc + 2LL * nSteps * MZR_OB_CAP * nSrc;
-    hipLaunchKernelGGL(k_unpack_solute, dim3((nSrc + 63) / 64, nSteps), block, 0, h->stream, rec_dev + base, h->cfg.nRoutes, nSteps, nSrc, h->N, haloBase, h->haloInt.p, f);
+    hipLaunchKernelGGL(k_unpack_solute, dim3((nSrc + 63) / 64, nSteps), block, 0, h->stream, rec_dev, rec_dev + base, h->cfg.nRoutes, nSteps, nSrc, h->N, haloBase, h->haloInt.p, f);
   }
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_import_boundary/launch failed");
 }
@@ -1336,6 +1338,15 @@ int mzr_init_state(mzr_handle h) {
   if (h->cfg.doesBasinRoute == 1 && h->ntdhBas < 1) return fail(h, 20, "mzr_init_state/FRAC_FUTURE not set");
   try {
     h->runoffW.free();      // (made on first use: ensureRunoffW)
+    // what earlier windows of this handle left behind in buffers sized for the old network / maxWindow: the second set of rows of
+    // the overlapping windows, the retry snapshot, a window kept back, lake forcing written beside a window kept back
+    h->qlatAlt.free(); h->qiAlt.free();
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].Qalt.free();
+    h->lakeEvapAlt.free(); h->lakePrecipAlt.free(); h->calMonthAlt.free(); h->calDayAlt.free(); h->calDoyAlt.free();
+    h->lakeNextInAlt = false;
+    h->snapN.free(); h->snapQ.free(); h->snapTR.free(); h->snapQsum.free(); h->snapHIn.free();
+    h->retry.valid = false; h->retry.queued = 0;
+    h->tail.pending = false;
     if (h->cfg.doesBasinRoute == 1) {
       h->qi.alloc(W * N); h->qi.zero();      // halo reaches have no HRUs of their own: their rows stay zero (basin state getters)
       h->basS[0].alloc((size_t)h->ntdhBas * N); h->basS[1].alloc((size_t)h->ntdhBas * N);
@@ -1776,12 +1787,18 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     dk.kwtLight = h->kwtDepLight.p;
     const int nLaunch = nS + W - 1;
     {      // the state this window starts from, kept until the window is known to have finished (retry above)
-      const bool can = !h->nLake && !h->tracer && !h->cfg.is_flux_wm;
+      // (not for a domain that exports a boundary record -- the record of a stalled window may have been packed and sent before
+      // mzr_sync gets to route the window again -- and not when another method went through a persistent sweep in this window:
+      // k_sweep_route returns at once after an error, so that method would be left behind with nobody to say so)
+      bool otherSweep = false;
+      for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (h->route[ix].method != MZR_KWT && rtSweep && h->route[ix].rtCap >= 1) otherSweep = true;
+      const bool can = !h->nLake && !h->tracer && !h->cfg.is_flux_wm && h->nExp == 0 && !otherSweep;
       ++h->retry.queued;
       h->retry.valid = false;
       if (can && h->retry.queued == 1) {
         try {
-          if (!h->snapN.p) { h->snapN.alloc(h->kwN.n); h->snapQ.alloc(h->kwQ.n); h->snapTR.alloc(h->kwTR.n); h->snapQsum.alloc(N); if (rb.hInflow.p) h->snapHIn.alloc(N); }
+          if (!h->snapN.p) { h->snapN.alloc(h->kwN.n); h->snapQ.alloc(h->kwQ.n); h->snapTR.alloc(h->kwTR.n); h->snapQsum.alloc(N); }
+          if (rb.hInflow.p && !h->snapHIn.p) h->snapHIn.alloc(N);      // (mzr_set_history may have switched the sum on since the first snapshot)
           (void)hipMemcpyAsync(h->snapN.p, h->kwN.p, h->kwN.n * sizeof(int), hipMemcpyDeviceToDevice, sx);
           (void)hipMemcpyAsync(h->snapQ.p, h->kwQ.p, h->kwQ.n * sizeof(double), hipMemcpyDeviceToDevice, sx);
           (void)hipMemcpyAsync(h->snapTR.p, h->kwTR.p, h->kwTR.n * sizeof(double), hipMemcpyDeviceToDevice, sx);
@@ -1980,9 +1997,10 @@ int mzr_sync(mzr_handle h) {
   if (e != hipSuccess) return fail(h, 92, std::string("mzr_sync/") + hipGetErrorString(e));
   if (h->retry.valid && h->retry.queued == 1) {      // exactly one KWT window since the last synchronisation: did its sweep give up?
     int code = 0;
-    if (hipMemcpy(&code, h->err.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && code == 93) {
-      MzrErr e93;
-      (void)hipMemcpy(&e93, h->err.p, sizeof e93, hipMemcpyDeviceToHost);
+    MzrErr e93;
+    // (where 20 = a wait of the KWT sweep; a stall raised anywhere else -- the Eulerian sweeps raise 21 -- is not this window's to repair)
+    if (hipMemcpy(&code, h->err.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && code == 93 &&
+        hipMemcpy(&e93, h->err.p, sizeof e93, hipMemcpyDeviceToHost) == hipSuccess && e93.where == 20) {
       fprintf(stderr, "mzr: the persistent KWT sweep of a window of %d steps gave up waiting (ierr 93, reach index %d, schedule step %d); the window is routed "
                       "again with one launch per stage\n", h->retry.W, e93.reach, e93.s);
       if (retryKwtWindow(h) != 0) return fail(h, 93, "mzr_sync/the persistent KWT sweep gave up waiting and the window could not be routed again");

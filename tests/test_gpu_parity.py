@@ -927,33 +927,38 @@ def test_long_window_with_chunked_hillslope_prepass(hip_lib):
 
 
 # ---- bench.py as the driver runs it for N > 1: two ranks (here on one GPU, gloo transport) must route what one rank routes
-def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib):
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib, ranks):
+    """`bench.py --gpus N` launched as the driver launches it (torch.distributed.run, one process per rank -- here all on the one
+    GPU of the box, records over gloo): N = 2 and N = 8, the rank count of the north-star configuration (7 peers, recv_many, the
+    reference's assign_node with 8 nodes).  Interval means and particle counts of every reach equal the one-rank run's, bit for bit."""
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--reaches", "3000", "--window", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
-              "--no-h2d", "--no-single-step"]
+    total = 6000 if ranks == 2 else 12000
+    common = ["--config", "c2", "--reaches", str(total // ranks), "--window", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+              "--no-h2d", "--no-single-step", "--no-configs"]
     env = dict(os.environ, MZR_BENCH_SINGLE_DEVICE="1", MZR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = str(tmp_path / "one")
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--reaches", "6000"] + common[2:] + ["--dump", one],
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "c2", "--reaches", str(total)] + common[4:] + ["--dump", one],
                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    two = str(tmp_path / "two")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common + ["--dump", two],
+    two = str(tmp_path / "many")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common + ["--dump", two],
                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     line = [l for l in r2.stdout.splitlines() if l.startswith("{")][-1]
     import json
     j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["config"]["reaches_total"] == 6000 and j["value"] > 0
+    assert j["n_gpus"] == ranks and j["config"]["reaches_total"] == total and j["value"] > 0
     a = np.load(one + ".rank0.npz")
-    parts = [np.load(f"{two}.rank{r}.npz") for r in range(2)]
+    parts = [np.load(f"{two}.rank{r}.npz") for r in range(ranks)]
     reach = np.concatenate([p["reach"] for p in parts]); q = np.concatenate([p["q"] for p in parts]); nw = np.concatenate([p["nw"] for p in parts])
-    assert np.array_equal(np.sort(reach), np.arange(6000)), "every reach is routed by exactly one rank"
+    assert np.array_equal(np.sort(reach), np.arange(total)), "every reach is routed by exactly one rank"
     order = np.argsort(reach)
     assert np.array_equal(nw[order], a["nw"]), "particle counts differ between the partitioned and the one-rank run"
     assert np.array_equal(q[order], a["q"]), "interval means differ between the partitioned and the one-rank run"

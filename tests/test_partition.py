@@ -72,8 +72,11 @@ class RecordingDomain:
         self.imports = {}
         self.ran = []
 
+    HDR, MAGIC = 4, 20260929.0      # the record's header (mzr_host.hip MZR_REC_HDR / MZR_REC_MAGIC): {magic, nRoutes, steps, reaches}
+
     def boundary_size(self, w, n):
-        return (1 * w + (w + 1) + w + 2 * w * 21) * n
+        # mzr_boundary_size: header | Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB], one method
+        return self.HDR + (1 * w + (w + 1) + w + 2 * w * 21) * n
 
     def run_device(self, w, t_start, ptr):
         self.ran.append((w, t_start))
@@ -85,7 +88,8 @@ class RecordingDomain:
         n = self.exp.size
         ids = self.spec.net.reachId[self.exp - 1].astype(np.float64)
         rec = np.zeros(self.boundary_size(w, n))
-        rec[: w * n] = (np.arange(w)[:, None] * 1000.0 + ids[None, :]).ravel()   # Q[t][b] = 1000 t + id
+        rec[:self.HDR] = (self.MAGIC, 1.0, float(w), float(n))
+        rec[self.HDR: self.HDR + w * n] = (np.arange(w)[:, None] * 1000.0 + ids[None, :]).ravel()   # Q[t][b] = 1000 t + id
         return self.torch.from_numpy(rec)
 
     def import_boundary(self, w, ptr, n, base):
@@ -109,6 +113,12 @@ def _worker(rank, world, port, q):
         def recv(self, t, src):
             dist.recv(t, src)
             got[src] = t.clone()
+        def recv_many(self, pairs):      # the records of all peers at once, as the RCCL transports do (bench.py, mzr_comm_recv_many)
+            works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, t, src) for t, src in pairs])
+            for wk in works:
+                wk.wait()
+            for t, src in pairs:
+                got[src] = t.clone()
 
     domains = {}
 
@@ -139,22 +149,28 @@ def _worker(rank, world, port, q):
             ok &= main.imports.get(base) == (w, n)
             ids = P.trib[p].net.reachId[P.trib[p].export_local - 1].astype(np.float64)
             expect = (np.arange(w)[:, None] * 1000.0 + ids[None, :]).ravel()
-            ok &= bool(np.array_equal(got[p][: w * n].numpy(), expect))
+            H = RecordingDomain.HDR
+            ok &= bool(np.array_equal(got[p][:H].numpy(), np.array([RecordingDomain.MAGIC, 1.0, w, n])))      # the header the importer checks
+            ok &= got[p].numel() == H + (w + (w + 1) + w + 2 * w * 21) * n
+            ok &= bool(np.array_equal(got[p][H: H + w * n].numpy(), expect))
         ok &= main.ran == [(w, 0.0), (w, w * 3600.0)]
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_boundary_exchange_over_gloo_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_boundary_exchange_over_gloo(world):
+    """The N > 1 path of PartitionedRouter over torch.distributed (gloo): two ranks, and the eight of the north-star configuration
+    (seven peers, all their records received at once, the reference's assign_node with eight nodes)."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
