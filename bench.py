@@ -410,22 +410,29 @@ class Loopback:
                 dom.set_lake_forcing(0, W)
             dom.run_device(W, k * W * DT, ros[k % 2].data_ptr()); dom.sync()
         win(0); win(1)
-        dom.timing(DOM, reset=True); dom.set_profiling(1)
-        win(2)
-        dom.set_profiling(0)
-        pt = dom.timing(DOM, reset=True)
-        launches = max(1, pt["launches"])
+        clock_ms = None
         if self.methods == [m.KWT]:
+            # the sweep times itself (mzr_get_sweep_clock: first wavefront in -> last wavefront out on the device's clock): four windows
+            dom.sweep_clock(reset=True)
+            for k in range(2, 6):
+                win(k)
+            clock_ms = [x for x in dom.sweep_clock(4) if x > 0]
+            pt = {"launches": len(clock_ms), "kernel_ms": float(sum(clock_ms)), "reach_steps": float(sp.net.N) * W * len(clock_ms)}
             dom.set_profiling(2); dom.kwt_traffic(reset=True)
-            win(3)
+            win(6)
             dom.set_profiling(0)
             tr = dom.kwt_traffic(reset=True)
             per_rs = kwt_bytes(tr) / max(1, tr["n_route"] + tr["n_head"])
             kernel = "k_sweep_kwt"
         else:
+            dom.timing(DOM, reset=True); dom.set_profiling(1)
+            win(2)
+            dom.set_profiling(0)
+            pt = dom.timing(DOM, reset=True)
             U = float(sp.net.upIndex.size) / sp.net.N
             per_rs = float(cfg["bytes"](U))
             kernel = f"k_stage<{DOM}>"
+        launches = max(1, pt["launches"])
         achieved = per_rs * pt["reach_steps"] / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
         sw = dom.sweep_info() if m.KWT in self.methods else None
         dom.close(); del dom, ros
@@ -433,6 +440,8 @@ class Loopback:
         return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": per_rs * pt["reach_steps"] / launches,
                 "bytes_per_reach_step": per_rs, "avg_launch_us": pt["kernel_ms"] / launches * 1e3, "launches": launches,
+                "launch_us": [x * 1e3 for x in clock_ms] if clock_ms else None,
+                "timed_by": "device clock of the sweep itself (mzr_get_sweep_clock)" if clock_ms else "HIP events around every stage launch",
                 "domain": f"trib{p}: {sp.n_real} reaches, window of {W} steps", "kwt_sweep": sw}
 
     def cpu(self, n_spin, n_smp):
@@ -544,6 +553,8 @@ def main():
     ap.add_argument("--cpu-sample-configs", type=int, default=16, help="timed steps of the CPU baseline of a `configs` object")
     ap.add_argument("--cpu-spinup", type=int, default=48, help="with --loopback: untimed steps of the CPU baseline on the full network")
     ap.add_argument("--cpu-sample", type=int, default=48, help="with --loopback: timed steps of the CPU baseline on the full network")
+    ap.add_argument("--event-roofline", action="store_true", help="also time K more windows with HIP events on the sweep launches (the round-4 measurement; "
+                    "roofline.avg_launch_us comes from the sweep's own device clock inside the K timed windows either way)")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the event-timed and the traffic-counter windows (used under rocprofv3)")
     args = ap.parse_args()
@@ -730,7 +741,12 @@ def main():
         # without events: 3.28-3.30 x 10^9 every one; with events, as markers or attached to the dispatch: 2.77-3.30;
         # profiles/r04_experiments.md).  So the K timed windows run without them and K more windows right behind carry the events.
         events_in_timed = False
-        events_behind = world == 1 and kwt_run and not args.no_roofline
+        # Round 5: the sweep times itself -- its first wavefront in and its last wavefront out leave the device's 100 MHz clock in two
+        # words per launch (mzr_get_sweep_clock) -- so roofline.avg_launch_us is measured INSIDE the K timed windows with no host event
+        # anywhere near the stream.  --event-roofline keeps the old leg (K more windows with HIP events) beside it.
+        events_behind = world == 1 and kwt_run and not args.no_roofline and args.event_roofline
+        if kwt_run:
+            dom.sweep_clock(reset=True)
 
         if dist is not None:
             dist.barrier()
@@ -742,6 +758,7 @@ def main():
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        clock_ms = [x for x in dom.sweep_clock(K)] if kwt_run else None      # the K timed launches of this rank's (tributary) domain
         tm = dom.timing(DOM, reset=True)
         if dist is not None:
             tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -860,13 +877,22 @@ def main():
     post_error = None
     value_events = None
     try:
-        if args.no_roofline:
+        clock_roof = kwt_run and not args.no_roofline      # KWT: the launches of the timed region timed themselves (device clock)
+        pt_clock = None
+        if clock_roof:
+            ok = [x for x in (clock_ms or []) if x > 0]
+            dom_N = net.N if router is None else (router.trib_spec.net.N if router.trib is not None else router.main_spec.net.N)
+            if ok:
+                pt_clock = {"kernel_ms": float(sum(ok)), "launches": len(ok), "reach_steps": float(dom_N) * W * len(ok), "min_ms": min(ok), "max_ms": max(ok)}
+                ktf = pt_clock["kernel_ms"] * 1e-3 / elapsed if elapsed else None
+        if args.no_roofline or clock_roof:
             pass
         elif world > 1:      # every rank takes part in the profiled window (the exchange is collective)
             if rank != 0:
                 dist.barrier()
                 run_batches(1)
                 sync_all()
+        pt_events = None
         if rank == 0 and not args.no_roofline and events_behind:      # the same K windows once more, HIP events on every sweep launch
             dom.timing(DOM, reset=True)
             dom.set_profiling(1)
@@ -877,10 +903,9 @@ def main():
             torch.cuda.synchronize()
             t_prof = time.perf_counter() - t_prof
             dom.set_profiling(0)
-            pt = dom.timing(DOM, reset=True)
-            ktf = pt["kernel_ms"] * 1e-3 / t_prof if t_prof > 0 else None
+            pt_events = dom.timing(DOM, reset=True)
             value_events = float(net.N) * K * W * len(methods) / t_prof
-        elif rank == 0 and not args.no_roofline:
+        elif rank == 0 and not args.no_roofline and not clock_roof:
             dom.timing(DOM, reset=True)
             dom.set_profiling(1)
             torch.cuda.synchronize()
@@ -921,34 +946,34 @@ def main():
             dom.set_profiling(0)
             tr = dom.kwt_traffic(reset=True)
             per_rs = kwt_bytes(tr) / max(1, tr["n_route"] + tr["n_head"])
+            pt = pt_clock
+            if pt is None:
+                raise RuntimeError("the sweep's device clock returned no launch of the timed region")
             bytes_total = per_rs * pt["reach_steps"]
             launches = max(1, pt["launches"])
             avg_ms = pt["kernel_ms"] / launches
             achieved = bytes_total / (pt["kernel_ms"] * 1e-3) / 1e9 if pt["kernel_ms"] > 0 else 0.0
-            traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "kwt_hbm_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if world == 1 and tj.get("reaches") == net.N and tj.get("window") == W:
-                        traffic = tj["hbm_bytes_per_launch"]
-                        tsrc = "bundle " + str(tj.get("tag", "?"))
-                except Exception:
-                    traffic = None
             sw = dom.sweep_info()
+            ev = None
+            if pt_events is not None and pt_events["launches"] > 0:      # --event-roofline: the round-4 measurement beside it
+                ev = {"avg_launch_us": pt_events["kernel_ms"] / pt_events["launches"] * 1e3, "launches": pt_events["launches"],
+                      "min_launch_us": pt_events.get("min_ms", 0.0) * 1e3, "max_launch_us": pt_events.get("max_ms", 0.0) * 1e3, "value_with_events": value_events,
+                      "what": f"{K} more windows right behind the timed ones with HIP events attached to the sweep launches (the events themselves slow some windows)"}
             roof = {"bound": "hbm", "kernel": "k_sweep_kwt" if sw[0] > 0 and os.environ.get("MZR_KWT_SWEEP", "1") != "0" else "k_stage_kwt",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_source": (f"profiles/kwt_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate run of the same workload and build "
-                                       f"({tsrc}); NOT measured in this run") if traffic is not None else None,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    # HBM traffic from the PMC counters needs rocprofv3 passes of its own (MI355X_MICROARCH.md): not measurable in this run.
+                    # The per-round figure for this workload is in profiles/ (r05*_summary.md, kwt_hbm_traffic.json); null here by rule.
+                    "traffic": None,
                     "algorithmic_bytes_per_launch": bytes_total / launches,
                     "bytes_per_reach_step": per_rs,
                     "avg_launch_us": avg_ms * 1e3, "launches": launches,
-                    "min_launch_us": pt.get("min_ms", 0.0) * 1e3, "max_launch_us": pt.get("max_ms", 0.0) * 1e3,
-                    "frac_of_shortest_launch": (bytes_total / launches / (pt["min_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if pt.get("min_ms") else None,
-                    "timed_over": (f"{K} windows right behind the K timed ones, HIP events attached to every sweep launch on the library's stream; the events themselves slow "
-                                   "some windows (see value_with_events against value), so `value` is timed without them") if events_behind else "one window behind the timed region",
-                    "value_with_events": value_events if events_behind else None,
+                    "min_launch_us": pt["min_ms"] * 1e3, "max_launch_us": pt["max_ms"] * 1e3,
+                    "launch_us": [x * 1e3 for x in (clock_ms or [])],
+                    "frac_of_shortest_launch": (bytes_total / launches / (pt["min_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if pt["min_ms"] else None,
+                    "timed_over": (f"the {launches} sweep launches of the K timed windows themselves, each timed on the device's own 100 MHz clock: first wavefront in -> "
+                                   "last wavefront out (mzr_get_sweep_clock); no HIP events in or near the timed region"),
+                    "hip_events": ev,
                     "particles_per_routed_reach": (tr["w_in"] + tr["w_up"] + tr["w_out"]) / max(1, tr["n_route"])}
 
 

@@ -291,6 +291,12 @@ int mzr_get_sweep_retries(mzr_handle h, long long *nRetries);
    wavefront that starts more than 20 us (MZR_SWEEP_LATE_TICKS = 2000 ticks of the 100 MHz clock) after the first one of its launch leaves at once), and since
    mzr_init_state the number of wavefronts by start delay: hist32[k] counts delays below 2^k ticks of 10 ns */
 int mzr_get_sweep_arrivals(mzr_handle h, int *arrivedLast, int *joinedLast, long long *hist32);
+/* KWT persistent sweep, duration of its launches on the DEVICE's clock: the first wavefront of a launch to arrive and the last one
+   to leave write the 100 MHz counter (s_memrealtime) into a pair of words of the launch's own; no host events involved (events
+   with timing on a stream next to a persistent launch were measured to slow it).  ms[0..*n) = the latest min(maxN,
+   launches since the last reset, 1024) launches, oldest first, in milliseconds (0 = the launch did not run to its end);
+   synchronises the handle's stream; reset != 0 starts counting anew. */
+int mzr_get_sweep_clock(mzr_handle h, int maxN, double *ms, int *n, int reset);
 /* measurement modes (bit mask, default 0):
    1  kernel-time accounting of the routing sweep: launches and summed device time [ms] per method
       (HIP events around every stage launch on the handle's stream), read with mzr_get_timing;

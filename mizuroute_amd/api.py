@@ -58,7 +58,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
            "mzr_get_sweep_info", "mzr_run_async", "mzr_run_async_f32", "mzr_comm_unique_id", "mzr_comm_init", "mzr_comm_send", "mzr_comm_recv",
            "mzr_comm_recv_many", "mzr_comm_destroy", "mzr_comm_last_error", "mzr_comm_sync", "mzr_set_history", "mzr_get_mean",
-           "mzr_reset_means", "mzr_get_sweep_arrivals", "mzr_get_sweep_retries"]
+           "mzr_reset_means", "mzr_get_sweep_arrivals", "mzr_get_sweep_retries", "mzr_get_sweep_clock"]
 
 
 def load_library():
@@ -148,6 +148,7 @@ def load_library():
     L.mzr_get_schedule.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.mzr_get_sweep_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.mzr_get_sweep_arrivals.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(C.c_longlong)]
+    L.mzr_get_sweep_clock.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(ci), ci]
     L.mzr_set_profiling.argtypes = [vp, ci]
     LL = C.POINTER(C.c_longlong)
     L.mzr_get_timing.argtypes = [vp, ci, LL, C.POINTER(cd), LL, ci]
@@ -482,6 +483,13 @@ class RoutingDomain:
         hist = (C.c_longlong * 32)()
         self._check(self.L.mzr_get_sweep_arrivals(self.h, C.byref(a), C.byref(j), hist))
         return a.value, j.value, [int(x) for x in hist]
+
+    def sweep_clock(self, max_n=1024, reset=False):
+        """durations [ms] of the latest KWT sweep launches on the device's own clock (first wavefront in -> last wavefront out), oldest first"""
+        ms = (C.c_double * max(1, max_n))()
+        n = C.c_int(0)
+        self._check(self.L.mzr_get_sweep_clock(self.h, max_n, ms, C.byref(n), 1 if reset else 0))
+        return [float(ms[k]) for k in range(n.value)]
 
     def sweep_retries(self):
         """windows whose persistent KWT sweep gave up (ierr 93) and that were routed again through one launch per stage"""

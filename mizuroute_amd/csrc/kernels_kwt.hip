@@ -1810,7 +1810,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
 #endif
   if (sEnd < 0) { mzr_census(d0.swHead + 8 * 16); return; }      // host: mzr_sweep_kwt_capacity
   if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
-  const int arr = mzr_sweep_join(d0.swHead);      // (a wavefront that starts behind time does not join)
+  const int arr = mzr_sweep_join(d0.swHead, d0.swClock);      // (a wavefront that starts behind time does not join)
   if (arr < 0) return;
   if (d0.sweepPrio) __builtin_amdgcn_s_setprio(3);      // mzr_config.sweepPriority: a small, deep domain sweeping beside a large one
   const int Wm1 = d0.W - 1;
@@ -1902,6 +1902,8 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
     }
   }
   kwt_beat(d0, 3, 9);
+  // the launch's duration on the device's own clock (mzr_get_sweep_clock): the last wavefront to leave leaves the latest time
+  if (d0.swClock && mzr_lane() == 0) atomicMax(d0.swClock + 1, (unsigned long long)wall_clock64());
 }
 
 // Start of a KWT window in persistent mode: progress counters back to zero, and the headwater reaches
@@ -2033,6 +2035,7 @@ void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream
 __global__ void k_sweep_heads(MzrDev d, int sBegin) {
   if (d.err->code != 0) return;
   if (threadIdx.x < 8) d.swHead[threadIdx.x * 16] = d.swP[sBegin * 8 + threadIdx.x];
+  if (d.swClock && threadIdx.x >= 12 && threadIdx.x < 14) d.swClock[threadIdx.x - 12] = 0ull;
   mzr_sweep_join_reset(d.swHead);
 }
 

@@ -207,6 +207,7 @@ struct MzrDev {
   const int *rtItemInfo;      // [nItems] stage | 1 << 30 when the item holds lakes (their plain state needs fences)
   const int *rtRA, *rtP;      // per launch: first active item, ticket prefix per queue (as swRA / swP)
   int *rtHead;                // [8][16] ticket counters
+  unsigned long long *swClock;   // [2] of this launch of the KWT sweep: the 100 MHz clock when its first wavefront arrived / when its last one left (mzr_get_sweep_clock)
   int *swBeat;                // [wavefronts][8] what every wavefront of a persistent sweep is doing (launch, item, queue, phase, items done): only with MZR_SWEEP_DEBUG=1
   int sweepPrio;              // 1: wavefronts of this handle's persistent sweeps keep the highest wave priority (mzr_config.sweepPriority)
   long long stallTicks;       // a polling wavefront gives up (code 93) when nothing it polls has changed for this many ticks of the 100 MHz clock
@@ -254,11 +255,12 @@ __device__ __forceinline__ void mzr_census(int *cnt) {
 #ifndef MZR_SWEEP_LATE_TICKS
 #define MZR_SWEEP_LATE_TICKS 2000
 #endif
-__device__ __forceinline__ int mzr_sweep_join(int *head) {
+__device__ __forceinline__ int mzr_sweep_join(int *head, unsigned long long *clk = nullptr) {
   int j = 0;
   if ((threadIdx.x & 63) == 0) {
     const long long now = wall_clock64();
     const unsigned long long t0 = atomicCAS((unsigned long long *)(head + 8 * 16 + 4), 0ull, (unsigned long long)now);
+    if (clk && t0 == 0ull) clk[0] = (unsigned long long)now;      // the launch's first wavefront
     const int arr = atomicAdd(head + 8 * 16 + 2, 1);
     const long long dt = t0 ? now - (long long)t0 : 0;
     atomicAdd(head + 8 * 16 + 16 + (dt <= 0 ? 0 : min(31, 64 - __clzll(dt))), 1);      // delays below 2^k ticks

@@ -253,6 +253,7 @@ struct mzr_domain {
   struct { bool valid = false; int W = 0, queued = 0; double t_start = 0.0, T1_single = 0.0; } retry;
   DBuf<int> snapN; DBuf<double> snapQ, snapTR, snapQsum, snapHIn;
   long long sweepRetries = 0;
+  DBuf<unsigned long long> swClock; long long swClockN = 0;      // {first wavefront in, last wavefront out} of the last MZR_CLOCK_LOG sweep launches (device clock)
   // kwt
   DBuf<int> kwN, obN, kwtLight;
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
@@ -605,6 +606,7 @@ int checkDeviceError(mzr_handle h) {
 // Grid of a persistent sweep from the wavefronts the device holds of its kernel (measured, mzr_sweep_*_capacity): a
 // margin below it -- other kernels of the window (hillslope chunks, history sums) come and go beside the sweep, and a
 // sweep with workgroups left waiting for a slot can stall -- times the handle's share of the device.
+#define MZR_CLOCK_LOG 1024      // sweep launches whose device-clock pair is kept (a ring)
 int sweepGrid(mzr_handle h, int held) {
   if (held < 1) return 0;      // the capacity could not be measured: the caller decides (the Eulerian methods then keep one launch per stage)
   const double share = (h->cfg.sweepShare > 0.0 && h->cfg.sweepShare <= 1.0) ? h->cfg.sweepShare : 1.0;
@@ -614,6 +616,7 @@ int sweepGrid(mzr_handle h, int held) {
 
 void kwt_build_sweep(mzr_handle h) {
   const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
+  if (!h->swClock.p) { try { h->swClock.alloc(2 * MZR_CLOCK_LOG); h->swClock.zero(); h->swClockN = 0; } catch (const std::string &) { (void)hipGetLastError(); } }
   if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }      // eight ticket heads (one cache line each), census and arrival counters, histogram of the start delays
   int cap = 0;
   { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream)); }
@@ -1808,6 +1811,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         } catch (const std::string &) { (void)hipGetLastError(); }
       }
     }
+    if (h->swClock.p) { dk.swClock = h->swClock.p + 2 * (size_t)(h->swClockN % MZR_CLOCK_LOG); ++h->swClockN; }
     mzr_launch_kwt_window_init(dk, 0, W, sx);
     if (prof) {      // the event pair rides on the sweep's own dispatch (see mzr_launch_sweep_kwt)
       if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
@@ -2718,6 +2722,27 @@ int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems) {
 int mzr_get_sweep_retries(mzr_handle h, long long *nRetries) {
   if (!h || !nRetries) return 1;
   *nRetries = h->sweepRetries;
+  return 0;
+}
+
+int mzr_get_sweep_clock(mzr_handle h, int maxN, double *ms, int *n, int reset) {
+  MZR_FLUSH(h);
+  if (!h || !n) return 1;
+  *n = 0;
+  if (!h->swClock.p) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, 92, "mzr_get_sweep_clock/device error");
+  const long long have = std::min<long long>(h->swClockN, MZR_CLOCK_LOG);
+  std::vector<unsigned long long> v(2 * MZR_CLOCK_LOG);
+  if (hipMemcpy(v.data(), h->swClock.p, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return fail(h, 92, "mzr_get_sweep_clock/hipMemcpy failed");
+  const long long take = std::min<long long>(have, maxN > 0 ? maxN : 0);
+  for (long long k = 0; k < take; ++k) {      // the latest `take` launches, oldest first
+    const long long seq = h->swClockN - take + k;
+    const unsigned long long a = v[2 * (seq % MZR_CLOCK_LOG)], b = v[2 * (seq % MZR_CLOCK_LOG) + 1];
+    if (ms) ms[k] = (a && b > a) ? (double)(b - a) * 1e-5 : 0.0;      // 100 MHz ticks -> ms (0: the launch did not run to its end)
+  }
+  *n = (int)take;
+  if (reset) h->swClockN = 0;
   return 0;
 }
 

@@ -47,7 +47,7 @@ MODULE mzr_c
             mzr_set_lake_target, mzr_set_wm_vol, mzr_comm_unique_id, mzr_comm_init, mzr_comm_send, mzr_comm_recv, mzr_comm_recv_many, mzr_comm_destroy, mzr_comm_last_error, mzr_comm_sync, &
             mzr_get_global_wb, mzr_set_lake_forcing_dev, mzr_set_da, mzr_set_obs, &
             mzr_set_tracer, mzr_set_solute, mzr_get_solute, mzr_get_window_solute, mzr_get_tracer_state, mzr_set_tracer_state, &
-            mzr_set_history, mzr_get_mean, mzr_reset_means, mzr_get_sweep_arrivals, mzr_get_sweep_retries
+            mzr_set_history, mzr_get_mean, mzr_reset_means, mzr_get_sweep_arrivals, mzr_get_sweep_retries, mzr_get_sweep_clock
   public :: mzr_message
 
   INTERFACE
@@ -243,6 +243,14 @@ MODULE mzr_c
       import :: c_ptr, c_int, c_long_long
       type(c_ptr), value :: h
       integer(c_long_long), intent(out) :: nRetries
+    end function
+    ! durations [ms] of the latest KWT sweep launches on the device's own clock
+    integer(c_int) function mzr_get_sweep_clock(h, maxN, ms, n, reset) bind(C, name='mzr_get_sweep_clock')
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: h
+      integer(c_int), value :: maxN, reset
+      real(c_double), intent(out) :: ms(*)
+      integer(c_int), intent(out) :: n
     end function
     integer(c_int) function mzr_get_sweep_arrivals(h, arrivedLast, joinedLast, hist32) bind(C, name='mzr_get_sweep_arrivals')
       import :: c_ptr, c_int, c_long_long

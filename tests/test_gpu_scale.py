@@ -355,3 +355,54 @@ def test_window_whose_sweep_gave_up_is_routed_again(hip_lib, monkeypatch):
     assert ra >= 1 and rb == 0, (ra, rb)
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
     assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb)
+
+
+def test_short_window_stall_beside_another_sweep_is_reported(hip_lib, monkeypatch):
+    """with KWT and an Eulerian method in a window of at most 8 steps both go through persistent sweeps on one
+    stream; after a KWT stall k_sweep_route returns at once, so a retry of the KWT part alone would leave IRF behind without
+    a word.  The retry must not be armed there: the caller gets ierr 93."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    net = m.make_network(20_000, seed=52)
+    frac, off, v = _uh(net)
+    W = 4
+    ro = bench.device_runoff(torch, net.H, W, 0, 7, dev)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MZR_KWT_SWEEP", "1")
+    monkeypatch.setenv("MZR_ROUTE_SWEEP", "1")
+    monkeypatch.setenv("MZR_SWEEP_TIMEOUT_S", "1e-8")
+    dom = m.RoutingDomain(net, DT, [m.KWT, m.IRF], frac_future=frac, uh_offset=off, uh=v, max_window=W)
+    dom.run_device(W, 0.0, ro.data_ptr())
+    with pytest.raises(m.MzrError) as ei:
+        dom.sync()
+    assert ei.value.ierr == 93
+    assert dom.sweep_retries() == 0
+    dom.close()
+
+
+def test_sweep_times_itself_on_the_device_clock(hip_lib):
+    """mzr_get_sweep_clock: every launch of the persistent KWT sweep leaves the device clock of its first wavefront in and its last
+    wavefront out; the durations are positive, one per window, and their sum fits the wall time of the windows."""
+    import time
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    net = m.make_network(30_000, seed=53)
+    frac, _, _ = _uh(net)
+    W, K = 256, 4
+    ro = bench.device_runoff(torch, net.H, W, 0, 7, dev)
+    torch.cuda.synchronize()
+    dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W)
+    dom.run_device(W, 0.0, ro.data_ptr()); dom.sync()
+    assert len(dom.sweep_clock(reset=True)) == 1
+    t0 = time.perf_counter()
+    for k in range(1, 1 + K):
+        dom.run_device(W, k * W * DT, ro.data_ptr())
+    dom.sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ms = dom.sweep_clock()
+    assert len(ms) == K and all(x > 0 for x in ms), ms
+    assert sum(ms) <= wall_ms * 1.001, (ms, wall_ms)
+    assert dom.sweep_clock(2) == ms[-2:]
+    dom.close()
