@@ -122,11 +122,12 @@ __device__ __forceinline__ void kwt_beat(const MzrDev &d, int k, int v) {
 #else
 #define MZR_BEAT_ON(d) false
 #endif
-// (64-bit words: steps in bits 0-15, the at-rest count in 16-20, the counts of the MZR_OB_RING outbox slots in 21-40)
+// (64-bit words: steps in bits 0-15, the at-rest count in 16-20, the counts of the MZR_OB_RING outbox slots from bit 21 on, five bits each)
 #define MZR_KWD_STEPS(w) ((int)((w) & 0xffffull))
 #define MZR_KWD_OWN(w) ((int)(((w) >> 16) & 31ull))
 #define MZR_KWD_OUT(w, slot) ((int)(((w) >> (21 + 5 * (slot))) & 31ull))
 #define MZR_KWD_OUTMASK(slot) (31ull << (21 + 5 * (slot)))
+#define MZR_KWD_ALLOUT (((MZR_OB_RING * 5 + 21) >= 64 ? ~0ull : ((1ull << (MZR_OB_RING * 5 + 21)) - 1ull)) & ~((1ull << 21) - 1ull))      // the counts of every slot
 // kwOwn: steps of the window whose at-rest list is in memory (low 16 bits), its particle count above them
 #define MZR_KWO_OWN(w) ((int)(((w) >> 16) & 31ull))
 typedef unsigned long long mzr_word;
@@ -600,15 +601,16 @@ __device__ __forceinline__ KwtStep kwt_step(const MzrDev &d, int t) {
 // Reaches that do not route particles: headwaters (kwt_route.f90:181-205), lake reaches
 // (lake_route replaces kwt_rch) and halo reaches of a partition (replay of the imported record).
 template <bool FULL, bool PERS>
-__device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int ltEnd) {
+__device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int ltEnd, int tMul = 1, int tAdd = 0) {
   const int N = d.N;
   unsigned long long st_head = 0;
   int r = -1, t = -1;
   bool act = false;
   if (item < ltEnd) {
     r = d.kwtLight[item];
-    t = s - d.sigma[r];
-    act = t >= 0 && t < d.W;
+    const int tb = s - d.sigma[r];
+    t = tb * tMul + tAdd;      // (a sweep that visits in blocks of tMul steps: step tAdd of block tb)
+    act = tb >= 0 && t < d.W;
   }
   if (PERS) {   // a lake needs the discharge of its upstream reaches, a halo reach overwrites the outbox its downstream reach read two steps ago
     const bool halo = act && FULL && d.haloSlot && d.haloSlot[r] >= 0;
@@ -726,41 +728,76 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 // PERS: the persistent sweep -- wait for the reaches this step depends on, exchange outbox rows and
 // discharge with other wavefronts through sc1 accesses, publish the step in kwDone.  Returns bit 0: the
 // reach needs more than `cap` entries, bit 1: the sweep is abandoned (error raised somewhere).
-template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN, bool PERS>
-__device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
-                                         int off, int cap, double *sA, double *sB, double *sC, double *sD, double *ctx) {
-  const int lane = mzr_lane(), gl = lane & (G - 1);
-  const int N = d.N;
+// KBLK > 1 (persistent sweep only): a VISIT takes the reach through the KBLK consecutive steps [KBLK tb, KBLK tb + KBLK) of block
+// tb = s - stage: the record is fetched and decoded once, the reach's own list is loaded once, stays in the group's LDS slice from
+// step to step (what is left at rest after a step is moved to the front of the slice instead of written out and read back) and is
+// written once; the reach's own previous step is waited for once (it is this visit's own work from the second step on), and the
+// progress words of the upstream and downstream reaches are polled again only when the words of the last poll do not already
+// cover the step (an upstream reach is usually a whole block ahead: one poll per visit).  Discharge, outbox row and the progress
+// word are still published step by step, so a downstream reach follows one STEP behind, not one block.  kFirst: the first step
+// of the block this group routes (> 0: a narrower group of the same wavefront ran out of room there and handed the reach on).
+// KBLK == 1: one step per call, t = (s - stage) * tMul + tAdd (the stage launches; the confluences of more than two reaches
+// and single-step windows of the sweep).
+template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN, bool PERS, int KBLK>
+__device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
+                                         int offIn, int cap, double *sA, double *sB, double *sC, double *sD, double *ctxIn,
+                                         int kFirst = 0, int tMul = 1, int tAdd = 0) {
+  constexpr bool BLK = KBLK > 1;
+  static_assert(!BLK || (PERS && !GEN), "blocks of steps: the persistent sweep's binary-confluence passes");
   bool ovf = false;
+  int ovfStep = 0;         // (BLK) step of the block at which the reach outgrew this group
+  bool failed = false;     // (BLK) an error was raised for this reach: its remaining steps are left alone
   // The sweep is as fast as its slowest chain of passes, and those are the wide ones (long particle lists, thinning):
   // they go first whenever the SIMD has a choice.
-  const bool boost = PERS && d.sweepPrio;      // the whole sweep of this handle runs at priority 3 (set once in k_sweep_kwt)
+  const bool boost = PERS && dIn.sweepPrio;      // the whole sweep of this handle runs at priority 3 (set once in k_sweep_kwt)
 #ifndef MZR_NO_PRIO
   if (G >= 16 && !PERS) __builtin_amdgcn_s_setprio(2);      // (the persistent sweep raises it after its wait: a wavefront that polls has no business in front of one that computes)
 #endif
   // ---- round trip 1: the static record of the reach (host-packed, one 64-byte line), fetched by eight lanes of
   // the group into LDS (ctx[4..11]) and read from there when a field is needed, not held in registers
-  double *rc = ctx + 4;
-  for (int k = gl; k < 8; k += G) rc[k] = ((const double *)(recs + (have ? item : lastItem)))[k];
-  grp_sync();
-  const int *rci = (const int *)rc;      // r, sigma | u0, nup flags upGood goodMask | width | CW | length | scA | scB | down, -
-  if (PERS && MZR_BEAT_ON(d) && have && gl < 4) {      // debugging aid: the record as the caches hold it against what memory holds
-    const int fresh = ldx<true>((const int *)(recs + item) + gl);
-    if (fresh != rci[gl]) mzr_raise_stall(d, 40 + gl, rci[0], s, item, rci[gl], fresh, -1, lane, 0, 0, d.swHead);
+  {
+    const int gl0 = mzr_lane() & (G - 1);
+    double *rc0 = ctxIn + 4;
+    for (int k = gl0; k < 8; k += G) rc0[k] = ((const double *)(recs + (have ? item : lastItem)))[k];
+    grp_sync();
+    if (PERS && MZR_BEAT_ON(dIn) && have && gl0 < 4) {      // debugging aid: the record as the caches hold it against what memory holds
+      const int *rci0 = (const int *)rc0;
+      const int fresh = ldx<true>((const int *)(recs + item) + gl0);
+      if (fresh != rci0[gl0]) mzr_raise_stall(dIn, 40 + gl0, rci0[0], s, item, rci0[gl0], fresh, -1, mzr_lane(), 0, 0, dIn.swHead);
+    }
   }
+  mzr_word wword = 0;      // the progress word this lane polled
+  mzr_word wSelf = 0;      // the reach's own progress word as last seen / published (its outbox counts of the other slots ride on)
+  int n_own = 0;           // at-rest particles of the reach (BLK: carried from step to step of the visit)
+  int kb = BLK ? kFirst : 0;
+#pragma unroll 1
+  for (;;) {               // the steps of the visit (BLK); once otherwise
+  // (BLK: what a step needs of the reach and the domain is read again from the record in LDS and from the kernel arguments, behind
+  // values made opaque per step -- kept live across the loop, or hoisted out of it, they spill: 340 VGPRs and 170 SGPRs did)
+  const MzrDev *dp_ = &dIn;
+  int off = offIn;
+  // (the context pointer is made opaque as an LDS pointer: a generic pointer of unknown origin would turn every access through
+  // it into a FLAT instruction, and those are not ordered with the ds_ instructions of the same wavefront -- grp_sync relies on
+  // the in-order LDS queue)
+  typedef __attribute__((address_space(3))) double *LdsPtr;
+  LdsPtr ctx3 = (LdsPtr)ctxIn;
+  if (BLK) {      // (the domain description of a blocked sweep lives in the kernel-argument segment: k_sweep_kwt; scalar loads)
+    typedef const MzrDev __attribute__((address_space(4))) *MzrDevK;
+    MzrDevK dk_ = (MzrDevK)dp_;
+    asm volatile("" : "+s"(dk_)); asm volatile("" : "+v"(off)); asm volatile("" : "+v"(ctx3));
+    dp_ = (const MzrDev *)dk_;
+  }
+  double *ctx = (double *)ctx3;
+  const MzrDev &d = *dp_;
+  const int lane = mzr_lane(), gl = lane & (G - 1);
+  const int N = d.N;
+  double *rc = ctx + 4;
+  const int *rci = (const int *)rc;      // r, sigma | u0, nup flags upGood goodMask | width | CW | length | scA | scB | down, -
   const int r = uni<G>(rci[0]);
-  const int t = uni<G>(have ? s - rci[1] : -1);
+  const int tb = have ? s - rci[1] : -1;                                  // block (BLK) or step of the reach in this launch of the schedule
+  const int tBase = BLK ? tb * KBLK : tb * tMul + tAdd;                   // first step of the visit's block
   const unsigned rcb = (unsigned)rci[3];
-  const bool live = t >= 0 && t < d.W;
-  const KwtStep ks = kwt_step(d, t);
-  const double T0 = ks.T0, T1 = ks.T1;
-  const double T_START = T0, T_END = T1;                    // RSTEP = 0
-  double *Qrow = ks.Qrow;
-  const double *qlat_prev = ks.qlat_prev, *qlat_cur = ks.qlat_cur;
-  const int par = ks.par;
-  const int *obN = d.obN + (size_t)par * N;
-  const double *obQT = d.obQT + 2 * (size_t)par * MZR_OB_STRIDE * N;      // this step's parity of the {Q, exit time} rows
-  const __amdgpu_buffer_rsrc_t obRs = mzr_rsrc(obQT), kwRs = mzr_rsrc(d.kwQT);
+  const __amdgpu_buffer_rsrc_t kwRs = mzr_rsrc(d.kwQT);
   const int nup = (int)(rcb & 0xff), ng = (int)((rcb >> 8) & 15), u0 = rci[2];
   const unsigned upGood = (rcb >> 16) & 0xff, goodMask = rcb >> 24;
   const bool isOut = (rcb & 0x8000u) != 0;
@@ -782,9 +819,22 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   // reaches only, fetches and MERGES the incoming particles (qexmul_rch), and only then waits for its own step t - 1; (2) it
   // publishes its at-rest list (kwOwn) as soon as kinwav has decided who stays, and works out the step's discharge and outbox
   // (interp_rch, the stores its downstream reach waits for: kwDone) after that.  Merge, time-step average and outbox stores
-  // leave the chain; the arithmetic and its order are untouched.
-  constexpr bool SPLIT = PERS && !GEN && G == 16;
-  mzr_word wword = 0;      // the progress word this lane polled
+  // leave the chain; the arithmetic and its order are untouched.  (One step per visit only: a visit of several steps waits for
+  // the reach's own previous step once per block.)
+  constexpr bool SPLIT = PERS && !GEN && G == 16 && !BLK;
+  const int t = uni<G>((have && tb >= 0) ? tBase + kb : -1);
+  const bool live = t >= 0 && t < d.W && !(BLK && (ovf || failed || kb >= KBLK));      // (groups of one wavefront may start at different steps of their blocks: kFirst)
+  const bool firstOfVisit = !BLK || kb == kFirst;
+  const bool lastOfVisit = !BLK || kb == KBLK - 1 || t == d.W - 1;
+  const KwtStep ks = kwt_step(d, t);
+  const double T0 = ks.T0, T1 = ks.T1;
+  const double T_START = T0, T_END = T1;                    // RSTEP = 0
+  double *Qrow = ks.Qrow;
+  const double *qlat_prev = ks.qlat_prev, *qlat_cur = ks.qlat_cur;
+  const int par = ks.par;
+  const int *obN = d.obN + (size_t)par * N;
+  const double *obQT = d.obQT + 2 * (size_t)par * MZR_OB_STRIDE * N;      // this step's parity of the {Q, exit time} rows
+  const __amdgpu_buffer_rsrc_t obRs = mzr_rsrc(obQT);
   if (PERS) {
     // step t of this reach needs step t of every upstream reach (their outbox rows and discharge), its own
     // step t - 1, and overwrites the outbox slot its downstream reach read in step t - MZR_OB_RING
@@ -794,10 +844,18 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     if (live) {
       if (gl < nup) { wp = d.kwDone + u0 + gl; wneed = t + 1; }
       else if (gl == nup && dn >= 0 && t >= MZR_OB_RING) { wp = d.kwDone + dn; wneed = t - (MZR_OB_RING - 1); }
-      else if (!SPLIT && gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
+      else if (!SPLIT && firstOfVisit && gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
-    if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
-    for (int _rep = 1; _rep < MZR_DUP_WAIT; ++_rep) { asm volatile("" ::: "memory"); if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2; }
+    // (BLK, later steps of a visit: the words of the last poll usually cover this step too -- the upstream reaches are a block ahead)
+#ifdef MZR_DBG_NOCOVER
+    const bool covered = false;
+#else
+    const bool covered = BLK && !firstOfVisit && __ballot(wp != nullptr && MZR_KWD_STEPS(wword) < wneed) == 0ull;
+#endif
+    if (!covered) {
+      if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
+      for (int _rep = 1; _rep < MZR_DUP_WAIT; ++_rep) { asm volatile("" ::: "memory"); if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2; }
+    }
 #ifndef MZR_NO_PRIO
     if (G >= 16 && !boost) __builtin_amdgcn_s_setprio(2);
 #endif
@@ -808,7 +866,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   // hillslope inflow of the upstream basins, upstream discharge, own particle row (getusq_rch
   // :598-608; element 0 = last routed particle) and, for the binary confluence, the outbox rows of
   // the upstream reaches.  Rows are fixed-size, so they are read whole before their counts are known.
-  int need = 0, n_own = 0, NUPS = 0, IMAX = 0, nrA = 0, nrB = 0;
+  int need = 0, NUPS = 0, IMAX = 0, nrA = 0, nrB = 0;
   double q_up = 0.0;
   int st_up = 0;
   KwtBasin bs;
@@ -823,17 +881,17 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   // half of them -- and the count loads go away.  Otherwise counts and whole rows are fetched together.
   const bool exact = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u)) && t >= 1;
   const bool exactNext = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u));      // the next step of the window takes the count from the progress word
-  mzr_word wSelf = 0;
+  if (!BLK) { n_own = 0; wSelf = 0; }
   if (live) {
-    int n_own_v = 0, nrA_v = 0, nrB_v = 0;
+    int n_own_v = n_own, nrA_v = 0, nrB_v = 0;      // (BLK, later steps of the visit: the list and its count are where the step before left them)
     const int gbase = lane & ~(G - 1);
-    if (!SPLIT && PERS && t >= 1) wSelf = (mzr_word)__shfl((long long)wword, gbase + nup + 1, 64);      // (also carries the count of the other outbox parity on)
+    if (!SPLIT && PERS && t >= 1 && firstOfVisit) wSelf = (mzr_word)__shfl((long long)wword, gbase + nup + 1, 64);      // (also carries the counts of the other outbox slots on)
     if (exact) {
-      if (!SPLIT) n_own_v = MZR_KWD_OWN(wSelf);
+      if (!SPLIT && firstOfVisit) n_own_v = MZR_KWD_OWN(wSelf);
       if (ns > 0) nrA_v = MZR_KWD_OUT((mzr_word)__shfl((long long)wword, gbase + (uA - u0), 64), par);
       if (ns > 1) nrB_v = MZR_KWD_OUT((mzr_word)__shfl((long long)wword, gbase + (uB - u0), 64), par);
     } else {
-      if (!SPLIT) n_own_v = ldx<PERS>(d.kwN + r);
+      if (!SPLIT && firstOfVisit) n_own_v = ldx<PERS>(d.kwN + r);
       if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
     }
     // exit time of the reach's last routed particle = the end of its previous step (the first at-rest element's TR, :1304): inside a
@@ -841,13 +899,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     // written) per reach-step less; the first step of a window takes it from the state
     // (SPLIT: everything of the reach's own state -- count, list, X0, the history sum -- is fetched behind the merge, kwt_own below)
     const double X0 = SPLIT ? 0.0 : (PERS && t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<PERS>(d.kwTR + MZR_KWI(0, r));
-    const double hin = (d.hInflow && !SPLIT) ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
+    const double hin = (d.hInflow && !SPLIT && firstOfVisit) ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
     if (nup > 1) { bs.b1q0 = qlat_prev[u0 + 1]; b1q1 = qlat_cur[u0 + 1]; }
     if (!GEN) { up0 = ldx<PERS>(Qrow + u0); if (nup > 1) up1 = ldx<PERS>(Qrow + u0 + 1); }
-    if (!SPLIT) {
+    if (!SPLIT && firstOfVisit) {
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
         const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
@@ -888,7 +946,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     if (SPLIT) need = 1;      // (the reach's own count is not known yet: checked in kwt_own; the merge writes behind the 20 entries of a full list)
     if (upLake && nup > 1) need = 0;
     if (empty) { mzr_raise(d, 40, r, t, 11); need = 0; }
-    if (need > cap) { ovf = true; need = 0; }
+#ifdef MZR_DBG_HANDOVER
+    if (BLK && G < 16 && kb == MZR_DBG_HANDOVER) need = cap + 1;      // debugging aid: every narrow group hands its reach on at this step of the block
+#endif
+    if (need > cap) { ovf = true; ovfStep = kb; need = 0; }
     const double dT10 = T1 - T0;
     bs.b0sl = (bs.b0q1 - bs.b0q0) / dT10;
     if (nup > 1) bs.b1sl = (b1q1 - bs.b1q0) / dT10;
@@ -902,7 +963,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     if (gl == 0) {
       double *c = ctx;
       c[2] = q_up;                     // REACH_INFLOW, stored with the other results at the end
-      if (!SPLIT) { c[0] = n_own == 0 ? T0 : X0; c[3] = hin; }     // getusq_rch :587-596: a reach without particles starts at T0
+      if (!SPLIT) { c[0] = n_own == 0 ? T0 : X0; if (firstOfVisit) c[3] = hin; }     // getusq_rch :587-596: a reach without particles starts at T0
       c[1] = qlat_r;
       if (d.kwtStat && !ovf) {
         if (!SPLIT) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
@@ -912,17 +973,33 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
     }
   }
   TSTAMP(0);
+  if (BLK && live && need == 0 && !ovf) failed = true;      // (an error was raised above)
+#ifdef MZR_DBG_STOREALL
+  if (false) {
+#else
+  if (BLK && ovf && live && !firstOfVisit) {
+#endif
+    // The reach has outgrown this group in the middle of its visit: what the steps so far left at rest goes to memory, from
+    // where the wider group of this wavefront takes it up (same wavefront, program order: drained, no word needed; the
+    // count rides in the progress word the last step published).
+    const double *Q0 = sA + off, *T0p = sB + off;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) { const int k2 = gl + j * G; if (k2 < n_own) stq<true>(kwRs, d.kwQT, MZR_KWI(k2, r), Q0[k2], T0p[k2]); }
+    if (gl == 0) { if (d.hInflow) stx<true>(d.hInflow + r, ctx[3]); stx<true>(d.kwN + r, n_own); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 
   // work arrays: a fixed slice of the wavefront's LDS pool per group (GP entries: a binary
   // confluence needs at most 20 + 1 + 2 + 2*19 of them)
   if (need > 0) {
     {
       double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
+      bool stepDone = false;
       do {
         bool cold = (n_own == 0);
         int NJ = cold ? 0 : n_own - 1;
         const bool binary = !GEN && !upLake && NUPS != 1;   // GEN: launch over the confluences of more than two reaches
-        if (!SPLIT) {
+        if (!SPLIT && firstOfVisit) {
 #pragma unroll
           for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
         }
@@ -1602,9 +1679,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         if (gl == 0) {
           stx<PERS>(d.Q + (size_t)tq * N + r, Qout);
           if (!SPLIT) {
-            if (!exactNext || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
+            if ((!exactNext && lastOfVisit) || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
             if (!PERS || lastStep) d.inflow[r] = ctx[2];
-            if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
+            if (BLK) {      // the history sum of REACH_INFLOW runs along in LDS and goes to memory with the visit's last step
+              if (d.hInflow) { const double hs = ctx[3] + ctx[2]; ctx[3] = hs; if (lastOfVisit) stx<PERS>(d.hInflow + r, hs); }
+            } else if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
           }
         }
         TSTAMP(18);
@@ -1637,16 +1716,45 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         }
         TSTAMP(19);
         // at-rest state: KWAVE(NR+1:NQ2+1)
+#ifdef MZR_DBG_STOREALL
+        if (BLK && !lastOfVisit) {      // debugging aid: the list goes to memory after every step as well
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-          const int k2 = gl + j * G;
-          if (!SPLIT && k2 <= NN2) {
-            const bool first = k2 == 0;
-            stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
-            // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
-            if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
+          for (int j = 0; j < KS; ++j) {
+            const int k2 = gl + j * G;
+            if (k2 <= NN2) { const bool first = k2 == 0; stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]); }
           }
         }
+#endif
+        if (!BLK || lastOfVisit) {
+#pragma unroll
+          for (int j = 0; j < KS; ++j) {
+            const int k2 = gl + j * G;
+            if (!SPLIT && k2 <= NN2) {
+              const bool first = k2 == 0;
+              stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
+              // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
+              if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
+            }
+          }
+        } else {
+          // (BLK) ... which the visit's next step finds at the front of the group's slice, where a load would have put it
+          double nq[KS], nt[KS];
+#pragma unroll
+          for (int j = 0; j < KS; ++j) {
+            const int k2 = gl + j * G;
+            nq[j] = nt[j] = 0.0;
+            if (k2 <= NN2) { const bool first = k2 == 0; nq[j] = first ? Q_END : Qw[NR + k2]; nt[j] = first ? TIMEI : Tw[NR + k2]; }
+          }
+          grp_sync();
+          double *Q0 = sA + off, *T0p = sB + off;
+#pragma unroll
+          for (int j = 0; j < KS; ++j) { const int k2 = gl + j * G; if (k2 <= NN2) { Q0[k2] = nq[j]; T0p[k2] = nt[j]; } }
+          grp_sync();
+        }
+        if (BLK) n_own = NN2 + 1;
+#ifdef MZR_DBG_TRACE
+        if (PERS && gl == 0 && d.t_start >= MZR_DBG_TRACE) printf("TR ts %.0f r %d t %d G %d kb %d first %d last %d nown %d nrA %d nrB %d NR %d NQ2 %d NN2 %d Qout %.17g Qend %.17g q1 %.17g t1 %.17g X0 %.17g\n", d.t_start, r, t, G, kb, (int)firstOfVisit, (int)lastOfVisit, n_own, nrA, nrB, NR, NQ2, NN2, Qout, Q_END, Qw[1], Tw[1], ctx[0]);
+#endif
         if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
         TSTAMP(7); TSTAMP_WAVE(20);
         if (PERS) {   // results written through (sc1) and drained, then the step is published
@@ -1658,10 +1766,12 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (gl == 0) {
             const int pq = tq & (MZR_OB_RING - 1);
-            const mzr_word keep = wSelf & (MZR_KWD_OUTMASK(0) | MZR_KWD_OUTMASK(1) | MZR_KWD_OUTMASK(2) | MZR_KWD_OUTMASK(3)) & ~MZR_KWD_OUTMASK(pq);      // the other slots' counts stay (0 in the first step)
+            const mzr_word keep = wSelf & MZR_KWD_ALLOUT & ~MZR_KWD_OUTMASK(pq);      // the other slots' counts stay (0 in the first step)
             const int nOut = isOut ? 0 : NR + 2;
-            if (!SPLIT) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));
-            stx<true>(d.kwDone + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)) | ((mzr_word)(unsigned)nOut << (21 + 5 * pq)) | keep);
+            const mzr_word wNew = (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)) | ((mzr_word)(unsigned)nOut << (21 + 5 * pq)) | keep;
+            if (!SPLIT && !BLK) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));      // (a visit of several steps waits on kwDone alone)
+            stx<true>(d.kwDone + r, wNew);
+            if (BLK) wSelf = wNew;      // lane 0 of the group: the only one that reads it again
           }
           TSTAMP(22);
           kwt_beat(d, 3, 4);
@@ -1677,14 +1787,20 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             }
           }
         }
+        stepDone = true;
       } while (0);
+      if (BLK && !stepDone) failed = true;      // an error was raised for this reach (the sweep is abandoned anyway)
     }
   }
+  if (!BLK) break;
+  ++kb;
+  if (__ballot(kb < KBLK && live && !ovf && !failed) == 0ull) break;      // until no group of the wavefront has a step of its block left
+  }      // steps of the visit
 #ifdef MZR_KWT_TIMING
   if (PERS) TRECORD(G, _recSize, _recRem);
 #endif
   if ((CAN_THIN || G >= 16) && !boost) __builtin_amdgcn_s_setprio(0);
-  return ovf ? 1 : 0;
+  return (ovf ? 1 : 0) | (ovfStep << 8);
 }
 
 // Lane classes.  A routed reach is worked on by a group of adjacent lanes; how many is the host's choice
@@ -1734,7 +1850,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   if (cls == 1) {
     const int g8 = lane / GB;
     base = hbBegin + (b - nABlocks) * RB;
-    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, true, false>(d, s, d.kwtRoutedB, base + g8, base + g8 < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
+    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, true, false, 1>(d, s, d.kwtRoutedB, base + g8, base + g8 < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
     const unsigned long long bal = __ballot(ovf);
 #pragma unroll
     for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
@@ -1742,35 +1858,60 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   } else if (cls == 2) {
     const int g4 = lane / GC;
     base = hcBegin + (b - nABlocks - nBBlocks) * RC;
-    const bool ovf = kwt_reach<FULL, false, GC, KC, KC, false, false>(d, s, d.kwtRoutedC, base + g4, base + g4 < hcEnd, hcEnd - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]) & 1;
+    const bool ovf = kwt_reach<FULL, false, GC, KC, KC, false, false, 1>(d, s, d.kwtRoutedC, base + g4, base + g4 < hcEnd, hcEnd - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]) & 1;
     const unsigned long long bal = __ballot(ovf);
 #pragma unroll
     for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
     if (!ovfMask) return;
   }
+  // class A, or the reaches of this block that have outgrown their narrow group, four at a time; a reach that needs more than
+  // a quarter of the pool (GPA entries; a full binary confluence can ask for 60) is routed once more ALONE with the whole
+  // pool (`solo`: bit g = 16-lane group g of the pass before; the first group takes it)
   const int g16 = lane / GA;
+  unsigned solo = 0;
+  int itemKeep = 0;
 #pragma unroll 1
-  do {
+  for (;;) {
     const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : cls == 1 ? d.kwtRoutedB : d.kwtRoutedC;
     const int last = (cls == 0 ? haEnd : cls == 1 ? hbEnd : hcEnd) - 1;
-    int item = haBegin + b * RA + g16;
-    bool have = item <= last;
-    if (cls != 0) { const int sel = kwt_pick(ovfMask, g16); have = sel >= 0; item = base + (have ? sel : 0); }
-    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false>(d, s, recs, item, have, last, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]) & 1;
-    if (ovf) mzr_raise(d, 60, recs[have ? item : last].r, s, 10);      // work array bounds exceeded
-  } while (ovfMask);
+    const bool isSolo = solo != 0;
+    int item, offA = g16 * GPA, capA = GPA;
+    bool have;
+    if (isSolo) {
+      const int g = __ffs(solo) - 1; solo &= solo - 1u;
+      item = __shfl(itemKeep, g * GA, 64); have = g16 == 0; offA = 0; capA = POOL;
+    } else {
+      item = haBegin + b * RA + g16;
+      have = item <= last;
+      if (cls != 0) { const int sel = kwt_pick(ovfMask, g16); have = sel >= 0; item = base + (have ? sel : 0); }
+      itemKeep = item;
+    }
+    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false, 1>(d, s, recs, item, have, last, offA, capA, sA, sB, sC, sD, sCtx[g16]) & 1;
+    if (isSolo || GEN) { if (ovf) mzr_raise(d, 60, recs[have ? item : last].r, s, 10); }      // work array bounds exceeded
+    else { const unsigned long long bal = __ballot(ovf); solo = (unsigned)((bal & 1ull) | (((bal >> 16) & 1ull) << 1) | (((bal >> 32) & 1ull) << 2) | (((bal >> 48) & 1ull) << 3)); }
+    if (!solo && !ovfMask) break;
+  }
 }
 
 // The rare item kinds of the persistent sweep are real calls, so that their registers are not part of the loop body's.
-template <bool FULL, int POOL>
+// (a sweep that visits in blocks of KBLK steps takes these kinds through the block one step per call)
+template <bool FULL, int POOL, int KBLK>
 __device__ __noinline__ int kwt_item_generic(const MzrDev &d, int s, int bi, double *sA, double *sB, double *sC, double *sD, double *ctx) {
   constexpr int GA = KwtCls::GA, KA = KwtCls::KA, OA = KwtCls::OA;
   const int g16 = mzr_lane() / GA;
-  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + MZR_CTX * g16);
+  int st = 0;
+#pragma unroll 1
+  for (int kb = 0; kb < KBLK; ++kb) {
+    st = kwt_reach<FULL, true, GA, KA, OA, true, true, 1>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + MZR_CTX * g16, 0, KBLK, kb);
+    if (__ballot(st & 3) != 0ull) break;
+  }
+  return st;
 }
-template <bool FULL>
+template <bool FULL, int KBLK>
 __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
-  return kwt_light<FULL, true>(d, s, bi * 64 + mzr_lane(), d.nDepLight);
+#pragma unroll 1
+  for (int kb = 0; kb < KBLK; ++kb) if (kwt_light<FULL, true>(d, s, bi * 64 + mzr_lane(), d.nDepLight, KBLK, kb)) return true;
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1788,8 +1929,13 @@ __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
 // that wait sleep, and give up when an error was raised or nothing has moved for seconds.
 // Results cross CUs, so state, outbox rows and discharge go through sc1 accesses (ldx / stx).
 // Headwater reaches need nothing from anybody and are filled in by k_kwt_window_init.
-template <bool FULL, int POOL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC)))
+// KBLK: steps of a reach per visit (kwt_reach): launch s of the schedule takes the reaches of stage j through block s - j of
+// the window, so a window of W steps is nStages + ceil(W / KBLK) - 1 launches of tickets.
+#ifndef MZR_KWT_OCC_BLK
+#define MZR_KWT_OCC_BLK 4      // wavefronts per SIMD the blocked flavour is compiled for (LDS: 9 KB per wavefront hold 4 of them anyway)
+#endif
+template <bool FULL, int POOL, int KBLK>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC, KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC)))
 k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   // The domain description has ~100 fields; kept live around the item loop they spill.  They are read
   // through the kernel-argument segment instead (scalar loads, constant address space) and the
@@ -1813,7 +1959,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   const int arr = mzr_sweep_join(d0.swHead, d0.swClock);      // (a wavefront that starts behind time does not join)
   if (arr < 0) return;
   if (d0.sweepPrio) __builtin_amdgcn_s_setprio(3);      // mzr_config.sweepPriority: a small, deep domain sweeping beside a large one
-  const int Wm1 = d0.W - 1;
+  const int Wm1 = (d0.W + KBLK - 1) / KBLK - 1;      // the window in blocks, less one
   const int q0 = arr < 64 ? (arr & 7) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7);     // HW_REG_XCC_ID: a speed hint only
   kwt_beat(d0, 5, q0); kwt_beat(d0, 3, 1); kwt_beat(d0, 4, 0);
   int nDone = 0;
@@ -1860,45 +2006,69 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
       const int cls = it >> 28, bi = it & 0x0fffffff;      // 0 A, 1 B, 2 generic, 3 lake / halo, 4 C
       if (cls == 3) {
-        if (kwt_item_light<FULL>(d, s, bi)) return;
+        if (kwt_item_light<FULL, KBLK>(d, s, bi)) return;
         continue;
       }
       if (cls == 2) {   // one confluence of more than two reaches, first lane group, the whole pool
-        const int st = kwt_item_generic<FULL, POOL>(d, s, bi, sA, sB, sC, sD, &sCtx[0][0]);
+        const int st = kwt_item_generic<FULL, POOL, KBLK>(d, s, bi, sA, sB, sC, sD, &sCtx[0][0]);
         if (__ballot(st & 2) != 0ull) return;
         if (st & 1) mzr_raise(d, 60, d.kwtGeneric[bi].r, s, 10);
         continue;
       }
       unsigned ovfMask = 0;
+      int stNarrow = 0;      // per lane: what the narrow pass said about its group's reach (bit 0: outgrown, from bit 8: at which step of the block)
       if (cls == 1) {
         const int g8 = lane / GB, item = bi * RB + g8;
-        const int st = kwt_reach<FULL, false, GB, KB, KB, true, true>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
-        if (__ballot(st & 2) != 0ull) return;
-        const unsigned long long bal = __ballot(st & 1);
+        stNarrow = kwt_reach<FULL, false, GB, KB, KB, true, true, KBLK>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+        if (__ballot(stNarrow & 2) != 0ull) return;
+        const unsigned long long bal = __ballot(stNarrow & 1);
 #pragma unroll
         for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
         if (!ovfMask) continue;
       } else if (cls == 4) {
         const int g4 = lane / GC, item = bi * RC + g4;
-        const int st = kwt_reach<FULL, false, GC, KC, KC, false, true>(d, s, d.kwtRoutedC, item, item < d.nC, d.nC - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]);
-        if (__ballot(st & 2) != 0ull) return;
-        const unsigned long long bal = __ballot(st & 1);
+        stNarrow = kwt_reach<FULL, false, GC, KC, KC, false, true, KBLK>(d, s, d.kwtRoutedC, item, item < d.nC, d.nC - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]);
+        if (__ballot(stNarrow & 2) != 0ull) return;
+        const unsigned long long bal = __ballot(stNarrow & 1);
 #pragma unroll
         for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
         if (!ovfMask) continue;
       }
-      // class A, or the reaches of this item that have outgrown their narrow group, four at a time
+      // class A, or the reaches of this item that have outgrown their narrow group, four at a time -- from the step of the block at
+      // which they did; a reach that needs more than a quarter of the pool (GPA entries; a full binary confluence can ask for 60)
+      // is taken up once more ALONE with the whole pool (`solo`: bit g = 16-lane group g of the pass before)
+      unsigned solo = 0;
+      int itemKeep = 0, stKeep = 0;
 #pragma unroll 1
-      do {
+      for (;;) {
         const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : cls == 1 ? d.kwtRoutedB : d.kwtRoutedC;
         const int last = (cls == 0 ? d.nA : cls == 1 ? d.nB : d.nC) - 1;
-        int item = bi * RA + g16;
-        bool have = item <= last;
-        if (cls != 0) { const int sel = kwt_pick(ovfMask, g16); have = sel >= 0; item = bi * (cls == 1 ? RB : RC) + (have ? sel : 0); }
-        const int st = kwt_reach<FULL, false, GA, KA, OA, true, true>(d, s, recs, item, have, last, g16 * GPA, GPA, sA, sB, sC, sD, sCtx[g16]);
+        const bool isSolo = solo != 0;
+        int item, offA = g16 * GPA, capA = GPA, kFirst = 0;
+        bool have;
+        if (isSolo) {
+          const int g = __ffs(solo) - 1; solo &= solo - 1u;
+          item = __shfl(itemKeep, g * GA, 64); kFirst = __shfl(stKeep, g * GA, 64) >> 8; have = g16 == 0; offA = 0; capA = POOL;
+        } else {
+          item = bi * RA + g16;
+          have = item <= last;
+          if (cls != 0) {
+            const int sel = kwt_pick(ovfMask, g16);
+            have = sel >= 0; item = bi * (cls == 1 ? RB : RC) + (have ? sel : 0);
+            kFirst = __shfl(stNarrow, (have ? sel : 0) * (cls == 1 ? GB : GC), 64) >> 8;
+          }
+          itemKeep = item;
+        }
+        const int st = kwt_reach<FULL, false, GA, KA, OA, true, true, KBLK>(d, s, recs, item, have, last, offA, capA, sA, sB, sC, sD, sCtx[g16], kFirst);
         if (__ballot(st & 2) != 0ull) return;
-        if (st & 1) mzr_raise(d, 60, recs[have ? item : last].r, s, 10);
-      } while (ovfMask);
+        if (isSolo) { if (st & 1) mzr_raise(d, 60, recs[have ? item : last].r, s, 10); }
+        else {
+          stKeep = st;
+          const unsigned long long bal = __ballot(st & 1);
+          solo = (unsigned)((bal & 1ull) | (((bal >> 16) & 1ull) << 1) | (((bal >> 32) & 1ull) << 2) | (((bal >> 48) & 1ull) << 3));
+        }
+        if (!solo && !ovfMask) break;
+      }
     }
   }
   kwt_beat(d0, 3, 9);
@@ -1995,29 +2165,35 @@ static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exp
 // workgroup per CU high for this kernel (17 against 16), so the number is measured: the kernel itself is launched in
 // census mode (sEnd < 0: every wavefront counts itself in, stays 300 us, counts itself out; the peak is the answer).
 // cnt: two ints of device memory (swHead + 128).  Measured once per process, device and kernel flavour.
-int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream) {
-  static int cached[16][2];
-  static std::mutex mu;      // handles of several host threads share the cache; the census itself must not run twice at once either
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0, cus = 0, perCu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (dev >= 0 && dev < 16 && cached[dev][full]) return cached[dev][full];
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  const hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<true, MZR_KWT_POOL>, 64, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<false, MZR_KWT_POOL>, 64, 0);
-  if (e != hipSuccess) return 0;
+template <bool FULL, int KBLK>
+static int kwt_sweep_census(const MzrDev &d, hipStream_t stream, int cus) {
+  int perCu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>, 64, 0) != hipSuccess) return 0;
   const int api = cus * perCu;
   int peak[2] = {0, 0};
   int *cnt = d.swHead + 8 * 16;
   if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) return 0;
   const int grid = api + api / 4;
-  if (full) hipLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
-  else hipLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
+  hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
   if (hipStreamSynchronize(stream) != hipSuccess) return 0;
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
-  if (dev >= 0 && dev < 16 && 2 * cap >= api) cached[dev][full] = cap;      // (a census far below the occupancy query ran beside other work: measured again next time)
-  return cap;
+  return 2 * cap >= api ? cap : -cap;      // (negative: a census far below the occupancy query ran beside other work -- not to be remembered)
+}
+// kblk: steps per visit of the flavour asked about (1 or MZR_KWT_KBLK; their register and LDS footprints may differ)
+int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream, int kblk) {
+  static int cached[16][2][2];
+  static std::mutex mu;      // handles of several host threads share the cache; the census itself must not run twice at once either
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0, cus = 0;
+  const int kx = kblk > 1 ? 1 : 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 16 && cached[dev][full][kx]) return cached[dev][full][kx];
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const int c = full ? (kx ? kwt_sweep_census<true, MZR_KWT_KBLK>(d, stream, cus) : kwt_sweep_census<true, 1>(d, stream, cus))
+                     : (kx ? kwt_sweep_census<false, MZR_KWT_KBLK>(d, stream, cus) : kwt_sweep_census<false, 1>(d, stream, cus));
+  if (dev >= 0 && dev < 16 && c > 0) cached[dev][full][kx] = c;
+  return c > 0 ? c : -c;
 }
 
 // headwater reaches for steps [tBegin, tEnd) of the window; tBegin == 0 also resets the progress counters
@@ -2043,14 +2219,22 @@ __global__ void k_sweep_heads(MzrDev d, int sBegin) {
 // marker packets in front of and behind a persistent launch were measured to slow some windows by a quarter (446 -> 560 ms, a
 // pattern with a period of eight windows; without events, and with events attached to the dispatch, every window takes 447 ms:
 // profiles/r04_experiments.md)
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
+// kblk: steps of a reach per visit -- 1 or MZR_KWT_KBLK (the schedule tables must have been made for it: kwt_sweep_tables)
+template <bool FULL, int KBLK>
+static void kwt_sweep_launch(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
+  if (evStart && evStop) hipExtLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3(nWaves), dim3(64), 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
+  else hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
+}
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk) {
   if (nWaves < 1 || sEnd <= sBegin) return;
   hipLaunchKernelGGL(k_sweep_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
-  if (evStart && evStop) {
-    if (kwt_full(d)) hipExtLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
-    else hipExtLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
-    return;
-  }
-  if (kwt_full(d)) hipLaunchKernelGGL((k_sweep_kwt<true, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
-  else hipLaunchKernelGGL((k_sweep_kwt<false, MZR_KWT_POOL>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
+  const bool full = kwt_full(d);
+  if (kblk > 1) { if (full) kwt_sweep_launch<true, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
+  else { if (full) kwt_sweep_launch<true, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
+}
+int mzr_kwt_class_caps(int *capB, int *capC) {      // entries a class-B / class-C group holds (the host's regrouping stays below them)
+  constexpr int GPB = MZR_KWT_POOL / KwtCls::RB, GPC = MZR_KWT_POOL / KwtCls::RC;
+  *capB = KwtCls::GB * MZR_KWT_KTB - 1 < GPB ? KwtCls::GB * MZR_KWT_KTB - 1 : GPB;
+  *capC = KwtCls::GC * KwtCls::KC - 1 < GPC ? KwtCls::GC * KwtCls::KC - 1 : GPC;
+  return MZR_KWT_POOL / KwtCls::RA;
 }

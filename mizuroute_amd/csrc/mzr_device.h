@@ -20,8 +20,14 @@
 // The outbox of a reach is a ring over the time steps (slot = step mod MZR_OB_RING): step t of a reach overwrites what its
 // downstream reach read in step t - MZR_OB_RING.  With two slots (rounds 1-3) a heavy reach r and its heavy downstream reach
 // d were chained both ways -- d(t) needs r(t), r(t+2) needs d(t) -- so that two steps of r cost a pass of r AND a pass of d
-// however fast r's own steps follow each other; with four, r runs up to four steps ahead and the loop no longer binds.
-#define MZR_OB_RING  4
+// however fast r's own steps follow each other; with four (round 4), r runs up to four steps ahead and the loop no longer binds.
+// Round 5: a visit of the persistent sweep takes a reach through MZR_KWT_KBLK consecutive steps, and the ring is twice that:
+// block b + 1 of a reach overwrites what its downstream reach read in block b - 1, which is two launches of the schedule back.
+#ifndef MZR_KWT_KBLK
+#define MZR_KWT_KBLK 4     // steps of a reach per visit of the persistent KWT sweep (k_sweep_kwt<.., KBLK>); a power of two
+#endif
+#define MZR_OB_RING  (2 * MZR_KWT_KBLK < 4 ? 4 : 2 * MZR_KWT_KBLK)
+static_assert((MZR_OB_RING & (MZR_OB_RING - 1)) == 0 && 21 + 5 * MZR_OB_RING <= 64, "outbox ring: a power of two whose particle counts fit the progress word");
 // rows start on 64-byte sectors (24 doubles = 192 bytes per reach): a row of 20 / 21 doubles packed back to back straddles
 // sector boundaries and every partial sector is fetched / written whole (profiles/r03a_summary.md)
 #ifndef MZR_KW_STRIDE

@@ -44,9 +44,10 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
                           int ltBegin, int ltEnd, hipStream_t stream);
 
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream);
-int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream);
+int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream, int kblk);
+int mzr_kwt_class_caps(int *capB, int *capC);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart = nullptr, hipEvent_t evStop = nullptr);
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk);
 
 namespace {
 
@@ -271,7 +272,8 @@ struct mzr_domain {
   std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
   std::vector<int> h_sigma, h_swCode, h_swP, h_swRA;   // host copies for the stall report of a sweep that gave up (code 93)
   std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
-  int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1;
+  int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1, swTablesK = 0;
+  int swKblk = MZR_KWT_KBLK, swCapK[2] = {0, 0};      // steps per visit of the sweep flavour in use; wavefront capacity of the one-step / the blocked flavour
   long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff, kwtCOff;   // [nStages+1] stage offsets in h_kwtRouted / in the class-B and class-C lists (kwtRoutedOff: class A)
@@ -614,19 +616,30 @@ int sweepGrid(mzr_handle h, int held) {
   return std::max(8, g & ~7);
 }
 
+// Wavefronts the sweep is launched with at most: what the device holds of the kernel flavour (one step per visit / MZR_KWT_KBLK steps
+// per visit: measured when first used, mzr_sweep_kwt_capacity), less a margin, times the handle's share
+void kwt_measure_cap(mzr_handle h, int kblk) {
+  const int kx = kblk > 1 ? 1 : 0;
+  if (h->swCapK[kx] < 1) {
+    const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
+    if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }
+    int cap = 0;
+    { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream, kx ? MZR_KWT_KBLK : 1)); }
+    if (cap < 1) {      // census failed: a conservative grid (four wavefronts per CU always fit) and a word about it
+      int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+      cap = std::max(8, cus * 4);
+      fprintf(stderr, "mzr: the wavefront capacity of the KWT sweep could not be measured on device %d; sweeping with %d wavefronts\n", h->cfg.device, cap);
+    }
+    if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = v; }      // experiments only: any grid, also one the device does not hold
+    h->swCapK[kx] = cap;
+  }
+  h->swKblk = kblk; h->swCap = h->swCapK[kx];
+}
+
 void kwt_build_sweep(mzr_handle h) {
-  const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
   if (!h->swClock.p) { try { h->swClock.alloc(2 * MZR_CLOCK_LOG); h->swClock.zero(); h->swClockN = 0; } catch (const std::string &) { (void)hipGetLastError(); } }
   if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }      // eight ticket heads (one cache line each), census and arrival counters, histogram of the start delays
-  int cap = 0;
-  { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream)); }
-  if (cap < 1) {      // census failed: a conservative grid (four wavefronts per CU always fit) and a word about it
-    int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
-    cap = std::max(8, cus * 4);
-    fprintf(stderr, "mzr: the wavefront capacity of the KWT sweep could not be measured on device %d; sweeping with %d wavefronts\n", h->cfg.device, cap);
-  }
-  if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = v; }      // experiments only: any grid, also one the device does not hold
-  h->swCap = cap;
+  kwt_measure_cap(h, h->swKblk);
   struct It { int code, lo, hi; };
   std::vector<It> items;
   auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, size_t per) {
@@ -652,7 +665,7 @@ void kwt_build_sweep(mzr_handle h) {
   if (code.empty()) { code.push_back(0); hi.push_back(-1); }
   (void)hipStreamSynchronize(h->stream);
   h->swItem.upload(code); h->swLo.upload(lo.empty() ? std::vector<int>(1, 1 << 30) : lo); h->swHi.upload(hi);
-  if (!h->swBeat.p && getenv("MZR_SWEEP_DEBUG") && atoi(getenv("MZR_SWEEP_DEBUG")) != 0) { h->swBeat.alloc((size_t)std::max(cap, 8) * MZR_BEAT); h->swBeat.zero(); }
+  if (!h->swBeat.p && getenv("MZR_SWEEP_DEBUG") && atoi(getenv("MZR_SWEEP_DEBUG")) != 0) { h->swBeat.alloc((size_t)std::max(std::max(h->swCapK[0], h->swCapK[1]), 8192) * MZR_BEAT); h->swBeat.zero(); }
   h->swItems = (int)items.size();
   h->h_swCode = code;
   h->swTablesW = -1;          // ticket tables have to be made again
@@ -710,9 +723,13 @@ void rt_sweep_tables(mzr_handle h, int W) {
   h->rtTablesW = W;
 }
 
-// launch ranges and ticket prefix sums of a window of W steps
-void kwt_sweep_tables(mzr_handle h, int W) {
-  if (h->swTablesW == W) return;
+// launch ranges and ticket prefix sums of a window of W steps routed in visits of kblk steps: launch s takes the reaches of stage j
+// through block s - j, so the window is its ceil(W / kblk) blocks long
+void kwt_sweep_tables(mzr_handle h, int Wsteps, int kblk) {
+  if (h->swTablesW == Wsteps && h->swTablesK == kblk) return;
+  (void)hipStreamSynchronize(h->stream);     // (a sweep still in flight reads the old tables; the census of a flavour's first use runs on this stream)
+  kwt_measure_cap(h, kblk);
+  const int W = (Wsteps + kblk - 1) / kblk;
   const int nS = h->nStages, nL = nS + W - 1, nI = h->swItems;
   std::vector<int> ra(nL, 0), P((size_t)(nL + 1) * 8, 0);
   int maxAct = 0;
@@ -731,7 +748,7 @@ void kwt_sweep_tables(mzr_handle h, int W) {
   h->swRA.upload(ra); h->swP.upload(P);
   h->h_swRA = ra; h->h_swP = P;
   h->swWaves = h->swItems > 0 ? std::max(8, std::min(h->swCap, maxAct)) : 0;
-  h->swTablesW = W;
+  h->swTablesW = Wsteps; h->swTablesK = kblk;
 }
 
 }  // namespace
@@ -1478,6 +1495,7 @@ int mzr_init_state(mzr_handle h) {
           if (depLight.empty()) depLight.push_back(0);
           h->kwtHead.upload(head); h->kwtDepLight.upload(depLight);
           h->kwDone.alloc(N); h->kwDone.zero(); h->kwOwn.alloc(N); h->kwOwn.zero();
+          h->swCapK[0] = h->swCapK[1] = 0;
           h->kwtHeadSteps = 0;
           kwt_build_sweep(h);
         }
@@ -1578,6 +1596,7 @@ static void kwt_regroup(mzr_handle h) {
   // (round 4, with the outbox ring of four steps and the split 16-lane pass the chain no longer punishes the narrower groups:
   // 24 there measured +4.6 %, 28 +-0)
   classBMax = (h->swCap > 0 && (double)h->h_kwtRouted.size() / 7.0 > 3.0 * h->swCap) ? 28 : 24;
+  { int capB = 0, capC = 0; (void)mzr_kwt_class_caps(&capB, &capC); classBMax = std::min(classBMax, capB - 2); classCMax = std::min(classCMax, capC - 2); }      // (room to grow by two before the fall-back)
   if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
   if (const char *e = getenv("MZR_KWT_CLASSC_MAX")) classCMax = atoi(e);
   const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
@@ -1781,14 +1800,19 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 1; ix < nR; ++ix) if (rst[ix] != st) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
   }
   const bool prof = h->profiling;
+  // Steps of a reach per visit of the sweep (kernels_kwt.hip, kwt_reach<.., KBLK>): blocks of MZR_KWT_KBLK in windows long enough to
+  // have several; one step per visit in the short ones (mzr_step: one level of the schedule per stage either way).  MZR_KWT_KBLK=1 / 4
+  // in the environment forces the flavour (tests run both).
+  int kblk = W > 8 ? MZR_KWT_KBLK : 1;
+  if (const char *e = getenv("MZR_KWT_KBLK_RUN")) kblk = atoi(e) > 1 ? MZR_KWT_KBLK : 1;
   if (sweep) {
-    kwt_sweep_tables(h, W);
+    kwt_sweep_tables(h, W, kblk);
     RouteBufs &rb = h->route[kwtIx];
     hipStream_t sx = rst[kwtIx];
     MzrDev dk = dr[kwtIx];
     dk.swRA = h->swRA.p; dk.swP = h->swP.p;
     dk.kwtLight = h->kwtDepLight.p;
-    const int nLaunch = nS + W - 1;
+    const int nLaunch = nS + (W + kblk - 1) / kblk - 1;
     {      // the state this window starts from, kept until the window is known to have finished (retry above)
       // (not for a domain that exports a boundary record -- the record of a stalled window may have been packed and sent before
       // mzr_sync gets to route the window again -- and not when another method went through a persistent sweep in this window:
@@ -1821,9 +1845,9 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       static const int how = getenv("MZR_EVENT_MARKERS") ? atoi(getenv("MZR_EVENT_MARKERS")) : 0;      // debugging aid: 1 markers, 2 attached
       if (how == 1) {
         (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
-        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk);
         (void)hipEventRecord(rb.events[rb.evUsed].second, sx);
-      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second);
+      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second, kblk);
       else {
         if (!h->timerStream) {
           (void)hipStreamCreateWithFlags(&h->timerStream, hipStreamNonBlocking);
@@ -1831,12 +1855,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         }
         (void)hipEventRecord(h->timerGate[0], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[0], 0);
         (void)hipEventRecord(rb.events[rb.evUsed].first, h->timerStream);
-        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk);
         (void)hipEventRecord(h->timerGate[1], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[1], 0);
         (void)hipEventRecord(rb.events[rb.evUsed].second, h->timerStream);
       }
       ++rb.evUsed;
-    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx);
+    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk);
     ++rb.nLaunches;
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
   }
