@@ -26,7 +26,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libmzr_hip.so")
+    # MZR_LIB: an experiment build of the same library (tools/build_variant.sh: instruction-accounting, timing and debugging builds)
+    return os.environ.get("MZR_LIB") or os.path.join(_HERE, "lib", "libmzr_hip.so")
 
 
 def build_library(verbose: bool = False) -> str:

@@ -766,6 +766,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
       if (fresh != rci0[gl0]) mzr_raise_stall(dIn, 40 + gl0, rci0[0], s, item, rci0[gl0], fresh, -1, mzr_lane(), 0, 0, dIn.swHead);
     }
   }
+#ifdef MZR_KWT_TIMING
+  long long _tprev = clock64();
+  unsigned _sec[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int _recSize = 0, _recRem = 0;
+#endif
   mzr_word wword = 0;      // the progress word this lane polled
   mzr_word wSelf = 0;      // the reach's own progress word as last seen / published (its outbox counts of the other slots ride on)
   int n_own = 0;           // at-rest particles of the reach (BLK: carried from step to step of the visit)
@@ -807,11 +812,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   const int ns = __popc(upGood);
   const int uA = u0 + (upGood ? __ffs(upGood) - 1 : 0);
   const int uB = u0 + ((upGood & (upGood - 1u)) ? __ffs(upGood & (upGood - 1u)) - 1 : 0);
-#ifdef MZR_KWT_TIMING
-  long long _tprev = clock64();
-  unsigned _sec[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int _recSize = 0, _recRem = 0;
-#endif
   // Round 4, the 16-lane passes of the sweep (SPLIT): the window is as long as its longest chain of passes, and that chain is one
   // heavy reach taking its W steps one after the other -- each step waiting for the step before.  What a step needs from the
   // step before is the reach's own at-rest list and nothing else; what it needs from upstream is there long before (upstream
@@ -1797,7 +1797,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   if (__ballot(kb < KBLK && live && !ovf && !failed) == 0ull) break;      // until no group of the wavefront has a step of its block left
   }      // steps of the visit
 #ifdef MZR_KWT_TIMING
-  if (PERS) TRECORD(G, _recSize, _recRem);
+  if (PERS) { const MzrDev &d = dIn; TRECORD(G, _recSize, _recRem); }
 #endif
   if ((CAN_THIN || G >= 16) && !boost) __builtin_amdgcn_s_setprio(0);
   return (ovf ? 1 : 0) | (ovfStep << 8);
