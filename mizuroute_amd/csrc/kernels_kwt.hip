@@ -821,7 +821,11 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   // (interp_rch, the stores its downstream reach waits for: kwDone) after that.  Merge, time-step average and outbox stores
   // leave the chain; the arithmetic and its order are untouched.  (One step per visit only: a visit of several steps waits for
   // the reach's own previous step once per block.)
+#ifdef MZR_NO_SPLIT
+  constexpr bool SPLIT = false;
+#else
   constexpr bool SPLIT = PERS && !GEN && G == 16 && !BLK;
+#endif
   const int t = uni<G>((have && tb >= 0) ? tBase + kb : -1);
   const bool live = t >= 0 && t < d.W && !(BLK && (ovf || failed || kb >= KBLK));      // (groups of one wavefront may start at different steps of their blocks: kFirst)
   const bool firstOfVisit = !BLK || kb == kFirst;
@@ -1934,8 +1938,15 @@ __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
 #ifndef MZR_KWT_OCC_BLK
 #define MZR_KWT_OCC_BLK 4      // wavefronts per SIMD the blocked flavour is compiled for (LDS: 9 KB per wavefront hold 4 of them anyway)
 #endif
+// Wavefronts per workgroup of the sweep.  The wavefronts of the sweep are independent of each other (no barrier, an LDS slice each);
+// workgroups of one wavefront stop at 16 per CU -- four per SIMD -- whatever registers and LDS would allow (the census of
+// mzr_sweep_kwt_capacity: 4 008 of them on 256 CUs with 8 KB as with 9 KB of LDS each), so more than four wavefronts per SIMD
+// take workgroups of two.
+#ifndef MZR_KWT_WG
+#define MZR_KWT_WG 1
+#endif
 template <bool FULL, int POOL, int KBLK>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC, KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC)))
+__global__ void __launch_bounds__(64 * MZR_KWT_WG) __attribute__((amdgpu_waves_per_eu(KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC, KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC)))
 k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   // The domain description has ~100 fields; kept live around the item loop they spill.  They are read
   // through the kernel-argument segment instead (scalar loads, constant address space) and the
@@ -1948,8 +1959,11 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   constexpr int GB = KwtCls::GB, RB = KwtCls::RB, KB = KwtCls::KB, GC = KwtCls::GC, RC = KwtCls::RC, KC = KwtCls::KC;
   constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
   constexpr int CAPB = GB * MZR_KWT_KTB - 1 < GPB ? GB * MZR_KWT_KTB - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
-  __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
-  __shared__ double sCtx[RC][MZR_CTX];
+  __shared__ double sA_[MZR_KWT_WG][POOL], sB_[MZR_KWT_WG][POOL], sC_[MZR_KWT_WG][POOL], sD_[MZR_KWT_WG][POOL];
+  __shared__ double sCtx_[MZR_KWT_WG][RC][MZR_CTX];
+  const int wv = MZR_KWT_WG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wavefront's slice of the workgroup's LDS
+  double *sA = sA_[wv], *sB = sB_[wv], *sC = sC_[wv], *sD = sD_[wv];
+  double (*sCtx)[MZR_CTX] = sCtx_[wv];
 #ifdef MZR_LDS_PAD      // experiment: more LDS per workgroup, so that fewer of them fit a CU
   __shared__ double sPad[MZR_LDS_PAD];
   if (sEnd == -12345) { sPad[threadIdx.x] = 1.0; __syncthreads(); if (sPad[(threadIdx.x + 1) & 63] != 1.0) return; }
@@ -2168,13 +2182,13 @@ static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exp
 template <bool FULL, int KBLK>
 static int kwt_sweep_census(const MzrDev &d, hipStream_t stream, int cus) {
   int perCu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>, 64, 0) != hipSuccess) return 0;
-  const int api = cus * perCu;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>, 64 * MZR_KWT_WG, 0) != hipSuccess) return 0;
+  const int api = cus * perCu * MZR_KWT_WG;      // wavefronts
   int peak[2] = {0, 0};
   int *cnt = d.swHead + 8 * 16;
   if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) return 0;
   const int grid = api + api / 4;
-  hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3(grid), dim3(64), 0, stream, d, 0, -1);
+  hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3((grid + MZR_KWT_WG - 1) / MZR_KWT_WG), dim3(64 * MZR_KWT_WG), 0, stream, d, 0, -1);
   if (hipStreamSynchronize(stream) != hipSuccess) return 0;
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
@@ -2222,8 +2236,9 @@ __global__ void k_sweep_heads(MzrDev d, int sBegin) {
 // kblk: steps of a reach per visit -- 1 or MZR_KWT_KBLK (the schedule tables must have been made for it: kwt_sweep_tables)
 template <bool FULL, int KBLK>
 static void kwt_sweep_launch(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
-  if (evStart && evStop) hipExtLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3(nWaves), dim3(64), 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
-  else hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3(nWaves), dim3(64), 0, stream, d, sBegin, sEnd);
+  const dim3 grid((nWaves + MZR_KWT_WG - 1) / MZR_KWT_WG), block(64 * MZR_KWT_WG);
+  if (evStart && evStop) hipExtLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), grid, block, 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
+  else hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), grid, block, 0, stream, d, sBegin, sEnd);
 }
 void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk) {
   if (nWaves < 1 || sEnd <= sBegin) return;

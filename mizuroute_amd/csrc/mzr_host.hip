@@ -260,6 +260,7 @@ struct mzr_domain {
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
   DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll, kwtRoutedCAll;   // classes A / B / C over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
+  bool swHeavyFirst = false;      // the sweep's items in order of weight regardless of stage (class lists = the *All arrays): MZR_KWT_HEAVY_FIRST
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<unsigned long long> kwOwn, kwDone; DBuf<int> down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
   DBuf<int> swBeat;                                // [swCap][8] per-wavefront record of the sweep (MZR_SWEEP_DEBUG=1)
@@ -643,8 +644,11 @@ void kwt_build_sweep(mzr_handle h) {
   struct It { int code, lo, hi; };
   std::vector<It> items;
   auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, size_t per) {
-    for (size_t b = 0; b * per < v.size(); ++b)
-      items.push_back(It{(cls << 28) | (int)b, v[b * per].sigma, v[std::min(v.size(), (b + 1) * per) - 1].sigma});
+    for (size_t b = 0; b * per < v.size(); ++b) {
+      int lo = 1 << 30, hi = -1;
+      for (size_t k = b * per; k < std::min(v.size(), (b + 1) * per); ++k) { lo = std::min(lo, v[k].sigma); hi = std::max(hi, v[k].sigma); }
+      items.push_back(It{(cls << 28) | (int)b, lo, hi});
+    }
   };
   addRouted(h->h_swA, 0, 4);
   addRouted(h->h_swB, 1, 8);
@@ -656,7 +660,7 @@ void kwt_build_sweep(mzr_handle h) {
     for (size_t b = 0; b * 64 < h->h_kwtDepLight.size(); ++b)
       items.push_back(It{(3 << 28) | (int)b, sg[h->h_kwtDepLight[b * 64]], sg[h->h_kwtDepLight[std::min(h->h_kwtDepLight.size(), (b + 1) * 64) - 1]]});
   }
-  std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.lo < b.lo; });
+  if (!h->swHeavyFirst) std::stable_sort(items.begin(), items.end(), [](const It &a, const It &b) { return a.lo < b.lo; });
   h->h_swLo.clear(); h->h_swHiMax.clear();
   std::vector<int> code, hi;
   int run = -1;
@@ -734,8 +738,9 @@ void kwt_sweep_tables(mzr_handle h, int Wsteps, int kblk) {
   std::vector<int> ra(nL, 0), P((size_t)(nL + 1) * 8, 0);
   int maxAct = 0;
   for (int s = 0; s < nL; ++s) {
-    const int b = (int)(std::upper_bound(h->h_swLo.begin(), h->h_swLo.end(), s) - h->h_swLo.begin());                 // items with lo <= s
-    const int a = std::min(b, (int)(std::lower_bound(h->h_swHiMax.begin(), h->h_swHiMax.end(), s - W + 1) - h->h_swHiMax.begin()));   // first with hi >= s-W+1
+    int b = (int)(std::upper_bound(h->h_swLo.begin(), h->h_swLo.end(), s) - h->h_swLo.begin());                 // items with lo <= s
+    int a = std::min(b, (int)(std::lower_bound(h->h_swHiMax.begin(), h->h_swHiMax.end(), s - W + 1) - h->h_swHiMax.begin()));   // first with hi >= s-W+1
+    if (h->swHeavyFirst) { a = 0; b = nI; }      // items in order of weight: every launch draws them all, an item without a step in the launch is dropped at once
     ra[s] = a;
     maxAct = std::max(maxAct, b - a);
     for (int q = 0; q < 8; ++q) {
@@ -743,7 +748,6 @@ void kwt_sweep_tables(mzr_handle h, int Wsteps, int kblk) {
       P[(size_t)(s + 1) * 8 + q] = P[(size_t)s * 8 + q] + (first < b ? (b - first + 7) / 8 : 0);
     }
   }
-  (void)nI;
   (void)hipStreamSynchronize(h->stream);     // a sweep still in flight reads the old tables
   h->swRA.upload(ra); h->swP.upload(P);
   h->h_swRA = ra; h->h_swP = P;
@@ -1625,6 +1629,17 @@ static void kwt_regroup(mzr_handle h) {
   }
   h->kwtAllValid = true;
   h->h_swA = L[0]; h->h_swB = L[1]; h->h_swC = L[2];
+  // MZR_KWT_HEAVY_FIRST=1: the sweep draws its items heaviest first regardless of stage (the class lists in order of weight: the
+  // *All arrays) -- the longest passes of a launch of the schedule start first
+  h->swHeavyFirst = getenv("MZR_KWT_HEAVY_FIRST") && atoi(getenv("MZR_KWT_HEAVY_FIRST")) != 0;
+  if (h->swHeavyFirst) for (int c = 0; c < 3; ++c) {
+    std::vector<std::pair<int, int>> k2; k2.reserve(L[c].size());
+    for (size_t i = 0; i < L[c].size(); ++i) k2.emplace_back(-need(L[c][i]), (int)i);
+    std::sort(k2.begin(), k2.end());
+    std::vector<MzrKwtRec> S; S.reserve(L[c].size());
+    for (const auto &k : k2) S.push_back(L[c][k.second]);
+    (c == 0 ? h->h_swA : c == 1 ? h->h_swB : h->h_swC) = S;
+  }
   kwt_build_sweep(h);
 }
 
@@ -1800,10 +1815,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 1; ix < nR; ++ix) if (rst[ix] != st) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
   }
   const bool prof = h->profiling;
-  // Steps of a reach per visit of the sweep (kernels_kwt.hip, kwt_reach<.., KBLK>): blocks of MZR_KWT_KBLK in windows long enough to
-  // have several; one step per visit in the short ones (mzr_step: one level of the schedule per stage either way).  MZR_KWT_KBLK=1 / 4
-  // in the environment forces the flavour (tests run both).
-  int kblk = W > 8 ? MZR_KWT_KBLK : 1;
+  // Steps of a reach per visit of the sweep (kernels_kwt.hip, kwt_reach<.., KBLK>): one (the default), or blocks of MZR_KWT_KBLK
+  // (MZR_KWT_KBLK_RUN=4).  Round 5 measured the blocked flavour (profiles/r05_kblk.md): 4 % fewer VALU, 3 % fewer SALU and 21 % fewer
+  // vector-memory instructions per window, 3 % fewer busy wave cycles -- and 12 % / 2 % MORE time at c2 / on the c3 shard, because a
+  // visit holds its wavefront slot through four steps of whatever its upstream reaches are doing (30 % of the wave cycles wait,
+  // 14 % with one step per visit), and the sweep's throughput follows the number of wavefronts that are not waiting.
+  int kblk = 1;
   if (const char *e = getenv("MZR_KWT_KBLK_RUN")) kblk = atoi(e) > 1 ? MZR_KWT_KBLK : 1;
   if (sweep) {
     kwt_sweep_tables(h, W, kblk);
@@ -1812,6 +1829,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     MzrDev dk = dr[kwtIx];
     dk.swRA = h->swRA.p; dk.swP = h->swP.p;
     dk.kwtLight = h->kwtDepLight.p;
+    if (h->swHeavyFirst && h->kwtAllValid) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; dk.kwtRoutedC = h->kwtRoutedCAll.p; }
     const int nLaunch = nS + (W + kblk - 1) / kblk - 1;
     {      // the state this window starts from, kept until the window is known to have finished (retry above)
       // (not for a domain that exports a boundary record -- the record of a stalled window may have been packed and sent before

@@ -25,13 +25,12 @@ def domain_from_golden(net, z, **kw):
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-@pytest.mark.parametrize("window,sweep", [(1000, "1"), (7, "1"), (1, "1"), (1000, "0"), (7, "0"), (1000, "1k1"), (7, "1k4"), (1, "1k4")])
+@pytest.mark.parametrize("window,sweep", [(1000, "1"), (7, "1"), (1, "1"), (1000, "0"), (7, "0"), (1000, "1k4"), (7, "1k4"), (1, "1k4")])
 def test_matches_reference_golden(name, window, sweep, hip_lib, monkeypatch):
     """window: steps per call (1 = mzr_step-like); sweep: "1" the persistent sweeps (k_sweep_kwt, and k_sweep_route for the
     Eulerian methods whatever the window length: progress counters instead of kernel boundaries), "0" one launch per stage
-    (k_stage_kwt, k_stage).  The KWT sweep visits a reach for MZR_KWT_KBLK (4) consecutive steps in windows of more than 8 steps
-    and for one step in shorter ones; "1k1" / "1k4" force the one-step / the blocked flavour on the other kind of window
-    (7 steps = a block of four and a ragged one of three)."""
+    (k_stage_kwt, k_stage).  "1k4": the flavour of the KWT sweep that visits a reach for MZR_KWT_KBLK (4) consecutive steps
+    (MZR_KWT_KBLK_RUN=4; 7 steps = a block of four and a ragged one of three; one step per visit is the default)."""
     if len(sweep) > 1:
         monkeypatch.setenv("MZR_KWT_KBLK_RUN", sweep[2:])
         sweep = sweep[0]
