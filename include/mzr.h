@@ -193,7 +193,8 @@ int mzr_step(mzr_handle h, double T0, double T1, const double *runoff);
    runoff[nSteps][nHru]; step k covers [t_start + k*dt, t_start + (k+1)*dt]. */
 int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff);
 /* same, runoff already resident in device memory (zero copy); launches are asynchronous on the
-   handle's stream, errors surface at the next mzr_sync / mzr_get_* call */
+   handle's stream, errors surface at the next mzr_sync / mzr_get_* call.  runoff_dev has to stay as it is until that
+   call returns (the kernels read it when they run; a window whose KWT sweep gave up is routed again from it, mzr_get_sweep_retries) */
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev);
 /* same, runoff in HOST memory (page-locked for the copy to overlap), returns at once: the window is copied on a
    stream of its own into one of two device buffers while the window before is still being routed -- the loop of
@@ -283,9 +284,12 @@ int mzr_get_schedule(mzr_handle h, int *nStages, int *maxStageWidth);
    holds at once, items (blocks of reaches) dealt to them */
 int mzr_get_sweep_info(mzr_handle h, int *nWaves, int *capacity, int *nItems);
 /* Windows whose persistent KWT sweep gave up waiting (ierr 93) and that were routed again through one launch per stage, since
-   mzr_create.  That happens at mzr_sync / any getter when the failed window is the only one queued since the last
-   synchronisation (its starting state is kept until then); the caller sees no error, only a slow window and a line on stderr.
-   With several windows queued the error is reported as before (later windows have built on nothing). */
+   mzr_create.  That happens at mzr_sync / any getter: the state the first failed window of the queue started from is kept (every
+   kernel of the windows queued behind it returns at once after an error), that window is routed again, and the windows behind it are
+   queued once more as they were -- which takes their forcing where it was: windows queued with mzr_run_dev, whose forcing the caller
+   leaves unchanged in device memory until the next synchronisation returns.  The caller sees no error, only a slow window and a line
+   on stderr.  Not taken back: domains that export a boundary record, lakes, water management, the constituent, a window in which
+   another method went through a persistent sweep; across several windows only the plain KWT domain.  The error is reported then. */
 int mzr_get_sweep_retries(mzr_handle h, long long *nRetries);
 /* KWT persistent sweep, start of its wavefronts: how many of the last launch arrived and how many of them joined (a
    wavefront that starts more than 20 us (MZR_SWEEP_LATE_TICKS = 2000 ticks of the 100 MHz clock) after the first one of its launch leaves at once), and since

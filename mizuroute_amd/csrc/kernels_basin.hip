@@ -24,6 +24,7 @@
 // grid: 1-D, 8 * ceil(tiles / 8) * nReachBlocks blocks.
 #define BT 4
 __global__ void __launch_bounds__(256) k_basin2reach(MzrDev d, int tBegin, int tEnd, int nRB) {
+  if (d.err->code != 0) return;      // an earlier window of the queue failed: its successors leave everything as it is (mzr_sync may route them again)
   const int L = blockIdx.x, xcd = L & 7, m = L >> 3;
   const int tile = (m / nRB) * 8 + xcd, rb = m % nRB;
   const int r = rb * blockDim.x + threadIdx.x;
@@ -109,6 +110,7 @@ __device__ __forceinline__ void hillslope_tile(const MzrDev &d, mzr_cptr Fpad, i
 
 // grid: x over reaches, y over tiles of HT steps: BASIN_QR(1) of steps [y*HT, y*HT+HT)
 __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d, int tBegin, int tEnd) {
+  if (d.err->code != 0) return;
   const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = r < d.N && !(d.haloSlot && d.haloSlot[r] >= 0);
@@ -119,6 +121,7 @@ __global__ void __launch_bounds__(256) k_hillslope_out(MzrDev d, int tBegin, int
 
 // grid: x over reaches, y over tiles of HT register slots: QFUTURE(j+1) after the window
 __global__ void __launch_bounds__(256) k_hillslope_state(MzrDev d) {
+  if (d.err->code != 0) return;
   const mzr_cptr Fpad = (mzr_cptr)(unsigned long long)d.fracPad;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   const int j0 = blockIdx.y * HT;

@@ -2128,9 +2128,10 @@ __global__ void __launch_bounds__(256) k_kwt_head_done(MzrDev d) {
 }
 
 // History sum of REACH_Q (histVars_data.f90:229-231 accumulates step by step): the window's rows added in step order.
-__global__ void __launch_bounds__(256) k_accum_qsum(const double *Q, double *qsum, int N, int W) {
+__global__ void __launch_bounds__(256) k_accum_qsum(const double *Q, double *qsum, int N, int W, const MzrErr *err) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
+  if (err && err->code != 0) return;      // the rows of a window that failed (or was never routed) are not a result
   double a = qsum[r];
   int t = 0;
   for (; t + 16 <= W; t += 16) {      // sixteen rows in flight per lane (100 k lanes are 1.5 wavefronts per SIMD: latency, not bandwidth); added in step order
@@ -2144,8 +2145,8 @@ __global__ void __launch_bounds__(256) k_accum_qsum(const double *Q, double *qsu
   qsum[r] = a;
 }
 
-void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream) {
-  hipLaunchKernelGGL(k_accum_qsum, dim3((N + 255) / 256), dim3(256), 0, stream, Q, qsum, N, W);
+void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream, const MzrErr *err) {
+  hipLaunchKernelGGL(k_accum_qsum, dim3((N + 255) / 256), dim3(256), 0, stream, Q, qsum, N, W, err);
 }
 
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int hcBegin, int hcEnd, int gnBegin, int gnEnd,

@@ -62,6 +62,7 @@ struct MzrErr {
   int lane, nBad;   // first unsatisfied lane of the wavefront, number of unsatisfied lanes
   long long waited; // ticks of the 100 MHz clock since the polled words last changed
   int heads[8];     // ticket heads at the time
+  int winSeq;                         // window (counted from the last synchronisation of the handle) whose kernel raised the error
   int nSlow; int raisedAt;            // (MZR_SWEEP_DEBUG) passes that took longer than 10 ms from the end of their wait to their publish; low word of the clock at the raise
   int slowT[32][24];                  // ... and (builds with -DMZR_SWEEP_TRACE) the clock at every section boundary of that pass, relative to the end of its wait
   int slow[32][8];                    // wavefront, launch, item, ticks, HW_ID, XCC, low word of the clock at the publish, -
@@ -215,6 +216,7 @@ struct MzrDev {
   int *rtHead;                // [8][16] ticket counters
   unsigned long long *swClock;   // [2] of this launch of the KWT sweep: the 100 MHz clock when its first wavefront arrived / when its last one left (mzr_get_sweep_clock)
   int *swBeat;                // [wavefronts][8] what every wavefront of a persistent sweep is doing (launch, item, queue, phase, items done): only with MZR_SWEEP_DEBUG=1
+  int winSeq;                 // this window's number since the handle was last synchronised (goes into the error record)
   int sweepPrio;              // 1: wavefronts of this handle's persistent sweeps keep the highest wave priority (mzr_config.sweepPriority)
   long long stallTicks;       // a polling wavefront gives up (code 93) when nothing it polls has changed for this many ticks of the 100 MHz clock
   MzrKwtStat *kwtStat;
@@ -224,7 +226,7 @@ struct MzrDev {
 
 __device__ __forceinline__ void mzr_raise(const MzrDev &d, int code, int reach, int step, int where) {
   if (atomicCAS(&d.err->code, 0, code) == 0) {
-    d.err->reach = reach; d.err->step = step; d.err->where = where;
+    d.err->reach = reach; d.err->step = step; d.err->where = where; d.err->winSeq = d.winSeq;
   }
 }
 // a wavefront of a persistent sweep gives up waiting: the record says what it waited for (one lane calls this)
@@ -234,7 +236,7 @@ __device__ __noinline__ void mzr_raise_stall(const MzrDev &d, int where, int rea
     MzrErr *e = d.err;
     e->reach = reach; e->step = -1; e->where = where; e->s = s; e->depReach = depReach; e->seen = seen; e->need = need;
     e->queue = queue; e->xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7; e->lane = lane; e->nBad = nBad; e->waited = waited;
-    e->raisedAt = (int)wall_clock64();
+    e->raisedAt = (int)wall_clock64(); e->winSeq = d.winSeq;
     for (int q = 0; q < 8; ++q) e->heads[q] = heads ? __hip_atomic_load(heads + q * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
   }
 }

@@ -43,7 +43,7 @@ void mzr_launch_sort_flux(int H, int nSteps, int nSrc, const int *srcOf, int rem
 void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hbBegin, int hbEnd, int hcBegin, int hcEnd, int gnBegin, int gnEnd,
                           int ltBegin, int ltEnd, hipStream_t stream);
 
-void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream);
+void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream, const MzrErr *err = nullptr);
 int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream, int kblk);
 int mzr_kwt_class_caps(int *capB, int *capC);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
@@ -98,13 +98,26 @@ __global__ void k_scatter_rows(const double *src, double *dst, const int *ext2in
 }
 
 // (overlapping windows: the window before keeps its rows, the new one has its own)
-__global__ void k_carry_qlat2(double *dst, const double *src, int lastW, int N, const int *haloSlot) {
+// the state a queue of windows can be taken back to (retry of a window whose sweep gave up): copied at the start of every window
+// unless an earlier window of the queue has failed -- so what is kept is the state at the start of the FIRST failed window
+__global__ void __launch_bounds__(256) k_snapshot(const MzrErr *err, int *sN, const int *kwN, size_t nN, double *sQ, const double *kwQ, size_t nQ,
+                                                   double *sTR, const double *kwTR, size_t nTR, double *sS, const double *qsum, double *sH, const double *hIn, size_t nR) {
+  if (err->code != 0) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = i0; i < nQ; i += stride) sQ[i] = kwQ[i];
+  for (size_t i = i0; i < nTR; i += stride) sTR[i] = kwTR[i];
+  for (size_t i = i0; i < nN; i += stride) sN[i] = kwN[i];
+  for (size_t i = i0; i < nR; i += stride) { sS[i] = qsum[i]; if (sH) sH[i] = hIn[i]; }
+}
+__global__ void k_carry_qlat2(double *dst, const double *src, int lastW, int N, const int *haloSlot, const MzrErr *err) {
+  if (err->code != 0) return;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
   if (haloSlot && haloSlot[r] >= 0) return;
   dst[r] = src[(size_t)lastW * N + r];
 }
-__global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot) {
+__global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot, const MzrErr *err) {
+  if (err->code != 0) return;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= N) return;
   if (haloSlot && haloSlot[r] >= 0) return;
@@ -251,7 +264,12 @@ struct mzr_domain {
   // per stage -- when the state it started from is still known: the at-rest particles are copied aside before every sweep
   // (580 bytes per reach), and the failed window must be the only one queued since the last synchronisation (later windows
   // see the error, skip their sweeps, and their hillslope pre-pass has moved on: nothing to go back to).
-  struct { bool valid = false; int W = 0, queued = 0; double t_start = 0.0, T1_single = 0.0; } retry;
+  // Windows queued since the handle was last synchronised, each with what it takes to route it again and the host-side bookkeeping
+  // as it was before the window was queued (retry of a KWT sweep that gave up, mzr_sync)
+  struct Book { int basCur = 0, lastW = 0; long long stepsDone = 0, totalSteps = 0, histSteps = 0, kwtWindows = 0, kwtStepsSince = 0, kwtHeadSteps = 0; long long reachSteps[6] = {0}, meanSteps[6] = {0}, nLaunches[6] = {0}; };
+  struct QWin { int W = 0; double t_start = 0.0, T1_single = 0.0; const double *runoff = nullptr; bool replayable = false, snap = false; Book before; };
+  struct { std::vector<QWin> q; bool armed = false; int failAt = -1; long long seen = 0; int depth = 0; } retry;
+  bool nextReplayable = false;      // the window being queued has its forcing in the caller's device memory (mzr_run_dev)
   DBuf<int> snapN; DBuf<double> snapQ, snapTR, snapQsum, snapHIn;
   long long sweepRetries = 0;
   DBuf<unsigned long long> swClock; long long swClockN = 0;      // {first wavefront in, last wavefront out} of the last MZR_CLOCK_LOG sweep launches (device clock)
@@ -1369,7 +1387,7 @@ int mzr_init_state(mzr_handle h) {
     h->lakeEvapAlt.free(); h->lakePrecipAlt.free(); h->calMonthAlt.free(); h->calDayAlt.free(); h->calDoyAlt.free();
     h->lakeNextInAlt = false;
     h->snapN.free(); h->snapQ.free(); h->snapTR.free(); h->snapQsum.free(); h->snapHIn.free();
-    h->retry.valid = false; h->retry.queued = 0;
+    h->retry.q.clear(); h->retry.seen = 0;
     h->tail.pending = false;
     if (h->cfg.doesBasinRoute == 1) {
       h->qi.alloc(W * N); h->qi.zero();      // halo reaches have no HRUs of their own: their rows stay zero (basin state getters)
@@ -1666,6 +1684,19 @@ static int stepBlockFor(mzr_handle h, int W, bool canOverlap) {
   return std::max(1, std::min(kb, W));
 }
 
+static mzr_domain::Book saveBook(mzr_handle h) {
+  mzr_domain::Book b;
+  b.basCur = h->basCur; b.lastW = h->lastW; b.stepsDone = h->stepsDone; b.totalSteps = h->totalSteps; b.histSteps = h->histSteps;
+  b.kwtWindows = h->kwtWindows; b.kwtStepsSince = h->kwtStepsSince; b.kwtHeadSteps = h->kwtHeadSteps;
+  for (int ix = 0; ix < h->cfg.nRoutes && ix < 6; ++ix) { b.reachSteps[ix] = h->route[ix].reachSteps; b.meanSteps[ix] = h->route[ix].meanSteps; b.nLaunches[ix] = h->route[ix].nLaunches; }
+  return b;
+}
+static void restoreBook(mzr_handle h, const mzr_domain::Book &b) {
+  h->basCur = b.basCur; h->lastW = b.lastW; h->stepsDone = b.stepsDone; h->totalSteps = b.totalSteps; h->histSteps = b.histSteps;
+  h->kwtWindows = b.kwtWindows; h->kwtStepsSince = b.kwtStepsSince; h->kwtHeadSteps = b.kwtHeadSteps;
+  for (int ix = 0; ix < h->cfg.nRoutes && ix < 6; ++ix) { h->route[ix].reachSteps = b.reachSteps[ix]; h->route[ix].meanSteps = b.meanSteps[ix]; h->route[ix].nLaunches = b.nLaunches[ix]; }
+}
+
 static int run_window(mzr_handle h, int W, double t_start, double T1_single, const double *runoff_dev) {
   if (!h->haveState) return fail(h, 20, "mzr_run/state not initialised (call mzr_init_state)");
   if (W < 1 || W > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
@@ -1675,6 +1706,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (h->nLake && h->lakeSteps < W) return fail(h, 20, "mzr_run/lakes are on: call mzr_set_lake_forcing for this window first");
   if (h->anyLakeTarget && h->wmVolSteps < W) return fail(h, 20, "mzr_run/target-volume lakes are on: call mzr_set_wm_vol for this window first");
   (void)hipSetDevice(h->cfg.device);
+  const mzr_domain::Book bookBefore = saveBook(h);
   if (h->kwN.p) {   // regroup after the first two windows (not before the first: no particles yet), then every 8 windows / 512 steps
     const bool early = W > 1 && (h->kwtWindows == 1 || h->kwtWindows == 2);
     if (h->kwtWindows > 0 && (early || h->kwtStepsSince >= std::max(512LL, 8LL * W))) { kwt_regroup(h); h->kwtStepsSince = 0; }
@@ -1728,8 +1760,8 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // carry BASIN_QR(1) of the last step of the previous window into row 0 (halo columns already
   // hold the imported row 0 of this window)
   if (h->lastW > 0) {
-    if (prevQlat != h->qlat.p) hipLaunchKernelGGL(k_carry_qlat2, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, prevQlat, h->lastW, N, d.haloSlot);
-    else hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot);
+    if (prevQlat != h->qlat.p) hipLaunchKernelGGL(k_carry_qlat2, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, prevQlat, h->lastW, N, d.haloSlot, h->err.p);
+    else hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->qlat.p, h->lastW, N, d.haloSlot, h->err.p);
   }
   // Which methods go through a persistent sweep (decided here because it decides their stream).  KWT: always (one launch
   // per chunk of the skewed schedule, progress words instead of kernel boundaries; single steps too: 842 dependent stages
@@ -1831,27 +1863,30 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     dk.kwtLight = h->kwtDepLight.p;
     if (h->swHeavyFirst && h->kwtAllValid) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; dk.kwtRoutedC = h->kwtRoutedCAll.p; }
     const int nLaunch = nS + (W + kblk - 1) / kblk - 1;
-    {      // the state this window starts from, kept until the window is known to have finished (retry above)
+    {      // the state the queue can be taken back to, and what it takes to route this window again (mzr_sync, retryKwtQueue)
       // (not for a domain that exports a boundary record -- the record of a stalled window may have been packed and sent before
       // mzr_sync gets to route the window again -- and not when another method went through a persistent sweep in this window:
       // k_sweep_route returns at once after an error, so that method would be left behind with nobody to say so)
       bool otherSweep = false;
       for (int ix = 0; ix < h->cfg.nRoutes; ++ix) if (h->route[ix].method != MZR_KWT && rtSweep && h->route[ix].rtCap >= 1) otherSweep = true;
       const bool can = !h->nLake && !h->tracer && !h->cfg.is_flux_wm && h->nExp == 0 && !otherSweep;
-      ++h->retry.queued;
-      h->retry.valid = false;
-      if (can && h->retry.queued == 1) {
+      mzr_domain::QWin qw;
+      qw.W = W; qw.t_start = t_start; qw.T1_single = T1_single; qw.runoff = runoff_dev; qw.replayable = h->nextReplayable; qw.before = bookBefore;
+      if (can) {
         try {
           if (!h->snapN.p) { h->snapN.alloc(h->kwN.n); h->snapQ.alloc(h->kwQ.n); h->snapTR.alloc(h->kwTR.n); h->snapQsum.alloc(N); }
           if (rb.hInflow.p && !h->snapHIn.p) h->snapHIn.alloc(N);      // (mzr_set_history may have switched the sum on since the first snapshot)
-          (void)hipMemcpyAsync(h->snapN.p, h->kwN.p, h->kwN.n * sizeof(int), hipMemcpyDeviceToDevice, sx);
-          (void)hipMemcpyAsync(h->snapQ.p, h->kwQ.p, h->kwQ.n * sizeof(double), hipMemcpyDeviceToDevice, sx);
-          (void)hipMemcpyAsync(h->snapTR.p, h->kwTR.p, h->kwTR.n * sizeof(double), hipMemcpyDeviceToDevice, sx);
-          (void)hipMemcpyAsync(h->snapQsum.p, rb.qsum.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, sx);
-          if (rb.hInflow.p && h->snapHIn.p) (void)hipMemcpyAsync(h->snapHIn.p, rb.hInflow.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, sx);
-          h->retry.valid = true; h->retry.W = W; h->retry.t_start = t_start; h->retry.T1_single = T1_single;
+          hipLaunchKernelGGL(k_snapshot, dim3(1024), dim3(256), 0, sx, h->err.p, h->snapN.p, h->kwN.p, h->kwN.n, h->snapQ.p, h->kwQ.p, h->kwQ.n,
+                             h->snapTR.p, h->kwTR.p, h->kwTR.n, h->snapQsum.p, rb.qsum.p, rb.hInflow.p ? h->snapHIn.p : (double *)nullptr, rb.hInflow.p, (size_t)N);
+          qw.snap = true;
         } catch (const std::string &) { (void)hipGetLastError(); }
       }
+      h->retry.q.push_back(qw);
+      // debugging aid (tests): MZR_SWEEP_FAIL_AT=n gives the n-th KWT window of the handle (0-based) a watchdog of one clock tick
+      if (h->retry.failAt == -1) { const char *e = getenv("MZR_SWEEP_FAIL_AT"); h->retry.failAt = e ? atoi(e) : -2; }
+      if (h->retry.failAt >= 0 && h->retry.seen == h->retry.failAt && h->retry.depth == 0) dk.stallTicks = 1;
+      if (h->retry.depth == 0) ++h->retry.seen;
+      dk.winSeq = (int)h->retry.q.size() - 1;
     }
     if (h->swClock.p) { dk.swClock = h->swClock.p + 2 * (size_t)(h->swClockN % MZR_CLOCK_LOG); ++h->swClockN; }
     mzr_launch_kwt_window_init(dk, 0, W, sx);
@@ -1953,7 +1988,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     // method's routing, the constituent pass over the same skewed schedule
     if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);
     if (h->lastW > 0 && h->basSol.p)
-      hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->basSol.p, h->lastW, N, (const int *)nullptr);
+      hipLaunchKernelGGL(k_carry_qlat, dim3((N + 255) / 256), dim3(256), 0, st, h->basSol.p, h->lastW, N, (const int *)nullptr, h->err.p);
     MzrDev dt2 = d;
     dt2.solS0 = h->solS[h->solCur].p; dt2.solS1 = h->solS[h->solCur ^ 1].p;
     mzr_launch_basin_solute(dt2, st);
@@ -1971,7 +2006,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
   }
   for (int ix = 0; ix < nR; ++ix) {
-    if (h->route[ix].method == MZR_KWT) mzr_launch_accum_qsum(h->route[ix].Q.p, h->route[ix].qsum.p, N, W, rst[ix]);
+    if (h->route[ix].method == MZR_KWT) mzr_launch_accum_qsum(h->route[ix].Q.p, h->route[ix].qsum.p, N, W, rst[ix], h->err.p);
     h->route[ix].reachSteps += (long long)N * W;
     h->route[ix].meanSteps += W;
     if (multi && ix > 0 && rst[ix] != st) { (void)hipEventRecord(h->routeEvent[ix], rst[ix]); (void)hipStreamWaitEvent(st, h->routeEvent[ix], 0); }
@@ -1979,9 +2014,9 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (chunked) (void)hipStreamWaitEvent(st, h->basinEvents[nChunks], 0);   // QFUTURE of the window is part of its result
   if (h->histFlags & MZR_H_RUNOFF) {      // histVars_data.f90:196-211: basin runoff, instantaneous and delayed runoff into the reaches, step by step
     const double *inst = (h->cfg.doesBasinRoute == 1 && h->qi.p) ? h->qi.p : h->qlat.p + N;
-    mzr_launch_accum_qsum(inst, h->hInst.p, N, W, st);
-    mzr_launch_accum_qsum(h->qlat.p + N, h->hDlay.p, N, W, st);
-    mzr_launch_accum_qsum(runoff_dev, h->hBas.p, h->H, W, st);
+    mzr_launch_accum_qsum(inst, h->hInst.p, N, W, st, h->err.p);
+    mzr_launch_accum_qsum(h->qlat.p + N, h->hDlay.p, N, W, st, h->err.p);
+    mzr_launch_accum_qsum(runoff_dev, h->hBas.p, h->H, W, st, h->err.p);
     h->histSteps += W;
   }
   h->lastW = W; h->stepsDone += W; h->obsSteps = 0; h->solSteps = 0; h->wmSteps = 0; h->totalSteps += W; h->lakeSteps = 0; h->wmVolSteps = 0;
@@ -2006,14 +2041,19 @@ int mzr_set_wm_flux(mzr_handle h, int nSteps, const double *flux) {
   return 0;
 }
 
-// The window just synchronised ended with ierr 93 and its starting state was kept (mzr_domain::retry): back to that state, and the
-// window's KWT routing once more through one launch per stage (k_stage_kwt: no progress words, no waiting -- the form the sweep
-// is tested against, bit for bit).  The hillslope series of the window (qlat) are untouched by the sweep and still there.
-static int retryKwtWindow(mzr_handle h) {
+// A window of the queue ended with ierr 93 (its persistent KWT sweep gave up waiting) and the state it started from was kept
+// (k_snapshot: the later windows of the queue left everything as it was -- every kernel of theirs returns at once after an error):
+// back to that state, the window's KWT routing once more through one launch per stage (k_stage_kwt: no progress words, no waiting --
+// the form the sweep is tested against, bit for bit; the hillslope series of the window (qlat) are untouched by the sweep and still
+// there), and the windows queued behind it once more as they were queued.
+static int retryKwtQueue(mzr_handle h, int k) {
   const int kwtIx = idxOf(h, MZR_KWT);
-  if (kwtIx < 0 || !h->retry.valid || !h->snapN.p) return 1;
+  const std::vector<mzr_domain::QWin> q = h->retry.q;      // (run_window below appends to the handle's own list)
+  if (kwtIx < 0 || k < 0 || k >= (int)q.size() || !q[k].snap || !h->snapN.p) return 1;
+  for (size_t j = k + 1; j < q.size(); ++j) if (!q[j].replayable) return 1;      // forcing that is no longer where it was
+  if (q.size() > (size_t)k + 1 && (h->cfg.nRoutes != 1 || h->nHalo || (h->histFlags & MZR_H_RUNOFF))) return 1;      // only the plain KWT domain is taken back across windows
   RouteBufs &rb = h->route[kwtIx];
-  const int N = h->N, W = h->retry.W, nS = h->nStages;
+  const int N = h->N, W = q[k].W, nS = h->nStages;
   hipStream_t st = h->stream;
   (void)hipMemset(h->err.p, 0, sizeof(MzrErr));
   (void)hipMemcpyAsync(h->kwN.p, h->snapN.p, h->kwN.n * sizeof(int), hipMemcpyDeviceToDevice, st);
@@ -2022,16 +2062,29 @@ static int retryKwtWindow(mzr_handle h) {
   (void)hipMemcpyAsync(rb.qsum.p, h->snapQsum.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st);
   if (rb.hInflow.p && h->snapHIn.p) (void)hipMemcpyAsync(rb.hInflow.p, h->snapHIn.p, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, st);
   MzrDev d; fillDev(h, d);
-  d.W = W; d.t_start = h->retry.t_start; d.T1_single = h->retry.T1_single; d.runoff = nullptr;
+  d.W = W; d.t_start = q[k].t_start; d.T1_single = q[k].T1_single; d.runoff = nullptr;
   setRoute(h, d, kwtIx);
   for (int s = 0; s < nS + W - 1; ++s) {
     const int sLo = std::max(0, s - (W - 1)), sHi = std::min(s, nS - 1);
     mzr_launch_stage_kwt(d, s, h->kwtRoutedOff[sLo], h->kwtRoutedOff[sHi + 1], h->kwtBOff[sLo], h->kwtBOff[sHi + 1], h->kwtCOff[sLo], h->kwtCOff[sHi + 1],
                          h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
   }
-  mzr_launch_accum_qsum(rb.Q.p, rb.qsum.p, N, W, st);
+  mzr_launch_accum_qsum(rb.Q.p, rb.qsum.p, N, W, st, h->err.p);
   if (hipStreamSynchronize(st) != hipSuccess) return 1;
   ++h->sweepRetries;
+  // the windows behind it: the bookkeeping as it was before the first of them was queued, then the same calls again
+  h->retry.q.clear();
+  if ((size_t)k + 1 < q.size()) {
+    restoreBook(h, q[k + 1].before);
+    ++h->retry.depth;
+    for (size_t j = k + 1; j < q.size(); ++j) {
+      h->nextReplayable = true;
+      const int rc = run_window(h, q[j].W, q[j].t_start, q[j].T1_single, q[j].runoff);
+      h->nextReplayable = false;
+      if (rc) { --h->retry.depth; return 1; }
+    }
+    --h->retry.depth;
+  }
   return 0;
 }
 
@@ -2039,20 +2092,21 @@ int mzr_sync(mzr_handle h) {
   MZR_FLUSH(h);
   if (!h) return 1;
   (void)hipSetDevice(h->cfg.device);
-  const hipError_t e = hipStreamSynchronize(h->stream);
-  if (e != hipSuccess) return fail(h, 92, std::string("mzr_sync/") + hipGetErrorString(e));
-  if (h->retry.valid && h->retry.queued == 1) {      // exactly one KWT window since the last synchronisation: did its sweep give up?
+  for (int round = 0; ; ++round) {
+    const hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(h, 92, std::string("mzr_sync/") + hipGetErrorString(e));
+    if (h->retry.q.empty() || round >= 4) break;
     int code = 0;
     MzrErr e93;
-    // (where 20 = a wait of the KWT sweep; a stall raised anywhere else -- the Eulerian sweeps raise 21 -- is not this window's to repair)
-    if (hipMemcpy(&code, h->err.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && code == 93 &&
-        hipMemcpy(&e93, h->err.p, sizeof e93, hipMemcpyDeviceToHost) == hipSuccess && e93.where == 20) {
-      fprintf(stderr, "mzr: the persistent KWT sweep of a window of %d steps gave up waiting (ierr 93, reach index %d, schedule step %d); the window is routed "
-                      "again with one launch per stage\n", h->retry.W, e93.reach, e93.s);
-      if (retryKwtWindow(h) != 0) return fail(h, 93, "mzr_sync/the persistent KWT sweep gave up waiting and the window could not be routed again");
-    }
+    // (where 20 = a wait of the KWT sweep; a stall raised anywhere else -- the Eulerian sweeps raise 21 -- is not this queue's to repair)
+    if (!(hipMemcpy(&code, h->err.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && code == 93 &&
+          hipMemcpy(&e93, h->err.p, sizeof e93, hipMemcpyDeviceToHost) == hipSuccess && e93.where == 20)) break;
+    const int k = e93.winSeq, nq = (int)h->retry.q.size();
+    fprintf(stderr, "mzr: the persistent KWT sweep of window %d of %d queued (%d steps) gave up waiting (ierr 93, reach index %d, schedule step %d); the window is routed "
+                    "again with one launch per stage%s\n", k + 1, nq, (k >= 0 && k < nq) ? h->retry.q[k].W : 0, e93.reach, e93.s, k + 1 < nq ? ", the windows behind it as they were queued" : "");
+    if (retryKwtQueue(h, k) != 0) return fail(h, 93, "mzr_sync/the persistent KWT sweep gave up waiting and the queued windows could not be routed again");
   }
-  h->retry.queued = 0; h->retry.valid = false;
+  h->retry.q.clear();
   if (h->profiling) {
     if (h->timerStream) (void)hipStreamSynchronize(h->timerStream);
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) {
@@ -2073,7 +2127,10 @@ int mzr_sync(mzr_handle h) {
 int mzr_run_dev(mzr_handle h, int nSteps, double t_start, const double *runoff_dev) {
   MZR_FLUSH_STEPS(h);
   if (!h) return 1;
-  return run_window(h, nSteps, t_start, t_start + h->cfg.dt, runoff_dev);
+  h->nextReplayable = true;      // the forcing stays in the caller's device memory, unchanged until the next synchronisation (include/mzr.h)
+  const int rc = run_window(h, nSteps, t_start, t_start + h->cfg.dt, runoff_dev);
+  h->nextReplayable = false;
+  return rc;
 }
 
 int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {

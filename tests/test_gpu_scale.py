@@ -406,3 +406,38 @@ def test_sweep_times_itself_on_the_device_clock(hip_lib):
     assert sum(ms) <= wall_ms * 1.001, (ms, wall_ms)
     assert dom.sweep_clock(2) == ms[-2:]
     dom.close()
+
+
+def test_queue_of_windows_is_taken_back_to_the_one_that_failed(hip_lib, monkeypatch):
+    """Five windows queued without a synchronisation in between (what bench.py does with twenty); the persistent KWT sweep of the third
+    gives up (MZR_SWEEP_FAIL_AT=2: a watchdog of one clock tick for that window alone).  Every kernel of the two windows behind it
+    returns at once; mzr_sync goes back to the state the third window started from, routes it through one launch per stage and
+    queues the two others again: one retry, and the bits of a run that never used the sweep."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    net = m.make_network(30_000, seed=54)
+    frac, _, _ = _uh(net)
+    W, K = 96, 5
+    ro = bench.device_runoff(torch, net.H, K * W, 0, 7, dev)
+    torch.cuda.synchronize()
+
+    def route(sweep, fail_at):
+        monkeypatch.setenv("MZR_KWT_SWEEP", "1" if sweep else "0")
+        if fail_at is None:
+            monkeypatch.delenv("MZR_SWEEP_FAIL_AT", raising=False)
+        else:
+            monkeypatch.setenv("MZR_SWEEP_FAIL_AT", str(fail_at))
+        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W)
+        for k in range(K):
+            dom.run_device(W, k * W * DT, ro[k * W:(k + 1) * W].data_ptr())
+        dom.sync()
+        out = dom.kwt_state(), dom.flux(m.KWT, m.api.F_Q), dom.mean_q(m.KWT), dom.basin_state(), dom.sweep_retries()
+        dom.close()
+        return out
+
+    sa, Qa, Ma, Ba, ra = route(True, 2)
+    sb, Qb, Mb, Bb, rb = route(False, None)
+    assert ra == 1 and rb == 0, (ra, rb)
+    assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb) and np.array_equal(Ba, Bb)
