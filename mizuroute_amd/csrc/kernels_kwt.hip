@@ -970,9 +970,18 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
       if (!SPLIT) { c[0] = n_own == 0 ? T0 : X0; if (firstOfVisit) c[3] = hin; }     // getusq_rch :587-596: a reach without particles starts at T0
       c[1] = qlat_r;
       if (d.kwtStat && !ovf) {
-        if (!SPLIT) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
-        atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
-        atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
+        // particle-traffic counters (mzr_set_profiling 2).  The persistent sweep keeps them per reach slot in LDS (ctx[12..15]) and
+        // adds them to the device counters once, when the wavefront leaves: five atomics per routed reach-step on six addresses
+        // made a counted window last 5.9 s instead of 0.45 s (profiles/r05_soak.md)
+        if (PERS) {
+          unsigned long long *cs = (unsigned long long *)(c + 12);
+          if (!SPLIT) cs[0] += (unsigned long long)n_own;
+          cs[1] += (unsigned long long)st_up; cs[3] += 1ull | ((unsigned long long)nup << 32);
+        } else {
+          if (!SPLIT) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
+          atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
+          atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
+        }
       }
     }
   }
@@ -1165,7 +1174,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
           for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
           if (gl == 0) {
             ctx[0] = n_own == 0 ? T0 : X0; ctx[3] = hin;
-            if (d.kwtStat) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
+            if (d.kwtStat) ((unsigned long long *)(ctx + 12))[0] += (unsigned long long)n_own;      // (SPLIT: the persistent sweep)
           }
           grp_sync();
         }
@@ -1759,7 +1768,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
 #ifdef MZR_DBG_TRACE
         if (PERS && gl == 0 && d.t_start >= MZR_DBG_TRACE) printf("TR ts %.0f r %d t %d G %d kb %d first %d last %d nown %d nrA %d nrB %d NR %d NQ2 %d NN2 %d Qout %.17g Qend %.17g q1 %.17g t1 %.17g X0 %.17g\n", d.t_start, r, t, G, kb, (int)firstOfVisit, (int)lastOfVisit, n_own, nrA, nrB, NR, NQ2, NN2, Qout, Q_END, Qw[1], Tw[1], ctx[0]);
 #endif
-        if (d.kwtStat && gl == 0) atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
+        if (d.kwtStat && gl == 0) {
+          if (PERS) ((unsigned long long *)(ctx + 12))[2] += (unsigned long long)(NQ2 + 2);
+          else atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
+        }
         TSTAMP(7); TSTAMP_WAVE(20);
         if (PERS) {   // results written through (sc1) and drained, then the step is published
           if (SPLIT) {      // the word of this reach's step t - 1 (its outbox count of the other parity stays): published long ago by now
@@ -1814,7 +1826,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
 //   class A  16 lanes,  4 reaches per wavefront, at most 60 entries (a full binary confluence)
 // A reach that has outgrown its class is left untouched by its group and routed right away by 16-lane groups
 // of the same wavefront, four at a time, so the classification only has to be usually right.
-#define MZR_CTX 12     // doubles of LDS per reach slot: X0, BASIN_QR(1), inflow, -, then the 64-byte record
+#define MZR_CTX 16     // doubles of LDS per reach slot: X0, BASIN_QR(1), inflow, history sum, the 64-byte record, then (persistent sweep) four particle-traffic counters
 struct KwtCls {
   static constexpr int GA = 16, RA = 4, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
   static constexpr int GB = 8, RB = 8, KB = MZR_KWT_KB;
@@ -1970,6 +1982,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
 #endif
   if (sEnd < 0) { mzr_census(d0.swHead + 8 * 16); return; }      // host: mzr_sweep_kwt_capacity
   if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
+  if (d0.kwtStat && mzr_lane() < RC) { unsigned long long *cs = (unsigned long long *)(sCtx[mzr_lane()] + 12); cs[0] = cs[1] = cs[2] = cs[3] = 0ull; }
   const int arr = mzr_sweep_join(d0.swHead, d0.swClock);      // (a wavefront that starts behind time does not join)
   if (arr < 0) return;
   if (d0.sweepPrio) __builtin_amdgcn_s_setprio(3);      // mzr_config.sweepPriority: a small, deep domain sweeping beside a large one
@@ -2086,6 +2099,14 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
     }
   }
   kwt_beat(d0, 3, 9);
+  if (d0.kwtStat) {      // the wavefront's particle-traffic counters (one set per reach slot) go to the device counters
+    grp_sync();
+    const int l = mzr_lane();
+    const unsigned long long *cs = (const unsigned long long *)(sCtx[l < RC ? l : 0] + 12);
+    const unsigned long long a = wave_sum(l < RC ? cs[0] : 0ull), b = wave_sum(l < RC ? cs[1] : 0ull), c = wave_sum(l < RC ? cs[2] : 0ull);
+    const unsigned long long nr = wave_sum(l < RC ? (cs[3] & 0xffffffffull) : 0ull), ne = wave_sum(l < RC ? (cs[3] >> 32) : 0ull);
+    if (l == 0) { atomicAdd(&d0.kwtStat->w_in, a); atomicAdd(&d0.kwtStat->w_up, b); atomicAdd(&d0.kwtStat->w_out, c); atomicAdd(&d0.kwtStat->n_route, nr); atomicAdd(&d0.kwtStat->n_edges, ne); }
+  }
   // the launch's duration on the device's own clock (mzr_get_sweep_clock): the last wavefront to leave leaves the latest time
   if (d0.swClock && mzr_lane() == 0) atomicMax(d0.swClock + 1, (unsigned long long)wall_clock64());
 }
