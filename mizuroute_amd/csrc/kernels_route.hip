@@ -550,6 +550,15 @@ __device__ __forceinline__ int stage_lane_reach(const MzrDev &d, int p, int rBeg
   const int r = d.lanePerm ? d.lanePerm[p] : p;
   return (r >= rBegin && r < rEnd) ? r : -1;
 }
+// lane position of a thread: the blocks [0, nHB) of a launch serve the heavy positions (mzr_device.h, nHeavyPos), the others the
+// positions from `base` on; heavy = the position is one of those (its reach is taken whatever block range the launch covers)
+__device__ __forceinline__ int stage_lane_reach_at(const MzrDev &d, int blk, int nHB, int base, int rBegin, int rEnd) {
+  if (blk < nHB) {
+    const int r = d.lanePerm[d.permN + blk * (int)blockDim.x + (int)threadIdx.x];
+    return (r >= rBegin && r < rEnd) ? r : -1;
+  }
+  return stage_lane_reach(d, stage_lane_pos(blk - nHB, base), rBegin, rEnd);
+}
 
 // Muskingum-Cunge without the rare branches needs 155 VGPRs (3 wavefronts per SIMD); MZR_MC_WAVES asks the compiler for more
 // wavefronts (fewer registers, spills if it must): measured, see DESIGN.md 6
@@ -581,7 +590,8 @@ __device__ __forceinline__ void stage_reach_block(const MzrDev &d, int r, int tb
 // runs once (DW 208 -> 260 VGPRs, Muskingum-Cunge 153 -> 202, IRF 74 -> 112), so the two are separate instantiations.
 template <int METHOD, bool FULL, bool BLK>
 __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage(MzrDev d, int s, int rBegin, int rEnd) {
-  const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x, rBegin & ~255), rBegin, rEnd);
+  const int nHB = d.lanePerm ? d.nHeavyPos / (int)blockDim.x : 0;
+  const int r = stage_lane_reach_at(d, (int)blockIdx.x, nHB, rBegin & ~255, rBegin, rEnd);
   if (r < 0) return;
   if (BLK) { stage_reach_block<METHOD, FULL>(d, r, s - d.sigma[r]); return; }
   const int t = s - d.sigma[r];
@@ -601,10 +611,14 @@ __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) 
 struct MzrDevPair { MzrDev a, b; };
 template <int METHOD, bool FULL, bool BLK>
 __global__ void __launch_bounds__(stage_wg(METHOD)) MZR_STAGE_OCC(METHOD, FULL) k_stage_pair(MzrDevPair p, int sA, int rBeginA, int rEndA, int sB, int rBeginB, int rEndB, int nBlocksB) {
-  const bool old = (int)blockIdx.x >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
+  // blocks: [heavy positions, new window | heavy positions, old window | new window | old window]
+  const int nHB = p.b.lanePerm ? p.b.nHeavyPos / (int)blockDim.x : 0;
+  const int bx = (int)blockIdx.x;
+  const bool old = bx < 2 * nHB ? bx >= nHB : bx - 2 * nHB >= nBlocksB;      // wave-uniform: the domain description is read through scalar loads either way
   const MzrDev &d = old ? p.a : p.b;
   const int rB = old ? rBeginA : rBeginB, rE = old ? rEndA : rEndB;
-  const int r = stage_lane_reach(d, stage_lane_pos((int)blockIdx.x - (old ? nBlocksB : 0), rB & ~255), rB, rE);
+  const int r = bx < 2 * nHB ? stage_lane_reach_at(d, bx - (old ? nHB : 0), nHB, 0, rB, rE)
+                             : stage_lane_reach(d, stage_lane_pos(bx - 2 * nHB - (old ? nBlocksB : 0), rB & ~255), rB, rE);
   if (r < 0) return;
   if (BLK) { stage_reach_block<METHOD, FULL>(d, r, (old ? sA : sB) - d.sigma[r]); return; }
   const int t = (old ? sA : sB) - d.sigma[r];
@@ -836,7 +850,8 @@ void mzr_launch_stage_pair(int method, const MzrDev &a, int sA, int rBeginA, int
   // (with a lane permutation the reaches of a 256-position block may sit anywhere in it: the covered range ends on a block boundary)
   auto blocks = [wg](const MzrDev &v, int rB, int rE) { const int e = v.lanePerm ? ((rE + 255) & ~255) : rE; return rE > rB ? (e - (rB & ~255) + wg - 1) / wg : 0; };
   const int nBlocksB = blocks(b, rBeginB, rEndB);
-  dim3 block(wg), grid(nBlocksB + blocks(a, rBeginA, rEndA));
+  const int nHB = b.lanePerm ? b.nHeavyPos / wg : 0;      // (the host keeps the two windows' heavy positions the same: mc_regroup)
+  dim3 block(wg), grid(2 * nHB + nBlocksB + blocks(a, rBeginA, rEndA));
   const bool full = (a.lakeSlot || a.is_flux_wm || a.qmod || a.trVol0) || (b.lakeSlot || b.is_flux_wm || b.qmod || b.trVol0);
   const bool blk = a.stepBlock > 1 || b.stepBlock > 1;
 #define MZR_PAIR(M) case M: \
@@ -856,7 +871,7 @@ void mzr_launch_stage(int method, const MzrDev &d, int s, int rBegin, int rEnd, 
   if (n <= 0) return;
   const int wg = stage_wg(method);
   const int rCover = d.lanePerm ? ((rEnd + 255) & ~255) : rEnd;      // a lane permutation moves reaches anywhere inside their 256-position block
-  dim3 block(wg), grid((rCover - (rBegin & ~255) + wg - 1) / wg);
+  dim3 block(wg), grid((d.lanePerm ? d.nHeavyPos / wg : 0) + (rCover - (rBegin & ~255) + wg - 1) / wg);
   const bool full = (d.lakeSlot || d.is_flux_wm || d.qmod || d.trVol0);
   const bool blk = d.stepBlock > 1;
 #define MZR_STAGE(M) case M: \

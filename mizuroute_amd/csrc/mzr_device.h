@@ -139,7 +139,12 @@ struct MzrDev {
   // 256 are therefore dealt to the block's four wavefronts by that count (lanePerm: position -> reach, a permutation inside
   // each block, so every reach is still served exactly once and the block still touches the same 256-reach span of every array)
   unsigned short *mcSub;      // [N] Muskingum-Cunge sub-steps the reach executed in its last step (written by the kernel, read by the host now and then)
-  const int *lanePerm;        // [ceil(N / 256) * 256] or null: reach served by a lane position (-1 = none)
+  const int *lanePerm;        // [ceil(N / 256) * 256 + nHeavyPos] or null: reach served by a lane position (-1 = none)
+  // ... and the few reaches that take many times the usual trip count (Muskingum-Cunge: 4 to 200 sub-steps where the others take 2)
+  // are taken out of their blocks altogether: they fill lane positions of their own behind the others (permN ..), heaviest first, and
+  // the blocks over those positions are the FIRST of every launch -- the longest wavefronts of a launch start first and hold no
+  // short ones hostage; their own positions hold -1
+  int permN, nHeavyPos;       // first heavy lane position (= ceil(N / 256) * 256), number of heavy positions (a multiple of 256; 0 = none)
   // ---- KWT
   int    *kwN;                // [N] at-rest particle count (0 = not yet initialised)
   double *kwQT, *kwTR;        // [N][MZR_KW_STRIDE][2] {Q, TI} pairs; [N][MZR_KW_STRIDE] expected exit times (state only: written at the last step of a window)

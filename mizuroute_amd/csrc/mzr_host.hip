@@ -73,6 +73,7 @@ struct RouteBufs {
   DBuf<double> hInflow, hEle, hFlood;               // [N] history sums beyond discharge (mzr_set_history)
   DBuf<double> mol;                                 // [nMol][N]
   DBuf<unsigned short> mcSub; long long mcWindows = 0;   // Muskingum-Cunge: sub-steps per reach as the kernel leaves them
+  int permN = 0, nHeavyPos = 0;      // heavy lane positions behind the block-wise ones (mzr_device.h)
   DBuf<int> lanePerm; bool havePerm = false;           // reaches of every aligned block of 256 dealt to its wavefronts by loop trip count (mzr_device.h)
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
@@ -421,7 +422,7 @@ void setRoute(mzr_handle h, MzrDev &d, int ix) {
   d.floodvol = rb.floodvol.p; d.wb = rb.wb.p; d.qsum = rb.qsum.p; d.mol = rb.mol.p; d.imQ = rb.imQ.p; d.wmact = rb.wmact.p;
   d.lakeMut = rb.lakeMut.p; d.lakeRing = rb.lakeRing.p; d.lakeHead = rb.lakeHead.p; d.lakeRingD = rb.lakeRingD.p; d.lakeHeadD = rb.lakeHeadD.p;
   d.rtDone = rb.rtDone.p; d.rtHead = rb.rtHead.p;
-  d.mcSub = rb.mcSub.p; d.lanePerm = rb.havePerm ? rb.lanePerm.p : nullptr;
+  d.mcSub = rb.mcSub.p; d.lanePerm = rb.havePerm ? rb.lanePerm.p : nullptr; d.permN = rb.permN; d.nHeavyPos = rb.havePerm ? rb.nHeavyPos : 0;
   d.qobs = rb.qobs.p; d.qerr = rb.qerr.p; d.qelapsed = rb.qelapsed.p;
   d.solFlux = rb.solFlux.p; d.solMass = rb.solMass.p; d.trVol0 = h->tracer ? rb.trVol0.p : nullptr;
 }
@@ -787,7 +788,7 @@ static int stageRow(mzr_handle h, int kind, const double *a, size_t na, const do
   r.staged = true; h->srAny = true;
   return 0;
 }
-static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key);
+static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key, int heavyMin = 0);
 // steps handed over with mzr_step that have not been routed yet (mzr_config.stepBatch > 1) go first ...
 #ifndef MZR_STEP_BLOCK_DEFAULT
 #define MZR_STEP_BLOCK_DEFAULT 8
@@ -1555,25 +1556,41 @@ int mzr_init_state(mzr_handle h) {
 // ones step after step), the IRF convolution 1 to maxtdh taps (irf_route.f90:210-264).  The reaches of every aligned block of 256
 // lane positions are dealt to the block's four wavefronts by that count, largest first (lanePerm): slow lanes sit with slow
 // lanes.  A permutation inside each block: every reach is served exactly once, by whichever lane -- results cannot change.
-static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key) {
+// heavyMin > 0: the reaches with a count of heavyMin and more (at most an eighth of all) are taken out of their blocks and fill lane
+// positions of their own behind the others, heaviest first (mzr_device.h nHeavyPos; Muskingum-Cunge, MZR_MC_HEAVY_MIN)
+static void build_lane_perm(mzr_handle h, int ix, const std::vector<int> &key, int heavyMin) {
   RouteBufs &rb = h->route[ix];
-  const int N = h->N, Np = (N + 255) & ~255;
-  std::vector<int> perm(Np, -1);
+  const int N = h->N, Np = (N + 255) & ~255, heavyCap = (((N / 8) + 255) & ~255);
+  std::vector<int> perm(Np + heavyCap, -1);
   std::vector<std::pair<int, int>> blk;
   bool any = false;
+  std::vector<char> isHeavy(N, 0);
+  int nHeavy = 0;
+  try { if (!rb.lanePerm.p) rb.lanePerm.alloc(Np + heavyCap); } catch (const std::string &) { rb.havePerm = false; rb.nHeavyPos = 0; (void)hipGetLastError(); return; }      // allocated once: a window kept back may still point at it
+  if (heavyMin > 0) {
+    std::vector<std::pair<int, int>> hv;
+    for (int r = 0; r < N; ++r) if (key[r] >= heavyMin) hv.emplace_back(-key[r], r);
+    std::stable_sort(hv.begin(), hv.end());
+    if ((int)hv.size() > heavyCap) hv.resize(heavyCap);
+    for (size_t k = 0; k < hv.size(); ++k) { perm[Np + k] = hv[k].second; isHeavy[hv[k].second] = 1; }
+    nHeavy = (int)hv.size();
+    if (nHeavy > 0) any = true;
+  }
   for (int b0 = 0; b0 < N; b0 += 256) {
     blk.clear();
-    for (int r = b0; r < std::min(N, b0 + 256); ++r) blk.emplace_back(-key[r], r);
+    for (int r = b0; r < std::min(N, b0 + 256); ++r) if (!isHeavy[r]) blk.emplace_back(-key[r], r);
+    if (blk.empty()) continue;
     std::stable_sort(blk.begin(), blk.end());
     if (blk.front().first != blk.back().first) any = true;
     for (size_t k = 0; k < blk.size(); ++k) perm[b0 + k] = blk[k].second;
   }
   if (const char *e = getenv("MZR_LANE_PERM")) if (atoi(e) == 0) any = false;
   try {
-    if (!rb.lanePerm.p) rb.lanePerm.alloc(Np);      // allocated once: a window kept back may still point at it
-    if (any) (void)hipMemcpy(rb.lanePerm.p, perm.data(), (size_t)Np * sizeof(int), hipMemcpyHostToDevice);
-    rb.havePerm = any;
-  } catch (const std::string &) { rb.havePerm = false; }
+    if (any) (void)hipMemcpy(rb.lanePerm.p, perm.data(), (size_t)(Np + heavyCap) * sizeof(int), hipMemcpyHostToDevice);
+    rb.havePerm = any; rb.permN = Np; rb.nHeavyPos = any ? ((nHeavy + 255) & ~255) : 0;
+  } catch (const std::string &) { rb.havePerm = false; rb.nHeavyPos = 0; }
+  // a window whose last launches are kept back (overlapping windows) goes out with the new positions
+  if (h->tail.pending) { h->tail.d[ix].lanePerm = rb.havePerm ? rb.lanePerm.p : nullptr; h->tail.d[ix].permN = rb.permN; h->tail.d[ix].nHeavyPos = rb.havePerm ? rb.nHeavyPos : 0; }
 }
 
 static void mc_regroup(mzr_handle h, int ix) {
@@ -1585,7 +1602,11 @@ static void mc_regroup(mzr_handle h, int ix) {
   std::vector<unsigned short> sub(N);
   if (hipMemcpy(sub.data(), rb.mcSub.p, (size_t)N * sizeof(unsigned short), hipMemcpyDeviceToHost) != hipSuccess) return;
   std::vector<int> key(sub.begin(), sub.end());
-  build_lane_perm(h, ix, key);
+  // (c4 shard, 625 k reaches IRF + MC, reach-steps/s by threshold: none 7.37, 4: 7.25, 6: 7.55, 10: 7.78-7.85, 16: 7.56, 24: 7.36 x 10^9;
+  // profiles/r05_experiments.md)
+  int heavyMin = 10;
+  if (const char *e = getenv("MZR_MC_HEAVY_MIN")) heavyMin = atoi(e);
+  build_lane_perm(h, ix, key, heavyMin);
 }
 
 static void kwt_regroup(mzr_handle h) {

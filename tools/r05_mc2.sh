@@ -1,0 +1,9 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+B="python bench.py --no-cpu-baseline --no-h2d --no-single-step --no-configs --config c4"
+for hm in 10 16 24 40; do
+  echo "=== MZR_MC_HEAVY_MIN=$hm"; MZR_MC_HEAVY_MIN=$hm $B --steps 5 --warmup 3 2>&1 | tail -1 | python -c "
+import sys, json
+j = json.loads(sys.stdin.read()); r = j.get('roofline') or {}
+print('value %.4g ms/step %.1f frac %s launch_us %s err %s' % (j['value'] or 0, j['ms_per_step'] or 0, r.get('frac'), r.get('avg_launch_us'), j.get('error')))"
+done
