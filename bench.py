@@ -187,6 +187,26 @@ def cpu_mpi_like(domains, frac, runoff_of, methods, uh_of=None, lakes_of=None, t
                       "mainstem domain and the per-step gather / scatter of mpi_route left out"}
 
 
+def cpu_mpi_like_cores(net, frac, runoff_of, methods, uh_of=None, lakes_of=None, spin=48, smp=48):
+    """The strongest form of the reference this host can run (its OpenMP scales badly: 16 threads are its best, 64 run three times
+    slower): P single-thread processes over the reference's own P-way decomposition, P = the host's physical cores (half the logical
+    ones), every rank's tributary domains in one ref_route process, all side by side.  The mainstem domain and the per-step gather /
+    scatter of mpi_route (mpi_process.f90:1245-1329) are left out, which flatters the CPU."""
+    from mizuroute_amd.partition import partition_network
+    cores = os.cpu_count() or 16
+    P = max(8, min(128, cores // 2))
+    t0 = time.perf_counter()
+    Pc = partition_network(net, P)
+    t_part = time.perf_counter() - t0
+    r = cpu_mpi_like(Pc.trib, frac, lambda dm: runoff_of(dm, spin + smp), methods, uh_of=uh_of, lakes_of=lakes_of, threads=1, spin=spin, smp=smp, also_one_thread=False)
+    if r is not None:
+        r["ranks"] = P
+        r["partition_s"] = t_part
+        r["sample"] = (f"the reference's {P}-way decomposition (domain_decomposition.f90:41-163), one single-thread ref_route process per rank (P = physical cores of "
+                       f"this host: {cores} logical / 2), side by side, {smp} steps timed after {spin}; mainstem domain and per-step gather / scatter left out")
+    return r
+
+
 FULL = {"c3": 3_000_000, "c4": 5_000_000, "c5": 3_000_000}      # reaches of the 8-GPU configurations (BASELINE.json configs[2..4])
 
 
@@ -479,6 +499,23 @@ class Loopback:
                                                also_one_thread=n_smp >= 32)
             except Exception as e:
                 cpu["mpi_like"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
+            try:      # one single-thread rank per physical core over the P-way decomposition of the FULL network, 48 + 48 steps
+                n2 = 96
+                ro2 = ro_cpu if ro_cpu.shape[0] >= n2 else device_runoff(self.torch, net.H, n2, 0, 7, self.dev).cpu().numpy()
+
+                def lk2(dm):
+                    if self.lakes is None:
+                        return None
+                    l2 = lakes_for_domain(self.lakes, dm, net.N)
+                    if l2 is None:
+                        return None
+                    return dict(l2, evap=np.zeros((n2, max(1, dm.hru_global.size))), precip=np.zeros((n2, max(1, dm.hru_global.size))), ymd=self.lakes["ymd"][:n2])
+
+                cpu["mpi_like_cores"] = cpu_mpi_like_cores(net, self.frac, lambda dm, n: ro2[:n, dm.hru_global], methods, uh_of=uh_pair,
+                                                           lakes_of=lk2 if self.lakes is not None else None)
+                del ro2
+            except Exception as e:
+                cpu["mpi_like_cores"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
         except Exception as e:
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
         return cpu
@@ -994,6 +1031,10 @@ def main():
                     cpu["mpi_like"] = cpu_mpi_like(P8.trib, frac, lambda dm: ro_cpu[:96, dm.hru_global], methods, threads=thr, spin=48, smp=48)
                 except Exception as e:
                     cpu["mpi_like"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
+                try:      # ... and at the reference's natural rank count on this host: one single-thread rank per physical core over the P-way decomposition
+                    cpu["mpi_like_cores"] = cpu_mpi_like_cores(net, frac, lambda dm, n: ro_cpu[:n, dm.hru_global], methods)
+                except Exception as e:
+                    cpu["mpi_like_cores"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
         except Exception as e:   # the baseline is reported, never required
             cpu = {"value": None, "unit": "reaches*timesteps/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
 
