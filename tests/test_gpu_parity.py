@@ -941,11 +941,12 @@ def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib, ranks):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     total = 6000 if ranks == 2 else 12000
-    common = ["--config", "c2", "--reaches", str(total // ranks), "--window", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+    # (no --config: N > 1 takes c3, the north-star network family, as the driver's run does; the reaches per rank are cut down for the test)
+    common = ["--reaches", str(total // ranks), "--window", "48", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
               "--no-h2d", "--no-single-step", "--no-configs"]
     env = dict(os.environ, MZR_BENCH_SINGLE_DEVICE="1", MZR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = str(tmp_path / "one")
-    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "c2", "--reaches", str(total)] + common[4:] + ["--dump", one],
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--config", "c3", "--reaches", str(total)] + common[2:] + ["--dump", one],
                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     with socket.socket() as s:
@@ -959,6 +960,7 @@ def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib, ranks):
     import json
     j = json.loads(line)
     assert j["n_gpus"] == ranks and j["config"]["reaches_total"] == total and j["value"] > 0
+    assert j["config"]["baseline_config"] == "c3" and "sub-basin partitions" in j["config"]["workload"]
     a = np.load(one + ".rank0.npz")
     parts = [np.load(f"{two}.rank{r}.npz") for r in range(ranks)]
     reach = np.concatenate([p["reach"] for p in parts]); q = np.concatenate([p["q"] for p in parts]); nw = np.concatenate([p["nw"] for p in parts])
