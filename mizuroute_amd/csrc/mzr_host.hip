@@ -293,7 +293,7 @@ struct mzr_domain {
   std::vector<int> h_sigma, h_swCode, h_swP, h_swRA;   // host copies for the stall report of a sweep that gave up (code 93)
   std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
   int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1, swTablesK = 0;
-  int swKblk = MZR_KWT_KBLK, swCapK[2] = {0, 0};      // steps per visit of the sweep flavour in use; wavefront capacity of the one-step / the blocked flavour
+  int swKblk = 1, swCapK[2] = {0, 0};      // steps per visit of the sweep flavour in use; wavefront capacity of the one-step / the blocked flavour
   long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff, kwtCOff;   // [nStages+1] stage offsets in h_kwtRouted / in the class-B and class-C lists (kwtRoutedOff: class A)

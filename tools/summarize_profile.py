@@ -79,7 +79,15 @@ for size, sfx, cmd in (("100k", "", "--window 16384 --steps 1 --warmup 1"), ("40
     pm = json.load(open(os.path.join(src, f"{tag}_{size}_pmc.json")))
     pm = {kname(k): v for k, v in pm.items()}
     pm_all[size] = {k: v for k, v in pm.items() if k.startswith("k_")}
-    stats = {kname(r["Name"]): r for r in csv.DictReader(open(os.path.join(sdir, "k_kernel_stats.csv")))}
+    stats = {}
+    for r in csv.DictReader(open(os.path.join(sdir, "k_kernel_stats.csv"))):      # instantiations of one kernel template are one row
+        k = kname(r["Name"])
+        if k in stats:
+            a = stats[k]
+            a["Calls"] = str(int(a["Calls"]) + int(r["Calls"])); a["TotalDurationNs"] = str(float(a["TotalDurationNs"]) + float(r["TotalDurationNs"]))
+            a["AverageNs"] = str(float(a["TotalDurationNs"]) / int(a["Calls"]))
+        else:
+            stats[k] = dict(r)
     lines += [f"## {size} reaches (`bench.py --no-cpu-baseline --no-roofline --no-h2d --no-single-step {cmd}`)", "",
               "| kernel | calls | avg us | total ms | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (calibrated) |", "|---|---|---|---|---|---|---|"]
     extra = ""
