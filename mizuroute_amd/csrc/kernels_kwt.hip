@@ -686,6 +686,9 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 5
 #endif
+#ifndef MZR_KWT_SPLIT
+#define MZR_KWT_SPLIT 0      // 1: the split 16-lane pass of round 4 (kwt_reach, SPLIT)
+#endif
 #ifndef MZR_KWT_POOL
 #define MZR_KWT_POOL 240   // entries of each of the four LDS work arrays of a wavefront: 60 per 16-lane reach, 30 per 8-lane reach
 #endif
@@ -821,11 +824,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   // (interp_rch, the stores its downstream reach waits for: kwDone) after that.  Merge, time-step average and outbox stores
   // leave the chain; the arithmetic and its order are untouched.  (One step per visit only: a visit of several steps waits for
   // the reach's own previous step once per block.)
-#ifdef MZR_NO_SPLIT
-  constexpr bool SPLIT = false;
-#else
-  constexpr bool SPLIT = PERS && !GEN && G == 16 && !BLK;
-#endif
+  // (round 5: off by default -- measured +-0 at c2, where it was built for, and -1.8 % on the c3 shard: 357.9 -> 351.6 ms per window;
+  // -DMZR_KWT_SPLIT=1 compiles it in.  It needs the full 60 entries per 16-lane reach: the merge writes behind a full own list.)
+  constexpr bool SPLIT = MZR_KWT_SPLIT && PERS && !GEN && G == 16 && !BLK;
   const int t = uni<G>((have && tb >= 0) ? tBase + kb : -1);
   const bool live = t >= 0 && t < d.W && !(BLK && (ovf || failed || kb >= KBLK));      // (groups of one wavefront may start at different steps of their blocks: kFirst)
   const bool firstOfVisit = !BLK || kb == kFirst;
@@ -1785,7 +1786,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
             const mzr_word keep = wSelf & MZR_KWD_ALLOUT & ~MZR_KWD_OUTMASK(pq);      // the other slots' counts stay (0 in the first step)
             const int nOut = isOut ? 0 : NR + 2;
             const mzr_word wNew = (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)) | ((mzr_word)(unsigned)nOut << (21 + 5 * pq)) | keep;
-            if (!SPLIT && !BLK) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));      // (a visit of several steps waits on kwDone alone)
+            if (MZR_KWT_SPLIT && !SPLIT && !BLK) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));      // (read by the split 16-lane pass only; a visit of several steps waits on kwDone alone)
             stx<true>(d.kwDone + r, wNew);
             if (BLK) wSelf = wNew;      // lane 0 of the group: the only one that reads it again
           }
