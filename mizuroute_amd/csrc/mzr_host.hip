@@ -58,6 +58,14 @@ template <typename T> struct DBuf {
     n = cnt;
     if (cnt) { if (hipMalloc((void **)&p, cnt * sizeof(T)) != hipSuccess) { p = nullptr; n = 0; throw std::string("hipMalloc failed"); } }
   }
+  // device memory that is not kept in the caches on its way in (experiment, MZR_H2D_UNCACHED=1: the staging buffers of host forcing)
+  void allocStaging(size_t cnt) {
+    static const bool unc = getenv("MZR_H2D_UNCACHED") && atoi(getenv("MZR_H2D_UNCACHED")) != 0;
+    if (!unc) { alloc(cnt); return; }
+    free();
+    n = cnt;
+    if (cnt) { if (hipExtMallocWithFlags((void **)&p, cnt * sizeof(T), hipDeviceMallocUncached) != hipSuccess) { p = nullptr; n = 0; throw std::string("hipExtMallocWithFlags failed"); } }
+  }
   void zero(hipStream_t s = 0) { if (p) (void)hipMemsetAsync(p, 0, n * sizeof(T), s); }
   void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); }
   void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
@@ -352,7 +360,7 @@ int fail(mzr_handle h, int code, const std::string &m) { h->msg = m; return code
 // mzr_run_src_dev, mzr_step) and the row-reordering scratch of the host getters / setters.  false = out of memory.
 bool ensureRunoffW(mzr_handle h) {
   if (h->runoffW.p) return true;
-  try { h->runoffW.alloc((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &) { (void)hipGetLastError(); return false; }
+  try { h->runoffW.allocStaging((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &) { (void)hipGetLastError(); return false; }
   return true;
 }
 bool ensureScratch(mzr_handle h) {
@@ -2179,7 +2187,7 @@ static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_si
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_run/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
   try {
-    if (!h->runoffW2.p) h->runoffW2.alloc((size_t)h->cfg.maxWindow * h->H);
+    if (!h->runoffW2.p) h->runoffW2.allocStaging((size_t)h->cfg.maxWindow * h->H);
   } catch (const std::string &e) { return fail(h, 91, "mzr_run_async/" + e); }
   if (!h->copyStream) {
     if (hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) != hipSuccess) return fail(h, 90, "mzr_run_async/hipStreamCreate failed");
@@ -2192,7 +2200,7 @@ static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_si
   if (k == 0 && h->rwOtherSet) { (void)hipStreamWaitEvent(h->copyStream, h->rwOther, 0); h->rwOtherSet = false; }   // ... also one queued by mzr_run_src_dev
   if (runoff32) {      // single-precision forcing: half the bytes across PCIe, widened behind the copy on the copy's stream
     const size_t n = (size_t)nSteps * h->H;
-    try { if (h->runoffF[k].n < (size_t)h->cfg.maxWindow * h->H) h->runoffF[k].alloc((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &e) { return fail(h, 91, "mzr_run_async_f32/" + e); }
+    try { if (h->runoffF[k].n < (size_t)h->cfg.maxWindow * h->H) h->runoffF[k].allocStaging((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &e) { return fail(h, 91, "mzr_run_async_f32/" + e); }
     if (hipMemcpyAsync(h->runoffF[k].p, runoff32, n * sizeof(float), hipMemcpyHostToDevice, h->copyStream) != hipSuccess)
       return fail(h, 92, "mzr_run_async_f32/hipMemcpyAsync failed");
     hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65536)), dim3(256), 0, h->copyStream, h->runoffF[k].p, buf, n);

@@ -441,3 +441,26 @@ def test_queue_of_windows_is_taken_back_to_the_one_that_failed(hip_lib, monkeypa
     assert ra == 1 and rb == 0, (ra, rb)
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
     assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb) and np.array_equal(Ba, Bb)
+
+
+@pytest.mark.parametrize("kblk", ["1", "4"])
+def test_c2_full_size_against_the_oracle(kblk, hip_lib, oracle_lib, monkeypatch):
+    """BASELINE.json configs[1] at its FULL size -- the bench's own 100 000-reach network -- against the C oracle (which is pinned to the
+    reference): 60 steps in windows of 16 (three regroupings: all three lane classes and the fall-backs between them), storms strong enough
+    to fill the particle lists and thin them, both flavours of the persistent sweep (one step / four steps per visit).  Discharge of every
+    reach and step within 1e-6 relative, particle counts equal."""
+    monkeypatch.setenv("MZR_KWT_KBLK_RUN", kblk)
+    net = m.make_network(100_000, seed=20240529)
+    frac, _, _ = _uh(net)
+    steps = 60
+    ro = m.make_runoff(net.H, steps, seed=12, storm_prob=0.02, storm_amp=2e-6)
+    dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=16)
+    Qg = dom.run(ro)
+    orc = oracle_lib.Oracle(net, DT, [m.KWT], frac, np.arange(net.N + 1, dtype=np.int32), np.ones(net.N))
+    Qo = orc.run(ro)
+    rep = parity_report(Qo[:, 0], Qg[:, 0])
+    print("c2 full size, steps per visit", kblk, rep)
+    assert rep["max_rel"] <= REL_TOL, rep
+    assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
+    assert dom.kwt_state()[0].max() >= 19      # lists full: thinning took place
+    dom.close()
