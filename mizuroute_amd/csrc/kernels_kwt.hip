@@ -1997,15 +1997,30 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
     const int q = (q0 + dq) & 7;
     const int pEnd = P[sEnd * 8 + q];
     int sCur = sBegin, pLo = P[sBegin * 8 + q], pHi = P[(sBegin + 1) * 8 + q];   // tickets [pLo, pHi) of queue q belong to launch sCur
+    // Round 5 experiment (-DMZR_KWT_TICKET_AHEAD=1, off): a wavefront draws its NEXT ticket before it works on the one it has, so that
+    // the atomic's round trip (1.5-2 k cycles of a pass of ~37 k) runs beside the pass.  Measured 2 % SLOWER (c2 440.6 -> 449.0 ms, c3
+    // shard 349.5 -> 357.7 ms): an item drawn by a wavefront that is still inside a long pass starts late, and its dependents wait
+    // (profiles/r05_experiments.md 8)
+#ifndef MZR_KWT_TICKET_AHEAD
+#define MZR_KWT_TICKET_AHEAD 0
+#endif
+    int kAhead = 0;
+    if (MZR_KWT_TICKET_AHEAD && mzr_lane() == 0) kAhead = atomicAdd(d0.swHead + q * 16, 1);
 #pragma unroll 1
     for (;;) {
       MzrDevK dk = dk0;
       asm volatile("" : "+s"(dk));
       const MzrDev &d = *(const MzrDev *)dk;
       int k = 0;
-      if (mzr_lane() == 0) k = atomicAdd(d.swHead + q * 16, 1);
-      k = __builtin_amdgcn_readfirstlane(k);
-      if (k >= pEnd) break;
+      if (MZR_KWT_TICKET_AHEAD) {
+        k = __builtin_amdgcn_readfirstlane(kAhead);
+        if (k >= pEnd) break;
+        if (mzr_lane() == 0) kAhead = atomicAdd(d.swHead + q * 16, 1);      // (a ticket beyond the queue's end is nobody's)
+      } else {
+        if (mzr_lane() == 0) k = atomicAdd(d.swHead + q * 16, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= pEnd) break;
+      }
       if (k >= pHi) {   // the next launch, or (after a pause, or in a queue taken over from another XCD) a later one
         ++sCur; pLo = pHi; pHi = P[(sCur + 1) * 8 + q];
         if (k >= pHi) {
@@ -2030,6 +2045,9 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
           mzr_raise_stall(d, 30 + bad, -1, s, i, cv[bad], fv[bad], q, k, 0, 0, d.swHead);
         }
       }
+#ifdef MZR_DBG_SLEEP      // experiment: idle cycles per pass (x 64 clocks) -- does the sweep's throughput follow a wavefront's latency or its instructions?
+      for (int _k = 0; _k < MZR_DBG_SLEEP; ++_k) __builtin_amdgcn_s_sleep(127);
+#endif
       const int lane = mzr_lane(), g16 = lane / GA;
       const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
       const int cls = it >> 28, bi = it & 0x0fffffff;      // 0 A, 1 B, 2 generic, 3 lake / halo, 4 C
