@@ -1992,6 +1992,8 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   kwt_beat(d0, 5, q0); kwt_beat(d0, 3, 1); kwt_beat(d0, 4, 0);
   int nDone = 0;
   IntK P = (IntK)d0.swP, RAs = (IntK)d0.swRA;
+  // (the item tables too: uniform indices into memory nobody writes during the launch -- scalar loads, not a vector-memory round trip per ticket)
+  IntK ILo = (IntK)d0.swLo, IHi = (IntK)d0.swHi, IIt = (IntK)d0.swItem;
 #pragma unroll 1
   for (int dq = 0; dq < 8; ++dq) {
     const int q = (q0 + dq) & 7;
@@ -2032,7 +2034,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       const int s = sCur;
       const int a = RAs[s];
       const int i = a + ((q - a) & 7) + 8 * (k - pLo);
-      if (s < d.swLo[i] || s > d.swHi[i] + Wm1) continue;        // none of the item's reaches has a step in this launch
+      if (s < ILo[i] || s > IHi[i] + Wm1) continue;        // none of the item's reaches has a step in this launch
       if (MZR_BEAT_ON(d)) {
         kwt_beat(d, 0, s); kwt_beat(d, 1, i); kwt_beat(d, 2, q); kwt_beat(d, 6, k); kwt_beat(d, 3, 1); kwt_beat(d, 4, ++nDone);
         // debugging aid: the schedule tables as the scalar cache holds them against what memory holds (sc1 vector loads)
@@ -2049,7 +2051,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
       for (int _k = 0; _k < MZR_DBG_SLEEP; ++_k) __builtin_amdgcn_s_sleep(127);
 #endif
       const int lane = mzr_lane(), g16 = lane / GA;
-      const int it = __builtin_amdgcn_readfirstlane(d.swItem[i]);
+      const int it = IIt[i];
       const int cls = it >> 28, bi = it & 0x0fffffff;      // 0 A, 1 B, 2 generic, 3 lake / halo, 4 C
       if (cls == 3) {
         if (kwt_item_light<FULL, KBLK>(d, s, bi)) return;
