@@ -684,7 +684,7 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #define MZR_KWT_KB 3   // particle slots per lane of the 8-lane class
 #endif
 #ifndef MZR_KWT_OCC
-#define MZR_KWT_OCC 5
+#define MZR_KWT_OCC 4      // wavefronts per SIMD the kernels are compiled for: 16 one-wavefront workgroups per CU is what the device holds (round 5: 5 -> 4, c3 shard 346.2 -> 342.8 ms)
 #endif
 #ifndef MZR_KWT_SPLIT
 #define MZR_KWT_SPLIT 0      // 1: the split 16-lane pass of round 4 (kwt_reach, SPLIT)
