@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # of that method for U immediate upstream reaches (KWT: from the particle counters instead).
 CONFIGS = {
     "c2": dict(reaches=100_000, methods="2", window=16384, workload="synthetic HDMA-CONUS-like sub-basin, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
-    "c3": dict(reaches=375_000, methods="2", window=4096, workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
+    "c3": dict(reaches=375_000, methods="2", window=8192, workload="one of 8 shards of a ~3 M-reach HDMA-CONUS-like network, KWT (route_opt 2), dt 3600 s, hillslope UH on"),
     "c4": dict(reaches=625_000, methods="14", window=3072, dominant=4, bytes=lambda U: 152 + 12 * U,
                workload="one of 8 shards of a ~5 M-reach MERIT-like network, IRF-UH + Muskingum-Cunge (route_opt 14), dt 3600 s, hillslope UH on"),
     "c5": dict(reaches=375_000, methods="5", window=2048, dominant=5, bytes=lambda U: 440 + 12 * U, lakes=0.01, floodplain=True,
@@ -568,7 +568,7 @@ def main():
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="BASELINE.json configuration.  --gpus 1: c2 (default, the metric's headline: 100 k reaches KWT) or the per-GPU shard of c3 / c4 / c5.  "
                          "--gpus N > 1: c3 (default: ONE network of N x 375 k reaches -- the ~3 M-reach north-star network at N = 8 -- cut into N sub-basin "
-                         "partitions by the reference's decomposition, windows of 4096) or c2 (N x 100 k reaches, windows of 16 384)")
+                         "partitions by the reference's decomposition, windows of 8192) or c2 (N x 100 k reaches, windows of 16 384)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default="", help="write <DUMP>.rank<r>.npz with the per-reach interval mean of REACH_Q and the particle "
                     "counts of the reaches this rank routes (tests: a partitioned run must equal the one-rank run); forcing is then "
