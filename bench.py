@@ -543,7 +543,7 @@ def loopback_bench(args, torch, m, uhmod):
     same = rep["partitioned_equals_whole_bit_for_bit"]
     out["config"]["whole_network"] = whole_info
     out["parity"] = rep
-    W, K = args.window or cfg["window"], max(2, args.steps)
+    W, K = args.window or min(cfg["window"], 4096), max(2, args.steps)      # (all partitions and their records on ONE GPU)
     tm = lb.timing(W, K)
     out.update({"value": tm["value"], "steps": K, "warmup": 1, "ms_per_step": tm["one_gpu_s"] * 1e3, "scaling": "strong",
                 "vs_baseline": None, "error": None if same else "partitioned run differs from the whole network"})
@@ -1061,7 +1061,7 @@ def main():
             try:
                 lb = Loopback(torch, m, uhmod, cname, 8)
                 rep, whole_info, _ = lb.parity(128, 1)
-                Wc = min(CONFIGS[cname]["window"], 2048 if cname == "c4" else 1 << 30)      # (c4: two domains of 625 k reaches side by side on one GPU)
+                Wc = min(CONFIGS[cname]["window"], 2048 if cname == "c4" else 4096)      # (c4: two domains of 625 k reaches side by side on one GPU; c3: the records of all eight partitions stay on this one GPU)
                 tmc = lb.timing(Wc, 5)
                 roofc = lb.roofline(Wc)
                 cpuc = None if args.no_cpu_baseline else lb.cpu(args.cpu_spinup_configs, args.cpu_sample_configs)
