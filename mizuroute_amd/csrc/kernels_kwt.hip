@@ -683,6 +683,9 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_KB
 #define MZR_KWT_KB 3   // particle slots per lane of the 8-lane class
 #endif
+#ifndef MZR_KWT_KC
+#define MZR_KWT_KC 3   // particle slots per lane of the 4-lane class
+#endif
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 4      // wavefronts per SIMD the kernels are compiled for: 16 one-wavefront workgroups per CU is what the device holds (round 5: 5 -> 4, c3 shard 346.2 -> 342.8 ms)
 #endif
@@ -1831,7 +1834,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
 struct KwtCls {
   static constexpr int GA = 16, RA = 4, KA = (MZR_KW_CAP + GA - 1) / GA, OA = (MZR_OB_CAP + GA - 1) / GA;
   static constexpr int GB = 8, RB = 8, KB = MZR_KWT_KB;
-  static constexpr int GC = 4, RC = 16, KC = 3;
+  static constexpr int GC = 4, RC = 16, KC = MZR_KWT_KC;
 };
 // class-B / class-C reaches of one item that overflowed (bit g = group g of the narrow pass): the k-th of them for wide group g16
 __device__ __forceinline__ int kwt_pick(unsigned &ovfMask, int g16) {

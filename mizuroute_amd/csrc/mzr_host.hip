@@ -1675,6 +1675,13 @@ static void kwt_regroup(mzr_handle h) {
     (void)hipMemcpy(devAll[c]->p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
   }
   h->kwtAllValid = true;
+  if (getenv("MZR_KWT_CLASS_LOG")) {      // debugging aid: how the routed reaches spread over the work-array need and the lane classes
+    int hist[64] = {0};
+    for (const auto &rc : v) hist[std::min(63, std::max(0, need(rc)))]++;
+    fprintf(stderr, "[mzr] kwt classes: A %zu B %zu C %zu reaches (cuts %d / %d); need histogram:", L[0].size(), L[1].size(), L[2].size(), classBMax, classCMax);
+    for (int i = 0; i < 64; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+    fprintf(stderr, "\n");
+  }
   h->h_swA = L[0]; h->h_swB = L[1]; h->h_swC = L[2];
   // MZR_KWT_HEAVY_FIRST=1: the sweep draws its items heaviest first regardless of stage (the class lists in order of weight: the
   // *All arrays) -- the longest passes of a launch of the schedule start first
