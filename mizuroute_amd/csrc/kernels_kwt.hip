@@ -686,6 +686,18 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_KC
 #define MZR_KWT_KC 3   // particle slots per lane of the 4-lane class
 #endif
+// The sweep exists a second time with MZR_KWT_KC_WIDE slots per lane of the 4-lane class (15 entries: all of the group's slice of the
+// pool), for domains whose sweep is bound by instructions alone: reaches of up to 13 entries then share a pass sixteen at a time instead
+// of eight.  The fourth slot costs every 4-lane pass, so it is a flavour, not the rule (kwt_regroup; profiles/r05_experiments.md 9), and
+// it is this file compiled once more as a translation unit of its own (kernels_kwt_wide.hip: MZR_KWT_TU_WIDE) -- as a second
+// instantiation next to the first it changed the register allocation of the first (100 k reaches: 442 -> 447 ms per window).
+#ifndef MZR_KWT_KC_WIDE
+#define MZR_KWT_KC_WIDE 4
+#endif
+#ifdef MZR_KWT_TU_WIDE
+#undef MZR_KWT_KC
+#define MZR_KWT_KC MZR_KWT_KC_WIDE
+#endif
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 4      // wavefronts per SIMD the kernels are compiled for: 16 one-wavefront workgroups per CU is what the device holds (round 5: 5 -> 4, c3 shard 346.2 -> 342.8 ms)
 #endif
@@ -1961,6 +1973,9 @@ __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
 #ifndef MZR_KWT_WG
 #define MZR_KWT_WG 1
 #endif
+#ifdef MZR_KWT_TU_WIDE
+namespace mzr_kwt_wide {      // (the kernel's name must differ from the first translation unit's: template instantiations are merged by the linker)
+#endif
 template <bool FULL, int POOL, int KBLK>
 __global__ void __launch_bounds__(64 * MZR_KWT_WG) __attribute__((amdgpu_waves_per_eu(KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC, KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC)))
 k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
@@ -2134,6 +2149,12 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   // the launch's duration on the device's own clock (mzr_get_sweep_clock): the last wavefront to leave leaves the latest time
   if (d0.swClock && mzr_lane() == 0) atomicMax(d0.swClock + 1, (unsigned long long)wall_clock64());
 }
+#ifdef MZR_KWT_TU_WIDE
+}  // namespace mzr_kwt_wide
+using mzr_kwt_wide::k_sweep_kwt;
+#endif
+
+#ifndef MZR_KWT_TU_WIDE
 
 // Start of a KWT window in persistent mode: progress counters back to zero, and the headwater reaches
 // (kwt_route.f90:181-205: REACH_Q = BASIN_QR(1), one sentinel particle) for every step of the window.
@@ -2215,9 +2236,11 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
   }
 }
 
+#endif      // MZR_KWT_TU_WIDE
 // ---- persistent sweep, host side
 static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exportSlot || (d.is_flux_wm && d.wm); }
 
+#ifndef MZR_KWT_TU_WIDE
 // Wavefronts of k_sweep_kwt the device really holds at once.  The grid of a sweep must not exceed this: a persistent
 // kernel with workgroups still waiting for a slot was measured (profiles/r03_soak.md) to freeze, now and then and for
 // as long as the others keep running, the vector-memory instructions of some of its last-launched resident wavefronts
@@ -2275,6 +2298,7 @@ __global__ void k_sweep_heads(MzrDev d, int sBegin) {
   mzr_sweep_join_reset(d.swHead);
 }
 
+#endif      // MZR_KWT_TU_WIDE
 // evStart / evStop (profiling): attached to the sweep's own dispatch (hipExtLaunchKernelGGL), not recorded as markers around it --
 // marker packets in front of and behind a persistent launch were measured to slow some windows by a quarter (446 -> 560 ms, a
 // pattern with a period of eight windows; without events, and with events attached to the dispatch, every window takes 447 ms:
@@ -2286,16 +2310,28 @@ static void kwt_sweep_launch(const MzrDev &d, int nWaves, int sBegin, int sEnd, 
   if (evStart && evStop) hipExtLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), grid, block, 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
   else hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), grid, block, 0, stream, d, sBegin, sEnd);
 }
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk) {
+#ifdef MZR_KWT_TU_WIDE
+void mzr_launch_sweep_kwt_wide(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
+  if (kwt_full(d)) kwt_sweep_launch<true, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
+}
+#else
+void mzr_launch_sweep_kwt_wide(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop);      // kernels_kwt_wide.hip
+// kcWide: the flavour with MZR_KWT_KC_WIDE particle slots per lane of the 4-lane class (one step per visit only; the class lists must
+// have been cut for it: mzr_kwt_class_caps)
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk, int kcWide) {
   if (nWaves < 1 || sEnd <= sBegin) return;
   hipLaunchKernelGGL(k_sweep_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
   const bool full = kwt_full(d);
-  if (kblk > 1) { if (full) kwt_sweep_launch<true, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
+  if (kcWide && kblk <= 1) mzr_launch_sweep_kwt_wide(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
+  else if (kblk > 1) { if (full) kwt_sweep_launch<true, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
   else { if (full) kwt_sweep_launch<true, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
 }
-int mzr_kwt_class_caps(int *capB, int *capC) {      // entries a class-B / class-C group holds (the host's regrouping stays below them)
+// entries a class-B / class-C group holds (the host's regrouping stays below them); kcWide: in the sweep flavour with MZR_KWT_KC_WIDE slots per lane
+int mzr_kwt_class_caps(int *capB, int *capC, int kcWide) {
   constexpr int GPB = MZR_KWT_POOL / KwtCls::RB, GPC = MZR_KWT_POOL / KwtCls::RC;
+  const int kc = kcWide ? MZR_KWT_KC_WIDE : KwtCls::KC;
   *capB = KwtCls::GB * MZR_KWT_KTB - 1 < GPB ? KwtCls::GB * MZR_KWT_KTB - 1 : GPB;
-  *capC = KwtCls::GC * KwtCls::KC - 1 < GPC ? KwtCls::GC * KwtCls::KC - 1 : GPC;
+  *capC = KwtCls::GC * kc - 1 < GPC ? KwtCls::GC * kc - 1 : GPC;
   return MZR_KWT_POOL / KwtCls::RA;
 }
+#endif      // MZR_KWT_TU_WIDE

@@ -45,9 +45,9 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
 
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream, const MzrErr *err = nullptr);
 int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream, int kblk);
-int mzr_kwt_class_caps(int *capB, int *capC);
+int mzr_kwt_class_caps(int *capB, int *capC, int kcWide = 0);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk);
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk, int kc);
 
 namespace {
 
@@ -287,6 +287,7 @@ struct mzr_domain {
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
   DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll, kwtRoutedCAll;   // classes A / B / C over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
+  int swKcWide = 0;               // the sweep runs the flavour with MZR_KWT_KC_WIDE particle slots per lane of the 4-lane class (class C was cut for it: kwt_regroup)
   bool swHeavyFirst = false;      // the sweep's items in order of weight regardless of stage (class lists = the *All arrays): MZR_KWT_HEAVY_FIRST
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
   DBuf<unsigned long long> kwOwn, kwDone; DBuf<int> down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
@@ -1519,7 +1520,7 @@ int mzr_init_state(mzr_handle h) {
           h->kwtBOff.assign(h->nStages + 1, 0); h->kwtCOff.assign(h->nStages + 1, 0);
           // persistent sweep: every routed reach starts in class A, in stage order
           h->h_swA = h->kwtRoutedOff[h->nStages] > 0 ? routed : std::vector<MzrKwtRec>();
-          h->h_swB.clear(); h->h_swC.clear();
+          h->h_swB.clear(); h->h_swC.clear(); h->swKcWide = 0;
           h->h_kwtGeneric = h->kwtGenericOff[h->nStages] > 0 ? generic : std::vector<MzrKwtRec>();
           h->h_kwtHead = head; h->h_kwtDepLight = depLight;
           if (head.empty()) head.push_back(0);
@@ -1646,8 +1647,19 @@ static void kwt_regroup(mzr_handle h) {
   // runs through the reaches that thin every step, and those are faster in 16-lane groups: 28 there measured -8 %.
   // (round 4, with the outbox ring of four steps and the split 16-lane pass the chain no longer punishes the narrower groups:
   // 24 there measured +4.6 %, 28 +-0)
-  classBMax = (h->swCap > 0 && (double)h->h_kwtRouted.size() / 7.0 > 3.0 * h->swCap) ? 28 : 24;
-  { int capB = 0, capC = 0; (void)mzr_kwt_class_caps(&capB, &capC); classBMax = std::min(classBMax, capB - 2); classCMax = std::min(classCMax, capC - 2); }      // (room to grow by two before the fall-back)
+  const bool byInstructions = h->swCap > 0 && (double)h->h_kwtRouted.size() / 7.0 > 3.0 * h->swCap;
+  classBMax = byInstructions ? 28 : 24;
+  // Round 5: the cut between C and B the same way.  The 4-lane groups' slice of the pool holds 15 entries, three slots per lane 11; the
+  // sweep flavour with four slots per lane takes reaches of up to 13 entries sixteen to a pass instead of eight, and the fourth slot
+  // costs every 4-lane pass: the 375 k shard (bound by instructions) 674.1 -> 655.4 ms per window of 8 192, 100 k reaches 442 -> 447.5 ms
+  // (profiles/r05_experiments.md 9).  MZR_KWT_KC_WIDE_RUN forces it (tests).  The stage launches keep three slots (a reach beyond them
+  // takes their wide fall-back).
+  int kcWide = byInstructions ? 1 : 0;
+  if (const char *e = getenv("MZR_KWT_KC_WIDE_RUN")) kcWide = atoi(e) != 0;
+  if (const char *e = getenv("MZR_KWT_KBLK_RUN")) if (atoi(e) > 1) kcWide = 0;      // (the flavour exists for one step per visit)
+  h->swKcWide = kcWide;
+  if (kcWide) classCMax = 13;
+  { int capB = 0, capC = 0; (void)mzr_kwt_class_caps(&capB, &capC, kcWide); classBMax = std::min(classBMax, capB - 2); classCMax = std::min(classCMax, capC - 2); }      // (room to grow by two before the fall-back)
   if (const char *e = getenv("MZR_KWT_CLASSB_MAX")) classBMax = atoi(e);
   if (const char *e = getenv("MZR_KWT_CLASSC_MAX")) classCMax = atoi(e);
   const std::vector<MzrKwtRec> &v = h->h_kwtRouted;
@@ -1890,6 +1902,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // 14 % with one step per visit), and the sweep's throughput follows the number of wavefronts that are not waiting.
   int kblk = 1;
   if (const char *e = getenv("MZR_KWT_KBLK_RUN")) kblk = atoi(e) > 1 ? MZR_KWT_KBLK : 1;
+  const int kc = (h->swKcWide && kblk == 1) ? 1 : 0;      // the sweep flavour with four particle slots per lane of the 4-lane class (kwt_regroup)
   if (sweep) {
     kwt_sweep_tables(h, W, kblk);
     RouteBufs &rb = h->route[kwtIx];
@@ -1934,9 +1947,9 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       static const int how = getenv("MZR_EVENT_MARKERS") ? atoi(getenv("MZR_EVENT_MARKERS")) : 0;      // debugging aid: 1 markers, 2 attached
       if (how == 1) {
         (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
-        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk, kc);
         (void)hipEventRecord(rb.events[rb.evUsed].second, sx);
-      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second, kblk);
+      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second, kblk, kc);
       else {
         if (!h->timerStream) {
           (void)hipStreamCreateWithFlags(&h->timerStream, hipStreamNonBlocking);
@@ -1944,12 +1957,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         }
         (void)hipEventRecord(h->timerGate[0], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[0], 0);
         (void)hipEventRecord(rb.events[rb.evUsed].first, h->timerStream);
-        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk, kc);
         (void)hipEventRecord(h->timerGate[1], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[1], 0);
         (void)hipEventRecord(rb.events[rb.evUsed].second, h->timerStream);
       }
       ++rb.evUsed;
-    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk);
+    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk, kc);
     ++rb.nLaunches;
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
   }

@@ -843,11 +843,13 @@ def test_restart_continues_bit_exact(tmp_path, hip_lib):
     f.close()
 
 
-@pytest.mark.parametrize("class_b_max,class_c_max", [("0", "0"), ("64", "0"), ("64", "64"), ("0", "64")])
-def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, hip_lib, monkeypatch):
+@pytest.mark.parametrize("class_b_max,class_c_max,kc_wide", [("0", "0", "0"), ("64", "0", "0"), ("64", "64", "0"), ("0", "64", "0"),
+                                                             ("64", "64", "1"), ("24", "13", "1"), ("0", "13", "1")])
+def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, kc_wide, hip_lib, monkeypatch):
     """Routed reaches are served by 16, 8 or 4 lanes depending on a host-side guess of their particle
     count; a wrong guess is caught in the wavefront (wide fall-back).  Forcing every reach into any one
-    class must not change a bit."""
+    class must not change a bit.  kc_wide: the sweep flavour whose 4-lane groups hold 15 entries instead of 11
+    (MZR_KWT_KC_WIDE_RUN; large domains pick it by themselves)."""
     net = m.make_network(4000, seed=51)
     ro = m.make_runoff(net.H, 120, seed=52, storm_prob=0.03, storm_amp=3e-6)
     ff = np.array([0.5, 0.3, 0.2])
@@ -855,6 +857,7 @@ def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, hip_lib
     Qr = ref.run(ro)
     monkeypatch.setenv("MZR_KWT_CLASSB_MAX", class_b_max)
     monkeypatch.setenv("MZR_KWT_CLASSC_MAX", class_c_max)
+    monkeypatch.setenv("MZR_KWT_KC_WIDE_RUN", kc_wide)
     dom = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=30)
     Qd = dom.run(ro)
     assert np.array_equal(Qd, Qr)
