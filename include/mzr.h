@@ -121,6 +121,19 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
 long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach);
 /* pack the export reaches' records of the last window into rec_dev (device memory) */
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev);
+/* Windows of the Eulerian methods overlap (the last nStages - 1 launches of a window go out with the first launches of the next one),
+   and mzr_export_boundary_dev has to issue the launches kept back before it can pack the last window's record: correct, but the
+   overlap is lost.  A tributary domain keeps it by exporting one window later:
+     mzr_run_dev(window k); if (mzr_get_export_lag(h)) mzr_export_boundary_prev_dev(h, rec)  -> the record of window k - 1,
+   packed on a stream of the library's own as soon as window k - 1 is complete (launch nStages - 1 of window k), mzr_wait_export(h)
+   = the host waits for that record and for nothing else.  mzr_get_export_lag: 1 while the last window's final launches are kept
+   back (same window length and options as the window before: the rule of DESIGN.md 2.6); the record of the LAST window of a run
+   comes from mzr_export_boundary_dev as before.  mzr_export_boundary_prev_dev refuses (ierr 20) when the rows of the window
+   before the last one are not kept (no overlap, or already exported).  (mpi_process.f90:1281-1312: the reference ships the outlet
+   fluxes of every step before the mainstem's step.) */
+int mzr_get_export_lag(mzr_handle h);
+int mzr_export_boundary_prev_dev(mzr_handle h, double *rec_dev);
+int mzr_wait_export(mzr_handle h);
 /* unpack a record of nSrc reaches (one source partition) into halo slots [haloBase, haloBase+nSrc)
    for the next window of nSteps steps */
 int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase);

@@ -53,7 +53,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_run_dev", "mzr_sync", "mzr_get_flux", "mzr_get_window_q", "mzr_get_mean_q",
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing", "mzr_get_timing_range",
-           "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev",
+           "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev", "mzr_export_boundary_prev_dev", "mzr_get_export_lag", "mzr_wait_export",
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute", "mzr_get_tracer_state", "mzr_set_tracer_state",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
@@ -97,6 +97,9 @@ def load_library():
     L.mzr_boundary_size.argtypes = [vp, ci, ci]
     L.mzr_boundary_size.restype = C.c_longlong
     L.mzr_export_boundary_dev.argtypes = [vp, vp]
+    L.mzr_export_boundary_prev_dev.argtypes = [vp, vp]
+    L.mzr_get_export_lag.argtypes = [vp]
+    L.mzr_wait_export.argtypes = [vp]
     L.mzr_import_boundary_dev.argtypes = [vp, ci, vp, ci, ci]
     L.mzr_step.argtypes = [vp, cd, cd, dp]
     L.mzr_run.argtypes = [vp, ci, cd, dp]
@@ -394,6 +397,19 @@ class RoutingDomain:
 
     def export_boundary(self, rec_dev_ptr):
         self._check(self.L.mzr_export_boundary_dev(self.h, C.c_void_p(int(rec_dev_ptr))))
+
+    def export_lag(self):
+        """True while the last window's final launches are kept back for the next window (overlapping windows): its boundary
+        record is then exported one window later, by export_boundary_prev after the next run of the same length."""
+        return bool(self.L.mzr_get_export_lag(self.h))
+
+    def export_boundary_prev(self, rec_dev_ptr):
+        """the record of the window BEFORE the last one (mzr_export_boundary_prev_dev)"""
+        self._check(self.L.mzr_export_boundary_prev_dev(self.h, C.c_void_p(int(rec_dev_ptr))))
+
+    def wait_export(self):
+        """the host waits for the last export's record, not for what has been queued since"""
+        self._check(self.L.mzr_wait_export(self.h))
 
     def import_boundary(self, n_steps, rec_dev_ptr, n_src, halo_base):
         self._check(self.L.mzr_import_boundary_dev(self.h, int(n_steps), C.c_void_p(int(rec_dev_ptr)), int(n_src), int(halo_base)))

@@ -253,6 +253,13 @@ struct mzr_domain {
   hipStream_t copyStream = nullptr;             // host -> device forcing windows of mzr_run_async, behind the sweep of the window before
   hipEvent_t rwCopied[2] = {nullptr, nullptr}, rwRead[2] = {nullptr, nullptr};
   hipEvent_t exportDone = nullptr;              // recorded behind the last mzr_export_boundary_dev: what mzr_comm_send waits for
+  // Export of the window BEFORE the last one (mzr_export_boundary_prev_dev): while the last launches of window k are kept back for window
+  // k + 1 (overlapping windows), the rows of window k - 1 sit complete in the second set of rows from launch nS - 1 of window k on
+  hipStream_t expStream = nullptr;              // the pack kernel of such an export runs here, behind prevRowsEv only -- not behind the rest of window k
+  hipEvent_t prevRowsEv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per method: the rows of the window before are complete (recorded inside run_window)
+  int prevW = 0;                                // steps of the window whose rows are the second set
+  bool prevInAlt = false;                       // the second set of rows holds the window before the last one, untouched
+  bool exportOnAux = false;                     // an export on expStream is in flight: the next window (which writes those rows) waits for exportDone
   bool rwUsed[2] = {false, false};
   int rwCur = 0;
   hipEvent_t rwOther = nullptr; bool rwOtherSet = false;   // a window queued by another entry point (mzr_run_src_dev) still reads runoffW
@@ -863,6 +870,8 @@ int mzr_destroy(mzr_handle h) {
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   if (h->exportDone) (void)hipEventDestroy(h->exportDone);
+  if (h->expStream) (void)hipStreamDestroy(h->expStream);
+  for (auto &e : h->prevRowsEv) if (e) (void)hipEventDestroy(e);
   if (h->rwOther) (void)hipEventDestroy(h->rwOther);
   for (int i = 0; i < 2; ++i) { if (h->stepHost[i]) (void)hipHostFree(h->stepHost[i]); if (h->stepCopied[i]) (void)hipEventDestroy(h->stepCopied[i]); }
   for (int i = 0; i < 2; ++i) { if (h->rwCopied[i]) (void)hipEventDestroy(h->rwCopied[i]); if (h->rwRead[i]) (void)hipEventDestroy(h->rwRead[i]); }
@@ -1342,6 +1351,39 @@ long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach) {
   return MZR_REC_HDR + R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B + (h->tracer ? R * W * B : 0);      // (header; + reach_solute_flux while the tracer is on)
 }
 
+/* The record of the window BEFORE the last one, while the last launches of the last one are still kept back (overlapping windows of
+   the Eulerian methods): its rows are the second set, complete from launch nS - 1 of the last window on; packed on a stream of its own
+   behind exactly that, so the record is there long before the last window is.  (mpi_process.f90:1281-1312 ships every step's outlet
+   fluxes before the mainstem's step; here a tributary domain's windows overlap, and the record travels one window later.) */
+int mzr_export_boundary_prev_dev(mzr_handle h, double *rec_dev) {
+  MZR_FLUSH_STEPS(h);
+  if (!h || !h->haveState) return h ? fail(h, 20, "mzr_export_boundary_prev/state not initialised") : 1;
+  if (h->nExp == 0) return 0;
+  if (!h->tail.pending || !h->prevInAlt || h->prevW < 1) return fail(h, 20, "mzr_export_boundary_prev/the rows of the window before the last one are not kept (mzr_get_export_lag)");
+  (void)hipSetDevice(h->cfg.device);
+  if (!h->expStream && hipStreamCreateWithFlags(&h->expStream, hipStreamNonBlocking) != hipSuccess) return fail(h, 90, "mzr_export_boundary_prev/hipStreamCreate failed");
+  for (int ix = 0; ix < h->cfg.nRoutes && ix < 6; ++ix) if (h->prevRowsEv[ix]) (void)hipStreamWaitEvent(h->expStream, h->prevRowsEv[ix], 0);
+  QPtrs q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].Qalt.p : nullptr;
+  dim3 block(64), grid((h->nExp + 63) / 64, h->prevW + 1);
+  hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->expStream, rec_dev, h->cfg.nRoutes, h->prevW, h->nExp, h->N,
+                     h->expInt.p, q, h->qlatAlt.p, h->exN.p, h->exOQ.p, h->exOT.p, 0, 0);
+  if (!h->exportDone) (void)hipEventCreateWithFlags(&h->exportDone, hipEventDisableTiming);
+  (void)hipEventRecord(h->exportDone, h->expStream);
+  h->exportOnAux = true;
+  h->prevInAlt = false;      // (exported once)
+  return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_export_boundary_prev/launch failed");
+}
+/* 1: the last window's final launches are kept back for the next window -- its record is exported by mzr_export_boundary_prev_dev
+   after the next mzr_run* of the same length (or by mzr_export_boundary_dev, which issues the kept-back launches first) */
+int mzr_get_export_lag(mzr_handle h) { return (h && h->tail.pending && h->nExp > 0) ? 1 : 0; }
+/* the host waits for the handle's last export (either kind) and for nothing else the handle has queued */
+int mzr_wait_export(mzr_handle h) {
+  if (!h) return 1;
+  if (!h->exportDone) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  return hipEventSynchronize(h->exportDone) == hipSuccess ? 0 : fail(h, 92, "mzr_wait_export/device error");
+}
+
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
   MZR_FLUSH(h);
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_export_boundary/state not initialised") : 1;
@@ -1799,9 +1841,15 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       if (h->tail.pending) flushTail(h);
     }
   }
+  if (h->exportOnAux) {      // a record of the window before the last one is being packed from the rows this window is about to write
+    if (h->exportDone) (void)hipStreamWaitEvent(st, h->exportDone, 0);
+    h->exportOnAux = false;
+  }
+  h->prevInAlt = false;
   if (pipe) {      // this window's rows: the second set (the set of the window before stays as it is until its last launches are out)
     h->qlat.swap(h->qlatAlt); if (h->qi.p) h->qi.swap(h->qiAlt);
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].Q.swap(h->route[ix].Qalt);
+    h->prevInAlt = h->lastW > 0 && h->nExp > 0; h->prevW = h->lastW;
   }
   MzrDev d; fillDev(h, d);
   d.W = W; d.t_start = t_start; d.T1_single = T1_single; d.runoff = runoff_dev; d.stepBlock = KB;
@@ -2029,6 +2077,13 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
       ++rb.nLaunches;
     }
+    // the rows of the window before are complete from here on (its kept-back launches went out with launches 0 .. nS - 2 of this
+    // one): what mzr_export_boundary_prev_dev waits for
+    if (h->prevInAlt && s == (withTail ? nS - 2 : 0))
+      for (int ix = 0; ix < nR && ix < 6; ++ix) {
+        if (!h->prevRowsEv[ix]) (void)hipEventCreateWithFlags(&h->prevRowsEv[ix], hipEventDisableTiming);
+        (void)hipEventRecord(h->prevRowsEv[ix], rst[ix]);
+      }
   }
   if (pipe && anyStage) { h->tail.pending = true; h->tail.W = WB; for (int ix = 0; ix < nR; ++ix) h->tail.d[ix] = dr[ix]; }
   else h->tail.pending = false;
@@ -3036,7 +3091,7 @@ int mzr_comm_destroy(mzr_comm c) {
 }
 
 int mzr_comm_send(mzr_comm c, mzr_handle h, const double *dev, long long n, int peer) {
-  MZR_FLUSH(h);
+  MZR_FLUSH_STEPS(h);      // (not the launches kept back for the next window: the record was packed by an export, which issued them if it needed them)
   if (!c || !h || !dev || n < 0 || peer < 0 || peer >= c->nRanks || peer == c->rank) return commFail(1, "mzr_comm_send/bad arguments");
   (void)hipSetDevice(c->device);
   // the record was packed by the handle's last mzr_export_boundary_dev; whatever the handle has queued since (the next

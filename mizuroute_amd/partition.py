@@ -297,7 +297,9 @@ class PartitionedRouter:
     """Drives the domains of ONE partition (rank) window by window.
 
     transport: object with send(tensor, dst) / recv(tensor, src) (torch.distributed P2P over RCCL
-    in production; an in-process loopback in the single-GPU test).  make_domain(domain, **kw) builds
+    in production; an in-process loopback in the single-GPU test).  alloc(n): n doubles of device memory with
+    no work pending on them (torch.empty, not torch.zeros: a record is packed on the library's own streams,
+    which do not wait for a fill kernel on torch's).  make_domain(domain, **kw) builds
     the compute object for a Domain (RoutingDomain in production).
     """
 
@@ -317,6 +319,7 @@ class PartitionedRouter:
                                     sweep_priority=1 if both else 0)
         self.n_routes = None
         self._pending = None            # (w, t_start, runoff_main_ptr, record, keep) of the window whose exchange is still due
+        self._late = False              # ... and whose record has not been packed yet (overlapping windows: export_boundary_prev)
 
     def _rec_size(self, dom, w, n):
         return dom.boundary_size(w, n)
@@ -330,18 +333,42 @@ class PartitionedRouter:
         boundary records of window k-1 travel (send on the tributary ranks; receive, import and
         mainstem window k-1 on rank 0), so the exchange and the host time of the mainstem launches
         hide behind the tributary sweep of window k.  sync() flushes the window still in flight.
-        All ranks must call run_window / sync in the same order."""
+        All ranks must call run_window / sync in the same order.
+
+        Where the tributary domain's windows overlap (Eulerian methods: the last launches of window k-1 go out
+        with the first ones of window k, RoutingDomain.export_lag), the record of window k-1 is packed AFTER window
+        k has been queued -- from the rows the library keeps, as soon as those launches are out (export_boundary_prev)
+        -- instead of right behind window k-1, which would make the library issue the kept-back launches on their own
+        and lose the overlap.  Same records, same order, same depth of the pipeline."""
         part = self.part
         n_exp = self.trib_spec.export_local.size
+        ships = bool(n_exp) and part.main is not None
         prev = self._pending
+        late = prev is not None and self._late            # the record of window k-1 has not been packed yet
         if prev is not None and self.trib is not None:
-            self.trib.sync()                              # window k-1 and its export are complete
+            if late and w == prev[0]:
+                pass                                      # ... and comes out of this window's first launches
+            else:
+                self.trib.sync()                          # window k-1 and its export are complete (a sync issues launches kept back)
+                if late:                                  # a window of another length does not overlap with it: the record now
+                    rec_prev = self.alloc(self.trib.boundary_size(prev[0], n_exp))
+                    self.trib.export_boundary(rec_prev.data_ptr()); self.trib.sync()
+                    prev = (prev[0], prev[1], prev[2], rec_prev, prev[4]); late = False
         rec = None
+        self._late = False
         if self.trib is not None:
             self.trib.run_device(w, t_start, runoff_trib_ptr)
-            if n_exp and part.main is not None:
-                rec = self.alloc(self.trib.boundary_size(w, n_exp))
-                self.trib.export_boundary(rec.data_ptr())
+            if ships:
+                if late:
+                    rec_prev = self.alloc(self.trib.boundary_size(prev[0], n_exp))
+                    self.trib.export_boundary_prev(rec_prev.data_ptr())
+                    self.trib.wait_export()               # (the record only: window k runs on)
+                    prev = (prev[0], prev[1], prev[2], rec_prev, prev[4])
+                if getattr(self.trib, "export_lag", None) is not None and self.trib.export_lag():
+                    self._late = True
+                else:
+                    rec = self.alloc(self.trib.boundary_size(w, n_exp))
+                    self.trib.export_boundary(rec.data_ptr())
         if prev is not None:
             self._exchange(*prev)
         self._pending = (w, t_start, runoff_main_ptr, rec, keep) if part.main is not None else None
@@ -380,6 +407,11 @@ class PartitionedRouter:
             if self.trib is not None:
                 self.trib.sync()
             prev, self._pending = self._pending, None
+            if self._late and self.trib is not None:      # the last window's record: its kept-back launches have just been issued
+                rec = self.alloc(self.trib.boundary_size(prev[0], self.trib_spec.export_local.size))
+                self.trib.export_boundary(rec.data_ptr()); self.trib.sync()
+                prev = (prev[0], prev[1], prev[2], rec, prev[4])
+            self._late = False
             self._exchange(*prev)
         if self.trib is not None:
             self.trib.sync()

@@ -424,6 +424,76 @@ def test_partitioned_network_equals_whole(hip_lib):
                 assert np.array_equal(dom.mean_q(meth)[:spec.n_real], whole2.mean_q(meth)[g]), (rank, meth)
 
 
+@pytest.mark.parametrize("methods,lakes", [([1, 5], False), ([4, 3], False), ([5], True)])
+def test_partitioned_eulerian_domains_keep_their_overlapping_windows(methods, lakes, hip_lib):
+    """Windows of the Eulerian methods overlap (the last launches of window k go out with the first ones of window k + 1).  A
+    tributary domain that ships boundary records keeps that: the record of window k is packed behind the START of window k + 1
+    from the rows the library keeps (mzr_export_boundary_prev_dev), not right behind window k (which makes the library issue the
+    kept-back launches on their own).  Same bits as the whole network: every window of every reach, and the interval means."""
+    import torch
+    from mizuroute_amd.partition import PartitionedRouter, partition_network, lakes_for_domain
+    from mizuroute_amd.synthetic import make_lakes
+    net = m.make_network(5000, seed=18, p3=0.02)
+    nparts, nwin = 3, 5
+    P = partition_network(net, nparts)
+    assert P.main is not None and sum(d.export_local.size for d in P.trib) > 0
+    ff = np.array([0.5, 0.3, 0.2])
+    uh_off = np.arange(0, 2 * net.N + 1, 2, dtype=np.int32)
+    uh = np.tile(np.array([0.6, 0.4]), net.N)
+    probe = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=8)
+    W = max(64, int(probe.schedule()[0]) + 8)          # at least as many steps as the deepest domain has stages: the windows overlap
+    probe.close()
+    steps = nwin * W
+    lk = make_lakes(net, steps, 3600.0, seed=3, frac=0.01, input_option=1) if lakes else None
+    ro = m.make_runoff(net.H, steps, seed=19, storm_prob=0.05, storm_amp=3e-6)
+    whole = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=W, lakes=lk)
+    Qw = whole.run(ro)
+
+    def make(spec, **kw):
+        g = spec.reach_global
+        off = np.zeros(g.size + 1, np.int32); off[1:] = np.cumsum(np.diff(uh_off)[g])
+        u = np.concatenate([uh[uh_off[x]:uh_off[x + 1]] for x in g])
+        return m.RoutingDomain(spec.net, 3600.0, methods, frac_future=ff, uh_offset=off, uh=u, max_window=W,
+                               lakes=lakes_for_domain(lk, spec, net.N) if lk is not None else None, **kw)
+
+    box = {}
+    dev = torch.device("cuda")
+    routers = []
+    for rank in range(nparts):
+        class T:
+            def __init__(self, me): self.me = me
+            def send(self, t, dst): box.setdefault((self.me, dst), []).append(t.clone())
+            def recv(self, t, src): t.copy_(box[(src, 0)].pop(0)); torch.cuda.synchronize()
+        # (torch.empty: a record is packed on the library's streams, which do not wait for a fill kernel on torch's)
+        routers.append(PartitionedRouter(P, rank, make, T(rank), lambda n: torch.empty(n, dtype=torch.float64, device="cuda"), W))
+    order = list(range(1, nparts)) + [0]
+    late = 0
+    got = {}
+    for k in range(nwin):
+        w0 = k * W
+        for rank in order:
+            r = routers[rank]
+            for dom in (r.trib, r.main):
+                if dom is not None and dom.lakes is not None:
+                    dom.set_lake_forcing(w0, W)
+            rt = torch.from_numpy(np.ascontiguousarray(ro[w0:w0 + W][:, r.trib_spec.hru_global])).to(dev) if r.trib is not None else None
+            rm = torch.from_numpy(np.ascontiguousarray(ro[w0:w0 + W][:, r.main_spec.hru_global])).to(dev) if r.main is not None else None
+            r.run_window(W, w0 * 3600.0, rt.data_ptr() if rt is not None else 0, rm.data_ptr() if rm is not None else 0, keep=(rt, rm))
+            late += int(r._late)
+    for rank in order:
+        routers[rank].sync()
+    assert late > 0, "no tributary domain kept its last launches back: the overlap this test is about did not happen"
+    for rank in order:
+        r = routers[rank]
+        for dom, spec in ((r.trib, r.trib_spec), (r.main, r.main_spec)):
+            if dom is None:
+                continue
+            g = spec.reach_global[:spec.n_real]
+            for ix, meth in enumerate(methods):
+                assert np.array_equal(dom.window_q(meth, W)[:, :spec.n_real], Qw[-W:, ix][:, g]), (rank, meth)
+                assert np.array_equal(dom.mean_q(meth)[:spec.n_real], whole.mean_q(meth)[g]), (rank, meth)
+
+
 def test_water_management_fluxes(hip_lib, oracle_lib):
     """is_flux_wm: abstraction cascade / injection in IRF, KW, MC, DW (irf_route.f90:118-142) and
     extract_from_rch in KWT (kwt_route.f90:351-455), incl. missing values (-9999)."""

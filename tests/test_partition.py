@@ -71,6 +71,7 @@ class RecordingDomain:
         self.exp = np.asarray(export_reaches if export_reaches is not None else [], dtype=np.int64)
         self.imports = {}
         self.ran = []
+        self.calls = []
 
     HDR, MAGIC = 4, 20260929.0      # the record's header (mzr_host.hip MZR_REC_HDR / MZR_REC_MAGIC): {magic, nRoutes, steps, reaches}
 
@@ -78,11 +79,23 @@ class RecordingDomain:
         # mzr_boundary_size: header | Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB], one method
         return self.HDR + (1 * w + (w + 1) + w + 2 * w * 21) * n
 
+    LAG = False      # True: a domain whose windows overlap (Eulerian methods) -- the record of a window is packed one window later
+
     def run_device(self, w, t_start, ptr):
-        self.ran.append((w, t_start))
+        self.ran.append((w, t_start)); self.calls.append(("run", w))
 
     def export_boundary(self, ptr):
-        pass
+        self.calls.append(("export",))
+
+    def export_lag(self):
+        return self.LAG
+
+    def export_boundary_prev(self, ptr):
+        assert self.LAG
+        self.calls.append(("export_prev",))
+
+    def wait_export(self):
+        self.calls.append(("wait_export",))
 
     def fabricate(self, w):
         n = self.exp.size
@@ -96,10 +109,10 @@ class RecordingDomain:
         self.imports[base] = (w, n)
 
     def sync(self):
-        pass
+        self.calls.append(("sync",))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, lag=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -121,6 +134,7 @@ def _worker(rank, world, port, q):
                 got[src] = t.clone()
 
     domains = {}
+    RecordingDomain.LAG = lag
 
     def make(spec, **kw):
         d = RecordingDomain(spec, **kw); domains[spec.kind] = d
@@ -154,20 +168,29 @@ def _worker(rank, world, port, q):
             ok &= got[p].numel() == H + (w + (w + 1) + w + 2 * w * 21) * n
             ok &= bool(np.array_equal(got[p][H: H + w * n].numpy(), expect))
         ok &= main.ran == [(w, 0.0), (w, w * 3600.0)]
+    if router.trib is not None and router.trib.exp.size and P.main is not None:
+        calls = [c[0] for c in router.trib.calls if c[0] != "sync"]
+        if lag:      # window 0's record is packed behind the START of window 1 (no synchronisation in between), window 1's by sync()
+            ok &= calls == ["run", "run", "export_prev", "wait_export", "export"]
+            ok &= [c[0] for c in router.trib.calls][:2] == ["run", "run"]
+        else:
+            ok &= calls == ["run", "export", "run", "export"]
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_boundary_exchange_over_gloo(world):
+@pytest.mark.parametrize("world,lag", [(2, False), (8, False), (2, True)])
+def test_boundary_exchange_over_gloo(world, lag):
     """The N > 1 path of PartitionedRouter over torch.distributed (gloo): two ranks, and the eight of the north-star configuration
-    (seven peers, all their records received at once, the reference's assign_node with eight nodes)."""
+    (seven peers, all their records received at once, the reference's assign_node with eight nodes).  lag: tributary domains whose
+    windows overlap -- the record of window k is packed behind the start of window k + 1 (export_boundary_prev), the same records
+    arrive in the same order."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, lag)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
