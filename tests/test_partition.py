@@ -170,7 +170,8 @@ def _worker(rank, world, port, q, lag=False):
         ok &= main.ran == [(w, 0.0), (w, w * 3600.0)]
     if router.trib is not None and router.trib.exp.size and P.main is not None:
         calls = [c[0] for c in router.trib.calls if c[0] != "sync"]
-        if lag:      # window 0's record is packed behind the START of window 1 (no synchronisation in between), window 1's by sync()
+        if lag and router._may_lag:      # window 0's record is packed behind the START of window 1 (no synchronisation in between), window 1's by sync();
+                                         # (rank 0 routes two domains on one GPU and exports right behind its window)
             ok &= calls == ["run", "run", "export_prev", "wait_export", "export"]
             ok &= [c[0] for c in router.trib.calls][:2] == ["run", "run"]
         else:
