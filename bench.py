@@ -408,17 +408,15 @@ class Loopback:
             ro_m = [self.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
             rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=self.dev) for _ in range(2)]
             tw = []
+            import threading
+            two_threads = m.KWT not in methods
             KS = K + EXTRA      # (two fresh domains: their first windows hold the regroupings and table builds)
             # (rank 0's tributary domain exports right behind its window, as PartitionedRouter does where two domains share a GPU: a
             # domain that keeps a window queued ahead holds the hardware queues its neighbour's launches need -- measured on c4: 1.33 s
             # per window with the record one window later against 0.71 s)
             for k in range(KS + 1):
                 torch.cuda.synchronize(); t1 = time.perf_counter()
-                if k < KS:
-                    if d_t.lakes is not None:
-                        d_t.set_lake_forcing(0, W)
-                    d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
-                if k >= 1:                                   # the mainstem follows one window behind
+                def main_side(k=k):                          # the mainstem follows one window behind
                     for p in range(self.nparts):
                         base, n = ms.halo_base[p]
                         if n:
@@ -426,6 +424,19 @@ class Loopback:
                     if d_m.lakes is not None:
                         d_m.set_lake_forcing(0, W)
                     d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
+                # Eulerian methods: a window is thousands of launches, and a launch blocks its thread while the stream's queue is full --
+                # the mainstem's window is queued from a host thread of its own (PartitionedRouter, main_thread)
+                th = None
+                if k >= 1 and two_threads:
+                    th = threading.Thread(target=main_side); th.start()
+                if k < KS:
+                    if d_t.lakes is not None:
+                        d_t.set_lake_forcing(0, W)
+                    d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
+                if th is not None:
+                    th.join()
+                elif k >= 1:
+                    main_side()
                 if k < KS:
                     d_t.sync()
                     d_t.export_boundary(rec0[k % 2].data_ptr())
@@ -433,7 +444,7 @@ class Loopback:
                 if 1 <= k < KS:
                     tw.append(time.perf_counter() - t1)
             t_rank0 = float(np.median(tw[len(tw) // 2:]))      # (the first windows of two fresh domains hold their regroupings and table builds)
-            times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share, sweep_priority_mainstem=1,
+            times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share, sweep_priority_mainstem=1, mainstem_queued_from_its_own_host_thread=two_threads,
                                                what="tributary window k and mainstem window k-1 of rank 0 queued together; median of the later half of the windows")
             d_t.close(); d_m.close()
         recs.clear()

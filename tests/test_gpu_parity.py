@@ -464,8 +464,9 @@ def test_partitioned_eulerian_domains_keep_their_overlapping_windows(methods, la
             def __init__(self, me): self.me = me
             def send(self, t, dst): box.setdefault((self.me, dst), []).append(t.clone())
             def recv(self, t, src): t.copy_(box[(src, 0)].pop(0)); torch.cuda.synchronize()
-        # (torch.empty: a record is packed on the library's streams, which do not wait for a fill kernel on torch's)
-        routers.append(PartitionedRouter(P, rank, make, T(rank), lambda n: torch.empty(n, dtype=torch.float64, device="cuda"), W))
+        # (torch.empty: a record is packed on the library's streams, which do not wait for a fill kernel on torch's; main_thread: rank 0
+        # queues its mainstem window from a host thread of its own)
+        routers.append(PartitionedRouter(P, rank, make, T(rank), lambda n: torch.empty(n, dtype=torch.float64, device="cuda"), W, main_thread=True))
     order = list(range(1, nparts)) + [0]
     late = 0
     got = {}

@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 c=${CONFIG:-c4}
 for spec in "$@"; do
   envs=$(echo "$spec" | tr ',' ' '); [ "$spec" = "-" ] && envs="X=1"
-  env $envs python bench.py --loopback --config $c --steps ${STEPS:-3} --no-cpu-baseline > gpurun_out/lb_tmp.json 2> gpurun_out/lb_tmp.err
+  env $envs python bench.py --loopback --config $c --steps ${STEPS:-3} --no-cpu-baseline ${ARGS:-} > gpurun_out/lb_tmp.json 2> gpurun_out/lb_tmp.err
   python - <<PY
 import json
 try:
