@@ -255,6 +255,7 @@ struct mzr_domain {
   hipEvent_t exportDone = nullptr;              // recorded behind the last mzr_export_boundary_dev: what mzr_comm_send waits for
   // Export of the window BEFORE the last one (mzr_export_boundary_prev_dev): while the last launches of window k are kept back for window
   // k + 1 (overlapping windows), the rows of window k - 1 sit complete in the second set of rows from launch nS - 1 of window k on
+  hipEvent_t sweepGo = nullptr;                 // recorded on the KWT stream right in front of the last sweep launch: that launch is eligible (mzr_run_async*: the next window's copy starts behind it)
   hipStream_t expStream = nullptr;              // the pack kernel of such an export runs here, behind prevRowsEv only -- not behind the rest of window k
   hipEvent_t prevRowsEv[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per method: the rows of the window before are complete (recorded inside run_window)
   int prevW = 0;                                // steps of the window whose rows are the second set
@@ -871,6 +872,7 @@ int mzr_destroy(mzr_handle h) {
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   if (h->exportDone) (void)hipEventDestroy(h->exportDone);
   if (h->expStream) (void)hipStreamDestroy(h->expStream);
+  if (h->sweepGo) (void)hipEventDestroy(h->sweepGo);
   for (auto &e : h->prevRowsEv) if (e) (void)hipEventDestroy(e);
   if (h->rwOther) (void)hipEventDestroy(h->rwOther);
   for (int i = 0; i < 2; ++i) { if (h->stepHost[i]) (void)hipHostFree(h->stepHost[i]); if (h->stepCopied[i]) (void)hipEventDestroy(h->stepCopied[i]); }
@@ -1987,6 +1989,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     if (h->swClock.p) { dk.swClock = h->swClock.p + 2 * (size_t)(h->swClockN % MZR_CLOCK_LOG); ++h->swClockN; }
     mzr_launch_kwt_window_init(dk, 0, W, sx);
+    // (mzr_run_async*: the copy of the next window starts behind this point plus a pause, not beside the launch itself; only where
+    // that entry point is in use -- the event is one more packet in front of k_sweep_heads, two launches in front of the sweep)
+    if (h->copyStream && getenv("MZR_H2D_HEAD_START") && atoi(getenv("MZR_H2D_HEAD_START")) != 0) {
+      if (!h->sweepGo) (void)hipEventCreateWithFlags(&h->sweepGo, hipEventDisableTiming);
+      (void)hipEventRecord(h->sweepGo, sx);
+    }
     if (prof) {      // the event pair rides on the sweep's own dispatch (see mzr_launch_sweep_kwt)
       if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
       // Timing-enabled events on the sweep's own stream -- as markers around the launch or attached to its dispatch -- slow some
@@ -2253,6 +2261,11 @@ int mzr_run(mzr_handle h, int nSteps, double t_start, const double *runoff) {
 // The stand-alone driver's loop (standalone/route_runoff.f90:80-108) reads forcing and routes, step after step;
 // here a whole window of forcing is handed over in host memory and the call returns at once: the copy runs on its
 // own stream into one of two device buffers while the window before is still being routed.
+// one wavefront that does nothing for `ticks` of the 100 MHz clock (mzr_run_async*: the head start of a sweep launch over the next window's copy)
+__global__ void __launch_bounds__(64) k_pause(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 __global__ void __launch_bounds__(256) k_widen_f32(const float *src, double *dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (double)src[i];
 }
@@ -2273,6 +2286,17 @@ static int run_async_impl(mzr_handle h, int nSteps, double t_start, double T1_si
   double *buf = k == 0 ? h->runoffW.p : h->runoffW2.p;
   if (h->rwUsed[k]) (void)hipStreamWaitEvent(h->copyStream, h->rwRead[k], 0);     // the window that last read this buffer
   if (k == 0 && h->rwOtherSet) { (void)hipStreamWaitEvent(h->copyStream, h->rwOther, 0); h->rwOtherSet = false; }   // ... also one queued by mzr_run_src_dev
+  // Round 5, measured and left OFF (MZR_H2D_HEAD_START=1 turns it on): the copy of window k + 1 starts when window k - 1 has finished, so it
+  // is in full swing when the persistent sweep of window k is launched ~50 ms later, and a sweep launched beside a copy now and then gets
+  // ~12 % of its wavefronts 20-80 us late (histogram of start delays, tools/r05_h2d2.py; without a copy every wavefront starts within
+  // 0.7 us); those do not join (DESIGN.md 2.4 iii) and the window takes 480-520 ms instead of 442.  Holding the copy back until that
+  // launch has been eligible for 300 us takes the late starts away (every sweep 444-446 ms) -- and the bench's host-forcing leg got
+  // SLOWER with it, twice on one box (value_with_h2d / value 0.907, 0.886 against 0.920, 0.952: tools/r05_h2d3.sh).  Not understood.
+  static const bool headStart = getenv("MZR_H2D_HEAD_START") && atoi(getenv("MZR_H2D_HEAD_START")) != 0;
+  if (headStart && h->sweepGo) {
+    (void)hipStreamWaitEvent(h->copyStream, h->sweepGo, 0);
+    hipLaunchKernelGGL(k_pause, dim3(1), dim3(64), 0, h->copyStream, 30000LL);
+  }
   if (runoff32) {      // single-precision forcing: half the bytes across PCIe, widened behind the copy on the copy's stream
     const size_t n = (size_t)nSteps * h->H;
     try { if (h->runoffF[k].n < (size_t)h->cfg.maxWindow * h->H) h->runoffF[k].allocStaging((size_t)h->cfg.maxWindow * h->H); } catch (const std::string &e) { return fail(h, 91, "mzr_run_async_f32/" + e); }

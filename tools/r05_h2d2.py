@@ -30,6 +30,7 @@ for mode in ("dev", "f32", "f64", "f32-syncEach"):
     if call: call(W, t, hosts[0].data_ptr())
     else: dom.run_device(W, t, pool[0].data_ptr())
     t += W * 3600.0; dom.sync(); dom.sweep_clock(reset=True)
+    h0 = dom.sweep_arrivals()[2]
     t0 = time.perf_counter(); tc = []
     for k in range(1, K + 1):
         a = time.perf_counter()
@@ -41,4 +42,7 @@ for mode in ("dev", "f32", "f64", "f32-syncEach"):
     dom.sync()
     el = time.perf_counter() - t0
     print(f"{mode:14s} {N * K * W / el:.4g} reach-steps/s  {el / K * 1e3:.1f} ms per window; sweep on the device clock: " + " ".join(f"{x:.0f}" for x in dom.sweep_clock(K)) + "; host ms per call: " + " ".join(f"{x:.0f}" for x in tc))
+    a, j, h1 = dom.sweep_arrivals()
+    dh = [y - x for x, y in zip(h0, h1)]
+    print("    last launch arrived / joined:", a, j, " start delays of the mode's launches (bucket k: < 2^k x 10 ns):", {k: v for k, v in enumerate(dh) if v})
     del hosts
