@@ -542,6 +542,10 @@ class Loopback:
             except Exception as e:
                 cpu["mpi_like"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
             try:      # one single-thread rank per physical core over the P-way decomposition of the FULL network, 48 + 48 steps
+                # (in the default line's `configs` objects for the KWT network only -- c3, the north-star configuration: 60-90 s per
+                # configuration, and the default bench has 900 s; `--loopback` reports it for every configuration)
+                if n_smp < 32 and methods != [self.m.KWT]:
+                    raise StopIteration("left out of the default line's time budget: bench.py --loopback --config " + self.config)
                 n2 = 96
                 ro2 = ro_cpu if ro_cpu.shape[0] >= n2 else device_runoff(self.torch, net.H, n2, 0, 7, self.dev).cpu().numpy()
 
@@ -556,6 +560,8 @@ class Loopback:
                 cpu["mpi_like_cores"] = cpu_mpi_like_cores(net, self.frac, lambda dm, n: ro2[:n, dm.hru_global], methods, uh_of=uh_pair,
                                                            lakes_of=lk2 if self.lakes is not None else None)
                 del ro2
+            except StopIteration as e:
+                cpu["mpi_like_cores"] = {"value": None, "sample": str(e)}
             except Exception as e:
                 cpu["mpi_like_cores"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
         except Exception as e:
