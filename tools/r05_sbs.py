@@ -13,15 +13,20 @@ P, net, methods = lb.P, lb.net, lb.methods
 sp, ms = P.trib[0], P.main
 DT = bench.DT
 mk = lambda spec, **kw: m.RoutingDomain(spec.net, DT, methods, frac_future=lb.frac, max_window=W, device=0, lakes=lakes_for_domain(lb.lakes, spec, net.N) if lb.lakes is not None else None, **lb.uh_of(spec), **kw)
-share = bench.main_sweep_share(ms, methods, m)
-d_t = mk(sp, export_reaches=sp.export_local, sweep_share=1.0 - share)
-d_m = mk(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good, sweep_share=share, sweep_priority=1)
-print("stages trib0", d_t.schedule(), "main", d_m.schedule(), "reaches", sp.n_real, ms.n_real, flush=True)
-ro_t = [lb.forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
-ro_m = [lb.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
-rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=lb.dev) for _ in range(2)]
+def create():
+    share = bench.main_sweep_share(ms, methods, m)
+    d_t = mk(sp, export_reaches=sp.export_local, sweep_share=1.0 - share)
+    d_m = mk(ms, halo_reaches=ms.halo_local, halo_good=ms.halo_good, sweep_share=share, sweep_priority=1)
+    print("stages trib0", d_t.schedule(), "main", d_m.schedule(), "reaches", sp.n_real, ms.n_real, flush=True)
+    ro_t = [lb.forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
+    ro_m = [lb.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
+    rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=lb.dev) for _ in range(2)]
+    return d_t, d_m, ro_t, ro_m, rec0
+if not os.environ.get('LATE_CREATE'):
+    d_t, d_m, ro_t, ro_m, rec0 = create()
 # records of the other partitions: zeros with the right header are not accepted; reuse rank 0's own record layout is per partition -> route the others once
 recs = {}
+hoard = []
 for p in range(1, 8):
     s2 = P.trib[p]
     base, n = ms.halo_base[p]
@@ -31,7 +36,10 @@ for p in range(1, 8):
     d.run_device(W, 0.0, ro.data_ptr()); d.sync()
     r = torch.empty(d.boundary_size(W, s2.export_local.size), dtype=torch.float64, device=lb.dev)
     d.export_boundary(r.data_ptr()); d.sync(); recs[p] = r
+    if os.environ.get('KEEP_RECS'): hoard.extend(torch.empty_like(r) for _ in range(6))
     d.close(); del d, ro; torch.cuda.empty_cache()
+if os.environ.get('LATE_CREATE'):
+    d_t, d_m, ro_t, ro_m, rec0 = create()
 def stamp(lbl, t0, out): out.append((lbl, round(time.perf_counter() - t0, 3)))
 for mode in sys.argv[3:] or ["plain"]:
     for k in range(6):
