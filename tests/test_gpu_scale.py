@@ -146,7 +146,8 @@ def test_bench_operating_point_sweep_equals_stage_launches(hip_lib, monkeypatch)
     """The driver's bench command at its own operating point: 100 000 reaches, windows of 16 384 steps, 25 windows queued
     without a synchronisation in between (5 + 20, as `bench.py --steps 20 --warmup 5` does), with the regroupings that
     fall into them (before windows 2, 3, 11 and 19).  The persistent sweep must finish (no ierr 93) and leave the same bits
-    as one launch per stage (MZR_KWT_SWEEP=0): particle state, last discharge and the interval mean of every reach."""
+    as one launch per stage (MZR_KWT_SWEEP=0): particle state, last discharge and the interval mean of every reach -- in both flavours
+    of the sweep (three and four particle slots per lane of the 4-lane class)."""
     import torch
     import bench
     dev = torch.device("cuda", 0)
@@ -156,8 +157,9 @@ def test_bench_operating_point_sweep_equals_stage_launches(hip_lib, monkeypatch)
     pool = [bench.device_runoff(torch, net.H, W, k * W, 7, dev) for k in range(2)]
     torch.cuda.synchronize()
 
-    def route(sweep):
+    def route(sweep, wide=False):
         monkeypatch.setenv("MZR_KWT_SWEEP", "1" if sweep else "0")
+        monkeypatch.setenv("MZR_KWT_KC_WIDE_RUN", "1" if wide else "0")
         dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W)
         for k in range(NWIN):
             dom.run_device(W, k * W * DT, pool[k % 2].data_ptr())
@@ -173,6 +175,10 @@ def test_bench_operating_point_sweep_equals_stage_launches(hip_lib, monkeypatch)
     sb, Qb, Mb = route(False)
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb)), "particle state differs between the sweep and one launch per stage"
     assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb)
+    # the sweep flavour the 375 k-reach shards pick by themselves (4-lane groups of 15 entries, kernels_kwt_wide.hip), here by force
+    sw, Qw, Mw = route(True, wide=True)
+    assert all(np.array_equal(x, y) for x, y in zip(sw, sb)), "particle state differs between the wide sweep flavour and one launch per stage"
+    assert np.array_equal(Qw, Qb) and np.array_equal(Mw, Mb)
     assert np.isfinite(Qa).all() and (Qa >= 0).all() and sa[0].max() <= 20
 
 
