@@ -341,9 +341,13 @@ def test_fortran_host_drives_the_c_abi(hip_lib, oracle_lib, tmp_path):
         assert rep["max_rel"] <= REL_TOL, (methods[ix], rep)
 
 
-def test_partitioned_network_equals_whole(hip_lib):
+@pytest.mark.parametrize("kc_wide", ["0", "1"])
+def test_partitioned_network_equals_whole(kc_wide, hip_lib, monkeypatch):
     """Sub-basin partitioning with one-way boundary records (mainstem on partition 0) reproduces the
     unpartitioned run bit for bit: every reach sees exactly the upstream records it would have seen.
+    kc_wide = 1: the partitions route through the wide flavour of the KWT sweep (the one the 375 k-reach shards of the
+    north-star configuration pick; here by force, with export and halo reaches: its FULL instantiation), the whole
+    network through the default one.
     All partitions run on this one GPU; the transport is an in-process loopback (the RCCL path is
     the same code with torch.distributed send/recv, tests/test_partition.py covers it over gloo)."""
     import torch
@@ -359,6 +363,11 @@ def test_partitioned_network_equals_whole(hip_lib):
     methods = [m.KWT, m.IRF, m.SUM]
     whole = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=W)
     Qw = whole.run(ro)
+    steps2 = 6 * W
+    ro2 = m.make_runoff(net.H, steps2, seed=10, storm_prob=0.05, storm_amp=3e-6)
+    whole2 = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=W)
+    Qw2 = whole2.run(ro2)
+    monkeypatch.setenv("MZR_KWT_KC_WIDE_RUN", kc_wide)
 
     box = {}
 
@@ -397,10 +406,6 @@ def test_partitioned_network_equals_whole(hip_lib):
     # the same with the exchange pipelined by one window (no sync between windows, as bench.py runs it):
     # interval means and the last window must come out the same
     box.clear()
-    steps2 = 4 * W
-    ro2 = m.make_runoff(net.H, steps2, seed=10, storm_prob=0.05, storm_amp=3e-6)
-    whole2 = m.RoutingDomain(net, 3600.0, methods, frac_future=ff, uh_offset=uh_off, uh=uh, max_window=W)
-    Qw2 = whole2.run(ro2)
     routers2 = []
     for rank in range(nparts):
         class T2:
