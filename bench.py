@@ -39,6 +39,121 @@ DT = 3600.0
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+LINE_LIMIT = 4096          # bytes of the LAST stdout line (the driver keeps a bounded tail of stdout and parses that line)
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the detail file keeps every digit)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d.get(k)) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _cpu_summary(c):
+    """cpu_baseline of the line: value / cores / kind / cpu_model and the two MPI-shaped forms as {value, cores}; prose stays in the detail"""
+    if not isinstance(c, dict):
+        return None
+    out = _pick(c, ("value", "unit", "cores", "kind", "host_cores", "cpu_model", "one_thread"))
+    s_ = c.get("sample")
+    if isinstance(s_, str):
+        out["sample"] = s_[:160]
+    for k in ("mpi_like", "mpi_like_cores"):
+        v = c.get(k)
+        if isinstance(v, dict) and v.get("value") is not None:
+            out[k] = _pick(v, ("value", "cores", "processes", "threads_per_process"))
+    return out
+
+
+def _roof_summary(r):
+    if not isinstance(r, dict):
+        return None
+    return _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "bytes_per_reach_step",
+                     "avg_launch_us", "launches", "min_launch_us", "max_launch_us"))
+
+
+def _config_summary(c):
+    """one flat object per full-size configuration"""
+    if not isinstance(c, dict):
+        return None
+    if c.get("value") is None:
+        return {"value": None, "error": str(c.get("error"))[:160]}
+    roof = c.get("roofline") or {}
+    mod = c.get("model_8gpu") or {}
+    cpu = c.get("cpu_baseline") or {}
+    par = c.get("parity") or {}
+    main = (c.get("domains") or {}).get("main") or {}
+    slow = mod.get("slowest_tributary_s")
+    out = {"value": _r(c.get("value")), "window_steps": c.get("window_steps"), "kernel": roof.get("kernel"), "frac": _r(roof.get("frac"), 4),
+           "avg_launch_us": _r(roof.get("avg_launch_us"), 5), "parity": par.get("partitioned_equals_whole_bit_for_bit"),
+           "model_8gpu": _r(mod.get("value")), "rank0_over_slowest": _r(mod.get("rank0_side_by_side_s") / slow, 4) if slow else None,
+           "record_bytes_per_window": main.get("record_bytes_per_window"),
+           "cpu": _r(cpu.get("value")), "cpu_cores": cpu.get("cores")}
+    for k in ("mpi_like", "mpi_like_cores"):
+        v = cpu.get(k)
+        if isinstance(v, dict) and v.get("value") is not None:
+            out["cpu_" + k] = {"value": _r(v["value"]), "cores": v.get("cores")}
+    return out
+
+
+def compact_line(detail, detail_path="bench_detail.json"):
+    """The ONE line the driver parses, <= LINE_LIMIT bytes: contract fields, `roofline`, `cpu_baseline` and one flat summary per
+    full-size configuration.  Per-launch lists, per-domain arrays, histograms and prose live in the detail object (bench_detail.json)."""
+    cfg = detail.get("config") or {}
+    out = {k: _r(detail.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                          "vs_baseline", "dtype", "data")}
+    c2 = _pick(cfg, ("baseline_config", "route_opt", "reaches_total", "reaches_per_gpu", "window_steps", "stages", "simulated_years_per_wallclock_day",
+                     "kernel_time_fraction"))
+    c2 = {"workload": str(cfg.get("workload", ""))[:420], **c2}
+    out["config"] = c2
+    for k in ("rccl_ranks", "backend"):
+        if k in detail:
+            out[k] = detail[k]
+    out["roofline"] = _roof_summary(detail.get("roofline"))
+    out["cpu_baseline"] = _cpu_summary(detail.get("cpu_baseline"))
+    for k in ("value_with_h2d", "value_with_h2d_f64"):
+        if isinstance(detail.get(k), (int, float)):
+            out[k] = _r(detail[k])
+    ss = detail.get("single_step")
+    if isinstance(ss, dict):
+        out["single_step"] = {"value": _r(ss.get("value")), "pipelined": _r(ss["pipelined"].get("value")) if isinstance(ss.get("pipelined"), dict) else None}
+    if detail.get("kwt_sweep_retries") is not None:
+        out["kwt_sweep_retries"] = detail["kwt_sweep_retries"]
+    if isinstance(detail.get("configs"), dict):
+        out["configs"] = {k: _config_summary(v) for k, v in detail["configs"].items()}
+    out["detail"] = detail_path
+    out["error"] = None if detail.get("error") is None else str(detail["error"])[:300]
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:      # never print a line the driver cannot keep: drop the optional parts, largest first
+        for k in ("configs", "single_step", "value_with_h2d_f64", "value_with_h2d"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
+
+
+def emit(detail):
+    """detail -> bench_detail.json (beside bench.py, and under gpurun_out/ so that it comes back from a GPU box), compact line -> stdout (last line)"""
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    god = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(god):
+        paths.append(os.path.join(god, "bench_detail.json"))
+    for p_ in paths:
+        try:
+            with open(p_, "w") as f:
+                json.dump(detail, f)
+        except OSError:
+            pass
+    sys.stdout.flush()
+    print(compact_line(detail), flush=True)
+
+
 # BASELINE.json configs as one GPU sees them: c2 = the headline (~100 k reaches, KWT); c3-c5 = one of eight shards
 # (SURVEY.md 8: ~3 M / 8 KWT; ~5 M / 8 IRF + Muskingum-Cunge; ~3 M / 8 diffusive wave, 1 % lakes, floodplains).
 # `dominant` = the method whose kernel the roofline object describes, `bytes` = SURVEY.md 8(d) bytes per reach-step
@@ -179,10 +294,17 @@ def cpu_mpi_like(domains, frac, runoff_of, methods, uh_of=None, lakes_of=None, t
         slowest = max(b for _, b in res)
         tried[str(thr)] = total / slowest
         if best is None or total / slowest > best[0]:
-            best = (total / slowest, thr, slowest, wall)
-    value, threads, slowest, wall = best
+            best = (total / slowest, thr, slowest, wall, res)
+    value, threads, slowest, wall, res = best
+    # why P ranks need not be P times one rank: value = all reach-steps / the SLOWEST process's time, so it is bounded by the largest
+    # domain of the decomposition (balance = mean process time / slowest; the reference's rule caps a tributary domain at N / P reaches,
+    # which at large P leaves few big domains and many tiny ones) and by what P processes streaming particle lists leave each other
+    # of the host's memory system (seconds per reach-step of the slowest process against the 1-process figure in `one_thread`)
+    times = [b for _, b in res]
     return {"value": value, "unit": "reaches*timesteps/s", "processes": len(doms), "threads_per_process": threads, "by_threads_per_process": tried,
             "cores": len(doms) * threads, "kind": "reference", "timed_s_slowest_process": slowest, "wall_s_with_case_io": wall,
+            "balance": float(np.mean(times) / slowest), "reaches_largest_domain": int(max(d.net.N for d in doms)),
+            "reach_steps_per_s_of_the_slowest_process": float(max(a / b for a, b in res if b == slowest)),
             "sample": f"{len(doms)} tributary domains of the reference's decomposition, one ref_route process each, side by side, {smp} steps timed after {spin}; "
                       "mainstem domain and the per-step gather / scatter of mpi_route left out"}
 
@@ -560,8 +682,8 @@ class Loopback:
                 cpu["mpi_like_cores"] = cpu_mpi_like_cores(net, self.frac, lambda dm, n: ro2[:n, dm.hru_global], methods, uh_of=uh_pair,
                                                            lakes_of=lk2 if self.lakes is not None else None)
                 del ro2
-            except StopIteration as e:
-                cpu["mpi_like_cores"] = {"value": None, "sample": str(e)}
+            except StopIteration:      # (not measured in this run: no key rather than a null)
+                pass
             except Exception as e:
                 cpu["mpi_like_cores"] = {"value": None, "sample": f"failed: {type(e).__name__}: {e}"}
         except Exception as e:
@@ -651,21 +773,49 @@ def main():
     if args.loopback:
         return loopback_bench(args, torch, m, uhmod)
 
+    # `--gpus N` is the rank count.  Launched through torch.distributed.run (WORLD_SIZE set) it must agree with it; launched PLAIN
+    # (`python bench.py --gpus N`, no WORLD_SIZE) the process launches the N ranks itself, one per visible GPU, and passes their exit
+    # code on (mpi_process.f90:1088-1342 is what the N ranks replace).  Fewer than N devices is an error unless
+    # MZR_BENCH_SINGLE_DEVICE=1 (all ranks on cuda:0, records over gloo: the test of the N-rank protocol on a one-GPU box).
+    single_dev = bool(os.environ.get("MZR_BENCH_SINGLE_DEVICE"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not single_dev:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible; one rank per GPU is the rule "
+                             "(MZR_BENCH_SINGLE_DEVICE=1 runs all ranks on cuda:0 over gloo, a protocol test and not a measurement)")
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if single_dev:
+            env.setdefault("MZR_BENCH_BACKEND", "gloo")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("MZR_BENCH_SINGLE_DEVICE"):      # debugging aid: several ranks share cuda:0 (gloo transport)
+    if single_dev:      # several ranks share cuda:0 (gloo transport)
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     dist = None
     backend = "nccl"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MZR_BENCH_BACKEND", "nccl")   # "gloo" only for single-GPU debugging
+        backend = os.environ.get("MZR_BENCH_BACKEND", "gloo" if single_dev else "nccl")   # "gloo" only on a one-GPU box
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()                   # what the communicator reports is what the line says
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -1131,7 +1281,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "reaches*timesteps/s", "value": value, "unit": "reaches*timesteps/s",
-            "n_gpus": world, "steps": K, "warmup": KW,
+            "n_gpus": world, "rccl_ranks": (world if (dist is not None and backend == "nccl") else 0), "backend": (backend if dist is not None else None),
+            "steps": K, "warmup": KW,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": args.config, "route_opt": cfg["methods"],
@@ -1150,7 +1301,7 @@ def main():
             "kwt_sweep_arrivals": sweep_arr, "kwt_sweep_retries": sweep_retries,
             "roofline": roof, "cpu_baseline": cpu, "configs": configs, "error": post_error,
         }
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1035,14 +1035,22 @@ def test_bench_two_ranks_equal_one_rank(tmp_path, hip_lib, ranks):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     two = str(tmp_path / "many")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common + ["--dump", two],
-                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    # two launch shapes: N = 2 through torch.distributed.run (the driver's documented shape), N = 8 as the PLAIN command
+    # `python bench.py --gpus 8 ...` with no WORLD_SIZE -- bench.py launches its eight ranks itself
+    launcher = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                 "--master-port", str(port)] if ranks == 2 else [sys.executable])
+    env2 = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if ranks != 2:
+        env2.pop("MZR_BENCH_BACKEND")          # the plain command picks gloo itself when all ranks share one device
+    r2 = subprocess.run(launcher + [os.path.join(root, "bench.py"), "--gpus", str(ranks)] + common + ["--dump", two],
+                        cwd=root, env=env2, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
-    line = [l for l in r2.stdout.splitlines() if l.startswith("{")][-1]
+    line = r2.stdout.strip().splitlines()[-1]      # the LAST stdout line is the one the driver parses
     import json
+    assert len(line) < 4096
     j = json.loads(line)
     assert j["n_gpus"] == ranks and j["config"]["reaches_total"] == total and j["value"] > 0
+    assert j["backend"] == "gloo" and j["rccl_ranks"] == 0      # (one GPU here: RCCL carries nothing; on N GPUs rccl_ranks = N)
     assert j["config"]["baseline_config"] == "c3" and "sub-basin partitions" in j["config"]["workload"]
     a = np.load(one + ".rank0.npz")
     parts = [np.load(f"{two}.rank{r}.npz") for r in range(ranks)]
