@@ -128,8 +128,6 @@ __device__ __forceinline__ void kwt_beat(const MzrDev &d, int k, int v) {
 #define MZR_KWD_OUT(w, slot) ((int)(((w) >> (21 + 5 * (slot))) & 31ull))
 #define MZR_KWD_OUTMASK(slot) (31ull << (21 + 5 * (slot)))
 #define MZR_KWD_ALLOUT (((MZR_OB_RING * 5 + 21) >= 64 ? ~0ull : ((1ull << (MZR_OB_RING * 5 + 21)) - 1ull)) & ~((1ull << 21) - 1ull))      // the counts of every slot
-// kwOwn: steps of the window whose at-rest list is in memory (low 16 bits), its particle count above them
-#define MZR_KWO_OWN(w) ((int)(((w) >> 16) & 31ull))
 typedef unsigned long long mzr_word;
 __device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const mzr_word *wp, int wneed, mzr_word *word = nullptr, int s = -1, int reach = -1) {
   long long t0 = 0;
@@ -171,7 +169,7 @@ __device__ __forceinline__ bool kwt_wait_deps(const MzrDev &d, const mzr_word *w
         const unsigned long long bad = __ballot(v < wneed);
         const int first = __ffsll((long long)bad) - 1;
         if (mzr_lane() == first)
-          mzr_raise_stall(d, 20, reach, s, wp ? (int)((wp >= d.kwOwn && wp < d.kwOwn + d.N) ? wp - d.kwOwn : wp - d.kwDone) : -1, (int)(w & 0xffffffffull), wneed, -1, first, __popcll(bad), now - t0, d.swHead);
+          mzr_raise_stall(d, 20, reach, s, wp ? (int)(wp - d.kwDone) : -1, (int)(w & 0xffffffffull), wneed, -1, first, __popcll(bad), now - t0, d.swHead);
         return true;
       }
       vlast = v;
@@ -601,16 +599,15 @@ __device__ __forceinline__ KwtStep kwt_step(const MzrDev &d, int t) {
 // Reaches that do not route particles: headwaters (kwt_route.f90:181-205), lake reaches
 // (lake_route replaces kwt_rch) and halo reaches of a partition (replay of the imported record).
 template <bool FULL, bool PERS>
-__device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int ltEnd, int tMul = 1, int tAdd = 0) {
+__device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int ltEnd) {
   const int N = d.N;
   unsigned long long st_head = 0;
   int r = -1, t = -1;
   bool act = false;
   if (item < ltEnd) {
     r = d.kwtLight[item];
-    const int tb = s - d.sigma[r];
-    t = tb * tMul + tAdd;      // (a sweep that visits in blocks of tMul steps: step tAdd of block tb)
-    act = tb >= 0 && t < d.W;
+    t = s - d.sigma[r];
+    act = t >= 0 && t < d.W;
   }
   if (PERS) {   // a lake needs the discharge of its upstream reaches, a halo reach overwrites the outbox its downstream reach read two steps ago
     const bool halo = act && FULL && d.haloSlot && d.haloSlot[r] >= 0;
@@ -701,40 +698,8 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 #ifndef MZR_KWT_OCC
 #define MZR_KWT_OCC 4      // wavefronts per SIMD the kernels are compiled for: 16 one-wavefront workgroups per CU is what the device holds (round 5: 5 -> 4, c3 shard 346.2 -> 342.8 ms)
 #endif
-#ifndef MZR_KWT_SPLIT
-#define MZR_KWT_SPLIT 0      // 1: the split 16-lane pass of round 4 (kwt_reach, SPLIT)
-#endif
 #ifndef MZR_KWT_POOL
 #define MZR_KWT_POOL 240   // entries of each of the four LDS work arrays of a wavefront: 60 per 16-lane reach, 30 per 8-lane reach
-#endif
-// Instruction accounting (tools/kwt_dup.sh): a section executed MZR_DUP_x times leaves the same results and, under
-// rocprofv3 --pmc SQ_INSTS_VALU, its instruction count as the difference to the plain build
-#ifndef MZR_DUP_MERGE
-#define MZR_DUP_MERGE 1
-#endif
-#ifndef MZR_DUP_THIN
-#define MZR_DUP_THIN 1
-#endif
-#ifndef MZR_DUP_KINWAV
-#define MZR_DUP_KINWAV 1
-#endif
-#ifndef MZR_DUP_INTERP
-#define MZR_DUP_INTERP 1
-#endif
-#ifndef MZR_DUP_COUNT
-#define MZR_DUP_COUNT 1
-#endif
-#ifndef MZR_DUP_STORES
-#define MZR_DUP_STORES 1
-#endif
-#ifndef MZR_DUP_WAIT
-#define MZR_DUP_WAIT 1
-#endif
-#ifndef MZR_DUP_STAGE
-#define MZR_DUP_STAGE 1
-#endif
-#ifndef MZR_THIN_LDS
-#define MZR_THIN_LDS 1     // remove_rch with the errors and the alive list in LDS (0: in registers and a bit mask, rounds 2-3)
 #endif
 #ifndef MZR_KWT_KTB
 #define MZR_KWT_KTB 4      // entries per lane an 8-lane group can thin (capacity 8 * KTB - 1, and at most its slice of the pool)
@@ -746,28 +711,14 @@ __device__ __forceinline__ bool kwt_light(const MzrDev &d, int s, int item, int 
 // PERS: the persistent sweep -- wait for the reaches this step depends on, exchange outbox rows and
 // discharge with other wavefronts through sc1 accesses, publish the step in kwDone.  Returns bit 0: the
 // reach needs more than `cap` entries, bit 1: the sweep is abandoned (error raised somewhere).
-// KBLK > 1 (persistent sweep only): a VISIT takes the reach through the KBLK consecutive steps [KBLK tb, KBLK tb + KBLK) of block
-// tb = s - stage: the record is fetched and decoded once, the reach's own list is loaded once, stays in the group's LDS slice from
-// step to step (what is left at rest after a step is moved to the front of the slice instead of written out and read back) and is
-// written once; the reach's own previous step is waited for once (it is this visit's own work from the second step on), and the
-// progress words of the upstream and downstream reaches are polled again only when the words of the last poll do not already
-// cover the step (an upstream reach is usually a whole block ahead: one poll per visit).  Discharge, outbox row and the progress
-// word are still published step by step, so a downstream reach follows one STEP behind, not one block.  kFirst: the first step
-// of the block this group routes (> 0: a narrower group of the same wavefront ran out of room there and handed the reach on).
-// KBLK == 1: one step per call, t = (s - stage) * tMul + tAdd (the stage launches; the confluences of more than two reaches
-// and single-step windows of the sweep).
-template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN, bool PERS, int KBLK>
-__device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
-                                         int offIn, int cap, double *sA, double *sB, double *sC, double *sD, double *ctxIn,
-                                         int kFirst = 0, int tMul = 1, int tAdd = 0) {
-  constexpr bool BLK = KBLK > 1;
-  static_assert(!BLK || (PERS && !GEN), "blocks of steps: the persistent sweep's binary-confluence passes");
+// One step of the reach per call: t = s - stage.
+template <bool FULL, bool GEN, int G, int KS, int OS, bool CAN_THIN, bool PERS>
+__device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec *recs, int item, bool have, int lastItem,
+                                         int off, int cap, double *sA, double *sB, double *sC, double *sD, double *ctx) {
   bool ovf = false;
-  int ovfStep = 0;         // (BLK) step of the block at which the reach outgrew this group
-  bool failed = false;     // (BLK) an error was raised for this reach: its remaining steps are left alone
   // The sweep is as fast as its slowest chain of passes, and those are the wide ones (long particle lists, thinning):
   // they go first whenever the SIMD has a choice.
-  const bool boost = PERS && dIn.sweepPrio;      // the whole sweep of this handle runs at priority 3 (set once in k_sweep_kwt)
+  const bool boost = PERS && d.sweepPrio;      // the whole sweep of this handle runs at priority 3 (set once in k_sweep_kwt)
 #ifndef MZR_NO_PRIO
   if (G >= 16 && !PERS) __builtin_amdgcn_s_setprio(2);      // (the persistent sweep raises it after its wait: a wavefront that polls has no business in front of one that computes)
 #endif
@@ -775,13 +726,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   // the group into LDS (ctx[4..11]) and read from there when a field is needed, not held in registers
   {
     const int gl0 = mzr_lane() & (G - 1);
-    double *rc0 = ctxIn + 4;
+    double *rc0 = ctx + 4;
     for (int k = gl0; k < 8; k += G) rc0[k] = ((const double *)(recs + (have ? item : lastItem)))[k];
     grp_sync();
-    if (PERS && MZR_BEAT_ON(dIn) && have && gl0 < 4) {      // debugging aid: the record as the caches hold it against what memory holds
+    if (PERS && MZR_BEAT_ON(d) && have && gl0 < 4) {      // debugging aid: the record as the caches hold it against what memory holds
       const int *rci0 = (const int *)rc0;
       const int fresh = ldx<true>((const int *)(recs + item) + gl0);
-      if (fresh != rci0[gl0]) mzr_raise_stall(dIn, 40 + gl0, rci0[0], s, item, rci0[gl0], fresh, -1, mzr_lane(), 0, 0, dIn.swHead);
+      if (fresh != rci0[gl0]) mzr_raise_stall(d, 40 + gl0, rci0[0], s, item, rci0[gl0], fresh, -1, mzr_lane(), 0, 0, d.swHead);
     }
   }
 #ifdef MZR_KWT_TIMING
@@ -791,34 +742,13 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
 #endif
   mzr_word wword = 0;      // the progress word this lane polled
   mzr_word wSelf = 0;      // the reach's own progress word as last seen / published (its outbox counts of the other slots ride on)
-  int n_own = 0;           // at-rest particles of the reach (BLK: carried from step to step of the visit)
-  int kb = BLK ? kFirst : 0;
-#pragma unroll 1
-  for (;;) {               // the steps of the visit (BLK); once otherwise
-  // (BLK: what a step needs of the reach and the domain is read again from the record in LDS and from the kernel arguments, behind
-  // values made opaque per step -- kept live across the loop, or hoisted out of it, they spill: 340 VGPRs and 170 SGPRs did)
-  const MzrDev *dp_ = &dIn;
-  int off = offIn;
-  // (the context pointer is made opaque as an LDS pointer: a generic pointer of unknown origin would turn every access through
-  // it into a FLAT instruction, and those are not ordered with the ds_ instructions of the same wavefront -- grp_sync relies on
-  // the in-order LDS queue)
-  typedef __attribute__((address_space(3))) double *LdsPtr;
-  LdsPtr ctx3 = (LdsPtr)ctxIn;
-  if (BLK) {      // (the domain description of a blocked sweep lives in the kernel-argument segment: k_sweep_kwt; scalar loads)
-    typedef const MzrDev __attribute__((address_space(4))) *MzrDevK;
-    MzrDevK dk_ = (MzrDevK)dp_;
-    asm volatile("" : "+s"(dk_)); asm volatile("" : "+v"(off)); asm volatile("" : "+v"(ctx3));
-    dp_ = (const MzrDev *)dk_;
-  }
-  double *ctx = (double *)ctx3;
-  const MzrDev &d = *dp_;
+  int n_own = 0;           // at-rest particles of the reach
   const int lane = mzr_lane(), gl = lane & (G - 1);
   const int N = d.N;
   double *rc = ctx + 4;
   const int *rci = (const int *)rc;      // r, sigma | u0, nup flags upGood goodMask | width | CW | length | scA | scB | down, -
   const int r = uni<G>(rci[0]);
-  const int tb = have ? s - rci[1] : -1;                                  // block (BLK) or step of the reach in this launch of the schedule
-  const int tBase = BLK ? tb * KBLK : tb * tMul + tAdd;                   // first step of the visit's block
+  const int tb = have ? s - rci[1] : -1;                                  // step of the reach in this launch of the schedule
   const unsigned rcb = (unsigned)rci[3];
   const __amdgpu_buffer_rsrc_t kwRs = mzr_rsrc(d.kwQT);
   const int nup = (int)(rcb & 0xff), ng = (int)((rcb >> 8) & 15), u0 = rci[2];
@@ -830,22 +760,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   const int ns = __popc(upGood);
   const int uA = u0 + (upGood ? __ffs(upGood) - 1 : 0);
   const int uB = u0 + ((upGood & (upGood - 1u)) ? __ffs(upGood & (upGood - 1u)) - 1 : 0);
-  // Round 4, the 16-lane passes of the sweep (SPLIT): the window is as long as its longest chain of passes, and that chain is one
-  // heavy reach taking its W steps one after the other -- each step waiting for the step before.  What a step needs from the
-  // step before is the reach's own at-rest list and nothing else; what it needs from upstream is there long before (upstream
-  // reaches run up to two steps ahead).  So the pass is cut in two at both ends: (1) it waits for its upstream and downstream
-  // reaches only, fetches and MERGES the incoming particles (qexmul_rch), and only then waits for its own step t - 1; (2) it
-  // publishes its at-rest list (kwOwn) as soon as kinwav has decided who stays, and works out the step's discharge and outbox
-  // (interp_rch, the stores its downstream reach waits for: kwDone) after that.  Merge, time-step average and outbox stores
-  // leave the chain; the arithmetic and its order are untouched.  (One step per visit only: a visit of several steps waits for
-  // the reach's own previous step once per block.)
-  // (round 5: off by default -- measured +-0 at c2, where it was built for, and -1.8 % on the c3 shard: 357.9 -> 351.6 ms per window;
-  // -DMZR_KWT_SPLIT=1 compiles it in.  It needs the full 60 entries per 16-lane reach: the merge writes behind a full own list.)
-  constexpr bool SPLIT = MZR_KWT_SPLIT && PERS && !GEN && G == 16 && !BLK;
-  const int t = uni<G>((have && tb >= 0) ? tBase + kb : -1);
-  const bool live = t >= 0 && t < d.W && !(BLK && (ovf || failed || kb >= KBLK));      // (groups of one wavefront may start at different steps of their blocks: kFirst)
-  const bool firstOfVisit = !BLK || kb == kFirst;
-  const bool lastOfVisit = !BLK || kb == KBLK - 1 || t == d.W - 1;
+  const int t = uni<G>((have && tb >= 0) ? tb : -1);
+  const bool live = t >= 0 && t < d.W;
   const KwtStep ks = kwt_step(d, t);
   const double T0 = ks.T0, T1 = ks.T1;
   const double T_START = T0, T_END = T1;                    // RSTEP = 0
@@ -864,18 +780,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
     if (live) {
       if (gl < nup) { wp = d.kwDone + u0 + gl; wneed = t + 1; }
       else if (gl == nup && dn >= 0 && t >= MZR_OB_RING) { wp = d.kwDone + dn; wneed = t - (MZR_OB_RING - 1); }
-      else if (!SPLIT && firstOfVisit && gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
+      else if (gl == nup + 1 && t >= 1) { wp = d.kwDone + r; wneed = t; }     // its own previous step (another wavefront's work)
     }
-    // (BLK, later steps of a visit: the words of the last poll usually cover this step too -- the upstream reaches are a block ahead)
-#ifdef MZR_DBG_NOCOVER
-    const bool covered = false;
-#else
-    const bool covered = BLK && !firstOfVisit && __ballot(wp != nullptr && MZR_KWD_STEPS(wword) < wneed) == 0ull;
-#endif
-    if (!covered) {
-      if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
-      for (int _rep = 1; _rep < MZR_DUP_WAIT; ++_rep) { asm volatile("" ::: "memory"); if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2; }
-    }
+    if (kwt_wait_deps(d, wp, wneed, &wword, s, r)) return 2;
 #ifndef MZR_NO_PRIO
     if (G >= 16 && !boost) __builtin_amdgcn_s_setprio(2);
 #endif
@@ -901,36 +808,32 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
   // half of them -- and the count loads go away.  Otherwise counts and whole rows are fetched together.
   const bool exact = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u)) && t >= 1;
   const bool exactNext = PERS && !GEN && !upLake && !(FULL && (rcb & 0x2000u));      // the next step of the window takes the count from the progress word
-  if (!BLK) { n_own = 0; wSelf = 0; }
   if (live) {
-    int n_own_v = n_own, nrA_v = 0, nrB_v = 0;      // (BLK, later steps of the visit: the list and its count are where the step before left them)
+    int n_own_v = 0, nrA_v = 0, nrB_v = 0;
     const int gbase = lane & ~(G - 1);
-    if (!SPLIT && PERS && t >= 1 && firstOfVisit) wSelf = (mzr_word)__shfl((long long)wword, gbase + nup + 1, 64);      // (also carries the counts of the other outbox slots on)
+    if (PERS && t >= 1) wSelf = (mzr_word)__shfl((long long)wword, gbase + nup + 1, 64);      // (also carries the counts of the other outbox slots on)
     if (exact) {
-      if (!SPLIT && firstOfVisit) n_own_v = MZR_KWD_OWN(wSelf);
+      n_own_v = MZR_KWD_OWN(wSelf);
       if (ns > 0) nrA_v = MZR_KWD_OUT((mzr_word)__shfl((long long)wword, gbase + (uA - u0), 64), par);
       if (ns > 1) nrB_v = MZR_KWD_OUT((mzr_word)__shfl((long long)wword, gbase + (uB - u0), 64), par);
     } else {
-      if (!SPLIT && firstOfVisit) n_own_v = ldx<PERS>(d.kwN + r);
+      n_own_v = ldx<PERS>(d.kwN + r);
       if (!GEN && !upLake) { if (ns > 0) nrA_v = ldx<PERS>(obN + uA); if (ns > 1) nrB_v = ldx<PERS>(obN + uB); }
     }
     // exit time of the reach's last routed particle = the end of its previous step (the first at-rest element's TR, :1304): inside a
     // window of the sweep that is T0 + dt of the step before, the same expression that produced it -- one sector read (and, below,
     // written) per reach-step less; the first step of a window takes it from the state
-    // (SPLIT: everything of the reach's own state -- count, list, X0, the history sum -- is fetched behind the merge, kwt_own below)
-    const double X0 = SPLIT ? 0.0 : (PERS && t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<PERS>(d.kwTR + MZR_KWI(0, r));
-    const double hin = (d.hInflow && !SPLIT && firstOfVisit) ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
+    const double X0 = (PERS && t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<PERS>(d.kwTR + MZR_KWI(0, r));
+    const double hin = d.hInflow ? ldx<PERS>(d.hInflow + r) : 0.0;      // history sum of REACH_INFLOW, when asked for
     const double qlat_r = qlat_cur[r];
     double b1q1 = 0.0, up0 = 0.0, up1 = 0.0;
     bs.b0q0 = qlat_prev[u0]; bs.b0q1 = qlat_cur[u0];
     if (nup > 1) { bs.b1q0 = qlat_prev[u0 + 1]; b1q1 = qlat_cur[u0 + 1]; }
     if (!GEN) { up0 = ldx<PERS>(Qrow + u0); if (nup > 1) up1 = ldx<PERS>(Qrow + u0 + 1); }
-    if (!SPLIT && firstOfVisit) {
 #pragma unroll
-      for (int j = 0; j < KS; ++j) {
-        const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
-        if (!exact || k < n_own_v) { const mzr_d2 v = ldq<PERS>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
-      }
+    for (int j = 0; j < KS; ++j) {
+      const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
+      if (!exact || k < n_own_v) { const mzr_d2 v = ldq<PERS>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
     }
     if (!GEN && !upLake) {
 #pragma unroll
@@ -963,13 +866,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
     NUPS = nup + NUPR;
     const int NJ0 = n_own == 0 ? 0 : n_own - 1;
     need = NJ0 + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX);
-    if (SPLIT) need = 1;      // (the reach's own count is not known yet: checked in kwt_own; the merge writes behind the 20 entries of a full list)
     if (upLake && nup > 1) need = 0;
     if (empty) { mzr_raise(d, 40, r, t, 11); need = 0; }
-#ifdef MZR_DBG_HANDOVER
-    if (BLK && G < 16 && kb == MZR_DBG_HANDOVER) need = cap + 1;      // debugging aid: every narrow group hands its reach on at this step of the block
-#endif
-    if (need > cap) { ovf = true; ovfStep = kb; need = 0; }
+    if (need > cap) { ovf = true; need = 0; }
     const double dT10 = T1 - T0;
     bs.b0sl = (bs.b0q1 - bs.b0q0) / dT10;
     if (nup > 1) bs.b1sl = (b1q1 - bs.b1q0) / dT10;
@@ -983,7 +882,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
     if (gl == 0) {
       double *c = ctx;
       c[2] = q_up;                     // REACH_INFLOW, stored with the other results at the end
-      if (!SPLIT) { c[0] = n_own == 0 ? T0 : X0; if (firstOfVisit) c[3] = hin; }     // getusq_rch :587-596: a reach without particles starts at T0
+      c[0] = n_own == 0 ? T0 : X0; c[3] = hin;     // getusq_rch :587-596: a reach without particles starts at T0
       c[1] = qlat_r;
       if (d.kwtStat && !ovf) {
         // particle-traffic counters (mzr_set_profiling 2).  The persistent sweep keeps them per reach slot in LDS (ctx[12..15]) and
@@ -991,10 +890,10 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         // made a counted window last 5.9 s instead of 0.45 s (profiles/r05_soak.md)
         if (PERS) {
           unsigned long long *cs = (unsigned long long *)(c + 12);
-          if (!SPLIT) cs[0] += (unsigned long long)n_own;
+          cs[0] += (unsigned long long)n_own;
           cs[1] += (unsigned long long)st_up; cs[3] += 1ull | ((unsigned long long)nup << 32);
         } else {
-          if (!SPLIT) atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
+          atomicAdd(&d.kwtStat->w_in, (unsigned long long)n_own);
           atomicAdd(&d.kwtStat->w_up, (unsigned long long)st_up);
           atomicAdd(&d.kwtStat->n_route, 1ull); atomicAdd(&d.kwtStat->n_edges, (unsigned long long)nup);
         }
@@ -1002,40 +901,19 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
     }
   }
   TSTAMP(0);
-  if (BLK && live && need == 0 && !ovf) failed = true;      // (an error was raised above)
-#ifdef MZR_DBG_STOREALL
-  if (false) {
-#else
-  if (BLK && ovf && live && !firstOfVisit) {
-#endif
-    // The reach has outgrown this group in the middle of its visit: what the steps so far left at rest goes to memory, from
-    // where the wider group of this wavefront takes it up (same wavefront, program order: drained, no word needed; the
-    // count rides in the progress word the last step published).
-    const double *Q0 = sA + off, *T0p = sB + off;
-#pragma unroll
-    for (int j = 0; j < KS; ++j) { const int k2 = gl + j * G; if (k2 < n_own) stq<true>(kwRs, d.kwQT, MZR_KWI(k2, r), Q0[k2], T0p[k2]); }
-    if (gl == 0) { if (d.hInflow) stx<true>(d.hInflow + r, ctx[3]); stx<true>(d.kwN + r, n_own); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
 
   // work arrays: a fixed slice of the wavefront's LDS pool per group (GP entries: a binary
   // confluence needs at most 20 + 1 + 2 + 2*19 of them)
   if (need > 0) {
     {
       double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
-      bool stepDone = false;
       do {
         bool cold = (n_own == 0);
         int NJ = cold ? 0 : n_own - 1;
         const bool binary = !GEN && !upLake && NUPS != 1;   // GEN: launch over the confluences of more than two reaches
-        if (!SPLIT && firstOfVisit) {
 #pragma unroll
-          for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
-        }
-#pragma unroll 1
-        for (int _rep = 0; _rep < MZR_DUP_STAGE; ++_rep)
+        for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
         if (binary) {
-          if (MZR_DUP_STAGE > 1) asm volatile("" ::: "memory");
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
             const int k = gl + j * G;
@@ -1046,9 +924,9 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         grp_sync();
         TSTAMP(10);
 
-        // ---- qexmul_rch (SPLIT: behind the MZR_KW_CAP entries a full own list takes; the own list is put in front of it below)
+        // ---- qexmul_rch
         int ND;
-        double *QD = Qw + (SPLIT ? MZR_KW_CAP : NJ + 1), *TD = Tw + (SPLIT ? MZR_KW_CAP : NJ + 1);
+        double *QD = Qw + NJ + 1, *TD = Tw + NJ + 1;
         if (upLake) {      // lake outflow enters the river as one particle, getusq_rch :554-559
           if (gl == 0) { QD[0] = ldx<PERS>(Qrow + u0) / RW; TD[0] = T1; }
           ND = 1;
@@ -1065,9 +943,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
           const int nA = ns > 0 ? nrA - 2 : 0, nB = ns > 1 ? nrB - 2 : 0;
           ND = nA + nB + 1;
           bool slow = false;
-#pragma unroll 1
-          for (int _rep = 0; _rep < MZR_DUP_MERGE; ++_rep) {
-          if (MZR_DUP_MERGE > 1) asm volatile("" ::: "memory");
           {   // the particle at T1, led by the first basin series: once per reach (every lane of the group the same; it used to sit
               // in the loop below, where one lane of one group makes the whole wavefront issue it in every turn)
             const double CT = T1;
@@ -1143,7 +1018,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
             QD[pos] = Q_AGG; TD[pos] = CT;
             TSTAMP(12);
           }
-          }
           if (grp_any<G>(slow)) {
             KCOUNT(8, 1);
             grp_sync();
@@ -1159,41 +1033,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         TSTAMP(1);
         if (ND < 0) { mzr_raise(d, -ND, r, t, 11); break; }
         grp_sync();
-        if (SPLIT) {
-          // ---- the reach's own step t - 1 (another wavefront's work; the only dependency on the window's longest chain): its
-          // at-rest list, fetched up to its count, goes in front of the merged particles
-          const int gbase = lane & ~(G - 1);
-          mzr_word wOwn = 0;
-#ifndef MZR_NO_PRIO
-          if (!boost) __builtin_amdgcn_s_setprio(0);
-#endif
-          if (kwt_wait_deps(d, (live && t >= 1 && gl == 0) ? d.kwOwn + r : nullptr, t, &wOwn, s, r)) return 2;
-#ifndef MZR_NO_PRIO
-          if (!boost) __builtin_amdgcn_s_setprio(2);
-#endif
-          TSTAMP(25);
-          wOwn = (mzr_word)__shfl((long long)wOwn, gbase, 64);
-          const int n_own_v = exact ? MZR_KWO_OWN(wOwn) : ldx<true>(d.kwN + r);
-          const double X0 = (t >= 1 && d.W > 1) ? kwt_step(d, t - 1).T1 : ldx<true>(d.kwTR + MZR_KWI(0, r));
-          const double hin = d.hInflow ? ldx<true>(d.hInflow + r) : 0.0;
-#pragma unroll
-          for (int j = 0; j < KS; ++j) {
-            const int k = gl + j * G, kk = k < MZR_KW_CAP ? k : 0;
-            if (!exact || k < n_own_v) { const mzr_d2 v = ldq<true>(kwRs, d.kwQT, MZR_KWI(kk, r)); q[j] = v.x; ti[j] = v.y; }
-          }
-          n_own = uni<G>(n_own_v);
-          cold = (n_own == 0);
-          NJ = cold ? 0 : n_own - 1;
-          if (NJ + 1 + ((NUPS == 1 || upLake) ? 1 : IMAX) > cap || n_own > MZR_KW_CAP) { ovf = true; break; }      // (nothing of the step has been written yet)
-          Qw += MZR_KW_CAP - 1 - NJ; Tw += MZR_KW_CAP - 1 - NJ;      // entry NJ + 1 = the first merged particle
-#pragma unroll
-          for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
-          if (gl == 0) {
-            ctx[0] = n_own == 0 ? T0 : X0; ctx[3] = hin;
-            if (d.kwtStat) ((unsigned long long *)(ctx + 12))[0] += (unsigned long long)n_own;      // (SPLIT: the persistent sweep)
-          }
-          grp_sync();
-        }
         if (cold) {   // getusq_rch :587-596
           const double DT = T1 - T0;
           if (gl == 0) { Qw[0] = Qw[1]; Tw[0] = T0 - DT - DT * 0; }
@@ -1202,9 +1041,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         int size = NJ + 1 + ND;
 #ifdef MZR_KWT_TIMING
         _recSize = size;
-#endif
-#ifdef MZR_KWT_HIST
-        if (gl == 0 && (blockIdx.x & 15) == 0) { const int b = size <= 4 ? 0 : size <= 8 ? 1 : size <= 12 ? 2 : size <= 16 ? 3 : size <= 20 ? 4 : size <= 32 ? 5 : size <= 48 ? 6 : 7; atomicAdd(&d.dbgCycles[8 + b], 1ull); }
 #endif
 
         {   // kwt_rch :163-174 (minval(Q) < 0: one vote of the group)
@@ -1234,7 +1070,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
             // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
             // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
             constexpr int KT = G >= 16 ? 64 / G : MZR_KWT_KTB;      // entries before thinning: at most 60 (16 lanes), 8 * KTB - 1 (8 lanes)
-#if MZR_THIN_LDS
             // Round 4: the errors and the alive list live in LDS -- Xw[i] = error of particle i, Yw[i] = {previous, next alive
             // particle} -- instead of four registers per lane and a 64-bit mask per lane: a removal costs one broadcast read of
             // the removed particle's links, one read of the neighbour's links (even lanes the lower, odd lanes the upper
@@ -1248,9 +1083,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
             // group of the wavefront needs them)
             constexpr int KN = KT < 2 ? KT : 2;
             const bool wide = KT > KN && __ballot(NPRT >= KN * G) != 0ull;
-#pragma unroll 1
-            for (int _rep = 0; _rep < MZR_DUP_THIN; ++_rep) {
-            if (MZR_DUP_THIN > 1) { asm volatile("" ::: "memory"); MPRT = NPRT; }
             auto err0 = [&](int j) {
               const int i = gl + j * G;
               if (i <= NPRT) {
@@ -1290,7 +1122,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
               grp_sync();
               --MPRT;
             }
-            }
             {   // who is left
               mask = 0ull;
 #pragma unroll
@@ -1301,62 +1132,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
               }
               grp_sync();
             }
-#else
-            double e[KT];
-            const unsigned long long mask0 = mask;
-            unsigned long long x = 0;
-            const bool side = gl & 1;
-            int ISEL = 0;
-#pragma unroll 1
-            for (int _rep = 0; _rep < MZR_DUP_THIN; ++_rep) {
-            if (MZR_DUP_THIN > 1) { asm volatile("" ::: "memory"); MPRT = NPRT; }
-#pragma unroll
-            for (int j = 0; j < KT; ++j) {
-              const int i = gl + j * G;
-              e[j] = DBL_MAX;
-              if (i >= 1 && i < NPRT) e[j] = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
-            }
-            // Even lanes look at the alive set as it is (bit i = particle i) and re-evaluate the neighbour below the
-            // removed particle; odd lanes hold it bit-reversed (bit 63-i) and re-evaluate the neighbour above, so that
-            // both sides run the same "nearest alive bit below" twice; the first neighbour of the other side comes
-            // through the lane pair.
-            x = side ? __brevll(mask0) : mask0;
-            ISEL = 0;
-            while (MPRT >= MZR_MAXQPAR_DEV) {
-              double emin = DBL_MAX; ISEL = 0;
-#pragma unroll
-              for (int j = 0; j < KT; ++j) if (e[j] < emin) { emin = e[j]; ISEL = gl + j * G; }
-              ISEL = grp_argmin_pos<G>(emin, ISEL);         // first minimum of ABSERR (removed entries hold +Inf)
-              if (ISEL == 0 || ISEL == 0x7fffffff) { ISEL = 0; break; }   // no finite interpolation error left (NaN/Inf input)
-              const int sx = side ? 63 - ISEL : ISEL;
-              x &= ~(1ull << sx);
-              const int p1 = 63 - __clzll((long long)(x & ((1ull << sx) - 1ull)));   // own side: INDEX1(ISEL -+ 1)
-              const int c = side ? 63 - p1 : p1;
-              const int q1 = (int)dpp_u<MZR_DPP_XOR1>((unsigned)c);                  // the other side's
-              const bool valid = (side ? NPRT - c : c) > 0;
-              double en = 0.0;
-              if (valid) {   // pm: between INDEX1(pm-1) and pn; pn: between pm and INDEX1(pn+1)
-                const int p2 = 63 - __clzll((long long)(x & ((1ull << p1) - 1ull)));
-                const int far = side ? 63 - p2 : p2;
-                const int a = side ? q1 : far, b = side ? far : q1;
-                en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
-              }
-              const double eo = dpp_d<MZR_DPP_XOR1>(en);   // the other side's result
-              const double e_pm = side ? eo : en, e_pn = side ? en : eo;
-              int pm = side ? q1 : c, pn = side ? c : q1;
-              pm = pm > 0 ? pm : -1; pn = pn < NPRT ? pn : -1;
-#pragma unroll
-              for (int j = 0; j < KT; ++j) {
-                const int i = gl + j * G;
-                if (i == pm) e[j] = e_pm;
-                if (i == pn) e[j] = e_pn;
-                if (i == ISEL) e[j] = INFINITY;           // removed: never the minimum again
-              }
-              --MPRT;
-            }
-            }
-            mask = side ? __brevll(x) : x;
-#endif
           } else {
           for (int i = gl; i <= NPRT; i += G) {
             double e = DBL_MAX;
@@ -1441,9 +1216,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
           bool shock = false;
           double tes[KS];
           bool zero = false;
-#pragma unroll 1
-          for (int _rep = 0; _rep < MZR_DUP_KINWAV; ++_rep) {
-          if (MZR_DUP_KINWAV > 1) asm volatile("" ::: "memory");
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
@@ -1498,7 +1270,6 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
               }
             }
           }
-          }      // (MZR_DUP_KINWAV)
           if (!shock) {
             if (grp_any<G>(zero)) { mzr_raise(d, 20, r, t, 13); break; }
             grp_sync();          // the neighbours have read the celerities this overwrites
@@ -1650,12 +1421,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
 
         // ---- time-step average and housekeeping, kwt_rch :257-311
         int NR = 0;
-#pragma unroll 1
-        for (int _rep = 0; _rep < MZR_DUP_COUNT; ++_rep) {
-        if (MZR_DUP_COUNT > 1) { asm volatile("" ::: "memory"); NR = 0; }
 #pragma unroll
         for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
-        }
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         TSTAMP(16);
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
@@ -1667,35 +1434,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         // registers since the loads at the top
         int tq = t;
         if (G < 64) asm volatile("" : "+v"(tq));
-        if (SPLIT) {
-          // ---- the at-rest state KWAVE(NR+1:NQ2+1) and what else the reach's own next step reads, written through, drained and
-          // published (kwOwn) BEFORE the time-step average and the outbox: the next step of this reach starts here
-          const bool lastS = tq == d.W - 1;
-#pragma unroll
-          for (int j = 0; j < KS; ++j) {
-            const int k2 = gl + j * G;
-            if (k2 <= NN2) {
-              const bool first = k2 == 0;
-              stq<true>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
-              if ((first && !(d.W > 1)) || lastS) stx<true>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
-            }
-          }
-          if (gl == 0) {
-            if (lastS || !exactNext) stx<true>(d.kwN + r, NN2 + 1);
-            if (lastS) d.inflow[r] = ctx[2];
-            if (d.hInflow) stx<true>(d.hInflow + r, ctx[3] + ctx[2]);
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (gl == 0) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));
-          TSTAMP(26);
-        }
         double QNEW;
-        int _ibad = 0;
-#pragma unroll 1
-        for (int _rep = 0; _rep < MZR_DUP_INTERP; ++_rep) {
-          if (MZR_DUP_INTERP > 1) asm volatile("" ::: "memory");
-          _ibad = grp_interp_step<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW);
-        }
+        const int _ibad = grp_interp_step<G, OS>(Xw, Qw, Yw, NR + 2, T_START, T_END, gl, &QNEW);
         if (_ibad) { mzr_raise(d, 1, r, t, 15); break; }
         TSTAMP(17);
         const double Qout = QNEW * rc[2] + ctx[1];
@@ -1707,22 +1447,15 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         const bool lastStep = tq == d.W - 1;
         if (gl == 0) {
           stx<PERS>(d.Q + (size_t)tq * N + r, Qout);
-          if (!SPLIT) {
-            if ((!exactNext && lastOfVisit) || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
-            if (!PERS || lastStep) d.inflow[r] = ctx[2];
-            if (BLK) {      // the history sum of REACH_INFLOW runs along in LDS and goes to memory with the visit's last step
-              if (d.hInflow) { const double hs = ctx[3] + ctx[2]; ctx[3] = hs; if (lastOfVisit) stx<PERS>(d.hInflow + r, hs); }
-            } else if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
-          }
+          if (!exactNext || lastStep) stx<PERS>(d.kwN + r, NN2 + 1);
+          if (!PERS || lastStep) d.inflow[r] = ctx[2];
+          if (d.hInflow) stx<PERS>(d.hInflow + r, ctx[3] + ctx[2]);
         }
         TSTAMP(18);
         // record for the downstream reach: KWAVE(0:NR+1) + first waiting particle (flow, exit time)
         const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
         const bool outbox = !isOut;
-#pragma unroll 1
-        for (int _rep = 0; _rep < MZR_DUP_STORES; ++_rep)
         if (outbox || es >= 0) {
-          if (MZR_DUP_STORES > 1) asm volatile("" ::: "memory");
           const int pq = tq & (MZR_OB_RING - 1);
           int *obNw = d.obN + (size_t)pq * N;
           double *obW = d.obQT + 2 * (size_t)pq * MZR_OB_STRIDE * N;
@@ -1745,65 +1478,29 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
         }
         TSTAMP(19);
         // at-rest state: KWAVE(NR+1:NQ2+1)
-#ifdef MZR_DBG_STOREALL
-        if (BLK && !lastOfVisit) {      // debugging aid: the list goes to memory after every step as well
 #pragma unroll
-          for (int j = 0; j < KS; ++j) {
-            const int k2 = gl + j * G;
-            if (k2 <= NN2) { const bool first = k2 == 0; stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]); }
+        for (int j = 0; j < KS; ++j) {
+          const int k2 = gl + j * G;
+          if (k2 <= NN2) {
+            const bool first = k2 == 0;
+            stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
+            // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
+            if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
           }
         }
-#endif
-        if (!BLK || lastOfVisit) {
-#pragma unroll
-          for (int j = 0; j < KS; ++j) {
-            const int k2 = gl + j * G;
-            if (!SPLIT && k2 <= NN2) {
-              const bool first = k2 == 0;
-              stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
-              // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
-              if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
-            }
-          }
-        } else {
-          // (BLK) ... which the visit's next step finds at the front of the group's slice, where a load would have put it
-          double nq[KS], nt[KS];
-#pragma unroll
-          for (int j = 0; j < KS; ++j) {
-            const int k2 = gl + j * G;
-            nq[j] = nt[j] = 0.0;
-            if (k2 <= NN2) { const bool first = k2 == 0; nq[j] = first ? Q_END : Qw[NR + k2]; nt[j] = first ? TIMEI : Tw[NR + k2]; }
-          }
-          grp_sync();
-          double *Q0 = sA + off, *T0p = sB + off;
-#pragma unroll
-          for (int j = 0; j < KS; ++j) { const int k2 = gl + j * G; if (k2 <= NN2) { Q0[k2] = nq[j]; T0p[k2] = nt[j]; } }
-          grp_sync();
-        }
-        if (BLK) n_own = NN2 + 1;
-#ifdef MZR_DBG_TRACE
-        if (PERS && gl == 0 && d.t_start >= MZR_DBG_TRACE) printf("TR ts %.0f r %d t %d G %d kb %d first %d last %d nown %d nrA %d nrB %d NR %d NQ2 %d NN2 %d Qout %.17g Qend %.17g q1 %.17g t1 %.17g X0 %.17g\n", d.t_start, r, t, G, kb, (int)firstOfVisit, (int)lastOfVisit, n_own, nrA, nrB, NR, NQ2, NN2, Qout, Q_END, Qw[1], Tw[1], ctx[0]);
-#endif
         if (d.kwtStat && gl == 0) {
           if (PERS) ((unsigned long long *)(ctx + 12))[2] += (unsigned long long)(NQ2 + 2);
           else atomicAdd(&d.kwtStat->w_out, (unsigned long long)(NQ2 + 2));
         }
         TSTAMP(7); TSTAMP_WAVE(20);
         if (PERS) {   // results written through (sc1) and drained, then the step is published
-          if (SPLIT) {      // the word of this reach's step t - 1 (its outbox count of the other parity stays): published long ago by now
-            mzr_word wk = 0;
-            if (kwt_wait_deps(d, (live && tq >= 1 && gl == 0) ? d.kwDone + r : nullptr, tq, &wk, s, r)) return 2;
-            wSelf = wk;
-          }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (gl == 0) {
             const int pq = tq & (MZR_OB_RING - 1);
             const mzr_word keep = wSelf & MZR_KWD_ALLOUT & ~MZR_KWD_OUTMASK(pq);      // the other slots' counts stay (0 in the first step)
             const int nOut = isOut ? 0 : NR + 2;
             const mzr_word wNew = (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)) | ((mzr_word)(unsigned)nOut << (21 + 5 * pq)) | keep;
-            if (MZR_KWT_SPLIT && !SPLIT && !BLK) stx<true>(d.kwOwn + r, (mzr_word)(unsigned)((tq + 1) | ((NN2 + 1) << 16)));      // (read by the split 16-lane pass only; a visit of several steps waits on kwDone alone)
             stx<true>(d.kwDone + r, wNew);
-            if (BLK) wSelf = wNew;      // lane 0 of the group: the only one that reads it again
           }
           TSTAMP(22);
           kwt_beat(d, 3, 4);
@@ -1819,20 +1516,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &dIn, int s, const MzrKwtR
             }
           }
         }
-        stepDone = true;
       } while (0);
-      if (BLK && !stepDone) failed = true;      // an error was raised for this reach (the sweep is abandoned anyway)
     }
   }
-  if (!BLK) break;
-  ++kb;
-  if (__ballot(kb < KBLK && live && !ovf && !failed) == 0ull) break;      // until no group of the wavefront has a step of its block left
-  }      // steps of the visit
 #ifdef MZR_KWT_TIMING
-  if (PERS) { const MzrDev &d = dIn; TRECORD(G, _recSize, _recRem); }
+  if (PERS) { TRECORD(G, _recSize, _recRem); }
 #endif
   if ((CAN_THIN || G >= 16) && !boost) __builtin_amdgcn_s_setprio(0);
-  return (ovf ? 1 : 0) | (ovfStep << 8);
+  return ovf ? 1 : 0;
 }
 
 // Lane classes.  A routed reach is worked on by a group of adjacent lanes; how many is the host's choice
@@ -1882,7 +1573,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   if (cls == 1) {
     const int g8 = lane / GB;
     base = hbBegin + (b - nABlocks) * RB;
-    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, true, false, 1>(d, s, d.kwtRoutedB, base + g8, base + g8 < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
+    const bool ovf = kwt_reach<FULL, false, GB, KB, KB, true, false>(d, s, d.kwtRoutedB, base + g8, base + g8 < hbEnd, hbEnd - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]) & 1;
     const unsigned long long bal = __ballot(ovf);
 #pragma unroll
     for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
@@ -1890,7 +1581,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   } else if (cls == 2) {
     const int g4 = lane / GC;
     base = hcBegin + (b - nABlocks - nBBlocks) * RC;
-    const bool ovf = kwt_reach<FULL, false, GC, KC, KC, false, false, 1>(d, s, d.kwtRoutedC, base + g4, base + g4 < hcEnd, hcEnd - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]) & 1;
+    const bool ovf = kwt_reach<FULL, false, GC, KC, KC, false, false>(d, s, d.kwtRoutedC, base + g4, base + g4 < hcEnd, hcEnd - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]) & 1;
     const unsigned long long bal = __ballot(ovf);
 #pragma unroll
     for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
@@ -1918,7 +1609,7 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
       if (cls != 0) { const int sel = kwt_pick(ovfMask, g16); have = sel >= 0; item = base + (have ? sel : 0); }
       itemKeep = item;
     }
-    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false, 1>(d, s, recs, item, have, last, offA, capA, sA, sB, sC, sD, sCtx[g16]) & 1;
+    const bool ovf = kwt_reach<FULL, GEN, GA, KA, OA, true, false>(d, s, recs, item, have, last, offA, capA, sA, sB, sC, sD, sCtx[g16]) & 1;
     if (isSolo || GEN) { if (ovf) mzr_raise(d, 60, recs[have ? item : last].r, s, 10); }      // work array bounds exceeded
     else { const unsigned long long bal = __ballot(ovf); solo = (unsigned)((bal & 1ull) | (((bal >> 16) & 1ull) << 1) | (((bal >> 32) & 1ull) << 2) | (((bal >> 48) & 1ull) << 3)); }
     if (!solo && !ovfMask) break;
@@ -1926,24 +1617,15 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
 }
 
 // The rare item kinds of the persistent sweep are real calls, so that their registers are not part of the loop body's.
-// (a sweep that visits in blocks of KBLK steps takes these kinds through the block one step per call)
-template <bool FULL, int POOL, int KBLK>
+template <bool FULL, int POOL>
 __device__ __noinline__ int kwt_item_generic(const MzrDev &d, int s, int bi, double *sA, double *sB, double *sC, double *sD, double *ctx) {
   constexpr int GA = KwtCls::GA, KA = KwtCls::KA, OA = KwtCls::OA;
   const int g16 = mzr_lane() / GA;
-  int st = 0;
-#pragma unroll 1
-  for (int kb = 0; kb < KBLK; ++kb) {
-    st = kwt_reach<FULL, true, GA, KA, OA, true, true, 1>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + MZR_CTX * g16, 0, KBLK, kb);
-    if (__ballot(st & 3) != 0ull) break;
-  }
-  return st;
+  return kwt_reach<FULL, true, GA, KA, OA, true, true>(d, s, d.kwtGeneric, bi, g16 == 0, d.nG - 1, 0, POOL, sA, sB, sC, sD, ctx + MZR_CTX * g16);
 }
-template <bool FULL, int KBLK>
+template <bool FULL>
 __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
-#pragma unroll 1
-  for (int kb = 0; kb < KBLK; ++kb) if (kwt_light<FULL, true>(d, s, bi * 64 + mzr_lane(), d.nDepLight, KBLK, kb)) return true;
-  return false;
+  return kwt_light<FULL, true>(d, s, bi * 64 + mzr_lane(), d.nDepLight);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1961,11 +1643,6 @@ __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
 // that wait sleep, and give up when an error was raised or nothing has moved for seconds.
 // Results cross CUs, so state, outbox rows and discharge go through sc1 accesses (ldx / stx).
 // Headwater reaches need nothing from anybody and are filled in by k_kwt_window_init.
-// KBLK: steps of a reach per visit (kwt_reach): launch s of the schedule takes the reaches of stage j through block s - j of
-// the window, so a window of W steps is nStages + ceil(W / KBLK) - 1 launches of tickets.
-#ifndef MZR_KWT_OCC_BLK
-#define MZR_KWT_OCC_BLK 4      // wavefronts per SIMD the blocked flavour is compiled for (LDS: 9 KB per wavefront hold 4 of them anyway)
-#endif
 // Wavefronts per workgroup of the sweep.  The wavefronts of the sweep are independent of each other (no barrier, an LDS slice each);
 // workgroups of one wavefront stop at 16 per CU -- four per SIMD -- whatever registers and LDS would allow (the census of
 // mzr_sweep_kwt_capacity: 4 008 of them on 256 CUs with 8 KB as with 9 KB of LDS each), so more than four wavefronts per SIMD
@@ -1976,8 +1653,8 @@ __device__ __noinline__ bool kwt_item_light(const MzrDev &d, int s, int bi) {
 #ifdef MZR_KWT_TU_WIDE
 namespace mzr_kwt_wide {      // (the kernel's name must differ from the first translation unit's: template instantiations are merged by the linker)
 #endif
-template <bool FULL, int POOL, int KBLK>
-__global__ void __launch_bounds__(64 * MZR_KWT_WG) __attribute__((amdgpu_waves_per_eu(KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC, KBLK > 1 ? MZR_KWT_OCC_BLK : MZR_KWT_OCC)))
+template <bool FULL, int POOL>
+__global__ void __launch_bounds__(64 * MZR_KWT_WG) __attribute__((amdgpu_waves_per_eu(MZR_KWT_OCC, MZR_KWT_OCC)))
 k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   // The domain description has ~100 fields; kept live around the item loop they spill.  They are read
   // through the kernel-argument segment instead (scalar loads, constant address space) and the
@@ -1995,17 +1672,13 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   const int wv = MZR_KWT_WG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wavefront's slice of the workgroup's LDS
   double *sA = sA_[wv], *sB = sB_[wv], *sC = sC_[wv], *sD = sD_[wv];
   double (*sCtx)[MZR_CTX] = sCtx_[wv];
-#ifdef MZR_LDS_PAD      // experiment: more LDS per workgroup, so that fewer of them fit a CU
-  __shared__ double sPad[MZR_LDS_PAD];
-  if (sEnd == -12345) { sPad[threadIdx.x] = 1.0; __syncthreads(); if (sPad[(threadIdx.x + 1) & 63] != 1.0) return; }
-#endif
   if (sEnd < 0) { mzr_census(d0.swHead + 8 * 16); return; }      // host: mzr_sweep_kwt_capacity
   if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
   if (d0.kwtStat && mzr_lane() < RC) { unsigned long long *cs = (unsigned long long *)(sCtx[mzr_lane()] + 12); cs[0] = cs[1] = cs[2] = cs[3] = 0ull; }
   const int arr = mzr_sweep_join(d0.swHead, d0.swClock);      // (a wavefront that starts behind time does not join)
   if (arr < 0) return;
   if (d0.sweepPrio) __builtin_amdgcn_s_setprio(3);      // mzr_config.sweepPriority: a small, deep domain sweeping beside a large one
-  const int Wm1 = (d0.W + KBLK - 1) / KBLK - 1;      // the window in blocks, less one
+  const int Wm1 = d0.W - 1;
   const int q0 = arr < 64 ? (arr & 7) : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7);     // HW_REG_XCC_ID: a speed hint only
   kwt_beat(d0, 5, q0); kwt_beat(d0, 3, 1); kwt_beat(d0, 4, 0);
   int nDone = 0;
@@ -2017,30 +1690,15 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
     const int q = (q0 + dq) & 7;
     const int pEnd = P[sEnd * 8 + q];
     int sCur = sBegin, pLo = P[sBegin * 8 + q], pHi = P[(sBegin + 1) * 8 + q];   // tickets [pLo, pHi) of queue q belong to launch sCur
-    // Round 5 experiment (-DMZR_KWT_TICKET_AHEAD=1, off): a wavefront draws its NEXT ticket before it works on the one it has, so that
-    // the atomic's round trip (1.5-2 k cycles of a pass of ~37 k) runs beside the pass.  Measured 2 % SLOWER (c2 440.6 -> 449.0 ms, c3
-    // shard 349.5 -> 357.7 ms): an item drawn by a wavefront that is still inside a long pass starts late, and its dependents wait
-    // (profiles/r05_experiments.md 8)
-#ifndef MZR_KWT_TICKET_AHEAD
-#define MZR_KWT_TICKET_AHEAD 0
-#endif
-    int kAhead = 0;
-    if (MZR_KWT_TICKET_AHEAD && mzr_lane() == 0) kAhead = atomicAdd(d0.swHead + q * 16, 1);
 #pragma unroll 1
     for (;;) {
       MzrDevK dk = dk0;
       asm volatile("" : "+s"(dk));
       const MzrDev &d = *(const MzrDev *)dk;
       int k = 0;
-      if (MZR_KWT_TICKET_AHEAD) {
-        k = __builtin_amdgcn_readfirstlane(kAhead);
-        if (k >= pEnd) break;
-        if (mzr_lane() == 0) kAhead = atomicAdd(d.swHead + q * 16, 1);      // (a ticket beyond the queue's end is nobody's)
-      } else {
-        if (mzr_lane() == 0) k = atomicAdd(d.swHead + q * 16, 1);
-        k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= pEnd) break;
-      }
+      if (mzr_lane() == 0) k = atomicAdd(d.swHead + q * 16, 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (k >= pEnd) break;
       if (k >= pHi) {   // the next launch, or (after a pause, or in a queue taken over from another XCD) a later one
         ++sCur; pLo = pHi; pHi = P[(sCur + 1) * 8 + q];
         if (k >= pHi) {
@@ -2065,27 +1723,24 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
           mzr_raise_stall(d, 30 + bad, -1, s, i, cv[bad], fv[bad], q, k, 0, 0, d.swHead);
         }
       }
-#ifdef MZR_DBG_SLEEP      // experiment: idle cycles per pass (x 64 clocks) -- does the sweep's throughput follow a wavefront's latency or its instructions?
-      for (int _k = 0; _k < MZR_DBG_SLEEP; ++_k) __builtin_amdgcn_s_sleep(127);
-#endif
       const int lane = mzr_lane(), g16 = lane / GA;
       const int it = IIt[i];
       const int cls = it >> 28, bi = it & 0x0fffffff;      // 0 A, 1 B, 2 generic, 3 lake / halo, 4 C
       if (cls == 3) {
-        if (kwt_item_light<FULL, KBLK>(d, s, bi)) return;
+        if (kwt_item_light<FULL>(d, s, bi)) return;
         continue;
       }
       if (cls == 2) {   // one confluence of more than two reaches, first lane group, the whole pool
-        const int st = kwt_item_generic<FULL, POOL, KBLK>(d, s, bi, sA, sB, sC, sD, &sCtx[0][0]);
+        const int st = kwt_item_generic<FULL, POOL>(d, s, bi, sA, sB, sC, sD, &sCtx[0][0]);
         if (__ballot(st & 2) != 0ull) return;
         if (st & 1) mzr_raise(d, 60, d.kwtGeneric[bi].r, s, 10);
         continue;
       }
       unsigned ovfMask = 0;
-      int stNarrow = 0;      // per lane: what the narrow pass said about its group's reach (bit 0: outgrown, from bit 8: at which step of the block)
+      int stNarrow = 0;      // per lane: what the narrow pass said about its group's reach (bit 0: outgrown)
       if (cls == 1) {
         const int g8 = lane / GB, item = bi * RB + g8;
-        stNarrow = kwt_reach<FULL, false, GB, KB, KB, true, true, KBLK>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
+        stNarrow = kwt_reach<FULL, false, GB, KB, KB, true, true>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
         if (__ballot(stNarrow & 2) != 0ull) return;
         const unsigned long long bal = __ballot(stNarrow & 1);
 #pragma unroll
@@ -2093,43 +1748,41 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
         if (!ovfMask) continue;
       } else if (cls == 4) {
         const int g4 = lane / GC, item = bi * RC + g4;
-        stNarrow = kwt_reach<FULL, false, GC, KC, KC, false, true, KBLK>(d, s, d.kwtRoutedC, item, item < d.nC, d.nC - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]);
+        stNarrow = kwt_reach<FULL, false, GC, KC, KC, false, true>(d, s, d.kwtRoutedC, item, item < d.nC, d.nC - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]);
         if (__ballot(stNarrow & 2) != 0ull) return;
         const unsigned long long bal = __ballot(stNarrow & 1);
 #pragma unroll
         for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
         if (!ovfMask) continue;
       }
-      // class A, or the reaches of this item that have outgrown their narrow group, four at a time -- from the step of the block at
-      // which they did; a reach that needs more than a quarter of the pool (GPA entries; a full binary confluence can ask for 60)
-      // is taken up once more ALONE with the whole pool (`solo`: bit g = 16-lane group g of the pass before)
+      // class A, or the reaches of this item that have outgrown their narrow group, four at a time; a reach that needs more than a
+      // quarter of the pool (GPA entries; a full binary confluence can ask for 60) is taken up once more ALONE with the whole pool
+      // (`solo`: bit g = 16-lane group g of the pass before)
       unsigned solo = 0;
-      int itemKeep = 0, stKeep = 0;
+      int itemKeep = 0;
 #pragma unroll 1
       for (;;) {
         const MzrKwtRec *recs = cls == 0 ? d.kwtRouted : cls == 1 ? d.kwtRoutedB : d.kwtRoutedC;
         const int last = (cls == 0 ? d.nA : cls == 1 ? d.nB : d.nC) - 1;
         const bool isSolo = solo != 0;
-        int item, offA = g16 * GPA, capA = GPA, kFirst = 0;
+        int item, offA = g16 * GPA, capA = GPA;
         bool have;
         if (isSolo) {
           const int g = __ffs(solo) - 1; solo &= solo - 1u;
-          item = __shfl(itemKeep, g * GA, 64); kFirst = __shfl(stKeep, g * GA, 64) >> 8; have = g16 == 0; offA = 0; capA = POOL;
+          item = __shfl(itemKeep, g * GA, 64); have = g16 == 0; offA = 0; capA = POOL;
         } else {
           item = bi * RA + g16;
           have = item <= last;
           if (cls != 0) {
             const int sel = kwt_pick(ovfMask, g16);
             have = sel >= 0; item = bi * (cls == 1 ? RB : RC) + (have ? sel : 0);
-            kFirst = __shfl(stNarrow, (have ? sel : 0) * (cls == 1 ? GB : GC), 64) >> 8;
           }
           itemKeep = item;
         }
-        const int st = kwt_reach<FULL, false, GA, KA, OA, true, true, KBLK>(d, s, recs, item, have, last, offA, capA, sA, sB, sC, sD, sCtx[g16], kFirst);
+        const int st = kwt_reach<FULL, false, GA, KA, OA, true, true>(d, s, recs, item, have, last, offA, capA, sA, sB, sC, sD, sCtx[g16]);
         if (__ballot(st & 2) != 0ull) return;
         if (isSolo) { if (st & 1) mzr_raise(d, 60, recs[have ? item : last].r, s, 10); }
         else {
-          stKeep = st;
           const unsigned long long bal = __ballot(st & 1);
           solo = (unsigned)((bal & 1ull) | (((bal >> 16) & 1ull) << 1) | (((bal >> 32) & 1ull) << 2) | (((bal >> 48) & 1ull) << 3));
         }
@@ -2163,7 +1816,7 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
   if (d.err->code != 0) return;      // a window that failed stays as it is
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (first && blockIdx.y == 0) {   // first slab of the first chunk of steps: also the per-reach bookkeeping
-    for (int r = i; r < d.N; r += gridDim.x * blockDim.x) { d.kwDone[r] = 0; d.kwOwn[r] = 0; }
+    for (int r = i; r < d.N; r += gridDim.x * blockDim.x) d.kwDone[r] = 0;
   }
   if (i >= d.nHead) return;
   const int r = d.kwtHead[i];
@@ -2248,34 +1901,31 @@ static bool kwt_full(const MzrDev &d) { return d.lakeSlot || d.haloSlot || d.exp
 // workgroup per CU high for this kernel (17 against 16), so the number is measured: the kernel itself is launched in
 // census mode (sEnd < 0: every wavefront counts itself in, stays 300 us, counts itself out; the peak is the answer).
 // cnt: two ints of device memory (swHead + 128).  Measured once per process, device and kernel flavour.
-template <bool FULL, int KBLK>
+template <bool FULL>
 static int kwt_sweep_census(const MzrDev &d, hipStream_t stream, int cus) {
   int perCu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>, 64 * MZR_KWT_WG, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_sweep_kwt<FULL, MZR_KWT_POOL>, 64 * MZR_KWT_WG, 0) != hipSuccess) return 0;
   const int api = cus * perCu * MZR_KWT_WG;      // wavefronts
   int peak[2] = {0, 0};
   int *cnt = d.swHead + 8 * 16;
   if (hipMemsetAsync(cnt, 0, 2 * sizeof(int), stream) != hipSuccess) return 0;
   const int grid = api + api / 4;
-  hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), dim3((grid + MZR_KWT_WG - 1) / MZR_KWT_WG), dim3(64 * MZR_KWT_WG), 0, stream, d, 0, -1);
+  hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL>), dim3((grid + MZR_KWT_WG - 1) / MZR_KWT_WG), dim3(64 * MZR_KWT_WG), 0, stream, d, 0, -1);
   if (hipStreamSynchronize(stream) != hipSuccess) return 0;
   if (hipMemcpy(peak, cnt, sizeof peak, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const int cap = peak[1] > 0 ? std::min(api, peak[1]) : 0;
   return 2 * cap >= api ? cap : -cap;      // (negative: a census far below the occupancy query ran beside other work -- not to be remembered)
 }
-// kblk: steps per visit of the flavour asked about (1 or MZR_KWT_KBLK; their register and LDS footprints may differ)
-int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream, int kblk) {
-  static int cached[16][2][2];
+int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream) {
+  static int cached[16][2];
   static std::mutex mu;      // handles of several host threads share the cache; the census itself must not run twice at once either
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0, cus = 0;
-  const int kx = kblk > 1 ? 1 : 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (dev >= 0 && dev < 16 && cached[dev][full][kx]) return cached[dev][full][kx];
+  if (dev >= 0 && dev < 16 && cached[dev][full]) return cached[dev][full];
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  const int c = full ? (kx ? kwt_sweep_census<true, MZR_KWT_KBLK>(d, stream, cus) : kwt_sweep_census<true, 1>(d, stream, cus))
-                     : (kx ? kwt_sweep_census<false, MZR_KWT_KBLK>(d, stream, cus) : kwt_sweep_census<false, 1>(d, stream, cus));
-  if (dev >= 0 && dev < 16 && c > 0) cached[dev][full][kx] = c;
+  const int c = full ? kwt_sweep_census<true>(d, stream, cus) : kwt_sweep_census<false>(d, stream, cus);
+  if (dev >= 0 && dev < 16 && c > 0) cached[dev][full] = c;
   return c > 0 ? c : -c;
 }
 
@@ -2303,28 +1953,27 @@ __global__ void k_sweep_heads(MzrDev d, int sBegin) {
 // marker packets in front of and behind a persistent launch were measured to slow some windows by a quarter (446 -> 560 ms, a
 // pattern with a period of eight windows; without events, and with events attached to the dispatch, every window takes 447 ms:
 // profiles/r04_experiments.md)
-// kblk: steps of a reach per visit -- 1 or MZR_KWT_KBLK (the schedule tables must have been made for it: kwt_sweep_tables)
-template <bool FULL, int KBLK>
+template <bool FULL>
 static void kwt_sweep_launch(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
   const dim3 grid((nWaves + MZR_KWT_WG - 1) / MZR_KWT_WG), block(64 * MZR_KWT_WG);
-  if (evStart && evStop) hipExtLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), grid, block, 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
-  else hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL, KBLK>), grid, block, 0, stream, d, sBegin, sEnd);
+  if (evStart && evStop) hipExtLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL>), grid, block, 0, stream, evStart, evStop, 0, d, sBegin, sEnd);
+  else hipLaunchKernelGGL((k_sweep_kwt<FULL, MZR_KWT_POOL>), grid, block, 0, stream, d, sBegin, sEnd);
 }
 #ifdef MZR_KWT_TU_WIDE
 void mzr_launch_sweep_kwt_wide(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop) {
-  if (kwt_full(d)) kwt_sweep_launch<true, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
+  if (kwt_full(d)) kwt_sweep_launch<true>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false>(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
 }
 #else
 void mzr_launch_sweep_kwt_wide(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop);      // kernels_kwt_wide.hip
-// kcWide: the flavour with MZR_KWT_KC_WIDE particle slots per lane of the 4-lane class (one step per visit only; the class lists must
-// have been cut for it: mzr_kwt_class_caps)
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk, int kcWide) {
+// kcWide: the flavour with MZR_KWT_KC_WIDE particle slots per lane of the 4-lane class (the class lists must have been cut for it:
+// mzr_kwt_class_caps)
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kcWide) {
   if (nWaves < 1 || sEnd <= sBegin) return;
   hipLaunchKernelGGL(k_sweep_heads, dim3(1), dim3(64), 0, stream, d, sBegin);
   const bool full = kwt_full(d);
-  if (kcWide && kblk <= 1) mzr_launch_sweep_kwt_wide(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
-  else if (kblk > 1) { if (full) kwt_sweep_launch<true, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, MZR_KWT_KBLK>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
-  else { if (full) kwt_sweep_launch<true, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); else kwt_sweep_launch<false, 1>(d, nWaves, sBegin, sEnd, stream, evStart, evStop); }
+  if (kcWide) mzr_launch_sweep_kwt_wide(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
+  else if (full) kwt_sweep_launch<true>(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
+  else kwt_sweep_launch<false>(d, nWaves, sBegin, sEnd, stream, evStart, evStop);
 }
 // entries a class-B / class-C group holds (the host's regrouping stays below them); kcWide: in the sweep flavour with MZR_KWT_KC_WIDE slots per lane
 int mzr_kwt_class_caps(int *capB, int *capC, int kcWide) {

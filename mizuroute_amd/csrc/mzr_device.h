@@ -21,12 +21,11 @@
 // downstream reach read in step t - MZR_OB_RING.  With two slots (rounds 1-3) a heavy reach r and its heavy downstream reach
 // d were chained both ways -- d(t) needs r(t), r(t+2) needs d(t) -- so that two steps of r cost a pass of r AND a pass of d
 // however fast r's own steps follow each other; with four (round 4), r runs up to four steps ahead and the loop no longer binds.
-// Round 5: a visit of the persistent sweep takes a reach through MZR_KWT_KBLK consecutive steps, and the ring is twice that:
-// block b + 1 of a reach overwrites what its downstream reach read in block b - 1, which is two launches of the schedule back.
-#ifndef MZR_KWT_KBLK
-#define MZR_KWT_KBLK 4     // steps of a reach per visit of the persistent KWT sweep (k_sweep_kwt<.., KBLK>); a power of two
+// (Round 5's flavour that visited a reach for four steps at a time needed a ring of eight; it was measured slower and is kept as a patch,
+// tools/patches/r06_removed_flavours.patch.)
+#ifndef MZR_OB_RING
+#define MZR_OB_RING 4
 #endif
-#define MZR_OB_RING  (2 * MZR_KWT_KBLK < 4 ? 4 : 2 * MZR_KWT_KBLK)
 static_assert((MZR_OB_RING & (MZR_OB_RING - 1)) == 0 && 21 + 5 * MZR_OB_RING <= 64, "outbox ring: a power of two whose particle counts fit the progress word");
 // rows start on 64-byte sectors (24 doubles = 192 bytes per reach): a row of 20 / 21 doubles packed back to back straddles
 // sector boundaries and every partial sector is fetched / written whole (profiles/r03a_summary.md)
@@ -158,9 +157,6 @@ struct MzrDev {
   // ---- KWT persistent sweep (k_sweep_kwt): wavefronts draw items (blocks of reaches) of the skewed schedule in
   // launch order from per-XCD ticket counters and hand results on through kwDone
   unsigned long long *kwDone; // [N] steps of the current window a reach has completed (headwaters: W from the start), particle counts above them (kernels_kwt.hip, MZR_KWD_*)
-  unsigned long long *kwOwn;                // [N] steps of the current window whose AT-REST particle list is in memory (low 16 bits; above them its count): what the
-                              // reach's own next step waits for.  A 16-lane pass publishes it before it works out the step's discharge and outbox,
-                              // the other passes together with kwDone.
   const int *down;            // [N] downstream reach (internal index), -1 = outlet
   const int *swItem;          // [nItems] stage-ordered; item = class << 28 | block index in the class list (0 A, 1 B, 2 generic, 3 lake / halo)
   const int *swLo, *swHi;     // [nItems] smallest / largest stage among the item's reaches

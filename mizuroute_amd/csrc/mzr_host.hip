@@ -44,10 +44,10 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
                           int ltBegin, int ltEnd, hipStream_t stream);
 
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream, const MzrErr *err = nullptr);
-int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream, int kblk);
+int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream);
 int mzr_kwt_class_caps(int *capB, int *capC, int kcWide = 0);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
-void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kblk, int kc);
+void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kc);
 
 namespace {
 
@@ -298,7 +298,7 @@ struct mzr_domain {
   int swKcWide = 0;               // the sweep runs the flavour with MZR_KWT_KC_WIDE particle slots per lane of the 4-lane class (class C was cut for it: kwt_regroup)
   bool swHeavyFirst = false;      // the sweep's items in order of weight regardless of stage (class lists = the *All arrays): MZR_KWT_HEAVY_FIRST
   // persistent sweep (k_sweep_kwt): items dealt to wavefronts, progress counters
-  DBuf<unsigned long long> kwOwn, kwDone; DBuf<int> down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
+  DBuf<unsigned long long> kwDone; DBuf<int> down, swItem, swLo, swHi, swRA, swP, swHead, kwtHead, kwtDepLight;
   DBuf<int> swBeat;                                // [swCap][8] per-wavefront record of the sweep (MZR_SWEEP_DEBUG=1)
   DBuf<int> rtItemR, rtItemInfo, rtRA, rtP;        // items of the Eulerian sweeps (k_sweep_route) and their per-launch tables
   int tracer = 0, solSteps = 0, solCur = 0; double time_conv_solute = 1.0, mass_conv_solute = 1.0;      // constituent routing (mzr_set_tracer / mzr_set_solute)
@@ -309,8 +309,7 @@ struct mzr_domain {
   std::vector<int> h_down, h_kwtHead, h_kwtDepLight, h_swLo, h_swHiMax;
   std::vector<int> h_sigma, h_swCode, h_swP, h_swRA;   // host copies for the stall report of a sweep that gave up (code 93)
   std::vector<MzrKwtRec> h_kwtGeneric, h_swA, h_swB, h_swC;   // class lists of the sweep, host copies (stage order)
-  int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1, swTablesK = 0;
-  int swKblk = 1, swCapK[2] = {0, 0};      // steps per visit of the sweep flavour in use; wavefront capacity of the one-step / the blocked flavour
+  int swWaves = 0, swCap = 0, swItems = 0, swTablesW = -1;
   long long kwtHeadSteps = 0;                   // headwater reach-steps filled in by the bulk kernel while the traffic counters were on
   std::vector<MzrKwtRec> h_kwtRouted;           // host copy of the routed list, stage-major (regrouped into classes A / B by load now and then)
   std::vector<int> kwtStageOff, kwtBOff, kwtCOff;   // [nStages+1] stage offsets in h_kwtRouted / in the class-B and class-C lists (kwtRoutedOff: class A)
@@ -410,7 +409,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.kwN = h->kwN.p; d.kwQT = h->kwQ.p; d.kwTR = h->kwTR.p;
   d.obN = h->obN.p; d.obQT = h->obQ.p;
   d.kwtRouted = h->kwtRouted.p; d.kwtRoutedB = h->kwtRoutedB.p; d.kwtRoutedC = h->kwtRoutedC.p; d.kwtGeneric = h->kwtGeneric.p; d.kwtLight = h->kwtLight.p;
-  d.kwDone = h->kwDone.p; d.kwOwn = h->kwOwn.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
+  d.kwDone = h->kwDone.p; d.down = h->down.p; d.swItem = h->swItem.p; d.swLo = h->swLo.p; d.swHi = h->swHi.p;
   d.swRA = h->swRA.p; d.swP = h->swP.p; d.swHead = h->swHead.p; d.swBeat = h->swBeat.p;
   d.kwtHead = h->kwtHead.p; d.nHead = (int)h->h_kwtHead.size(); d.nDepLight = (int)h->h_kwtDepLight.size();
   d.nA = (int)h->h_swA.size(); d.nB = (int)h->h_swB.size(); d.nC = (int)h->h_swC.size(); d.nG = (int)h->h_kwtGeneric.size();
@@ -653,30 +652,28 @@ int sweepGrid(mzr_handle h, int held) {
   return std::max(8, g & ~7);
 }
 
-// Wavefronts the sweep is launched with at most: what the device holds of the kernel flavour (one step per visit / MZR_KWT_KBLK steps
-// per visit: measured when first used, mzr_sweep_kwt_capacity), less a margin, times the handle's share
-void kwt_measure_cap(mzr_handle h, int kblk) {
-  const int kx = kblk > 1 ? 1 : 0;
-  if (h->swCapK[kx] < 1) {
+// Wavefronts the sweep is launched with at most: what the device holds of the kernel (measured when first used,
+// mzr_sweep_kwt_capacity), less a margin, times the handle's share
+void kwt_measure_cap(mzr_handle h) {
+  if (h->swCap < 1) {
     const bool full = h->nLake || h->nHalo || h->nExp || h->cfg.is_flux_wm;
     if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }
     int cap = 0;
-    { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream, kx ? MZR_KWT_KBLK : 1)); }
+    { MzrDev dc; memset(&dc, 0, sizeof dc); dc.swHead = h->swHead.p; dc.err = h->err.p; cap = sweepGrid(h, mzr_sweep_kwt_capacity(full, dc, h->stream)); }
     if (cap < 1) {      // census failed: a conservative grid (four wavefronts per CU always fit) and a word about it
       int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
       cap = std::max(8, cus * 4);
       fprintf(stderr, "mzr: the wavefront capacity of the KWT sweep could not be measured on device %d; sweeping with %d wavefronts\n", h->cfg.device, cap);
     }
     if (const char *e = getenv("MZR_KWT_SWEEP_WAVES")) { const int v = atoi(e); if (v > 0) cap = v; }      // experiments only: any grid, also one the device does not hold
-    h->swCapK[kx] = cap;
+    h->swCap = cap;
   }
-  h->swKblk = kblk; h->swCap = h->swCapK[kx];
 }
 
 void kwt_build_sweep(mzr_handle h) {
   if (!h->swClock.p) { try { h->swClock.alloc(2 * MZR_CLOCK_LOG); h->swClock.zero(); h->swClockN = 0; } catch (const std::string &) { (void)hipGetLastError(); } }
   if (!h->swHead.p) { h->swHead.alloc(8 * 16 + 16 + 32); h->swHead.zero(); }      // eight ticket heads (one cache line each), census and arrival counters, histogram of the start delays
-  kwt_measure_cap(h, h->swKblk);
+  kwt_measure_cap(h);
   struct It { int code, lo, hi; };
   std::vector<It> items;
   auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, size_t per) {
@@ -705,7 +702,7 @@ void kwt_build_sweep(mzr_handle h) {
   if (code.empty()) { code.push_back(0); hi.push_back(-1); }
   (void)hipStreamSynchronize(h->stream);
   h->swItem.upload(code); h->swLo.upload(lo.empty() ? std::vector<int>(1, 1 << 30) : lo); h->swHi.upload(hi);
-  if (!h->swBeat.p && getenv("MZR_SWEEP_DEBUG") && atoi(getenv("MZR_SWEEP_DEBUG")) != 0) { h->swBeat.alloc((size_t)std::max(std::max(h->swCapK[0], h->swCapK[1]), 8192) * MZR_BEAT); h->swBeat.zero(); }
+  if (!h->swBeat.p && getenv("MZR_SWEEP_DEBUG") && atoi(getenv("MZR_SWEEP_DEBUG")) != 0) { h->swBeat.alloc((size_t)std::max(h->swCap, 8192) * MZR_BEAT); h->swBeat.zero(); }
   h->swItems = (int)items.size();
   h->h_swCode = code;
   h->swTablesW = -1;          // ticket tables have to be made again
@@ -763,13 +760,11 @@ void rt_sweep_tables(mzr_handle h, int W) {
   h->rtTablesW = W;
 }
 
-// launch ranges and ticket prefix sums of a window of W steps routed in visits of kblk steps: launch s takes the reaches of stage j
-// through block s - j, so the window is its ceil(W / kblk) blocks long
-void kwt_sweep_tables(mzr_handle h, int Wsteps, int kblk) {
-  if (h->swTablesW == Wsteps && h->swTablesK == kblk) return;
-  (void)hipStreamSynchronize(h->stream);     // (a sweep still in flight reads the old tables; the census of a flavour's first use runs on this stream)
-  kwt_measure_cap(h, kblk);
-  const int W = (Wsteps + kblk - 1) / kblk;
+// launch ranges and ticket prefix sums of a window of W steps: launch s takes the reaches of stage j through step s - j
+void kwt_sweep_tables(mzr_handle h, int W) {
+  if (h->swTablesW == W) return;
+  (void)hipStreamSynchronize(h->stream);     // (a sweep still in flight reads the old tables; the census of the kernel's first use runs on this stream)
+  kwt_measure_cap(h);
   const int nS = h->nStages, nL = nS + W - 1, nI = h->swItems;
   std::vector<int> ra(nL, 0), P((size_t)(nL + 1) * 8, 0);
   int maxAct = 0;
@@ -788,7 +783,7 @@ void kwt_sweep_tables(mzr_handle h, int Wsteps, int kblk) {
   h->swRA.upload(ra); h->swP.upload(P);
   h->h_swRA = ra; h->h_swP = P;
   h->swWaves = h->swItems > 0 ? std::max(8, std::min(h->swCap, maxAct)) : 0;
-  h->swTablesW = Wsteps; h->swTablesK = kblk;
+  h->swTablesW = W;
 }
 
 }  // namespace
@@ -1570,8 +1565,8 @@ int mzr_init_state(mzr_handle h) {
           if (head.empty()) head.push_back(0);
           if (depLight.empty()) depLight.push_back(0);
           h->kwtHead.upload(head); h->kwtDepLight.upload(depLight);
-          h->kwDone.alloc(N); h->kwDone.zero(); h->kwOwn.alloc(N); h->kwOwn.zero();
-          h->swCapK[0] = h->swCapK[1] = 0;
+          h->kwDone.alloc(N); h->kwDone.zero();
+          h->swCap = 0;
           h->kwtHeadSteps = 0;
           kwt_build_sweep(h);
         }
@@ -1700,7 +1695,6 @@ static void kwt_regroup(mzr_handle h) {
   // takes their wide fall-back).
   int kcWide = byInstructions ? 1 : 0;
   if (const char *e = getenv("MZR_KWT_KC_WIDE_RUN")) kcWide = atoi(e) != 0;
-  if (const char *e = getenv("MZR_KWT_KBLK_RUN")) if (atoi(e) > 1) kcWide = 0;      // (the flavour exists for one step per visit)
   h->swKcWide = kcWide;
   if (kcWide) classCMax = 13;
   { int capB = 0, capC = 0; (void)mzr_kwt_class_caps(&capB, &capC, kcWide); classBMax = std::min(classBMax, capB - 2); classCMax = std::min(classCMax, capC - 2); }      // (room to grow by two before the fall-back)
@@ -1945,23 +1939,16 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     for (int ix = 1; ix < nR; ++ix) if (rst[ix] != st) (void)hipStreamWaitEvent(rst[ix], h->routeEvent[0], 0);
   }
   const bool prof = h->profiling;
-  // Steps of a reach per visit of the sweep (kernels_kwt.hip, kwt_reach<.., KBLK>): one (the default), or blocks of MZR_KWT_KBLK
-  // (MZR_KWT_KBLK_RUN=4).  Round 5 measured the blocked flavour (profiles/r05_kblk.md): 4 % fewer VALU, 3 % fewer SALU and 21 % fewer
-  // vector-memory instructions per window, 3 % fewer busy wave cycles -- and 12 % / 2 % MORE time at c2 / on the c3 shard, because a
-  // visit holds its wavefront slot through four steps of whatever its upstream reaches are doing (30 % of the wave cycles wait,
-  // 14 % with one step per visit), and the sweep's throughput follows the number of wavefronts that are not waiting.
-  int kblk = 1;
-  if (const char *e = getenv("MZR_KWT_KBLK_RUN")) kblk = atoi(e) > 1 ? MZR_KWT_KBLK : 1;
-  const int kc = (h->swKcWide && kblk == 1) ? 1 : 0;      // the sweep flavour with four particle slots per lane of the 4-lane class (kwt_regroup)
+  const int kc = h->swKcWide ? 1 : 0;      // the sweep flavour with four particle slots per lane of the 4-lane class (kwt_regroup)
   if (sweep) {
-    kwt_sweep_tables(h, W, kblk);
+    kwt_sweep_tables(h, W);
     RouteBufs &rb = h->route[kwtIx];
     hipStream_t sx = rst[kwtIx];
     MzrDev dk = dr[kwtIx];
     dk.swRA = h->swRA.p; dk.swP = h->swP.p;
     dk.kwtLight = h->kwtDepLight.p;
     if (h->swHeavyFirst && h->kwtAllValid) { dk.kwtRouted = h->kwtRoutedAll.p; dk.kwtRoutedB = h->kwtRoutedBAll.p; dk.kwtRoutedC = h->kwtRoutedCAll.p; }
-    const int nLaunch = nS + (W + kblk - 1) / kblk - 1;
+    const int nLaunch = nS + W - 1;
     {      // the state the queue can be taken back to, and what it takes to route this window again (mzr_sync, retryKwtQueue)
       // (not for a domain that exports a boundary record -- the record of a stalled window may have been packed and sent before
       // mzr_sync gets to route the window again -- and not when another method went through a persistent sweep in this window:
@@ -2003,9 +1990,9 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       static const int how = getenv("MZR_EVENT_MARKERS") ? atoi(getenv("MZR_EVENT_MARKERS")) : 0;      // debugging aid: 1 markers, 2 attached
       if (how == 1) {
         (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
-        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk, kc);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kc);
         (void)hipEventRecord(rb.events[rb.evUsed].second, sx);
-      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second, kblk, kc);
+      } else if (how == 2) mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, rb.events[rb.evUsed].first, rb.events[rb.evUsed].second, kc);
       else {
         if (!h->timerStream) {
           (void)hipStreamCreateWithFlags(&h->timerStream, hipStreamNonBlocking);
@@ -2013,12 +2000,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
         }
         (void)hipEventRecord(h->timerGate[0], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[0], 0);
         (void)hipEventRecord(rb.events[rb.evUsed].first, h->timerStream);
-        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk, kc);
+        mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kc);
         (void)hipEventRecord(h->timerGate[1], sx); (void)hipStreamWaitEvent(h->timerStream, h->timerGate[1], 0);
         (void)hipEventRecord(rb.events[rb.evUsed].second, h->timerStream);
       }
       ++rb.evUsed;
-    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kblk, kc);
+    } else mzr_launch_sweep_kwt(dk, h->swWaves, 0, nLaunch, sx, nullptr, nullptr, kc);
     ++rb.nLaunches;
     if (h->countTraffic) h->kwtHeadSteps += (long long)h->h_kwtHead.size() * W;
   }
@@ -2164,6 +2151,10 @@ static int retryKwtQueue(mzr_handle h, int k) {
   if (kwtIx < 0 || k < 0 || k >= (int)q.size() || !q[k].snap || !h->snapN.p) return 1;
   for (size_t j = k + 1; j < q.size(); ++j) if (!q[j].replayable) return 1;      // forcing that is no longer where it was
   if (q.size() > (size_t)k + 1 && (h->cfg.nRoutes != 1 || h->nHalo || (h->histFlags & MZR_H_RUNOFF))) return 1;      // only the plain KWT domain is taken back across windows
+  // runoff history sums: the three accumulations of the failed window ran behind its sweep and returned at once (error word set);
+  // they are made again below -- the basin-runoff sum from the window's forcing, which must still be where it was
+  const bool histRunoff = (h->histFlags & MZR_H_RUNOFF) != 0;
+  if (histRunoff && !(q[k].replayable && q[k].runoff)) return 1;
   RouteBufs &rb = h->route[kwtIx];
   const int N = h->N, W = q[k].W, nS = h->nStages;
   hipStream_t st = h->stream;
@@ -2182,6 +2173,12 @@ static int retryKwtQueue(mzr_handle h, int k) {
                          h->kwtGenericOff[sLo], h->kwtGenericOff[sHi + 1], h->kwtLightOff[sLo], h->kwtLightOff[sHi + 1], st);
   }
   mzr_launch_accum_qsum(rb.Q.p, rb.qsum.p, N, W, st, h->err.p);
+  if (histRunoff) {      // as at the end of run_window (histSteps has counted the window already)
+    const double *inst = (h->cfg.doesBasinRoute == 1 && h->qi.p) ? h->qi.p : h->qlat.p + N;
+    mzr_launch_accum_qsum(inst, h->hInst.p, N, W, st, h->err.p);
+    mzr_launch_accum_qsum(h->qlat.p + N, h->hDlay.p, N, W, st, h->err.p);
+    mzr_launch_accum_qsum(q[k].runoff, h->hBas.p, h->H, W, st, h->err.p);
+  }
   if (hipStreamSynchronize(st) != hipSuccess) return 1;
   ++h->sweepRetries;
   // the windows behind it: the bookkeeping as it was before the first of them was queued, then the same calls again

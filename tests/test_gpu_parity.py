@@ -25,19 +25,15 @@ def domain_from_golden(net, z, **kw):
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
-@pytest.mark.parametrize("window,sweep", [(1000, "1"), (7, "1"), (1, "1"), (1000, "0"), (7, "0"), (1000, "1k4"), (7, "1k4"), (1, "1k4"), (7, "1w"), (1, "1w")])
+@pytest.mark.parametrize("window,sweep", [(1000, "1"), (7, "1"), (1, "1"), (1000, "0"), (7, "0"), (7, "1w"), (1, "1w")])
 def test_matches_reference_golden(name, window, sweep, hip_lib, monkeypatch):
     """window: steps per call (1 = mzr_step-like); sweep: "1" the persistent sweeps (k_sweep_kwt, and k_sweep_route for the
     Eulerian methods whatever the window length: progress counters instead of kernel boundaries), "0" one launch per stage
-    (k_stage_kwt, k_stage).  "1k4": the flavour of the KWT sweep that visits a reach for MZR_KWT_KBLK (4) consecutive steps
-    (MZR_KWT_KBLK_RUN=4; 7 steps = a block of four and a ragged one of three; one step per visit is the default).  "1w": the flavour
+    (k_stage_kwt, k_stage).  "1w": the flavour
     with four particle slots per lane of the 4-lane class (windows of 7 and of 1 step: the reaches are regrouped after the second window)."""
     if sweep == "1w":      # the sweep flavour whose 4-lane groups hold 15 entries (kernels_kwt_wide.hip; large domains pick it by themselves)
         monkeypatch.setenv("MZR_KWT_KC_WIDE_RUN", "1")
         sweep = "1"
-    if len(sweep) > 1:
-        monkeypatch.setenv("MZR_KWT_KBLK_RUN", sweep[2:])
-        sweep = sweep[0]
     monkeypatch.setenv("MZR_KWT_SWEEP", sweep)
     monkeypatch.setenv("MZR_ROUTE_SWEEP", sweep)
     net, z = load_golden(name)

@@ -348,19 +348,22 @@ def test_window_whose_sweep_gave_up_is_routed_again(hip_lib, monkeypatch):
     def route(sweep, timeout):
         monkeypatch.setenv("MZR_KWT_SWEEP", "1" if sweep else "0")
         monkeypatch.setenv("MZR_SWEEP_TIMEOUT_S", timeout)
-        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W)
+        dom = m.RoutingDomain(net, DT, [m.KWT], frac_future=frac, max_window=W, history=m.api.H_RUNOFF)
         for k in range(K):
             dom.run_device(W, k * W * DT, ro[k * W:(k + 1) * W].data_ptr())
             dom.sync()
-        out = dom.kwt_state(), dom.flux(m.KWT, m.api.F_Q), dom.mean_q(m.KWT), dom.sweep_retries()
+        # (the runoff history sums of a window routed again -- instantaneous, delayed and basin runoff -- are made again too)
+        hist = [dom.mean(m.KWT, w) for w in (m.api.M_INST_RUNOFF, m.api.M_DLAY_RUNOFF, m.api.M_BAS_RUNOFF)]
+        out = dom.kwt_state(), dom.flux(m.KWT, m.api.F_Q), dom.mean_q(m.KWT), dom.sweep_retries(), hist
         dom.close()
         return out
 
-    sa, Qa, Ma, ra = route(True, "1e-8")
-    sb, Qb, Mb, rb = route(False, "8")
+    sa, Qa, Ma, ra, Ha = route(True, "1e-8")
+    sb, Qb, Mb, rb, Hb = route(False, "8")
     assert ra >= 1 and rb == 0, (ra, rb)
     assert all(np.array_equal(x, y) for x, y in zip(sa, sb))
     assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb)
+    assert all(np.array_equal(x, y) and np.abs(x).max() > 0 for x, y in zip(Ha, Hb))
 
 
 def test_short_window_stall_beside_another_sweep_is_reported(hip_lib, monkeypatch):
@@ -449,13 +452,13 @@ def test_queue_of_windows_is_taken_back_to_the_one_that_failed(hip_lib, monkeypa
     assert np.array_equal(Qa, Qb) and np.array_equal(Ma, Mb) and np.array_equal(Ba, Bb)
 
 
-@pytest.mark.parametrize("kblk", ["1", "4"])
-def test_c2_full_size_against_the_oracle(kblk, hip_lib, oracle_lib, monkeypatch):
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_c2_full_size_against_the_oracle(wide, hip_lib, oracle_lib, monkeypatch):
     """BASELINE.json configs[1] at its FULL size -- the bench's own 100 000-reach network -- against the C oracle (which is pinned to the
     reference): 60 steps in windows of 16 (three regroupings: all three lane classes and the fall-backs between them), storms strong enough
-    to fill the particle lists and thin them, both flavours of the persistent sweep (one step / four steps per visit).  Discharge of every
-    reach and step within 1e-6 relative, particle counts equal."""
-    monkeypatch.setenv("MZR_KWT_KBLK_RUN", kblk)
+    to fill the particle lists and thin them, both flavours of the persistent sweep (three / four particle slots per lane of the 4-lane
+    class: kernels_kwt.hip / kernels_kwt_wide.hip).  Discharge of every reach and step within 1e-6 relative, particle counts equal."""
+    monkeypatch.setenv("MZR_KWT_KC_WIDE_RUN", wide)
     net = m.make_network(100_000, seed=20240529)
     frac, _, _ = _uh(net)
     steps = 60
@@ -465,7 +468,7 @@ def test_c2_full_size_against_the_oracle(kblk, hip_lib, oracle_lib, monkeypatch)
     orc = oracle_lib.Oracle(net, DT, [m.KWT], frac, np.arange(net.N + 1, dtype=np.int32), np.ones(net.N))
     Qo = orc.run(ro)
     rep = parity_report(Qo[:, 0], Qg[:, 0])
-    print("c2 full size, steps per visit", kblk, rep)
+    print("c2 full size, wide 4-lane class", wide, rep)
     assert rep["max_rel"] <= REL_TOL, rep
     assert np.array_equal(dom.kwt_state()[0], orc.kwt_state()[0])
     assert dom.kwt_state()[0].max() >= 19      # lists full: thinning took place
