@@ -906,7 +906,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
   // confluence needs at most 20 + 1 + 2 + 2*19 of them)
   if (need > 0) {
     {
-      double *Qw = sA + off, *Tw = sB + off, *Xw = sC + off, *Yw = sD + off;
+      double *const Qw = sA + off, *const Tw = sB + off, *const Xw = sC + off, *const Yw = sD + off;
       do {
         bool cold = (n_own == 0);
         int NJ = cold ? 0 : n_own - 1;
@@ -1165,11 +1165,20 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           }
           }
           if (MPRT >= MZR_MAXQPAR_DEV) { mzr_raise(d, 62, r, t, 16); break; }
-          if (!big) {   // compact into the two free arrays, then swap roles
-            for (int i = gl; i <= NPRT; i += G) {
-              if ((mask >> i) & 1ull) { const int k = __popcll(mask & ((1ull << i) - 1ull)); Yw[k] = Qw[i]; Xw[k] = Tw[i]; }
+          if (!big) {
+            // compact in place: every lane takes its survivors into registers, then writes them to their new places (k <= i).  The
+            // arrays keep their roles, so their addresses stay base + constant for the rest of the pass (the round-2 form compacted
+            // into the two free arrays and swapped the pointers: every LDS access behind it paid an address addition)
+            constexpr int KC_ = G >= 16 ? 64 / G : MZR_KWT_KTB;
+            double cq[KC_], ct[KC_];
+#pragma unroll
+            for (int j = 0; j < KC_; ++j) { const int i = gl + j * G; cq[j] = ct[j] = 0.0; if (i <= NPRT && ((mask >> i) & 1ull)) { cq[j] = Qw[i]; ct[j] = Tw[i]; } }
+            grp_sync();
+#pragma unroll
+            for (int j = 0; j < KC_; ++j) {
+              const int i = gl + j * G;
+              if (i <= NPRT && ((mask >> i) & 1ull)) { const int k = __popcll(mask & ((1ull << i) - 1ull)); Qw[k] = cq[j]; Tw[k] = ct[j]; }
             }
-            double *p = Qw; Qw = Yw; Yw = p; p = Tw; Tw = Xw; Xw = p;
           } else if (gl == 0) {
             int k = 0;
             for (int i = 0; i <= NPRT; ++i) if (Xw[i] != INFINITY) { Qw[k] = Qw[i]; Tw[k] = Tw[i]; ++k; }
@@ -1560,7 +1569,10 @@ k_stage_kwt(MzrDev d, int s, int haBegin, int haEnd, int nABlocks, int hbBegin, 
   constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
   // entries 0..G*K-1 (the outbox write reaches index NR+2 <= size) within the group's slice of the pool
   constexpr int CAPB = GB * MZR_KWT_KTB - 1 < GPB ? GB * MZR_KWT_KTB - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
-  __shared__ double sA[POOL], sB[POOL], sC[POOL], sD[POOL];
+  // the four work arrays are one block: an entry's address in one of them is its address in the first plus a constant, which the
+  // LDS instructions carry as their immediate offset (one address register per entry instead of four)
+  __shared__ double sW[4 * POOL];
+  double *sA = sW, *sB = sW + POOL, *sC = sW + 2 * POOL, *sD = sW + 3 * POOL;
   __shared__ double sCtx[RC][MZR_CTX];
   const int b = blockIdx.x, lane = threadIdx.x & 63;
   if (!GEN && b >= nABlocks + nBBlocks + nCBlocks) {
@@ -1667,10 +1679,10 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   constexpr int GB = KwtCls::GB, RB = KwtCls::RB, KB = KwtCls::KB, GC = KwtCls::GC, RC = KwtCls::RC, KC = KwtCls::KC;
   constexpr int GPA = POOL / RA, GPB = POOL / RB, GPC = POOL / RC;
   constexpr int CAPB = GB * MZR_KWT_KTB - 1 < GPB ? GB * MZR_KWT_KTB - 1 : GPB, CAPC = GC * KC - 1 < GPC ? GC * KC - 1 : GPC;
-  __shared__ double sA_[MZR_KWT_WG][POOL], sB_[MZR_KWT_WG][POOL], sC_[MZR_KWT_WG][POOL], sD_[MZR_KWT_WG][POOL];
+  __shared__ double sW_[MZR_KWT_WG][4 * POOL];      // the four work arrays, one block (constant distances: immediate offsets of the LDS instructions)
   __shared__ double sCtx_[MZR_KWT_WG][RC][MZR_CTX];
   const int wv = MZR_KWT_WG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // this wavefront's slice of the workgroup's LDS
-  double *sA = sA_[wv], *sB = sB_[wv], *sC = sC_[wv], *sD = sD_[wv];
+  double *sA = sW_[wv], *sB = sA + POOL, *sC = sA + 2 * POOL, *sD = sA + 3 * POOL;
   double (*sCtx)[MZR_CTX] = sCtx_[wv];
   if (sEnd < 0) { mzr_census(d0.swHead + 8 * 16); return; }      // host: mzr_sweep_kwt_capacity
   if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
@@ -1743,17 +1755,17 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
         stNarrow = kwt_reach<FULL, false, GB, KB, KB, true, true>(d, s, d.kwtRoutedB, item, item < d.nB, d.nB - 1, g8 * GPB, CAPB, sA, sB, sC, sD, sCtx[g8]);
         if (__ballot(stNarrow & 2) != 0ull) return;
         const unsigned long long bal = __ballot(stNarrow & 1);
+        if (bal == 0ull) continue;      // (nearly always)
 #pragma unroll
         for (int g = 0; g < RB; ++g) ovfMask |= (unsigned)((bal >> (g * GB)) & 1ull) << g;
-        if (!ovfMask) continue;
       } else if (cls == 4) {
         const int g4 = lane / GC, item = bi * RC + g4;
         stNarrow = kwt_reach<FULL, false, GC, KC, KC, false, true>(d, s, d.kwtRoutedC, item, item < d.nC, d.nC - 1, g4 * GPC, CAPC, sA, sB, sC, sD, sCtx[g4]);
         if (__ballot(stNarrow & 2) != 0ull) return;
         const unsigned long long bal = __ballot(stNarrow & 1);
+        if (bal == 0ull) continue;
 #pragma unroll
         for (int g = 0; g < RC; ++g) ovfMask |= (unsigned)((bal >> (g * GC)) & 1ull) << g;
-        if (!ovfMask) continue;
       }
       // class A, or the reaches of this item that have outgrown their narrow group, four at a time; a reach that needs more than a
       // quarter of the pool (GPA entries; a full binary confluence can ask for 60) is taken up once more ALONE with the whole pool

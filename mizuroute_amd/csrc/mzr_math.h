@@ -17,12 +17,15 @@ namespace {
 // differ from 2/5 and 3/5 by -+2.22e-17; the factor (1 + delta*ln x) restores that.  Measured
 // against the correctly rounded power: max 2.3 ulp, mean 0.44 ulp (same class as libm's pow).
 __device__ __forceinline__ double pow_fifths(double x, bool three) {
-  if (!(x > 0.0)) return x == 0.0 ? 0.0 : NAN;
-  if (isinf(x)) return x;
+  // ordinary arguments are positive and finite: one class test (v_cmp_class_f64: positive normal or subnormal) and one rare
+  // branch for everything else -- zero -> 0, negative or NaN -> NaN, +Inf -> +Inf
+  if (__builtin_expect(!__builtin_isfpclass(x, 0x180), 0)) return x == 0.0 ? 0.0 : (x > 0.0 ? x : NAN);
   int e;
   const double m = frexp(x, &e);            // x = m * 2**e, m in [0.5,1)
   const int e1 = e - 1;                     // x = (2m) * 2**e1 ; e1 = 5k + j, j in 0..4
-  const int k = (e1 >= 0) ? e1 / 5 : -((4 - e1) / 5);
+  // k = floor(e1 / 5) without a branch on the sign (e1 >= -1074: the dividend is positive; lanes with small and large
+  // discharge share wavefronts, so a branch here ran both sides)
+  const int k = (int)((unsigned)(e1 + 1100) / 5u) - 220;
   const int j = e1 - 5 * k;
   const double z = ldexp(m, j + 1);
   const float lz = __builtin_amdgcn_logf((float)z);                        // log2(z)
