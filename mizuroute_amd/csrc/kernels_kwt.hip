@@ -1070,15 +1070,17 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
             // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
             constexpr int KT = G >= 16 ? 64 / G : MZR_KWT_KTB;      // entries before thinning: at most 60 (16 lanes), 8 * KTB - 1 (8 lanes)
-            // Round 4: the errors and the alive list live in LDS -- Xw[i] = error of particle i, Yw[i] = {previous, next alive
-            // particle} -- instead of four registers per lane and a 64-bit mask per lane: a removal costs one broadcast read of
+            // Round 4: the errors and the alive list live in LDS -- Xw[i] = error of particle i, Yw[i] = its links (round 6: one
+            // word, i << 16 | previous alive << 8 | next alive, which is also the PAYLOAD of the arg-min: the winner's links come out
+            // of the reduction with its index and the broadcast read of L[ISEL] -- one LDS round trip of the four a removal had, on
+            // the longest chain of the window -- is gone) -- instead of four registers per lane and a 64-bit mask per lane: a removal costs one broadcast read of
             // the removed particle's links, one read of the neighbour's links (even lanes the lower, odd lanes the upper
             // neighbour), the six values of the re-evaluation, and three small writes; what it no longer costs is the patch of
             // the register copies (three compares and six selects per slot) and the 64-bit mask arithmetic that found the
             // neighbours (VALU issue is what bounds the sweep).  Same errors, same MINLOC order, same survivors.
             const bool side = gl & 1;
             double *E = Xw;
-            int2 *L = (int2 *)Yw;
+            int *LK = (int *)Yw;      // LK[2 i]: the word of particle i (8-byte slots: E[i] and LK[2 i] are one ds_read2_b64)
             // (most lists that thin hold fewer than 2 G particles: the slots beyond the second are only looked at when some
             // group of the wavefront needs them)
             constexpr int KN = KT < 2 ? KT : 2;
@@ -1088,7 +1090,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               if (i <= NPRT) {
                 double ei = DBL_MAX;
                 if (i >= 1 && i < NPRT) ei = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
-                E[i] = ei; L[i] = make_int2(i - 1, i + 1);
+                E[i] = ei; LK[2 * i] = (i << 16) | (((i - 1) & 0xff) << 8) | (i + 1);
               }
             };
 #pragma unroll
@@ -1098,26 +1100,41 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               for (int j = KN; j < KT; ++j) err0(j);
             }
             grp_sync();
-            int ISEL = 0;
             while (MPRT >= MZR_MAXQPAR_DEV) {
-              double emin = DBL_MAX; ISEL = 0;
-              auto take = [&](int j) { const int i = gl + j * G; const double ev = i <= NPRT ? E[i] : DBL_MAX; if (ev < emin) { emin = ev; ISEL = i; } };
+              double emin = DBL_MAX;
+              int pay = 0;
+              // (error and word of a slot are read together and unconditionally -- one ds_read2_b64 -- and chosen by selects: a
+              // word fetched only where its error wins is a second, dependent LDS round trip per slot)
+              double evs[KT];
+              int pks[KT];
+              auto fetch = [&](int j) { const int i = gl + j * G, ii = i <= NPRT ? i : 0; evs[j] = E[ii]; pks[j] = (int)((const long long *)Yw)[ii]; };      // (the word's 8-byte slot: fuses with E[ii])
+              auto take = [&](int j) {
+                const int i = gl + j * G;
+                const double ev = i <= NPRT ? evs[j] : DBL_MAX;
+                const bool lt = ev < emin;
+                emin = lt ? ev : emin; pay = lt ? pks[j] : pay;
+              };
+#pragma unroll
+              for (int j = 0; j < KN; ++j) fetch(j);
 #pragma unroll
               for (int j = 0; j < KN; ++j) take(j);
               if (wide) {
 #pragma unroll
+                for (int j = KN; j < KT; ++j) fetch(j);
+#pragma unroll
                 for (int j = KN; j < KT; ++j) take(j);
               }
-              ISEL = grp_argmin_pos<G>(emin, ISEL);         // first minimum of ABSERR (removed entries hold +Inf)
-              if (ISEL == 0 || ISEL == 0x7fffffff) { ISEL = 0; break; }   // no finite interpolation error left (NaN/Inf input)
-              const int2 ls = L[ISEL];                     // INDEX1(ISEL - 1), INDEX1(ISEL + 1)
-              const int c = side ? ls.y : ls.x;
-              const int2 lc = L[c];
+              pay = grp_argmin_pos<G>(emin, pay);          // first minimum of ABSERR (removed entries hold +Inf); the index leads the word
+              if (pay == 0 || pay == 0x7fffffff) break;     // no finite interpolation error left (NaN/Inf input)
+              const int ISEL = pay >> 16, lsx = (pay >> 8) & 0xff, lsy = pay & 0xff;      // INDEX1(ISEL - 1), INDEX1(ISEL + 1)
+              const int c = side ? lsy : lsx;
+              const int lcw = LK[2 * c];
+              const int lcx = (lcw >> 8) & 0xff, lcy = lcw & 0xff;
               const bool valid = side ? c < NPRT : c > 0;
-              const int a = !valid ? c : side ? ls.x : lc.x, b = !valid ? c : side ? lc.y : ls.y;
+              const int a = !valid ? c : side ? lsx : lcx, b = !valid ? c : side ? lcy : lsy;
               const double en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
               grp_sync();
-              if (gl < 2) { L[c] = make_int2(side ? ls.x : lc.x, side ? lc.y : ls.y); if (valid) E[c] = en; }
+              if (gl < 2) { LK[2 * c] = (c << 16) | ((side ? lsx : lcx) << 8) | (side ? lcy : lsy); if (valid) E[c] = en; }
               if (gl == 2) E[ISEL] = INFINITY;              // removed: never the minimum again
               grp_sync();
               --MPRT;
