@@ -458,13 +458,16 @@ class Loopback:
                     base, n = ms.halo_base[p]
                     if n:
                         dom.import_boundary(W, recs[(p, k)].data_ptr(), n, base)
-                dom.sync()
+                # (no dom.sync() between the windows: the mainstem's windows overlap too since round 6 -- a synchronisation of the
+                # handle would issue the launches it keeps back for the next window; the device-wide one below does not)
+                dom.wait_import()
                 if dom.lakes is not None:
                     dom.set_lake_forcing(0, W)
                 torch.cuda.synchronize(); t1 = time.perf_counter()
-                dom.run_device(W, k * W * DT, ro.data_ptr()); dom.sync()
+                dom.run_device(W, k * W * DT, ro.data_ptr()); torch.cuda.synchronize()
                 tw.append(time.perf_counter() - t1)
                 del ro
+            dom.sync()
             times["main"] = dict(reaches=int(ms.n_real), halos=int(ms.halo_local.size), stages=dom.schedule()[0], s_per_window=tw,
                                  record_bytes_per_window=int(sum(r.numel() for (p, k), r in recs.items() if k == 0) * 8))
             for mm in methods:
@@ -543,6 +546,7 @@ class Loopback:
                         base, n = ms.halo_base[p]
                         if n:
                             d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
+                    d_m.wait_import()                        # (the record buffers may go; the mainstem's overlapping windows stay)
                     if d_m.lakes is not None:
                         d_m.set_lake_forcing(0, W)
                     d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
@@ -562,9 +566,10 @@ class Loopback:
                 if k < KS:
                     d_t.sync()
                     d_t.export_boundary(rec0[k % 2].data_ptr())
-                d_t.sync(); d_m.sync()
+                d_t.sync(); torch.cuda.synchronize()      # (not d_m.sync(): the mainstem keeps its window's last launches back for the next one)
                 if 1 <= k < KS:
                     tw.append(time.perf_counter() - t1)
+            d_m.sync()
             t_rank0 = float(np.median(tw[len(tw) // 2:]))      # (the first windows of two fresh domains hold their regroupings and table builds)
             times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share, sweep_priority_mainstem=1, mainstem_queued_from_its_own_host_thread=two_threads,
                                                what="tributary window k and mainstem window k-1 of rank 0 queued together; median of the later half of the windows")
@@ -1259,7 +1264,10 @@ def main():
             try:
                 lb = Loopback(torch, m, uhmod, cname, 8)
                 rep, whole_info, _ = lb.parity(128, 1)
-                Wc = min(CONFIGS[cname]["window"], 2048 if cname == "c4" else 4096)      # (c4: two domains of 625 k reaches side by side on one GPU; c3: the records of all eight partitions stay on this one GPU)
+                # (c3: the KWT records of all eight partitions -- particle rows of 4 400 outlets -- stay on this one GPU: windows of 4 096.  c4 / c5: the
+                # configuration's own window; their records are the outlets' discharge alone since round 6, 0.1-0.2 GB per window, so c4's windows of
+                # 3 072 -- longer than its tributary domains are deep: they overlap -- fit beside rank 0's two domains)
+                Wc = min(CONFIGS[cname]["window"], 4096)
                 tmc = lb.timing(Wc, 5)
                 roofc = lb.roofline(Wc)
                 cpuc = None if args.no_cpu_baseline else lb.cpu(args.cpu_spinup_configs, args.cpu_sample_configs)

@@ -110,11 +110,13 @@ int mzr_set_frac_future(mzr_handle h, int n, const double *frac);
    after mzr_set_network, before mzr_init_state. */
 int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHalo, const int *haloReach,
                      const int *haloGood);
-/* number of doubles of a boundary record of nReach reaches over nSteps steps:
-   header[4] | Q[nRoutes][nSteps][nReach] | BASIN_QR[nSteps+1][nReach] | obN[nSteps][nReach] |
-   obQ[nSteps][21][nReach] | obT[nSteps][21][nReach]  (the per-partition wire format); while constituent routing is on
-   (mzr_set_tracer: the same on EVERY domain, before the first mzr_boundary_size) reach_solute_flux[nRoutes][nSteps][nReach]
-   follows.  header = {format tag, nRoutes, nSteps, nReach (+ 2^30 with the constituent)}: written by
+/* number of doubles of a boundary record of nReach reaches over nSteps steps (the per-partition wire format; it carries what the
+   importing domain reads and nothing else -- mpi_process.f90:1245-1329 ships the outlets' fluxes):
+   header[4] | Q[nRoutes][nSteps][nReach]
+   | only when KWT is among routeMethods: BASIN_QR[nSteps+1][nReach] | obN[nSteps][nReach] | obQ[nSteps][21][nReach] | obT[nSteps][21][nReach]
+   | only while constituent routing is on (mzr_set_tracer: the same on EVERY domain, before the first mzr_boundary_size):
+     reach_solute_flux[nRoutes][nSteps][nReach].
+   header = {format tag (layout version), nRoutes, nSteps, nReach (+ 2^30 with the constituent, + 2^31 with the KWT part)}: written by
    mzr_export_boundary_dev, checked by mzr_import_boundary_dev -- a record that is not what the importing domain expects
    (other methods, window length, reach count, constituent on one side only) raises ierr 20 at the next synchronisation
    and nothing of it is used */
@@ -137,6 +139,12 @@ int mzr_wait_export(mzr_handle h);
 /* unpack a record of nSrc reaches (one source partition) into halo slots [haloBase, haloBase+nSrc)
    for the next window of nSteps steps */
 int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase);
+/* The host waits until the handle's last mzr_import_boundary_dev has read its record (rec_dev may then be reused or freed) and for
+   nothing else.  Windows of a mainstem domain of the Eulerian methods overlap like any other domain's (round 6: the imported discharge
+   is kept twice, the next window's beside that of the window whose last launches are kept back), and mzr_sync -- which issues the
+   launches kept back -- between the import and the next mzr_run* would undo that: mzr_wait_import does not.  (The reference's rank 0
+   sweeps the mainstem once per step after the gather, mpi_process.f90:1281-1312.) */
+int mzr_wait_import(mzr_handle h);
 
 /* Lakes and reservoirs (lake_route.f90:28-472; <is_lake_sim> = T).  lakeReach[nLake] 1-based;
    modelType 0 endorheic, 1 Doll03, 2 Hanasaki06, 3 HYPE (lake_route.f90:14-17);

@@ -53,7 +53,7 @@ EXPORTS = ["mzr_default_config", "mzr_create", "mzr_destroy", "mzr_last_error", 
            "mzr_run_dev", "mzr_sync", "mzr_get_flux", "mzr_get_window_q", "mzr_get_mean_q",
            "mzr_get_kwt_state", "mzr_set_kwt_state", "mzr_get_irf_state", "mzr_get_mol_state",
            "mzr_get_basin_state", "mzr_get_schedule", "mzr_set_profiling", "mzr_get_timing", "mzr_get_timing_range",
-           "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev", "mzr_export_boundary_prev_dev", "mzr_get_export_lag", "mzr_wait_export",
+           "mzr_get_kwt_traffic", "mzr_set_boundary", "mzr_boundary_size", "mzr_export_boundary_dev", "mzr_export_boundary_prev_dev", "mzr_get_export_lag", "mzr_wait_export", "mzr_wait_import",
            "mzr_import_boundary_dev", "mzr_set_wm_flux", "mzr_set_lakes", "mzr_set_lake_forcing", "mzr_set_lake_forcing_dev", "mzr_set_lake_target", "mzr_set_wm_vol", "mzr_get_global_wb", "mzr_set_da", "mzr_set_obs", "mzr_set_tracer", "mzr_set_solute", "mzr_get_solute", "mzr_get_window_solute", "mzr_get_tracer_state", "mzr_set_tracer_state",
            "mzr_set_remap", "mzr_set_sort_map", "mzr_remap_runoff_dev", "mzr_run_src_dev",
            "mzr_set_irf_state", "mzr_set_mol_state", "mzr_set_basin_state", "mzr_set_volume",
@@ -100,6 +100,7 @@ def load_library():
     L.mzr_export_boundary_prev_dev.argtypes = [vp, vp]
     L.mzr_get_export_lag.argtypes = [vp]
     L.mzr_wait_export.argtypes = [vp]
+    L.mzr_wait_import.argtypes = [vp]
     L.mzr_import_boundary_dev.argtypes = [vp, ci, vp, ci, ci]
     L.mzr_step.argtypes = [vp, cd, cd, dp]
     L.mzr_run.argtypes = [vp, ci, cd, dp]
@@ -413,6 +414,10 @@ class RoutingDomain:
 
     def import_boundary(self, n_steps, rec_dev_ptr, n_src, halo_base):
         self._check(self.L.mzr_import_boundary_dev(self.h, int(n_steps), C.c_void_p(int(rec_dev_ptr)), int(n_src), int(halo_base)))
+
+    def wait_import(self):
+        """the host waits until the last import_boundary has read its record -- and for nothing the handle keeps back (overlapping windows stay)"""
+        self._check(self.L.mzr_wait_import(self.h))
 
     # ---- results / state
     def flux(self, method, which=F_Q):

@@ -26,10 +26,11 @@ constexpr double c23 = 2.0 / 3.0, c53 = 5.0 / 3.0, c103 = 10.0 / 3.0;
 
 struct Chan { double b, zc, S, n, zf, D; double Qbf;       // width, side slope, slope, Manning n, floodplain slope, bank depth;
                                                                  // per reach, once: bankfull discharge (hydraulic.f90:345)
-              double sq1zc, sq1zf, sqSn, isqSn, ib3, Abf, Pbf, Bbf;
+              double sq1zc, sq1zf, isqSn, ib3, Abf, Pbf, Bbf;
               mutable double obC1 = -1.0, obC2 = 0.0; };   // coefficients of the above-bankfull depth iteration, on first use   // ... and the sub-expressions the Newton iterations and Muskingum-Cunge's sub-steps
                                                                  // would evaluate again and again with the same operands: sqrt(1+zc**2), sqrt(1+zf**2),
-                                                                 // sqrt(S)/n and its inverse, 1/b**3, bankfull A, P, B
+                                                                 // n/sqrt(S), 1/b**3, bankfull A, P, B
+#define MZR_CHAN_TAB 10      // doubles per reach of the channel table (MzrDev::chanTab, slot-major [MZR_CHAN_TAB][N])
 
 __device__ __forceinline__ double d_Btop(double y, const Chan &c) {
   if (y <= c.D) return c.b + 2 * y * c.zc;
@@ -56,10 +57,15 @@ __device__ double d_water_height(double flowArea, const Chan &c) {
   if (c.zc == 0) return flowArea / c.b;
   return (-c.b + sqrt(c.b * c.b + 4.0 * flowArea * c.zc)) / (2.0 * c.zc);
 }
+__device__ __forceinline__ void d_chan_overbank(const Chan &c) {
+  const double sqS = sqrt(c.S), zh = c.zf / 2, czh = cbrt(zh);
+  c.obC1 = sqS / c.n / pow_2_3(c.Pbf);
+  c.obC2 = 2 * (zh * (czh * czh)) * sqS / c.n / cbrt(c.zf * c.zf + 1.0);
+}
 // Newton-Raphson normal depth, hydraulic.f90:306-433 (integer powers as left-to-right products)
 __device__ double d_flow_depth(double Qin, const Chan &c) {
   if (!(Qin > 1.e-50)) return 0.0;
-  const double Abf = c.Abf, Pbf = c.Pbf, Bbf = c.Bbf;
+  const double Abf = c.Abf, Bbf = c.Bbf;
   const double Qbf = c.Qbf;
   double fd = 0.0;
   if (Qin < Qbf) {
@@ -86,11 +92,7 @@ __device__ double d_flow_depth(double Qin, const Chan &c) {
     // pow() (a few hundred instructions each, and a flooding reach is typically also one with many Muskingum-Cunge
     // sub-steps); the two coefficients are the reach's own and are kept for the next call.  Negative ye: NaN like pow().
     double y0 = c.D + 2.0;
-    if (c.obC1 < 0.0) {
-      const double sqS = sqrt(c.S), zh = c.zf / 2, czh = cbrt(zh);
-      c.obC1 = sqS / c.n / pow_2_3(Pbf);
-      c.obC2 = 2 * (zh * (czh * czh)) * sqS / c.n / cbrt(c.zf * c.zf + 1.0);
-    }
+    if (c.obC1 < 0.0) d_chan_overbank(c);
     const double Coef1 = c.obC1, Coef2 = c.obC2;
     int guard = 0;
     bool more = true;
@@ -195,17 +197,46 @@ __device__ __forceinline__ double d_wb(double vol1, double vol0, double Qup, dou
   return dVol - (Qin + Qlateral + precip + Qtake + Qo + evapo);
 }
 
-__device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
+// The channel of a reach: its six parameters and what the solvers derive from them alone.  Round 6: the derived values -- four square
+// roots, two cube roots, a 2/3 power and seven divisions, ~300 dependent FP64 instructions that every reach-step of Muskingum-Cunge,
+// KW and DW used to start with -- are computed ONCE per parameter set by k_chan_table (this very function, so the same bits) and
+// loaded: ten coalesced doubles per reach-step.
+__device__ __forceinline__ Chan d_chan_compute(const MzrDev &d, int r) {
   Chan c; c.b = d.width[r]; c.zc = d.side[r]; c.S = d.slope[r]; c.n = d.mann[r]; c.zf = d.fldp[r]; c.D = d.depth[r];
   c.sq1zc = sqrt(1 + c.zc * c.zc); c.sq1zf = sqrt(1 + c.zf * c.zf);
-  c.sqSn = sqrt(c.S) / c.n; c.isqSn = c.n / sqrt(c.S); c.ib3 = 1.0 / (c.b * c.b * c.b);
+  c.isqSn = c.n / sqrt(c.S); c.ib3 = 1.0 / (c.b * c.b * c.b);
   const double Abf = d_area(c.D, c), Pbf = d_Pwet(c.D, c);
   c.Abf = Abf; c.Pbf = Pbf; c.Bbf = d_Btop(c.D, c);
   c.Qbf = Abf * pow_2_3(Abf / Pbf) * sqrt(c.S) / c.n;      // hydraulic.f90:345
   return c;
 }
+__device__ __forceinline__ Chan d_chan(const MzrDev &d, int r) {
+  if (!d.chanTab) return d_chan_compute(d, r);      // (wave-uniform: a kernel argument)
+  Chan c; c.b = d.width[r]; c.zc = d.side[r]; c.S = d.slope[r]; c.n = d.mann[r]; c.zf = d.fldp[r]; c.D = d.depth[r];
+  const double *t = d.chanTab + r;
+  const size_t N = d.N;
+  c.sq1zc = t[0]; c.sq1zf = t[N]; c.isqSn = t[2 * N]; c.ib3 = t[3 * N]; c.Abf = t[4 * N]; c.Pbf = t[5 * N]; c.Bbf = t[6 * N]; c.Qbf = t[7 * N];
+  c.obC1 = t[8 * N]; c.obC2 = t[9 * N];
+  return c;
+}
 
 }  // namespace
+
+__global__ void __launch_bounds__(256) k_chan_table(MzrDev d, double *tab) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= d.N) return;
+  MzrDev dd = d; dd.chanTab = nullptr;
+  const Chan c = d_chan_compute(dd, r);
+  d_chan_overbank(c);
+  const size_t N = d.N;
+  double *t = tab + r;
+  t[0] = c.sq1zc; t[N] = c.sq1zf; t[2 * N] = c.isqSn; t[3 * N] = c.ib3; t[4 * N] = c.Abf; t[5 * N] = c.Pbf; t[6 * N] = c.Bbf; t[7 * N] = c.Qbf;
+  t[8 * N] = c.obC1; t[9 * N] = c.obC2;
+}
+int mzr_chan_table_doubles() { return MZR_CHAN_TAB; }
+void mzr_launch_chan_table(const MzrDev &d, double *tab, hipStream_t stream) {
+  hipLaunchKernelGGL(k_chan_table, dim3((d.N + 255) / 256), dim3(256), 0, stream, d, tab);
+}
 
 // ------------------------------------------------------------------------------------------------
 // main_route.f90:125-148 (observations of this step, or one more step since the last ones) and direct_insertion
@@ -406,9 +437,15 @@ __device__ __forceinline__ void stage_reach(const MzrDev &d, int r, int t) {
             double qo;
             Qbar = (qin + qin_prev + qout_prev) / 3.0;
             if (Qbar > 1.e-50) {
-              depth = d_flow_depth(fabs(Qbar), c);
+              // (the first sub-step's mean discharge is the step's own -- (Q10 + Q00 + Q01) / 3 = (Q00 + Q10 + Q01) / 3 bit for bit, the
+              // first addition commutes -- so its normal depth and celerity are the ones the sub-step count was worked out from: the
+              // reference solves twice (mc_route.f90:246-262 and :283-296), same arguments, same results.  Half the work of the
+              // reaches with one sub-step, which most are)
+              if (ix > 1) {
+                depth = d_flow_depth(fabs(Qbar), c);
+                ck = d_celerity(fabs(Qbar), depth, c);
+              }
               const double topWidth = d_Btop(depth, c);
-              ck = d_celerity(fabs(Qbar), depth, c);
               const double X = 0.5 * (1.0 - Qbar / (topWidth * SL * ck));
               Cn = ck * thSub;
               // C0 qin + C1 qin_prev + C2 qout_prev with the common denominator of the three coefficients (:305-312)

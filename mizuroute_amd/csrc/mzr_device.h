@@ -104,6 +104,7 @@ struct MzrDev {
   const double   *hruW;       // [nHru]
   // ---- parameters (RPARAM, dataTypes.f90:183-195)
   const double *slope, *mann, *width, *depth, *length, *storage, *side, *fldp, *basarea, *minflow;
+  const double *chanTab;      // [10][N] what the Eulerian solvers derive from a reach's channel parameters alone (kernels_route.hip d_chan; null: computed per reach-step)
   const double *kwK, *kwCW;   // KWT: K = sqrt(slope)/n and ALFA*K**(1/ALFA), precomputed on the host
   // ---- configuration
   double dt, min_length_route, runoffMin, negRunoffTol, time_conv, length_conv, t_start;

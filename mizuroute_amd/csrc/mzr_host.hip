@@ -45,6 +45,8 @@ void mzr_launch_stage_kwt(const MzrDev &d, int s, int haBegin, int haEnd, int hb
 
 void mzr_launch_accum_qsum(const double *Q, double *qsum, int N, int W, hipStream_t stream, const MzrErr *err = nullptr);
 int mzr_sweep_kwt_capacity(bool full, const MzrDev &d, hipStream_t stream);
+int mzr_chan_table_doubles();
+void mzr_launch_chan_table(const MzrDev &d, double *tab, hipStream_t stream);
 int mzr_kwt_class_caps(int *capB, int *capC, int kcWide = 0);
 void mzr_launch_kwt_window_init(const MzrDev &d, int tBegin, int tEnd, hipStream_t stream);
 void mzr_launch_sweep_kwt(const MzrDev &d, int nWaves, int sBegin, int sEnd, hipStream_t stream, hipEvent_t evStart, hipEvent_t evStop, int kc);
@@ -84,6 +86,7 @@ struct RouteBufs {
   int permN = 0, nHeavyPos = 0;      // heavy lane positions behind the block-wise ones (mzr_device.h)
   DBuf<int> lanePerm; bool havePerm = false;           // reaches of every aligned block of 256 dealt to its wavefronts by loop trip count (mzr_device.h)
   DBuf<double> imQ;                                 // [maxWindow][nHalo] imported REACH_Q of halo reaches
+  DBuf<double> imQAlt;                              // ... of the NEXT window while the last launches of the window before are kept back (overlapping windows of a mainstem domain)
   DBuf<double> lakeMut, lakeRing, lakeRingD; DBuf<int> lakeHead, lakeHeadD;   // per-method mutable Hanasaki parameters / inflow and demand memory
   DBuf<int> rtDone, rtHead;                         // persistent sweep of an Eulerian method: progress per reach, ticket counters
   DBuf<double> solFlux, solMass, trVol0;            // constituent routing (mzr_set_tracer): [maxWindow][N], [N], [maxWindow][N]
@@ -133,14 +136,20 @@ __global__ void k_carry_qlat(double *qlat, int lastW, int N, const int *haloSlot
   qlat[r] = qlat[(size_t)lastW * N + r];
 }
 
-// boundary record (include/mzr.h): header[4] | Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB] [| solute flux[R][W][nB]]
-// header = {magic, nRoutes, steps, reaches + 2^30 while the constituent is on}: what the sender packed, checked by the receiver
-// (a sender and a receiver that disagree on any of them -- e.g. mzr_set_tracer on one side only -- would otherwise read each
-// other's records at the wrong offsets without a word)
+// boundary record (include/mzr.h), round 6: what the importer READS and nothing else (mpi_process.f90:1245-1329 ships the outlet
+// fluxes only) --
+//   header[4] | Q[R][W][nB] | KWT among the methods: qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB] | constituent on: solute flux[R][W][nB]
+// (rounds 3-5 shipped the particle rows, their counts and the hillslope series of every domain: 3.2-3.8 GB per 2 048-step window
+// into rank 0 of the Eulerian configurations where 0.07-0.15 GB are read)
+// header = {magic = layout version, nRoutes, steps, reaches + 2^30 while the constituent is on + 2^31 with the KWT part}: what the
+// sender packed, checked by the receiver (a sender and a receiver that disagree on any of them -- e.g. mzr_set_tracer on one side
+// only -- would otherwise read each other's records at the wrong offsets without a word)
 #define MZR_REC_HDR 4
-#define MZR_REC_MAGIC 20260929.0
+#define MZR_REC_MAGIC 20260930.0
+__host__ __device__ inline double recTag(int nB, int hasKwt, int tracer) { return (double)nB + (tracer ? 1073741824.0 : 0.0) + (hasKwt ? 2147483648.0 : 0.0); }
+__host__ __device__ inline long long recKwtPart(long long W, long long nB, int hasKwt) { return hasKwt ? (W + 1) * nB + W * nB + 2 * W * MZR_OB_CAP * nB : 0; }
 struct RecView { double *Q, *ql, *n, *oq, *ot; };
-__host__ __device__ inline RecView recView(double *rec, int R, int W, int nB) {
+__host__ __device__ inline RecView recView(double *rec, int R, int W, int nB) {      // (ql .. ot exist with the KWT part only)
   RecView v;
   v.Q = rec + MZR_REC_HDR; v.ql = v.Q + (size_t)R * W * nB; v.n = v.ql + (size_t)(W + 1) * nB;
   v.oq = v.n + (size_t)W * nB; v.ot = v.oq + (size_t)W * MZR_OB_CAP * nB;
@@ -155,18 +164,18 @@ __global__ void k_pack_boundary(double *rec, int R, int W, int nB, int N, const 
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (b >= nB) return;
-  if (b == 0 && t == 0) { rec[0] = MZR_REC_MAGIC; rec[1] = (double)R; rec[2] = (double)W; rec[3] = (double)nB + (tracer ? 1073741824.0 : 0.0); }
+  if (b == 0 && t == 0) { rec[0] = MZR_REC_MAGIC; rec[1] = (double)R; rec[2] = (double)W; rec[3] = recTag(nB, hasKwt, tracer); }
   const RecView v = recView(rec, R, W, nB);
   const int r = expInt[b];
-  v.ql[(size_t)t * nB + b] = qlat[(size_t)t * N + r];
+  if (hasKwt) v.ql[(size_t)t * nB + b] = qlat[(size_t)t * N + r];      // BASIN_QR(0:1) of the outlet's basin: read by the KWT merge downstream only
   if (t >= W) return;
   for (int m = 0; m < R; ++m) v.Q[((size_t)m * W + t) * nB + b] = Q.p[m][(size_t)t * N + r];
-  int n = 0;
-  if (hasKwt) n = exN[(size_t)t * nB + b];
+  if (!hasKwt) return;
+  const int n = exN[(size_t)t * nB + b];
   v.n[(size_t)t * nB + b] = (double)n;
   for (int k = 0; k < MZR_OB_CAP; ++k) {
     const size_t o = ((size_t)t * MZR_OB_CAP + k) * nB + b;
-    const bool have = hasKwt && n > 0 && k <= n;
+    const bool have = n > 0 && k <= n;
     v.oq[o] = have ? exOQ[o] : 0.0; v.ot[o] = have ? exOT[o] : 0.0;
   }
 }
@@ -177,14 +186,14 @@ __global__ void k_unpack_boundary(const double *rec, int R, int W, int nB, int N
   const int t = blockIdx.y;
   if (b >= nB) return;
   // the record must be what this domain expects (ierr 20 at the next synchronisation; nothing of it is used)
-  if (!(rec[0] == MZR_REC_MAGIC && rec[1] == (double)R && rec[2] == (double)W && rec[3] == (double)nB + (tracer ? 1073741824.0 : 0.0))) {
+  if (!(rec[0] == MZR_REC_MAGIC && rec[1] == (double)R && rec[2] == (double)W && rec[3] == recTag(nB, hasKwt, tracer))) {
     if (b == 0 && t == 0 && atomicCAS(&err->code, 0, 20) == 0) { err->reach = -1; err->step = (int)rec[2]; err->where = 30; }
     return;
   }
   const RecView v = recView(const_cast<double *>(rec), R, W, nB);
   const int hs = haloBase + b;
   const int r = haloInt[hs];
-  qlat[(size_t)t * N + r] = v.ql[(size_t)t * nB + b];
+  if (hasKwt) qlat[(size_t)t * N + r] = v.ql[(size_t)t * nB + b];
   if (t >= W) return;
   for (int m = 0; m < R; ++m) imQ.p[m][(size_t)t * nHalo + hs] = v.Q[((size_t)m * W + t) * nB + b];
   if (hasKwt) {
@@ -204,12 +213,12 @@ __global__ void k_pack_solute(double *sf, int R, int W, int nB, int N, const int
   const int r = expInt[b];
   for (int m = 0; m < R; ++m) sf[((size_t)m * W + t) * nB + b] = F.p[m] ? F.p[m][(size_t)t * N + r] : 0.0;
 }
-__global__ void k_unpack_solute(const double *rec, const double *sf, int R, int W, int nB, int N, int haloBase, const int *haloInt, QPtrsW F) {
+__global__ void k_unpack_solute(const double *rec, const double *sf, int R, int W, int nB, int N, int haloBase, const int *haloInt, QPtrsW F, int hasKwt) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (b >= nB || t >= W) return;
   // (a record this domain does not expect: k_unpack_boundary has raised ierr 20; nothing of it is used here either)
-  if (!(rec[0] == MZR_REC_MAGIC && rec[1] == (double)R && rec[2] == (double)W && rec[3] == (double)nB + 1073741824.0)) return;
+  if (!(rec[0] == MZR_REC_MAGIC && rec[1] == (double)R && rec[2] == (double)W && rec[3] == recTag(nB, hasKwt, 1))) return;
   const int r = haloInt[haloBase + b];
   for (int m = 0; m < R; ++m) if (F.p[m]) F.p[m][(size_t)t * N + r] = sf[((size_t)m * W + t) * nB + b];
 }
@@ -252,7 +261,9 @@ struct mzr_domain {
   DBuf<float> runoffF[2];                        // single-precision forcing windows of mzr_run_async_f32 as they arrive, widened into runoffW / runoffW2
   hipStream_t copyStream = nullptr;             // host -> device forcing windows of mzr_run_async, behind the sweep of the window before
   hipEvent_t rwCopied[2] = {nullptr, nullptr}, rwRead[2] = {nullptr, nullptr};
-  hipEvent_t exportDone = nullptr;              // recorded behind the last mzr_export_boundary_dev: what mzr_comm_send waits for
+  hipEvent_t exportDone = nullptr;              // recorded behind the last mzr_export_boundary_dev (main stream): what mzr_comm_send waits for
+  hipEvent_t exportPrevDone = nullptr;          // ... behind the last mzr_export_boundary_prev_dev (expStream): an event of its own, so that an export on the main
+                                                // stream in between cannot take the wait for the pack on expStream away
   // Export of the window BEFORE the last one (mzr_export_boundary_prev_dev): while the last launches of window k are kept back for window
   // k + 1 (overlapping windows), the rows of window k - 1 sit complete in the second set of rows from launch nS - 1 of window k on
   hipEvent_t sweepGo = nullptr;                 // recorded on the KWT stream right in front of the last sweep launch: that launch is eligible (mzr_run_async*: the next window's copy starts behind it)
@@ -276,6 +287,8 @@ struct mzr_domain {
   struct { bool pending = false; int W = 0; MzrDev d[6]; } tail;      // (W: launches of the window = its steps in blocks of d.stepBlock)
   DBuf<double> qiAlt, qlatAlt, lakeEvapAlt, lakePrecipAlt; DBuf<int> calMonthAlt, calDayAlt, calDoyAlt;
   bool lakeNextInAlt = false;                    // mzr_set_lake_forcing wrote the NEXT window's lake forcing into the *Alt buffers
+  bool imNextInAlt = false;                      // mzr_import_boundary_dev wrote the NEXT window's halo discharge into imQAlt (run_window swaps it in)
+  hipEvent_t importDone = nullptr;               // recorded behind the last mzr_import_boundary_dev: what mzr_wait_import waits for
   long long pairLaunches = 0, tailFlushes = 0;
   // A KWT window that ended with ierr 93 (the persistent sweep gave up waiting: DESIGN.md 2.4) is routed again through one launch
   // per stage -- when the state it started from is still known: the at-rest particles are copied aside before every sweep
@@ -357,6 +370,7 @@ struct mzr_domain {
   bool srApplying = false;        // flushSteps is handing rows to the setters (they neither stage nor flush then)
   int histFlags = 0;                            // MZR_H_*: which history sums beyond discharge are kept
   long long histSteps = 0;                      // steps in the runoff sums since the last reset
+  DBuf<double> chanTab; bool chanDirty = true;      // channel table of the Eulerian solvers (kernels_route.hip d_chan), made again when a parameter changes
   DBuf<double> hInst, hDlay, hBas;              // [N], [N], [H] sums of BASIN_QI, BASIN_QR(1), basin runoff
 };
 
@@ -394,6 +408,7 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.slope = h->par[0].p; d.mann = h->par[1].p; d.width = h->par[2].p; d.depth = h->par[3].p;
   d.length = h->par[4].p; d.storage = h->par[5].p; d.side = h->par[6].p; d.fldp = h->par[7].p;
   d.basarea = h->par[8].p; d.minflow = h->par[10].p;
+  d.chanTab = h->chanDirty ? nullptr : h->chanTab.p;
   d.kwK = h->kwK.p; d.kwCW = h->kwCW.p;
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
   d.mcTailTol = h->cfg.mcTailTol >= 0.0 ? h->cfg.mcTailTol : 0.0;
@@ -866,6 +881,8 @@ int mzr_destroy(mzr_handle h) {
   if (h->basinStream) (void)hipStreamDestroy(h->basinStream);
   if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
   if (h->exportDone) (void)hipEventDestroy(h->exportDone);
+  if (h->exportPrevDone) (void)hipEventDestroy(h->exportPrevDone);
+  if (h->importDone) (void)hipEventDestroy(h->importDone);
   if (h->expStream) (void)hipStreamDestroy(h->expStream);
   if (h->sweepGo) (void)hipEventDestroy(h->sweepGo);
   for (auto &e : h->prevRowsEv) if (e) (void)hipEventDestroy(e);
@@ -892,6 +909,7 @@ int mzr_set_network(mzr_handle h, int N, int H, const int *downIndex, const int 
   (void)hipSetDevice(h->cfg.device);
   try {
     h->N = N; h->H = H;
+    h->chanTab.free(); h->chanDirty = true;
     // ---- breadth-first levels from the outlets; upstreams appended in UREACHI order
     std::vector<int> level; level.reserve(N);
     std::vector<int> levelStart{0};
@@ -993,6 +1011,7 @@ int mzr_set_param(mzr_handle h, const char *name, const double *values) {
       (void)hipMemcpy(h->par[p].p, v.data(), h->N * sizeof(double), hipMemcpyHostToDevice);
       if (p == 0) h->h_slope = v;
       if (p == 1) h->h_mann = v;
+      h->chanDirty = true;      // the channel table of the Eulerian solvers is derived from slope, n, width, depth and the two side slopes
       // the KWT records hold derived copies (width ratios, K, celerity factor, length): a change after
       // mzr_init_state must not go unnoticed -- the state has to be initialised (or restored) again
       if (h->haveState && h->kwN.p) h->haveState = false;
@@ -1345,7 +1364,8 @@ int mzr_set_boundary(mzr_handle h, int nExport, const int *exportReach, int nHal
 long long mzr_boundary_size(mzr_handle h, int nSteps, int nReach) {
   if (!h) return -1;
   const long long R = h->cfg.nRoutes, W = nSteps, B = nReach;
-  return MZR_REC_HDR + R * W * B + (W + 1) * B + W * B + 2 * W * MZR_OB_CAP * B + (h->tracer ? R * W * B : 0);      // (header; + reach_solute_flux while the tracer is on)
+  const int hasKwt = idxOf(h, MZR_KWT) >= 0;
+  return MZR_REC_HDR + R * W * B + recKwtPart(W, B, hasKwt) + (h->tracer ? R * W * B : 0);      // (header; discharge; the KWT part; reach_solute_flux while the tracer is on)
 }
 
 /* The record of the window BEFORE the last one, while the last launches of the last one are still kept back (overlapping windows of
@@ -1361,11 +1381,11 @@ int mzr_export_boundary_prev_dev(mzr_handle h, double *rec_dev) {
   if (!h->expStream && hipStreamCreateWithFlags(&h->expStream, hipStreamNonBlocking) != hipSuccess) return fail(h, 90, "mzr_export_boundary_prev/hipStreamCreate failed");
   for (int ix = 0; ix < h->cfg.nRoutes && ix < 6; ++ix) if (h->prevRowsEv[ix]) (void)hipStreamWaitEvent(h->expStream, h->prevRowsEv[ix], 0);
   QPtrs q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].Qalt.p : nullptr;
-  dim3 block(64), grid((h->nExp + 63) / 64, h->prevW + 1);
+  dim3 block(64), grid((h->nExp + 63) / 64, h->prevW);      // (overlapping windows: no KWT among the methods, no row W)
   hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->expStream, rec_dev, h->cfg.nRoutes, h->prevW, h->nExp, h->N,
                      h->expInt.p, q, h->qlatAlt.p, h->exN.p, h->exOQ.p, h->exOT.p, 0, 0);
-  if (!h->exportDone) (void)hipEventCreateWithFlags(&h->exportDone, hipEventDisableTiming);
-  (void)hipEventRecord(h->exportDone, h->expStream);
+  if (!h->exportPrevDone) (void)hipEventCreateWithFlags(&h->exportPrevDone, hipEventDisableTiming);
+  (void)hipEventRecord(h->exportPrevDone, h->expStream);
   h->exportOnAux = true;
   h->prevInAlt = false;      // (exported once)
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_export_boundary_prev/launch failed");
@@ -1376,9 +1396,11 @@ int mzr_get_export_lag(mzr_handle h) { return (h && h->tail.pending && h->nExp >
 /* the host waits for the handle's last export (either kind) and for nothing else the handle has queued */
 int mzr_wait_export(mzr_handle h) {
   if (!h) return 1;
-  if (!h->exportDone) return 0;
+  if (!h->exportDone && !h->exportPrevDone) return 0;
   (void)hipSetDevice(h->cfg.device);
-  return hipEventSynchronize(h->exportDone) == hipSuccess ? 0 : fail(h, 92, "mzr_wait_export/device error");
+  if (h->exportPrevDone && hipEventSynchronize(h->exportPrevDone) != hipSuccess) return fail(h, 92, "mzr_wait_export/device error");
+  if (h->exportDone && hipEventSynchronize(h->exportDone) != hipSuccess) return fail(h, 92, "mzr_wait_export/device error");
+  return 0;
 }
 
 int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
@@ -1388,12 +1410,13 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
   if (h->lastW < 1) return fail(h, 20, "mzr_export_boundary/no window has been run");
   (void)hipSetDevice(h->cfg.device);
   QPtrs q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].Q.p : nullptr;
-  dim3 block(64), grid((h->nExp + 63) / 64, h->lastW + 1);
+  const int hasKwt = h->kwN.p ? 1 : 0;
+  dim3 block(64), grid((h->nExp + 63) / 64, h->lastW + hasKwt);      // (row W carries the last BASIN_QR row: KWT only)
   hipLaunchKernelGGL(k_pack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, h->lastW, h->nExp, h->N,
-                     h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, h->kwN.p ? 1 : 0, h->tracer ? 1 : 0);
+                     h->expInt.p, q, h->qlat.p, h->exN.p, h->exOQ.p, h->exOT.p, hasKwt, h->tracer ? 1 : 0);
   if (h->tracer) {
     QPtrs f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
-    const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * h->lastW * h->nExp + (long long)(h->lastW + 1) * h->nExp + (long long)h->lastW * h->nExp + 2LL * h->lastW * MZR_OB_CAP * h->nExp;
+    const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * h->lastW * h->nExp + recKwtPart(h->lastW, h->nExp, hasKwt);
     hipLaunchKernelGGL(k_pack_solute, dim3((h->nExp + 63) / 64, h->lastW), block, 0, h->stream, rec_dev + base, h->cfg.nRoutes, h->lastW, h->nExp, h->N, h->expInt.p, f);
   }
   if (!h->exportDone) (void)hipEventCreateWithFlags(&h->exportDone, hipEventDisableTiming);
@@ -1402,22 +1425,45 @@ int mzr_export_boundary_dev(mzr_handle h, double *rec_dev) {
 }
 
 int mzr_import_boundary_dev(mzr_handle h, int nSteps, const double *rec_dev, int nSrc, int haloBase) {
-  MZR_FLUSH(h);
+  MZR_FLUSH_STEPS(h);
+  // Round 6: a mainstem domain of the Eulerian methods keeps its windows overlapping too (mpi_process.f90:1281-1312 is one serial
+  // sweep of the mainstem per step on rank 0; here its nStages + W - 1 dependent launches per window were what rank 0 waited for).
+  // The launches kept back of the window before still read THAT window's halo discharge, so the next window's goes into a second
+  // buffer, which run_window swaps in -- the lake forcing's scheme (mzr_set_lake_forcing).
+  if (h && h->tail.pending && (h->kwN.p || h->tracer)) flushTail(h);      // (cannot happen: such domains never keep launches back)
   if (!h || !h->haveState) return h ? fail(h, 20, "mzr_import_boundary/state not initialised") : 1;
   if (nSrc == 0) return 0;
   if (haloBase < 0 || haloBase + nSrc > h->nHalo) return fail(h, 20, "mzr_import_boundary/halo slot range out of bounds");
   if (nSteps < 1 || nSteps > h->cfg.maxWindow) return fail(h, 20, "mzr_import_boundary/nSteps exceeds maxWindow");
   (void)hipSetDevice(h->cfg.device);
-  QPtrsW q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? h->route[m].imQ.p : nullptr;
-  dim3 block(64), grid((nSrc + 63) / 64, nSteps + 1);
+  const bool beside = h->tail.pending || h->imNextInAlt;      // (every import of one window goes to the same buffer)
+  if (beside) {
+    try {
+      for (int m = 0; m < h->cfg.nRoutes; ++m) if (!h->route[m].imQAlt.p) { h->route[m].imQAlt.alloc(h->route[m].imQ.n); h->route[m].imQAlt.zero(h->stream); }
+    } catch (const std::string &e) { return fail(h, 91, "mzr_import_boundary/" + e); }
+    h->imNextInAlt = true;
+  }
+  QPtrsW q; for (int m = 0; m < 6; ++m) q.p[m] = m < h->cfg.nRoutes ? (beside ? h->route[m].imQAlt.p : h->route[m].imQ.p) : nullptr;
+  const int hasKwt = h->kwN.p ? 1 : 0;
+  dim3 block(64), grid((nSrc + 63) / 64, nSteps + hasKwt);
   hipLaunchKernelGGL(k_unpack_boundary, grid, block, 0, h->stream, rec_dev, h->cfg.nRoutes, nSteps, nSrc, h->N, h->nHalo,
-                     haloBase, h->haloInt.p, q, h->qlat.p, h->imN.p, h->imOQ.p, h->imOT.p, h->kwN.p ? 1 : 0, h->tracer ? 1 : 0, h->err.p);
+                     haloBase, h->haloInt.p, q, h->qlat.p, h->imN.p, h->imOQ.p, h->imOT.p, hasKwt, h->tracer ? 1 : 0, h->err.p);
   if (h->tracer) {      // the halo reaches' reach_solute_flux goes straight into the window's rows: the constituent pass skips halo reaches
     QPtrsW f; for (int m = 0; m < 6; ++m) f.p[m] = m < h->cfg.nRoutes ? h->route[m].solFlux.p : nullptr;
-    const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * nSteps * nSrc + (long long)(nSteps + 1) * nSrc + (long long)nSteps * nSrc + 2LL * nSteps * MZR_OB_CAP * nSrc;
-    hipLaunchKernelGGL(k_unpack_solute, dim3((nSrc + 63) / 64, nSteps), block, 0, h->stream, rec_dev, rec_dev + base, h->cfg.nRoutes, nSteps, nSrc, h->N, haloBase, h->haloInt.p, f);
+    const long long base = MZR_REC_HDR + (long long)h->cfg.nRoutes * nSteps * nSrc + recKwtPart(nSteps, nSrc, hasKwt);
+    hipLaunchKernelGGL(k_unpack_solute, dim3((nSrc + 63) / 64, nSteps), block, 0, h->stream, rec_dev, rec_dev + base, h->cfg.nRoutes, nSteps, nSrc, h->N, haloBase, h->haloInt.p, f, hasKwt);
   }
+  if (!h->importDone) (void)hipEventCreateWithFlags(&h->importDone, hipEventDisableTiming);
+  (void)hipEventRecord(h->importDone, h->stream);
   return hipGetLastError() == hipSuccess ? 0 : fail(h, 92, "mzr_import_boundary/launch failed");
+}
+/* the host waits until the handle's last mzr_import_boundary_dev has read its record (the buffer may go) -- and for nothing the
+   handle keeps back: unlike mzr_sync it leaves overlapping windows overlapping */
+int mzr_wait_import(mzr_handle h) {
+  if (!h) return 1;
+  if (!h->importDone) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  return hipEventSynchronize(h->importDone) == hipSuccess ? 0 : fail(h, 92, "mzr_wait_import/device error");
 }
 
 int mzr_init_state(mzr_handle h) {
@@ -1434,7 +1480,7 @@ int mzr_init_state(mzr_handle h) {
     h->qlatAlt.free(); h->qiAlt.free();
     for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].Qalt.free();
     h->lakeEvapAlt.free(); h->lakePrecipAlt.free(); h->calMonthAlt.free(); h->calDayAlt.free(); h->calDoyAlt.free();
-    h->lakeNextInAlt = false;
+    h->lakeNextInAlt = false; h->imNextInAlt = false;
     h->snapN.free(); h->snapQ.free(); h->snapTR.free(); h->snapQsum.free(); h->snapHIn.free();
     h->retry.q.clear(); h->retry.seen = 0;
     h->tail.pending = false;
@@ -1455,11 +1501,13 @@ int mzr_init_state(mzr_handle h) {
       h->calMonth.alloc(W); h->calDay.alloc(W); h->calDoy.alloc(W);
       h->lakeWmVol.alloc(W * h->nLake); h->lakeWmVol.zero(); h->wmVolSteps = 0;
     }
-    if (h->nHalo) {
+    const bool kwtAmong = idxOf(h, MZR_KWT) >= 0;      // (particle rows of the boundary reaches: only where KWT routes)
+    h->imN.free(); h->imOQ.free(); h->imOT.free(); h->exN.free(); h->exOQ.free(); h->exOT.free();
+    if (h->nHalo && kwtAmong) {
       h->imN.alloc(W * h->nHalo); h->imN.zero();
       h->imOQ.alloc(W * MZR_OB_CAP * h->nHalo); h->imOT.alloc(W * MZR_OB_CAP * h->nHalo); h->imOQ.zero(); h->imOT.zero();
     }
-    if (h->nExp) {
+    if (h->nExp && kwtAmong) {
       h->exN.alloc(W * h->nExp); h->exN.zero();
       h->exOQ.alloc(W * MZR_OB_CAP * h->nExp); h->exOT.alloc(W * MZR_OB_CAP * h->nExp); h->exOQ.zero(); h->exOT.zero();
     }
@@ -1468,6 +1516,7 @@ int mzr_init_state(mzr_handle h) {
       const int m = rb.method;
       rb.Q.alloc(W * N); rb.Q.zero();
       if (h->nHalo) { rb.imQ.alloc(W * h->nHalo); rb.imQ.zero(); }
+      rb.imQAlt.free();
       if (h->nLake) {   // mutable Hanasaki parameters start from the static ones: I_months, D_months, E_rel_ini
         std::vector<double> mut((size_t)25 * h->nLake);
         for (int l = 0; l < h->nLake; ++l) {
@@ -1806,6 +1855,26 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   }
   const int N = h->N;
   hipStream_t st = h->stream;
+  // The channel table (kernels_route.hip d_chan): built and bit-identical, but OFF unless MZR_CHAN_TABLE=1 -- measured on the c4 shard
+  // (625 k reaches, IRF + Muskingum-Cunge): k_stage<4> 92.8 us per launch with the table against 86.8 us without.  The launch lasts as
+  // long as its reach with the most sub-steps (a chain of dependent FP64 operations), the other wavefronts wait for memory, and ten
+  // more loads per lane cost them more than the ~300 instructions they save (profiles/r06_experiments.md).
+  const bool chanTableOn = getenv("MZR_CHAN_TABLE") && atoi(getenv("MZR_CHAN_TABLE")) != 0;
+  if (chanTableOn && h->chanDirty && (idxOf(h, MZR_MC) >= 0 || idxOf(h, MZR_KW) >= 0 || idxOf(h, MZR_DW) >= 0)) {
+    // once per parameter set, on the handle's stream in front of everything the window queues
+    if (h->tail.pending) flushTail(h);
+    try {
+      if (!h->chanTab.p) h->chanTab.alloc((size_t)mzr_chan_table_doubles() * N);
+      MzrDev dc; fillDev(h, dc);
+      mzr_launch_chan_table(dc, h->chanTab.p, st);
+      (void)hipStreamSynchronize(st);      // (the methods' own streams read it)
+      h->chanDirty = false;
+    } catch (const std::string &) { (void)hipGetLastError(); }      // no room: the solvers compute the values per reach-step as before
+  }
+  if (h->imNextInAlt) {        // this window's halo discharge was imported beside that of a window kept back
+    for (int ix = 0; ix < h->cfg.nRoutes; ++ix) h->route[ix].imQ.swap(h->route[ix].imQAlt);
+    h->imNextInAlt = false;
+  }
   if (h->lakeNextInAlt) {      // this window's lake forcing was written beside the forcing of a window kept back
     h->lakeEvap.swap(h->lakeEvapAlt); h->lakePrecip.swap(h->lakePrecipAlt);
     h->calMonth.swap(h->calMonthAlt); h->calDay.swap(h->calDayAlt); h->calDoy.swap(h->calDoyAlt);
@@ -1817,8 +1886,10 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // steps as the network has stages (so that never more than two windows are in flight).
   const int nSt = h->nStages;
   // Steps per launch of the Eulerian stage kernels (kernels_route.hip, stage_reach_block): see stepBlockFor
-  bool pipe = nSt >= 2 && idxOf(h, MZR_KWT) < 0 && !h->tracer && !h->qmod && !h->cfg.is_flux_wm && h->nHalo == 0 &&
+  // (round 6: halo rows no longer rule it out -- the imported discharge exists twice, mzr_import_boundary_dev)
+  bool pipe = nSt >= 2 && idxOf(h, MZR_KWT) < 0 && !h->tracer && !h->qmod && !h->cfg.is_flux_wm &&
               !h->anyLakeTarget && !(W <= 8 && h->rtItems > 0);
+  if (h->nHalo && getenv("MZR_OVERLAP_HALO") && atoi(getenv("MZR_OVERLAP_HALO")) == 0) pipe = false;
   if (const char *e = getenv("MZR_OVERLAP_WINDOWS")) pipe = pipe && atoi(e) != 0;
   if (const char *e = getenv("MZR_ROUTE_SWEEP")) pipe = pipe && atoi(e) == 0;      // (a forced persistent sweep routes whole windows)
   const int KB = stepBlockFor(h, W, pipe && h->nExp == 0);      // (an export asks for the window's last launches at once: no overlap)
@@ -1838,7 +1909,7 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
   }
   if (h->exportOnAux) {      // a record of the window before the last one is being packed from the rows this window is about to write
-    if (h->exportDone) (void)hipStreamWaitEvent(st, h->exportDone, 0);
+    if (h->exportPrevDone) (void)hipStreamWaitEvent(st, h->exportPrevDone, 0);
     h->exportOnAux = false;
   }
   h->prevInAlt = false;
@@ -3118,6 +3189,7 @@ int mzr_comm_send(mzr_comm c, mzr_handle h, const double *dev, long long n, int 
   // the record was packed by the handle's last mzr_export_boundary_dev; whatever the handle has queued since (the next
   // window) must not hold the transfer up, so it runs on the communicator's own stream behind that export only
   if (h->exportDone) (void)hipStreamWaitEvent(c->stream, h->exportDone, 0);
+  if (h->exportPrevDone) (void)hipStreamWaitEvent(c->stream, h->exportPrevDone, 0);
   return rcclCheck(g_rccl.Send(dev, (size_t)n, ncclDouble, peer, c->comm, c->stream), "ncclSend");
 }
 

@@ -40,7 +40,7 @@ MODULE mzr_c
             mzr_set_uh, mzr_set_frac_future, mzr_init_state, mzr_step, mzr_run, mzr_sync, mzr_get_flux, &
             mzr_get_window_q, mzr_get_mean_q, mzr_get_kwt_state, mzr_set_kwt_state, mzr_get_irf_state, &
             mzr_get_mol_state, mzr_get_basin_state, mzr_get_schedule, mzr_set_boundary, mzr_boundary_size, &
-            mzr_export_boundary_dev, mzr_export_boundary_prev_dev, mzr_get_export_lag, mzr_wait_export, mzr_import_boundary_dev, mzr_run_dev, mzr_set_wm_flux, &
+            mzr_export_boundary_dev, mzr_export_boundary_prev_dev, mzr_get_export_lag, mzr_wait_export, mzr_import_boundary_dev, mzr_wait_import, mzr_run_dev, mzr_set_wm_flux, &
             mzr_set_remap, mzr_set_sort_map, mzr_remap_runoff_dev, mzr_run_src_dev, &
             mzr_set_irf_state, mzr_set_mol_state, mzr_set_basin_state, mzr_set_volume, &
             mzr_set_lakes, mzr_set_lake_forcing, mzr_get_sweep_info, mzr_run_async, mzr_run_async_f32, &
@@ -295,6 +295,10 @@ MODULE mzr_c
       import :: c_ptr, c_int
       type(c_ptr), value :: h, rec_dev
       integer(c_int), value :: nSteps, nSrc, haloBase
+    end function
+    integer(c_int) function mzr_wait_import(h) bind(C, name='mzr_wait_import')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
     end function
     integer(c_int) function mzr_set_wm_flux(h, nSteps, flux) bind(C, name='mzr_set_wm_flux')
       import :: c_ptr, c_int, c_double

@@ -423,7 +423,13 @@ class PartitionedRouter:
                 continue
             buf = rec if p == 0 else bufs[p]
             self.main.import_boundary(w, buf.data_ptr(), n, base)
-        self.main.sync()                                   # the imports have consumed the buffers
+        # the imports have consumed the buffers.  (wait_import, not sync: a mainstem domain of the Eulerian methods keeps the last
+        # launches of its window back for the next one -- its windows overlap like a tributary domain's -- and sync would issue them)
+        wait = getattr(self.main, "wait_import", None)
+        if wait is not None:
+            wait()
+        else:
+            self.main.sync()
         self.main.run_device(w, t_start, runoff_main_ptr)
 
     def sync(self):

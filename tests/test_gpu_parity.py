@@ -489,6 +489,12 @@ def test_partitioned_eulerian_domains_keep_their_overlapping_windows(methods, la
     for rank in order:
         routers[rank].sync()
     assert late > 0, "no tributary domain kept its last launches back: the overlap this test is about did not happen"
+    # round 6: the MAINSTEM domain's windows overlap too (its imported halo discharge is kept twice; PartitionedRouter waits for the
+    # import with wait_import, not sync): a window costs W launches per method, not nStages + W - 1 (a pair of windows is one launch)
+    main = routers[0].main
+    nS_main = int(main.schedule()[0])
+    n_launch = int(main.timing(methods[0])["launches"])
+    assert nS_main >= 8 and n_launch <= nwin * W + nS_main, (n_launch, nwin, W, nS_main)
     for rank in order:
         r = routers[rank]
         for dom, spec in ((r.trib, r.trib_spec), (r.main, r.main_spec)):
@@ -626,6 +632,37 @@ def test_mc_substep_tail_closed_form(hip_lib, oracle_lib, monkeypatch):
     rel = np.abs(Q[None] - Q["0"])[big] / np.abs(Qo[big])
     assert rel.max() < 1e-8, float(rel.max())          # second order in the distance to the fixed point: ~1e-10 observed
     assert parity_report(Qo, Q["0"])["max_rel"] < 1e-10  # without the tail only rounding separates the two
+
+
+def test_channel_table_equals_values_computed_per_step(hip_lib, monkeypatch):
+    """Round 6: what KW, Muskingum-Cunge and DW derive from a reach's channel parameters alone (square and cube roots, bankfull
+    area / perimeter / discharge, the overbank coefficients) can be computed once into a table by the very code that runs every
+    reach-step (kernels_route.hip d_chan; MZR_CHAN_TABLE=1 -- off by default, it measured slower on the c4 shard): the same bits with
+    the table and without, floodplains included; and a parameter set after the first window makes the table again."""
+    net = m.make_network(5000, seed=33, floodplain=True)
+    dt, steps = 3600.0, 40
+    ro = m.make_runoff(net.H, steps, seed=34, storm_prob=0.05, storm_amp=2e-5)      # pulses large enough for overbank flow
+    ff = np.array([0.6, 0.4])
+    methods = [m.KW, m.MC, m.DW]
+    out = {}
+    for tab in ("1", None):      # "1": computed per reach-step (the default), None: through the table
+        monkeypatch.setenv("MZR_CHAN_TABLE", "0" if tab == "1" else "1")
+        dom = m.RoutingDomain(net, dt, methods, frac_future=ff, hw_drain_point=1, max_window=20)
+        Q1 = dom.run(ro[:20])
+        slope2 = net.params["R_SLOPE"] * 1.5
+        dom._check(dom.L.mzr_set_param(dom.h, b"R_SLOPE", np.ascontiguousarray(slope2)))      # (no KWT: the state stays)
+        Q2 = dom.run(ro[20:])
+        out[tab] = (Q1, Q2, [dom.flux(x, m.api.F_FLOODVOL) for x in methods])
+        dom.close()
+    for a, b in zip(out["1"][:2], out[None][:2]):
+        assert np.array_equal(a, b)
+    assert all(np.array_equal(a, b) for a, b in zip(out["1"][2], out[None][2]))
+    assert (out[None][2][1] > 0).any(), "the case should exercise the floodplain branch"
+    # the changed slope changed the second window (the table was made again)
+    monkeypatch.setenv("MZR_CHAN_TABLE", "1")
+    dom = m.RoutingDomain(net, dt, methods, frac_future=ff, hw_drain_point=1, max_window=20)
+    Qs = dom.run(ro)
+    assert np.array_equal(Qs[:20], out[None][0]) and not np.array_equal(Qs[20:], out[None][1])
 
 
 @pytest.mark.parametrize("case", ["plain", "lakes_wm"])

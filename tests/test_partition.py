@@ -73,13 +73,18 @@ class RecordingDomain:
         self.ran = []
         self.calls = []
 
-    HDR, MAGIC = 4, 20260929.0      # the record's header (mzr_host.hip MZR_REC_HDR / MZR_REC_MAGIC): {magic, nRoutes, steps, reaches}
+    HDR, MAGIC = 4, 20260930.0      # the record's header (mzr_host.hip MZR_REC_HDR / MZR_REC_MAGIC): {layout version, nRoutes, steps, reaches + flags}
+    KWT_FLAG = 2147483648.0         # ... reaches + 2^31 when the record carries the KWT part
+
+    LAG = False      # True: a domain whose windows overlap (an Eulerian method) -- the record of a window is packed one window later
 
     def boundary_size(self, w, n):
-        # mzr_boundary_size: header | Q[R][W][nB] | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB], one method
-        return self.HDR + (1 * w + (w + 1) + w + 2 * w * 21) * n
+        # mzr_boundary_size, one method: header | Q[R][W][nB] and, with KWT, | qlat[W+1][nB] | obN[W][nB] | obQ[W][21][nB] | obT[W][21][nB].
+        # The overlapping (LAG) domain stands for an Eulerian method: its record is the discharge alone
+        return self.HDR + (w * n if self.LAG else (1 * w + (w + 1) + w + 2 * w * 21) * n)
 
-    LAG = False      # True: a domain whose windows overlap (Eulerian methods) -- the record of a window is packed one window later
+    def tag(self, n):
+        return float(n) + (0.0 if self.LAG else self.KWT_FLAG)
 
     def run_device(self, w, t_start, ptr):
         self.ran.append((w, t_start)); self.calls.append(("run", w))
@@ -101,7 +106,7 @@ class RecordingDomain:
         n = self.exp.size
         ids = self.spec.net.reachId[self.exp - 1].astype(np.float64)
         rec = np.zeros(self.boundary_size(w, n))
-        rec[:self.HDR] = (self.MAGIC, 1.0, float(w), float(n))
+        rec[:self.HDR] = (self.MAGIC, 1.0, float(w), self.tag(n))
         rec[self.HDR: self.HDR + w * n] = (np.arange(w)[:, None] * 1000.0 + ids[None, :]).ravel()   # Q[t][b] = 1000 t + id
         return self.torch.from_numpy(rec)
 
@@ -164,8 +169,9 @@ def _worker(rank, world, port, q, lag=False):
             ids = P.trib[p].net.reachId[P.trib[p].export_local - 1].astype(np.float64)
             expect = (np.arange(w)[:, None] * 1000.0 + ids[None, :]).ravel()
             H = RecordingDomain.HDR
-            ok &= bool(np.array_equal(got[p][:H].numpy(), np.array([RecordingDomain.MAGIC, 1.0, w, n])))      # the header the importer checks
-            ok &= got[p].numel() == H + (w + (w + 1) + w + 2 * w * 21) * n
+            ok &= bool(np.array_equal(got[p][:H].numpy(), np.array([RecordingDomain.MAGIC, 1.0, w, main.tag(n)])))      # the header the importer checks
+            ok &= got[p].numel() == main.boundary_size(w, n)
+            ok &= got[p].numel() == H + (w * n if lag else (w + (w + 1) + w + 2 * w * 21) * n)      # an Eulerian record is the discharge alone
             ok &= bool(np.array_equal(got[p][H: H + w * n].numpy(), expect))
         ok &= main.ran == [(w, 0.0), (w, w * 3600.0)]
     if router.trib is not None and router.trib.exp.size and P.main is not None:
