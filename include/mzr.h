@@ -78,7 +78,9 @@ typedef struct mzr_config {
                                  (rank 0's mainstem beside its tributaries): its window is one long chain of dependent passes
                                  and a hundredth of the work, so its passes go first wherever they meet the other sweep's  */
   double sweepTimeout;        /* seconds without any progress on the reaches it waits for after which a wavefront of a
-                                 persistent sweep gives up with ierr 93 instead of hanging the device (default 8)      */
+                                 persistent sweep gives up with ierr 93 instead of hanging the device.  0 (default): the KWT
+                                 sweep takes four times the window's expected duration, between 1 s and 8 s; the sweeps of the
+                                 Eulerian methods 8 s */
 } mzr_config;
 
 void mzr_default_config(mzr_config *cfg);

@@ -839,7 +839,7 @@ void mzr_default_config(mzr_config *c) {
   if (const char *e = getenv("MZR_MC_TAIL_TOL")) c->mcTailTol = atof(e);
   c->sweepShare = 1.0;
   c->stepBatch = 1;
-  c->sweepTimeout = 8.0;
+  c->sweepTimeout = 0.0;      // automatic (include/mzr.h)
   if (const char *e = getenv("MZR_SWEEP_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0) c->sweepTimeout = v; }
 }
 
@@ -2040,6 +2040,15 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       }
       h->retry.q.push_back(qw);
       // debugging aid (tests): MZR_SWEEP_FAIL_AT=n gives the n-th KWT window of the handle (0-based) a watchdog of one clock tick
+      // The watchdog of the KWT sweep measures time WITHOUT PROGRESS on the words a wavefront polls; how long that may be before the
+      // window is given up follows from what the window is expected to take (round 6: it was 8 s whatever the window -- a stall cost
+      // 8 s plus the window once more): four times the window's expected duration -- W steps x 15 us x the passes a wavefront takes
+      // per launch of the schedule, the figure both operating points show (100 k reaches: 6 022 items for 4 008 wavefronts, 27 us per
+      // step; 375 k: 22 416 items, 80 us) -- but at least 1 s and at most 8 s.  mzr_config.sweepTimeout > 0 fixes it.
+      if (!(h->cfg.sweepTimeout > 0.0)) {
+        const double perStep = 15.e-6 * std::max(1.8, (double)h->swItems / (double)std::max(1, h->swWaves));
+        dk.stallTicks = (long long)(std::min(8.0, std::max(1.0, 4.0 * perStep * (double)W)) * 1.e8);
+      }
       if (h->retry.failAt == -1) { const char *e = getenv("MZR_SWEEP_FAIL_AT"); h->retry.failAt = e ? atoi(e) : -2; }
       if (h->retry.failAt >= 0 && h->retry.seen == h->retry.failAt && h->retry.depth == 0) dk.stallTicks = 1;
       if (h->retry.depth == 0) ++h->retry.seen;

@@ -165,15 +165,14 @@ def parse(elf, want):
     loops = []
     for i, (a, m, ops) in enumerate(rows):
         if m.startswith(("s_cbranch", "s_branch")):
-            # objdump prints the target as an address or as <symbol+0x..>; recompute from the symbol offset when present
-            mm = re.search(r"<[^+>]+\+0x([0-9a-f]+)>", ops)
+            # objdump prints the branch's signed 16-bit offset in dwords, relative to the next instruction
+            mm = re.match(r"\s*(\d+)\s*$", ops)
             tgt = None
             if mm:
-                tgt = rows[0][0] + int(mm.group(1), 16)
-            else:
-                mm = re.search(r"(0x)?([0-9a-f]{4,})", ops)
-                if mm:
-                    tgt = int(mm.group(2), 16)
+                off = int(mm.group(1))
+                if off >= 32768:
+                    off -= 65536
+                tgt = a + 4 + 4 * off
             if tgt is not None and tgt in index and index[tgt] <= i and i - index[tgt] < 700:
                 loops.append((index[tgt], i))
     insts = []
