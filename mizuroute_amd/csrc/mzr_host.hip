@@ -1742,7 +1742,9 @@ static void kwt_regroup(mzr_handle h) {
   // costs every 4-lane pass: the 375 k shard (bound by instructions) 674.1 -> 655.4 ms per window of 8 192, 100 k reaches 442 -> 447.5 ms
   // (profiles/r05_experiments.md 9).  MZR_KWT_KC_WIDE_RUN forces it (tests).  The stage launches keep three slots (a reach beyond them
   // takes their wide fall-back).
-  int kcWide = byInstructions ? 1 : 0;
+  // (round 6: also where the window is bound by its chain -- 100 k reaches 441 -> 435 ms per window, twice, turn about, once thinning and LDS
+  // addressing had been made cheaper: the fourth slot no longer costs what the reaches moved out of the 8-lane class save)
+  int kcWide = 1;
   if (const char *e = getenv("MZR_KWT_KC_WIDE_RUN")) kcWide = atoi(e) != 0;
   h->swKcWide = kcWide;
   if (kcWide) classCMax = 13;
