@@ -1703,6 +1703,13 @@ static void mc_regroup(mzr_handle h, int ix) {
   // profiles/r05_experiments.md)
   int heavyMin = 10;
   if (const char *e = getenv("MZR_MC_HEAVY_MIN")) heavyMin = atoi(e);
+  if (getenv("MZR_MC_LOG")) {      // debugging aid: the sub-steps the reaches executed in their last step (the longest one is the launch)
+    std::vector<int> srt(key); std::sort(srt.begin(), srt.end(), std::greater<int>());
+    int c[5] = {0, 0, 0, 0, 0};
+    for (int v : srt) { c[0] += v >= 10; c[1] += v >= 20; c[2] += v >= 40; c[3] += v >= 80; c[4] += v >= 160; }
+    fprintf(stderr, "[mzr] MC sub-steps executed: top %d %d %d %d %d %d; reaches with >= 10 / 20 / 40 / 80 / 160: %d %d %d %d %d of %d\n",
+            srt[0], srt[std::min(1, N - 1)], srt[std::min(2, N - 1)], srt[std::min(7, N - 1)], srt[std::min(63, N - 1)], srt[std::min(255, N - 1)], c[0], c[1], c[2], c[3], c[4], N);
+  }
   build_lane_perm(h, ix, key, heavyMin);
 }
 
@@ -1995,7 +2002,10 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     if (multi && ix > 0 && !persistent) {
       if (!h->routeStream[ix]) {      // (the other methods of a mainstem domain go to high-priority streams like its first: mzr_set_boundary)
         int lo = 0, hi = 0;
-        if (!(h->highPriority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+        // (experiment, MZR_MC_STREAM_PRIO=1: Muskingum-Cunge -- a launch as long as its longest sub-step chain -- on a high-priority stream
+        // beside the bandwidth-bound method of the first stream)
+        const bool mcPrio = h->route[ix].method == MZR_MC && getenv("MZR_MC_STREAM_PRIO") && atoi(getenv("MZR_MC_STREAM_PRIO")) != 0;
+        if (!((h->highPriority || mcPrio) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
               hipStreamCreateWithPriority(&h->routeStream[ix], hipStreamNonBlocking, hi) == hipSuccess))
           (void)hipStreamCreateWithFlags(&h->routeStream[ix], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&h->routeEvent[ix], hipEventDisableTiming);

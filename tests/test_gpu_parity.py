@@ -1330,3 +1330,24 @@ def test_boundary_record_that_does_not_fit_is_refused(hip_lib):
     with pytest.raises(m.MzrError) as e:
         bad2.sync()
     assert e.value.ierr == 20
+    # round 6: a record carries what the importer reads.  KWT: header | Q | BASIN_QR[W+1] | counts | 2 x 21 particle rows; an Eulerian
+    # method: header | Q and nothing else (mpi_process.f90:1245-1329 ships the outlets' fluxes) -- and the two are not mistaken for
+    # each other: the KWT part is flagged in the header
+    assert trib.boundary_size(W, n) == 4 + (W + (W + 1) + W + 2 * W * 21) * n
+    uh_off = np.arange(src.net.N + 1, dtype=np.int32)
+    tr_irf = m.RoutingDomain(src.net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=uh_off, uh=np.ones(src.net.N), max_window=W, export_reaches=src.export_local)
+    assert tr_irf.boundary_size(W, n) == 4 + 2 * W * n
+    tr_irf.run(ro[:, src.hru_global])
+    rec2 = torch.zeros(tr_irf.boundary_size(W, n), dtype=torch.float64, device="cuda")
+    tr_irf.export_boundary(rec2.data_ptr()); tr_irf.sync()
+    hdr = rec2[:4].cpu().numpy()
+    assert hdr[1] == 2 and hdr[2] == W and hdr[3] == n and rec.cpu().numpy()[3] == n + 2.0 ** 31
+    assert np.array_equal(rec2[4:4 + W * n].cpu().numpy().reshape(W, n), tr_irf.window_q(m.IRF, W)[:, src.export_local - 1])
+    mo = np.arange(P.main.net.N + 1, dtype=np.int32)
+    main_e = m.RoutingDomain(P.main.net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=mo, uh=np.ones(P.main.net.N), max_window=W,
+                             halo_reaches=P.main.halo_local, halo_good=P.main.halo_good)
+    main_e.import_boundary(W, rec2.data_ptr(), n, base); main_e.wait_import(); main_e.sync()      # fits
+    bad3 = mainstem(False)                                                    # an Eulerian record offered to a KWT domain
+    with pytest.raises(m.MzrError):
+        bad3.import_boundary(W, rec2.data_ptr(), n, base)      # (one method against two: refused)
+        bad3.sync()
