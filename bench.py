@@ -761,8 +761,8 @@ def main():
                     "--balance cuts rank 0's share of small tributaries by the mainstem's cost instead)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` objects of the default line (full-size c3 / c4 / c5 in 8 partitions on this GPU)")
     ap.add_argument("--configs", default="c3,c4,c5", help="which full-size configurations the default line carries")
-    ap.add_argument("--cpu-spinup-configs", type=int, default=8, help="untimed steps of the CPU baseline of a `configs` object (full network: about a second per step)")
-    ap.add_argument("--cpu-sample-configs", type=int, default=16, help="timed steps of the CPU baseline of a `configs` object")
+    ap.add_argument("--cpu-spinup-configs", type=int, default=16, help="untimed steps of the CPU baseline of a `configs` object (full network: about a second per step)")
+    ap.add_argument("--cpu-sample-configs", type=int, default=24, help="timed steps of the CPU baseline of a `configs` object")
     ap.add_argument("--cpu-spinup", type=int, default=48, help="with --loopback: untimed steps of the CPU baseline on the full network")
     ap.add_argument("--cpu-sample", type=int, default=48, help="with --loopback: timed steps of the CPU baseline on the full network")
     ap.add_argument("--event-roofline", action="store_true", help="also time K more windows with HIP events on the sweep launches (the round-4 measurement; "
