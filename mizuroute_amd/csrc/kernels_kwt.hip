@@ -1854,14 +1854,16 @@ __global__ void __launch_bounds__(256) k_kwt_window_init(MzrDev d, int tBegin, i
   const int tB = tBegin + blockIdx.y * per, tE = min(tEnd, tB + per);
   const int es = (FULL && d.exportSlot) ? d.exportSlot[r] : -1;
   int t = tB;
-  for (; t + 8 <= tE; t += 8) {      // eight rows in flight per lane
-    double v[8];
+  if (!d.kwHeadQ) {      // (otherwise k_hillslope_out has written the rows: mzr_device.h kwHeadQ)
+    for (; t + 8 <= tE; t += 8) {      // eight rows in flight per lane
+      double v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(d.qlat + (size_t)(t + j + 1) * N + r);
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(d.qlat + (size_t)(t + j + 1) * N + r);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d.Q[(size_t)(t + j) * N + r] = v[j];
+      for (int j = 0; j < 8; ++j) d.Q[(size_t)(t + j) * N + r] = v[j];
+    }
+    for (; t < tE; ++t) d.Q[(size_t)t * N + r] = d.qlat[(size_t)(t + 1) * N + r];
   }
-  for (; t < tE; ++t) d.Q[(size_t)t * N + r] = d.qlat[(size_t)(t + 1) * N + r];
   if (es >= 0) for (int t2 = tB; t2 < tE; ++t2) d.exN[(size_t)t2 * d.nExp + es] = 0;
   if (first && blockIdx.y == 0) {
     d.inflow[r] = 0.0;

@@ -165,6 +165,8 @@ struct MzrDev {
   const int *swP;             // [nLaunch+1][8] tickets of queue q before launch s (queue q = items i with i % 8 == q)
   int *swHead;                // [8][16] next ticket of each queue (one cache line each)
   const int *kwtHead;         // headwater reaches (bulk kernel before the sweep)
+  const uint8_t *kwHeadFlag; double *kwHeadQ;      // round 6: k_hillslope_out writes a headwater reach's discharge rows of the KWT method itself (REACH_Q =
+                                            // BASIN_QR(1), kwt_route.f90:181-205) where it has the value in a register; null: k_kwt_window_init copies the rows
   int nHead, nDepLight;       // entries of kwtHead / of kwtLight in persistent mode (lake and halo reaches only)
   int nA, nB, nC, nG;         // routed records per class
   // ---- lakes (null / 0 without lakes)

@@ -305,6 +305,7 @@ struct mzr_domain {
   DBuf<unsigned long long> swClock; long long swClockN = 0;      // {first wavefront in, last wavefront out} of the last MZR_CLOCK_LOG sweep launches (device clock)
   // kwt
   DBuf<int> kwN, obN, kwtLight;
+  DBuf<uint8_t> kwHeadFlag;      // [N] 1 = headwater reach of the KWT sweep (k_hillslope_out writes its discharge rows)
   DBuf<MzrKwtRec> kwtRouted, kwtRoutedB, kwtRoutedC, kwtGeneric;
   DBuf<MzrKwtRec> kwtRoutedAll, kwtRoutedBAll, kwtRoutedCAll;   // classes A / B / C over all stages, heaviest first: used by launches in which every stage is active
   bool kwtAllValid = false;
@@ -1614,6 +1615,7 @@ int mzr_init_state(mzr_handle h) {
           if (head.empty()) head.push_back(0);
           if (depLight.empty()) depLight.push_back(0);
           h->kwtHead.upload(head); h->kwtDepLight.upload(depLight);
+          { std::vector<uint8_t> hf(N, 0); for (int r : h->h_kwtHead) hf[r] = 1; h->kwHeadFlag.upload(hf); }
           h->kwDone.alloc(N); h->kwDone.zero();
           h->swCap = 0;
           h->kwtHeadSteps = 0;
@@ -1975,6 +1977,11 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   // the others keep running (ierr 93; profiles/r03_soak.md).  The whole hillslope pre-pass then runs first.
   bool chunked = nChunks > 2 && !multi && !anyPersistent;
   if (const char *e = getenv("MZR_BASIN_CHUNKED")) chunked = chunked && atoi(e) != 0;   // debugging aid
+  // (persistent KWT sweep with the hillslope delay on: k_hillslope_out also writes the headwater reaches' discharge rows of the KWT
+  // method -- the value it has just made -- and k_kwt_window_init no longer reads them back and copies them)
+  if (!chunked && sweep && h->cfg.doesBasinRoute == 1 && h->kwHeadFlag.p && !h->h_kwtHead.empty() && !getenv("MZR_NO_HEAD_FUSE")) {
+    d.kwHeadFlag = h->kwHeadFlag.p; d.kwHeadQ = h->route[kwtIx].Q.p;
+  }
   if (!chunked) mzr_launch_basin(d, st);
   else {
     if (!h->basinStream) (void)hipStreamCreateWithFlags(&h->basinStream, hipStreamNonBlocking);
