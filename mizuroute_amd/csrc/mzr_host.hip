@@ -68,7 +68,13 @@ template <typename T> struct DBuf {
     n = cnt;
     if (cnt) { if (hipExtMallocWithFlags((void **)&p, cnt * sizeof(T), hipDeviceMallocUncached) != hipSuccess) { p = nullptr; n = 0; throw std::string("hipExtMallocWithFlags failed"); } }
   }
-  void zero(hipStream_t s = 0) { if (p) (void)hipMemsetAsync(p, 0, n * sizeof(T), s); }
+  // zero(): set-up calls, no stream -- the fill runs on the null stream and the call returns when it is done.  (Round 6: it used to
+  // return at once.  A handle's own stream does not wait for the null stream where it was made non-blocking -- the high-priority
+  // stream of a mainstem domain, mzr_set_boundary -- so the first kernels of such a domain could overtake the fill of a buffer made
+  // by a later set-up call (mzr_set_da, mzr_set_tracer), and the fill then wiped what they had written: a partitioned run with gauge
+  // observations differed from the whole network once in a few runs on a fresh box.)  zero(stream): ordered in that stream.
+  void zero() { if (p) { (void)hipMemsetAsync(p, 0, n * sizeof(T), 0); (void)hipStreamSynchronize(0); } }
+  void zero(hipStream_t s) { if (p) (void)hipMemsetAsync(p, 0, n * sizeof(T), s); }
   void upload(const std::vector<T> &v) { alloc(v.size()); if (!v.empty()) (void)hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); }
   void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
   void swap(DBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
