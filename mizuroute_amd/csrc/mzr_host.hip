@@ -290,7 +290,7 @@ struct mzr_domain {
   // (s >= W) are kept back and issued together with the first launches of the next window, or on their own as soon as
   // anybody asks for a result (flushTail: every entry point but the run calls).  The window kept back owns its rows
   // (qlat / qi / Q / lake forcing: the *Alt buffers, swapped in and out); tail.d[ix] are the device views it was launched with.
-  struct { bool pending = false; int W = 0; MzrDev d[6]; } tail;      // (W: launches of the window = its steps in blocks of d.stepBlock)
+  struct { bool pending = false; int W = 0, next = 0; MzrDev d[6]; } tail;      // (W: launches of the window = its steps in blocks of d.stepBlock; next: the first of its nStages - 1 kept-back launches not yet issued)
   DBuf<double> qiAlt, qlatAlt, lakeEvapAlt, lakePrecipAlt; DBuf<int> calMonthAlt, calDayAlt, calDoyAlt;
   bool lakeNextInAlt = false;                    // mzr_set_lake_forcing wrote the NEXT window's lake forcing into the *Alt buffers
   bool imNextInAlt = false;                      // mzr_import_boundary_dev wrote the NEXT window's halo discharge into imQAlt (run_window swaps it in)
@@ -812,6 +812,7 @@ void kwt_sweep_tables(mzr_handle h, int W) {
 
 static int flushSteps(mzr_handle h, bool keepStaged = false);
 static void flushTail(mzr_handle h);
+static void issueTail(mzr_handle h, int jBegin, int jEnd);
 // the row of one kind for the coming step (a later call for the same step replaces it, as a second call of the setter would)
 static int stageRow(mzr_handle h, int kind, const double *a, size_t na, const double *b, size_t nb, const int *i0, const int *i1, const int *i2) {
   mzr_domain::StepRows &r = h->sr[kind];
@@ -1911,7 +1912,14 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
   if (const char *e = getenv("MZR_ROUTE_SWEEP")) pipe = pipe && atoi(e) == 0;      // (a forced persistent sweep routes whole windows)
   const int KB = stepBlockFor(h, W, pipe && h->nExp == 0);      // (an export asks for the window's last launches at once: no overlap)
   const int WB = (W + KB - 1) / KB;      // the window in blocks = launches in which a stage is active
-  pipe = pipe && WB >= nSt;
+  // Round 6: a window SHORTER than the network is deep overlaps too.  Its nStages - 1 kept-back launches no longer fit the next
+  // window's WB launches one for one: the first (nStages - 1 - WB) of them go out on their own in front of the next window, the last WB
+  // ride with its launches -- kept-back launch j + o with launch j, o = nStages - 1 - WB: the stages above j + o and the stages up to j,
+  // disjoint reaches; step 0 of a reach of stage s in the new window (launch s) needs its last step of the old one, kept-back launch
+  // s - 1, which went out before (on its own, or with launch s - 1 - o).  A window then costs nStages - 1 launches instead of
+  // nStages + WB - 1 (a mainstem domain of 3 756 stages in windows of 2 048: 3 755 instead of 5 803), and still no more than two
+  // windows are in flight.  MZR_OVERLAP_SHORT=0: only windows of at least nStages launches overlap (rounds 4-5).
+  if (WB < nSt && getenv("MZR_OVERLAP_SHORT") && atoi(getenv("MZR_OVERLAP_SHORT")) == 0) pipe = false;
   if (h->tail.pending && !pipe) flushTail(h);
   const double *prevQlat = h->qlat.p;      // rows of the window before (row lastW = its last BASIN_QR(1))
   if (pipe) {
@@ -2134,7 +2142,15 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
     ++rb.nLaunches;
   }
-  const bool withTail = pipe && h->tail.pending;      // the window before drains in this window's first nS - 1 launches
+  const bool withTail = pipe && h->tail.pending;      // the window before drains in this window's first launches
+  int nPair = 0, tailOff = 0;      // kept-back launches tailOff .. tailOff + nPair - 1 of the window before ride with launches 0 .. nPair - 1 of this one
+  if (withTail) {
+    const int left = (nS - 1) - h->tail.next;
+    nPair = std::min(left, WB);
+    issueTail(h, h->tail.next, h->tail.next + (left - nPair));      // (a window shorter than the network is deep: the others first, on their own)
+    tailOff = h->tail.next + (left - nPair);
+    h->tail.next = nS - 1;
+  }
   int nextChunk = 1;
   for (int s = 0; s < (pipe ? WB : nS + WB - 1); ++s) {
     if (!anyStage) break;
@@ -2148,12 +2164,12 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
       hipStream_t sx = rst[ix];
       if (sweep && ix == kwtIx) continue;
       if (rb.method != MZR_KWT && rtSweep && rb.rtCap >= 1) continue;
-      if (withTail && s < nS - 1) {      // launch W' + s of the window before (stages s+1 .. nS-1) and launch s of this one (stages 0 .. s) as one
+      if (withTail && s < nPair) {      // launch W' + tailOff + s of the window before (the stages above tailOff + s) and launch s of this one (stages 0 .. s) as one
         if (prof) {
           if (rb.evUsed == rb.events.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); rb.events.emplace_back(a, b); }
           (void)hipEventRecord(rb.events[rb.evUsed].first, sx);
         }
-        mzr_launch_stage_pair(rb.method, h->tail.d[ix], h->tail.W + s, h->stageStart[s + 1], N, dr[ix], s, rB, rE, sx);
+        mzr_launch_stage_pair(rb.method, h->tail.d[ix], h->tail.W + tailOff + s, h->stageStart[tailOff + s + 1], N, dr[ix], s, rB, rE, sx);
         if (prof) { (void)hipEventRecord(rb.events[rb.evUsed].second, sx); ++rb.evUsed; }
         ++rb.nLaunches; ++h->pairLaunches;
         continue;
@@ -2179,13 +2195,13 @@ static int run_window(mzr_handle h, int W, double t_start, double T1_single, con
     }
     // the rows of the window before are complete from here on (its kept-back launches went out with launches 0 .. nS - 2 of this
     // one): what mzr_export_boundary_prev_dev waits for
-    if (h->prevInAlt && s == (withTail ? nS - 2 : 0))
+    if (h->prevInAlt && s == (withTail ? std::max(0, nPair - 1) : 0))
       for (int ix = 0; ix < nR && ix < 6; ++ix) {
         if (!h->prevRowsEv[ix]) (void)hipEventCreateWithFlags(&h->prevRowsEv[ix], hipEventDisableTiming);
         (void)hipEventRecord(h->prevRowsEv[ix], rst[ix]);
       }
   }
-  if (pipe && anyStage) { h->tail.pending = true; h->tail.W = WB; for (int ix = 0; ix < nR; ++ix) h->tail.d[ix] = dr[ix]; }
+  if (pipe && anyStage) { h->tail.pending = true; h->tail.W = WB; h->tail.next = 0; for (int ix = 0; ix < nR; ++ix) h->tail.d[ix] = dr[ix]; }
   else h->tail.pending = false;
   if (h->tracer) {
     // constituent: lateral mass flux and its hillslope delay for the whole window (after the water's), then, behind every
@@ -2594,14 +2610,22 @@ int mzr_step(mzr_handle h, double T0, double T1, const double *runoff) {
 // The launches s = W .. W + nS - 2 of the last window, kept back for the next one (overlapping windows), on their own: somebody
 // wants a result, or the next window cannot take them along.  Same streams as the window's other launches; the handle's
 // stream then waits for the others, as it does at the end of every window.
+static void issueTail(mzr_handle h, int jBegin, int jEnd);
 static void flushTail(mzr_handle h) {
   if (!h->tail.pending) return;
   h->tail.pending = false;
   ++h->tailFlushes;
   (void)hipSetDevice(h->cfg.device);
-  const int nS = h->nStages, N = h->N, nR = h->cfg.nRoutes, W = h->tail.W;
+  issueTail(h, h->tail.next, h->nStages - 1);
+  h->tail.next = h->nStages - 1;
+  for (int ix = 1; ix < h->cfg.nRoutes; ++ix)
+    if (h->routeStream[ix]) { (void)hipEventRecord(h->routeEvent[ix], h->routeStream[ix]); (void)hipStreamWaitEvent(h->stream, h->routeEvent[ix], 0); }
+}
+// the kept-back launches [jBegin, jEnd) of the last window (launch W + j: the stages above j), each on its method's stream
+static void issueTail(mzr_handle h, int jBegin, int jEnd) {
+  const int N = h->N, nR = h->cfg.nRoutes, W = h->tail.W;
   const bool prof = h->profiling;
-  for (int j = 0; j < nS - 1; ++j) {
+  for (int j = jBegin; j < jEnd; ++j) {
     const int rB = h->stageStart[j + 1];
     if (rB >= N) break;
     for (int ix = 0; ix < nR; ++ix) {
@@ -2616,8 +2640,6 @@ static void flushTail(mzr_handle h) {
       ++rb.nLaunches;
     }
   }
-  for (int ix = 1; ix < nR; ++ix)
-    if (h->routeStream[ix]) { (void)hipEventRecord(h->routeEvent[ix], h->routeStream[ix]); (void)hipStreamWaitEvent(h->stream, h->routeEvent[ix], 0); }
 }
 
 // n rows of one kind to its window setter (srApplying: the setter neither stages them again nor flushes)

@@ -225,6 +225,64 @@ def test_full_size_network_partitioned_equals_whole(config, hip_lib):
         assert nw[g].mean() > nw.mean()          # long particle lists sit on the main stems
 
 
+@pytest.mark.parametrize("cfg", ["irf_mc", "dw_lakes"])
+def test_windows_shorter_than_the_network_is_deep_overlap_too(cfg, hip_lib, monkeypatch):
+    """Round 6: a window of fewer steps than the network has stages keeps its last launches back as well -- the first
+    (nStages - 1 - W) of them go out on their own in front of the next window, the last W ride with the next window's launches
+    (a mainstem domain of thousands of stages routed in windows of 2 048 is the case this is for: nStages - 1 launches per window
+    instead of nStages + W - 1).  Windows of 60-400 steps on a network ~450 stages deep, one of them longer than the network is deep:
+    the same bits as MZR_OVERLAP_WINDOWS=0, and exactly one launch fewer per kept-back launch that rode along."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    lakes = None
+    if cfg == "dw_lakes":
+        net = m.make_network(30_000, seed=31, floodplain=True)
+        methods = [m.DW]
+    else:
+        net = m.make_network(30_000, seed=32)
+        methods = [m.IRF, m.MC]
+    frac, off, v = _uh(net)
+    cuts = [300, 200, 60, 400, 700, 150, 150]
+    total = sum(cuts)
+    if cfg == "dw_lakes":
+        lakes = make_lakes(net, total, DT, seed=9, frac=0.01, input_option=1)
+    ro = bench.device_runoff(torch, net.H, total, 0, 7, dev)
+    torch.cuda.synchronize()
+
+    def route(overlap):
+        monkeypatch.setenv("MZR_OVERLAP_WINDOWS", "1" if overlap else "0")
+        monkeypatch.setenv("MZR_STEP_BLOCK", "1")
+        dom = m.RoutingDomain(net, DT, methods, frac_future=frac, uh_offset=off, uh=v, max_window=max(cuts), lakes=lakes)
+        nS = int(dom.schedule()[0])
+        assert 300 < nS <= 512, nS
+        t = 0
+        for w in cuts:
+            if lakes is not None:
+                dom.set_lake_forcing(t, w)
+            dom.run_device(w, t * DT, ro[t:t + w].data_ptr())
+            t += w
+        dom.sync()
+        out = {}
+        for mm in methods:
+            out[("Q", mm)] = dom.flux(mm, m.api.F_Q)
+            out[("mean", mm)] = dom.mean_q(mm)
+            out[("vol", mm)] = dom.flux(mm, m.api.F_VOL1)
+            if mm in (m.MC, m.DW):
+                out[("mol", mm)] = dom.mol_state(mm)
+        if m.IRF in methods:
+            out["irf"] = dom.irf_state()
+        launches = int(dom.timing(methods[0])["launches"])
+        dom.close()
+        return out, launches, nS
+
+    (a, la, nS), (b, lb_, _) = route(True), route(False)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert lb_ == sum(nS + w - 1 for w in cuts)
+    assert la == lb_ - sum(min(nS - 1, w) for w in cuts[1:]), (la, lb_, nS)
+
+
 @pytest.mark.parametrize("cfg", ["irf_mc", "dw_lakes", "kw_sum"])
 def test_overlapping_windows_equal_windows_one_after_the_other(cfg, hip_lib, monkeypatch):
     """Overlapping windows of the Eulerian methods (kernels_route.hip k_stage_pair; mc_route.f90:46-416, irf_route.f90:40-264,
