@@ -539,6 +539,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
             for key, vname, sc, of, flip in (("evap", ctl.get("vname_evapo", "evap"), sc_ep, of_ep, _truth(ctl.get("is_Ep_upward_negative", "F"))),
                                              ("precip", ctl.get("vname_precip", "precip"), sc_pr, of_pr, False)):
                 dstf = torch.zeros((w, net.H), dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()      # (the fill is done before the library's own stream writes into it)
                 flux_dev[key] = dstf
                 if lk["input_option"] == 1 or suppressed(sc, of):
                     continue
@@ -548,6 +549,7 @@ def run(control_path: str, window: int = 1024, device: int = 0, log=print) -> di
                 a = scale_forcing(a, sc, of)
                 srcf = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
                 dom.remap_device(w, srcf.data_ptr(), dstf.data_ptr())
+            torch.cuda.synchronize()      # (torch's fills and copies run on its stream; the library's streams do not wait for it)
             dom.sync()
             if is_vol_wm:
                 lk["wm_vol"] = np.stack([sort_flux(wm_ix, fwm.step(ctl["vname_vol_wm"], dt, done + k + 1), net.N, True) for k in range(w)])

@@ -18,6 +18,15 @@ from helpers import GOLDEN_CASES, REL_TOL, golden_lakes, load_golden, parity_rep
 pytestmark = pytest.mark.gpu
 
 
+def _filled(torch, n):
+    """n zeroed doubles on the device, the fill FINISHED: torch fills on its own stream, and the library packs records on streams of its
+    own that do not wait for it -- a fill that is still queued when the pack kernel runs wipes the record (seen as one partitioned test
+    in a few failing on a fresh box, where torch's first fill launch is slow)"""
+    t = torch.zeros(int(n), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    return t
+
+
 def domain_from_golden(net, z, **kw):
     methods = [int(x) for x in z["methods"]]
     return m.RoutingDomain(net, float(z["dt"]), methods, frac_future=z["frac_future"],
@@ -379,7 +388,7 @@ def test_partitioned_network_equals_whole(kc_wide, hip_lib, monkeypatch):
             def __init__(self, me): self.me = me
             def send(self, t, dst): box[(self.me, dst)] = t.clone()
             def recv(self, t, src): t.copy_(box[(src, 0)]); torch.cuda.synchronize()
-        routers.append(PartitionedRouter(P, rank, make, T(rank), lambda n: torch.zeros(n, dtype=torch.float64, device="cuda"), W))
+        routers.append(PartitionedRouter(P, rank, make, T(rank), lambda n: _filled(torch, n), W))
     Q = np.full((steps, len(methods), net.N), np.nan)
     dev = torch.device("cuda")
     for w0 in range(0, steps, W):
@@ -408,7 +417,7 @@ def test_partitioned_network_equals_whole(kc_wide, hip_lib, monkeypatch):
             def __init__(self, me): self.me = me
             def send(self, t, dst): box.setdefault((self.me, dst), []).append(t.clone())
             def recv(self, t, src): t.copy_(box[(src, 0)].pop(0)); torch.cuda.synchronize()
-        routers2.append(PartitionedRouter(P, rank, make, T2(rank), lambda n: torch.zeros(n, dtype=torch.float64, device="cuda"), W))
+        routers2.append(PartitionedRouter(P, rank, make, T2(rank), lambda n: _filled(torch, n), W))
     order = list(range(1, nparts)) + [0]
     for w0 in range(0, steps2, W):
         for rank in order:
@@ -792,7 +801,7 @@ def test_lakes_direct_insertion_and_constituent_in_partitioned_domains(hip_lib):
             Q[w0:w0 + W][:, :, sp.reach_global[:sp.n_real]] = q[:, :, :sp.n_real]
             F[w0:w0 + W][:, :, sp.reach_global[:sp.n_real]] = dom.solute_flux[:, :, :sp.n_real]
             if sp.export_local.size:
-                rec = torch.zeros(dom.boundary_size(W, sp.export_local.size), dtype=torch.float64, device="cuda")
+                rec = _filled(torch, dom.boundary_size(W, sp.export_local.size))
                 dom.export_boundary(rec.data_ptr()); dom.sync()
                 recs[p] = rec
         for p in range(nparts):
@@ -1281,7 +1290,7 @@ def test_kwt_lake_at_a_tributary_outlet_reaches_the_mainstem_as_a_lake(hip_lib):
         td = m.RoutingDomain(sp.net, 3600.0, [m.KWT], frac_future=ff, max_window=8, export_reaches=sp.export_local,
                              lakes=lakes_for_domain(lakes, sp, net.N))
         td.run(ro[:, sp.hru_global])
-        rec = torch.zeros(td.boundary_size(8, sp.export_local.size), dtype=torch.float64, device="cuda")
+        rec = _filled(torch, td.boundary_size(8, sp.export_local.size))
         td.export_boundary(rec.data_ptr()); td.sync()
         base, n = P.main.halo_base[sp.part]
         main.import_boundary(8, rec.data_ptr(), n, base); main.sync()
@@ -1307,7 +1316,7 @@ def test_boundary_record_that_does_not_fit_is_refused(hip_lib):
     trib = m.RoutingDomain(src.net, 3600.0, [m.KWT], frac_future=ff, max_window=W, export_reaches=src.export_local)
     trib.run(ro[:, src.hru_global])
     n = src.export_local.size
-    rec = torch.zeros(trib.boundary_size(W, n), dtype=torch.float64, device="cuda")
+    rec = _filled(torch, trib.boundary_size(W, n))
     trib.export_boundary(rec.data_ptr()); trib.sync()
     base, cnt = P.main.halo_base[src.part]
     assert cnt == n
@@ -1338,7 +1347,7 @@ def test_boundary_record_that_does_not_fit_is_refused(hip_lib):
     tr_irf = m.RoutingDomain(src.net, 3600.0, [m.IRF, m.DW], frac_future=ff, uh_offset=uh_off, uh=np.ones(src.net.N), max_window=W, export_reaches=src.export_local)
     assert tr_irf.boundary_size(W, n) == 4 + 2 * W * n
     tr_irf.run(ro[:, src.hru_global])
-    rec2 = torch.zeros(tr_irf.boundary_size(W, n), dtype=torch.float64, device="cuda")
+    rec2 = _filled(torch, tr_irf.boundary_size(W, n))
     tr_irf.export_boundary(rec2.data_ptr()); tr_irf.sync()
     hdr = rec2[:4].cpu().numpy()
     assert hdr[1] == 2 and hdr[2] == W and hdr[3] == n and rec.cpu().numpy()[3] == n + 2.0 ** 31
