@@ -532,9 +532,10 @@ class Loopback:
             ro_t = [self.forcing(W, k * W, sp.hru_global, shared=False) for k in range(2)]
             ro_m = [self.forcing(W, k * W, ms.hru_global, shared=False) for k in range(2)]
             rec0 = [torch.empty(d_t.boundary_size(W, sp.export_local.size), dtype=torch.float64, device=self.dev) for _ in range(2)]
-            tw = []
+            tw, tw_trib, tw_join = [], [], []
             import threading
             two_threads = m.KWT not in methods
+            kwt_leg = m.KWT in methods
             KS = K + EXTRA      # (two fresh domains: their first windows hold the regroupings and table builds)
             # (rank 0's tributary domain exports right behind its window, as PartitionedRouter does where two domains share a GPU: a
             # domain that keeps a window queued ahead holds the hardware queues its neighbour's launches need -- measured on c4: 1.33 s
@@ -546,7 +547,8 @@ class Loopback:
                         base, n = ms.halo_base[p]
                         if n:
                             d_m.import_boundary(W, (rec0[(k - 1) % 2] if p == 0 else recs[(p, k - 1)]).data_ptr(), n, base)
-                    d_m.wait_import()                        # (the record buffers may go; the mainstem's overlapping windows stay)
+                    if not kwt_leg:
+                        d_m.wait_import()                    # (the record buffers may go; the mainstem's overlapping windows stay)
                     if d_m.lakes is not None:
                         d_m.set_lake_forcing(0, W)
                     d_m.run_device(W, (k - 1) * W * DT, ro_m[(k - 1) % 2].data_ptr())
@@ -555,23 +557,37 @@ class Loopback:
                 th = None
                 if k >= 1 and two_threads:
                     th = threading.Thread(target=main_side); th.start()
+                main_first = kwt_leg and os.environ.get("MZR_BENCH_MAIN_FIRST", "1") != "0"
+                if k >= 1 and main_first:      # KWT: the small sweep is launched -- and resident -- before the large one's thousands of workgroups are dispatched
+                    main_side()
                 if k < KS:
                     if d_t.lakes is not None:
                         d_t.set_lake_forcing(0, W)
                     d_t.run_device(W, k * W * DT, ro_t[k % 2].data_ptr())
                 if th is not None:
                     th.join()
-                elif k >= 1:
+                elif k >= 1 and not main_first:
                     main_side()
                 if k < KS:
                     d_t.sync()
+                    t_trib = time.perf_counter() - t1
                     d_t.export_boundary(rec0[k % 2].data_ptr())
-                d_t.sync(); torch.cuda.synchronize()      # (not d_m.sync(): the mainstem keeps its window's last launches back for the next one)
+                d_t.sync()
+                if kwt_leg:
+                    d_m.sync()                            # (a KWT mainstem has nothing to keep back: the handle's own synchronisation, as in rounds 3-5)
+                else:
+                    torch.cuda.synchronize()              # (not d_m.sync(): the mainstem keeps its window's last launches back for the next one)
                 if 1 <= k < KS:
-                    tw.append(time.perf_counter() - t1)
+                    tw.append(time.perf_counter() - t1); tw_trib.append(t_trib)
+                    if m.KWT in methods:      # wavefronts of the mainstem's last sweep launch that arrived / joined (a launch whose wavefronts start late joins with few)
+                        try:
+                            a_ = d_m.sweep_arrivals(); c_ = d_m.sweep_clock(1); c2_ = d_t.sweep_clock(1)
+                            tw_join.append([int(a_[0]), int(a_[1]), round(c_[-1], 1) if c_ else None, round(c2_[-1], 1) if c2_ else None])
+                        except Exception:
+                            pass
             d_m.sync()
             t_rank0 = float(np.median(tw[len(tw) // 2:]))      # (the first windows of two fresh domains hold their regroupings and table builds)
-            times["rank0_side_by_side"] = dict(s_per_window=tw, sweep_share_mainstem=share, sweep_priority_mainstem=1, mainstem_queued_from_its_own_host_thread=two_threads,
+            times["rank0_side_by_side"] = dict(s_per_window=tw, s_until_the_tributary_window_is_done=tw_trib, mainstem_sweep_wavefronts_arrived_joined=tw_join, sweep_share_mainstem=share, sweep_priority_mainstem=1, mainstem_queued_from_its_own_host_thread=two_threads,
                                                what="tributary window k and mainstem window k-1 of rank 0 queued together; median of the later half of the windows")
             d_t.close(); d_m.close()
         recs.clear()

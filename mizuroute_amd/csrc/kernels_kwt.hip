@@ -1704,7 +1704,7 @@ k_sweep_kwt(MzrDev dArg, int sBegin, int sEnd) {
   if (sEnd < 0) { mzr_census(d0.swHead + 8 * 16); return; }      // host: mzr_sweep_kwt_capacity
   if (ldx<true>(&d0.err->code) != 0) return;      // a window that failed stays as it is (and is not built upon)
   if (d0.kwtStat && mzr_lane() < RC) { unsigned long long *cs = (unsigned long long *)(sCtx[mzr_lane()] + 12); cs[0] = cs[1] = cs[2] = cs[3] = 0ull; }
-  const int arr = mzr_sweep_join(d0.swHead, d0.swClock);      // (a wavefront that starts behind time does not join)
+  const int arr = mzr_sweep_join(d0.swHead, d0.swClock, d0.sweepAlways);      // (a wavefront that starts behind time does not join)
   if (arr < 0) return;
   if (d0.sweepPrio) __builtin_amdgcn_s_setprio(3);      // mzr_config.sweepPriority: a small, deep domain sweeping beside a large one
   const int Wm1 = d0.W - 1;

@@ -222,6 +222,7 @@ struct MzrDev {
   int *swBeat;                // [wavefronts][8] what every wavefront of a persistent sweep is doing (launch, item, queue, phase, items done): only with MZR_SWEEP_DEBUG=1
   int winSeq;                 // this window's number since the handle was last synchronised (goes into the error record)
   int sweepPrio;              // 1: wavefronts of this handle's persistent sweeps keep the highest wave priority (mzr_config.sweepPriority)
+  int sweepAlways;            // wavefronts of a sweep launch that join however late they start (64; the whole grid for the small partner of two sweeps on one device)
   long long stallTicks;       // a polling wavefront gives up (code 93) when nothing it polls has changed for this many ticks of the 100 MHz clock
   MzrKwtStat *kwtStat;
   unsigned long long *dbgCycles;   // [32] per-section wave cycles (only with -DMZR_KWT_TIMING)
@@ -267,7 +268,7 @@ __device__ __forceinline__ void mzr_census(int *cnt) {
 #ifndef MZR_SWEEP_LATE_TICKS
 #define MZR_SWEEP_LATE_TICKS 2000
 #endif
-__device__ __forceinline__ int mzr_sweep_join(int *head, unsigned long long *clk = nullptr) {
+__device__ __forceinline__ int mzr_sweep_join(int *head, unsigned long long *clk = nullptr, int always = 64) {
   int j = 0;
   if ((threadIdx.x & 63) == 0) {
     const long long now = wall_clock64();
@@ -278,7 +279,7 @@ __device__ __forceinline__ int mzr_sweep_join(int *head, unsigned long long *clk
     atomicAdd(head + 8 * 16 + 16 + (dt <= 0 ? 0 : min(31, 64 - __clzll(dt))), 1);      // delays below 2^k ticks
     // (the first 64 to arrive always join -- a launch on a GPU that has just woken up can be slow as a whole -- so that
     // every queue has servers whatever happens: joiners 0..63 take queue j % 8)
-    if (dt > MZR_SWEEP_LATE_TICKS && arr >= 64) j = -1;
+    if (dt > MZR_SWEEP_LATE_TICKS && arr >= (always > 64 ? always : 64)) j = -1;
     else j = atomicAdd(head + 8 * 16 + 3, 1);
   }
   return __builtin_amdgcn_readfirstlane(j);

@@ -420,6 +420,14 @@ void fillDev(mzr_handle h, MzrDev &d) {
   d.dt = h->cfg.dt; d.min_length_route = h->cfg.min_length_route; d.runoffMin = h->cfg.runoffMin;
   d.mcTailTol = h->cfg.mcTailTol >= 0.0 ? h->cfg.mcTailTol : 0.0;
   d.sweepPrio = h->cfg.sweepPriority != 0;
+  // Round 6: the SMALL partner of two sweeps on one device (rank 0's mainstem beside its tributary sweep: sweepShare < 0.5) takes every
+  // wavefront of its launch however late it starts.  Its few hundred workgroups are dispatched beside the other domain's kernels, and one
+  // launch in ten or so most of them started 20+ us behind the first: only the 64 that always join took part and the window took 1.2-1.4 s
+  // instead of 0.3 (bench.py --loopback --config c3: joined 64 of 480).  Together with the order of the two launches (PartitionedRouter:
+  // the mainstem's window first, so that its sweep is resident when the large one's thousands of workgroups arrive): 0 slow windows in 32,
+  // against 1 in 8 with either measure alone (profiles/r06_experiments.md 7).  Both grids together fit the device (the shares are of the
+  // measured capacity): these wavefronts are late, not waiting for a slot; the watchdog and the retry stay behind the rule.
+  d.sweepAlways = (h->cfg.sweepShare > 0.0 && h->cfg.sweepShare < 0.5) ? (1 << 30) : 64;
   d.stallTicks = (long long)((h->cfg.sweepTimeout > 0.0 ? h->cfg.sweepTimeout : 8.0) * 1.e8);      // wall_clock64: 100 MHz
   d.negRunoffTol = h->cfg.negRunoffTol; d.time_conv = h->cfg.time_conv; d.length_conv = h->cfg.length_conv;
   d.hw_drain_point = h->cfg.hw_drain_point; d.doesBasinRoute = h->cfg.doesBasinRoute;

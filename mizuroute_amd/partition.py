@@ -376,6 +376,15 @@ class PartitionedRouter:
                     box.append(e)
             worker = threading.Thread(target=_main_side); worker.start()
             prev = None
+        # Rank 0 with both domains queued from ONE thread (KWT: a window is one persistent launch per domain): the mainstem's window k-1
+        # goes out BEFORE the tributary's window k.  The mainstem's sweep is a few hundred wavefronts; launched right behind the
+        # tributary's, while the dispatcher is still placing that sweep's thousands of workgroups, one launch in ten or so saw its
+        # wavefronts start late -- and a sweep wavefront that starts 20 us behind the first of its launch does not join (DESIGN.md
+        # 2.4): the mainstem window then ran on 64 wavefronts, 1.2-1.4 s instead of 0.3 (round 6, bench.py --loopback --config c3).
+        # Launched first it is resident before the large sweep arrives.  Same records, same results.
+        if prev is not None and self.trib is not None and self.main is not None and not self._main_thread and not late:
+            self._exchange(*prev)
+            prev = None
         if self.trib is not None:
             self.trib.run_device(w, t_start, runoff_trib_ptr)
             if ships:
