@@ -83,6 +83,8 @@ def _config_summary(c):
         return None
     if c.get("value") is None:
         return {"value": None, "error": str(c.get("error"))[:160]}
+    if not isinstance(c.get("model_8gpu"), dict) and "rank0_over_slowest" in c:      # already a summary (a line fed back in): as it is
+        return {k: _r(v) for k, v in c.items()}
     roof = c.get("roofline") or {}
     mod = c.get("model_8gpu") or {}
     cpu = c.get("cpu_baseline") or {}

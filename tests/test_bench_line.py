@@ -22,6 +22,9 @@ def _detail(path):
 @pytest.mark.parametrize("path", RECORDED, ids=[os.path.basename(p) for p in RECORDED])
 def test_line_from_a_recorded_detail_is_small_and_round_trips(path):
     d = _detail(path)
+    if "detail" in d:      # a recorded LINE (round 6 on: profiles/r06*_bench_driver.json; the detail object is the *_detail.json beside it)
+        raw = open(path).read().strip().splitlines()[-1]
+        assert len(raw) < bench.LINE_LIMIT and d["roofline"]["frac"] > 0 and d["cpu_baseline"]["cores"] > 0
     line = bench.compact_line(d)
     assert "\n" not in line and len(line) < bench.LINE_LIMIT <= 4096
     j = json.loads(line)
