@@ -81,6 +81,7 @@ struct MzrKwtRec {
   int down, pad;              // downstream reach (internal index, -1 = outlet): whose progress the persistent sweep polls
 };
 
+#define MZR_KWT_HOLE (1 << 29)     // sigma of a record that stands for nobody: s - sigma < 0 in every launch, the lane group has no step (kwt_regroup)
 static_assert(sizeof(MzrKwtRec) == 64, "MzrKwtRec is one 64-byte line");
 
 // kwt traffic counters (particles), accumulated with wave-level reductions

@@ -498,7 +498,7 @@ std::string stallReportKwt(mzr_handle h, const MzrErr &e) {
       if (cls == 3) { for (size_t k = (size_t)bi * 64; k < std::min(h->h_kwtDepLight.size(), (size_t)(bi + 1) * 64); ++k) itemOf[h->h_kwtDepLight[k]] = (int)i; continue; }
       if (cls < 0 || cls > 4 || !lists[cls]) continue;
       const std::vector<MzrKwtRec> &v = *lists[cls];
-      for (size_t k = (size_t)bi * per[cls]; k < std::min(v.size(), (size_t)(bi + 1) * per[cls]); ++k) if (v[k].r >= 0 && v[k].r < N) itemOf[v[k].r] = (int)i;
+      for (size_t k = (size_t)bi * per[cls]; k < std::min(v.size(), (size_t)(bi + 1) * per[cls]); ++k) if (v[k].r >= 0 && v[k].r < N && v[k].sigma < MZR_KWT_HOLE) itemOf[v[k].r] = (int)i;
     }
   }
   const int nL = (int)h->h_swRA.size();
@@ -709,7 +709,7 @@ void kwt_build_sweep(mzr_handle h) {
   auto addRouted = [&](const std::vector<MzrKwtRec> &v, int cls, size_t per) {
     for (size_t b = 0; b * per < v.size(); ++b) {
       int lo = 1 << 30, hi = -1;
-      for (size_t k = b * per; k < std::min(v.size(), (b + 1) * per); ++k) { lo = std::min(lo, v[k].sigma); hi = std::max(hi, v[k].sigma); }
+      for (size_t k = b * per; k < std::min(v.size(), (b + 1) * per); ++k) { if (v[k].sigma >= MZR_KWT_HOLE) continue; lo = std::min(lo, v[k].sigma); hi = std::max(hi, v[k].sigma); }
       items.push_back(It{(cls << 28) | (int)b, lo, hi});
     }
   };
@@ -1779,12 +1779,38 @@ static void kwt_regroup(mzr_handle h) {
   std::vector<MzrKwtRec> L[3];    // A, B, C
   for (auto &l : L) l.reserve(v.size());
   std::vector<std::pair<int, int>> key;
+  // MZR_KWT_SOLO_MIN=n (0 = off): class-A reaches that needed n entries or more get MZR_KWT_SOLO_PER (1; 2) lane groups of a pass of four
+  int soloMin = 0, soloPer = 1, soloIn = 0;
+  bool soloOpen = false;
+  if (const char *e = getenv("MZR_KWT_SOLO_MIN")) soloMin = atoi(e);
+  if (const char *e = getenv("MZR_KWT_SOLO_PER")) soloPer = std::max(1, std::min(3, atoi(e)));
   for (int sg = 0; sg < h->nStages; ++sg) {
     h->kwtRoutedOff[sg] = (int)L[0].size(); h->kwtBOff[sg] = (int)L[1].size(); h->kwtCOff[sg] = (int)L[2].size();
     key.clear();
     for (int i = h->kwtStageOff[sg]; i < h->kwtStageOff[sg + 1]; ++i) key.emplace_back(-need(v[i]), i);
     std::sort(key.begin(), key.end());
-    for (const auto &k : key) L[-k.first <= classCMax ? 2 : -k.first <= classBMax ? 1 : 0].push_back(v[k.second]);
+    for (const auto &k : key) {
+      const int cl = -k.first <= classCMax ? 2 : -k.first <= classBMax ? 1 : 0;
+      if (cl == 0 && soloMin > 0) {
+        // latency path: the heaviest reaches share their pass with fewer others (soloPer per item of four lane groups; the other groups get
+        // HOLES -- records whose stage is out of reach of any launch, so the group never has a step).  A pass costs what the entries in it
+        // cost, and a reach's step t + 1 waits for its step t: the reaches with the longest lists set the window's longest chain.
+        const bool solo = -k.first >= soloMin;
+        const int inItem = (int)(L[0].size() & 3);
+        if (inItem != 0 && (solo ? (!soloOpen || soloIn >= soloPer) : soloOpen)) {      // close the item that is open
+          MzrKwtRec hole = v[k.second]; hole.sigma = MZR_KWT_HOLE;
+          while (L[0].size() & 3) L[0].push_back(hole);
+        }
+        if ((L[0].size() & 3) == 0) { soloOpen = solo; soloIn = 0; }
+        if (solo) ++soloIn;
+      }
+      L[cl].push_back(v[k.second]);
+    }
+    if (soloMin > 0 && soloOpen && (L[0].size() & 3)) {      // (the next stage starts an item of its own)
+      MzrKwtRec hole = L[0].back(); hole.sigma = MZR_KWT_HOLE;
+      while (L[0].size() & 3) L[0].push_back(hole);
+      soloOpen = false;
+    }
   }
   h->kwtRoutedOff[h->nStages] = (int)L[0].size(); h->kwtBOff[h->nStages] = (int)L[1].size(); h->kwtCOff[h->nStages] = (int)L[2].size();
   DBuf<MzrKwtRec> *devStage[3] = {&h->kwtRouted, &h->kwtRoutedB, &h->kwtRoutedC}, *devAll[3] = {&h->kwtRoutedAll, &h->kwtRoutedBAll, &h->kwtRoutedCAll};
