@@ -1100,45 +1100,65 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               for (int j = KN; j < KT; ++j) err0(j);
             }
             grp_sync();
-            while (MPRT >= MZR_MAXQPAR_DEV) {
+            // A removal is ~190 instructions of one wavefront, one after the other (the SIMD has other wavefronts to issue from, this
+            // chain does not): on the reaches that thin 25 particles a step -- the window's longest chain at 100 k reaches -- every
+            // instruction of the turn is ~0.2 % of the window.  So: ONE divergent region per turn for the writes (lanes 0-1 the two
+            // neighbours, lane 2 the removed particle: a neighbour that is an end point gets the DBL_MAX it holds anyway instead of a
+            // test, the removed particle its own word back), no test of the neighbour's range before the values are read (an end
+            // point's far link points one past the list, inside the wavefront's LDS; what is computed from it is not used), and the
+            // turn without a candidate leaves through the loop's own condition (MPRT < 0) instead of a break of its own.
+            const int sideEnd = side ? NPRT : 0;      // the end point on this lane's side: never re-evaluated
+            const bool isRem = gl == 2;
+            do {
               double emin = DBL_MAX;
               int pay = 0;
               // (error and word of a slot are read together and unconditionally -- one ds_read2_b64 -- and chosen by selects: a
               // word fetched only where its error wins is a second, dependent LDS round trip per slot)
               double evs[KT];
-              int pks[KT];
-              auto fetch = [&](int j) { const int i = gl + j * G, ii = i <= NPRT ? i : 0; evs[j] = E[ii]; pks[j] = (int)((const long long *)Yw)[ii]; };      // (the word's 8-byte slot: fuses with E[ii])
+              long long pkw[KT];
+              auto fetch = [&](int j) { const int i = gl + j * G, ii = i <= NPRT ? i : 0; evs[j] = E[ii]; pkw[j] = ((const long long *)Yw)[ii]; };      // (the word's 8-byte slot: fuses with E[ii])
+              // (a slot beyond the list reads entry 0, whose error is DBL_MAX for good -- the first particle is never removed or
+              // re-evaluated -- and is never below the minimum so far: no range test on the value.  A wide turn has its four reads in
+              // flight together: fetched behind the first two slots' compares they were a second LDS round trip per removal)
               auto take = [&](int j) {
-                const int i = gl + j * G;
-                const double ev = i <= NPRT ? evs[j] : DBL_MAX;
+                const double ev = evs[j];
                 const bool lt = ev < emin;
-                emin = lt ? ev : emin; pay = lt ? pks[j] : pay;
+                emin = lt ? ev : emin; pay = lt ? (int)pkw[j] : pay;
               };
-#pragma unroll
-              for (int j = 0; j < KN; ++j) fetch(j);
-#pragma unroll
-              for (int j = 0; j < KN; ++j) take(j);
+              // (`held`: the words are in registers before the first compare -- left to itself the compiler loads a slot's word only
+              // where its error wins, the dependent round trip again)
+              auto held = [&](int j) { asm volatile("" : "+v"(pkw[j])); };
               if (wide) {
 #pragma unroll
-                for (int j = KN; j < KT; ++j) fetch(j);
+                for (int j = 0; j < KT; ++j) fetch(j);
 #pragma unroll
-                for (int j = KN; j < KT; ++j) take(j);
+                for (int j = 0; j < KT; ++j) held(j);
+#pragma unroll
+                for (int j = 0; j < KT; ++j) take(j);
+              } else {
+#pragma unroll
+                for (int j = 0; j < KN; ++j) fetch(j);
+#pragma unroll
+                for (int j = 0; j < KN; ++j) held(j);
+#pragma unroll
+                for (int j = 0; j < KN; ++j) take(j);
               }
               pay = grp_argmin_pos<G>(emin, pay);          // first minimum of ABSERR (removed entries hold +Inf); the index leads the word
-              if (pay == 0 || pay == 0x7fffffff) break;     // no finite interpolation error left (NaN/Inf input)
+              const bool none = (unsigned)(pay - 1) >= 0x7ffffffeu;      // 0 (or 0x7fffffff): no finite interpolation error left (NaN/Inf input)
               const int ISEL = pay >> 16, lsx = (pay >> 8) & 0xff, lsy = pay & 0xff;      // INDEX1(ISEL - 1), INDEX1(ISEL + 1)
               const int c = side ? lsy : lsx;
               const int lcw = LK[2 * c];
               const int lcx = (lcw >> 8) & 0xff, lcy = lcw & 0xff;
-              const bool valid = side ? c < NPRT : c > 0;
-              const int a = !valid ? c : side ? lsx : lcx, b = !valid ? c : side ? lcy : lsy;
+              const int a = side ? lsx : lcx, b = side ? lcy : lsy;
               const double en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
+              const int x = isRem ? ISEL : c;
+              const int wx = isRem ? pay : ((c << 16) | (a << 8) | b);
+              const double vx = isRem ? (double)INFINITY : c != sideEnd ? en : DBL_MAX;      // removed: never the minimum again
               grp_sync();
-              if (gl < 2) { LK[2 * c] = (c << 16) | ((side ? lsx : lcx) << 8) | (side ? lcy : lsy); if (valid) E[c] = en; }
-              if (gl == 2) E[ISEL] = INFINITY;              // removed: never the minimum again
+              if (gl < 3 && !none) { LK[2 * x] = wx; E[x] = vx; }
               grp_sync();
-              --MPRT;
-            }
+              MPRT = none ? -1 : MPRT - 1;
+            } while (MPRT >= MZR_MAXQPAR_DEV);
             {   // who is left
               mask = 0ull;
 #pragma unroll
@@ -1181,7 +1201,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             grp_sync();
           }
           }
-          if (MPRT >= MZR_MAXQPAR_DEV) { mzr_raise(d, 62, r, t, 16); break; }
+          if (MPRT >= MZR_MAXQPAR_DEV || MPRT < 0) { mzr_raise(d, 62, r, t, 16); break; }
           if (!big) {
             // compact in place: every lane takes its survivors into registers, then writes them to their new places (k <= i).  The
             // arrays keep their roles, so their addresses stay base + constant for the rest of the pass (the round-2 form compacted

@@ -1784,8 +1784,9 @@ static void kwt_regroup(mzr_handle h) {
   bool soloOpen = false;
   if (const char *e = getenv("MZR_KWT_SOLO_MIN")) soloMin = atoi(e);
   if (const char *e = getenv("MZR_KWT_SOLO_PER")) soloPer = std::max(1, std::min(3, atoi(e)));
+  std::vector<int> offA(h->nStages + 1), offB(h->nStages + 1), offC(h->nStages + 1);      // (committed once the lists are on the device)
   for (int sg = 0; sg < h->nStages; ++sg) {
-    h->kwtRoutedOff[sg] = (int)L[0].size(); h->kwtBOff[sg] = (int)L[1].size(); h->kwtCOff[sg] = (int)L[2].size();
+    offA[sg] = (int)L[0].size(); offB[sg] = (int)L[1].size(); offC[sg] = (int)L[2].size();
     key.clear();
     for (int i = h->kwtStageOff[sg]; i < h->kwtStageOff[sg + 1]; ++i) key.emplace_back(-need(v[i]), i);
     std::sort(key.begin(), key.end());
@@ -1812,8 +1813,20 @@ static void kwt_regroup(mzr_handle h) {
       soloOpen = false;
     }
   }
-  h->kwtRoutedOff[h->nStages] = (int)L[0].size(); h->kwtBOff[h->nStages] = (int)L[1].size(); h->kwtCOff[h->nStages] = (int)L[2].size();
+  offA[h->nStages] = (int)L[0].size(); offB[h->nStages] = (int)L[1].size(); offC[h->nStages] = (int)L[2].size();
   DBuf<MzrKwtRec> *devStage[3] = {&h->kwtRouted, &h->kwtRoutedB, &h->kwtRoutedC}, *devAll[3] = {&h->kwtRoutedAll, &h->kwtRoutedBAll, &h->kwtRoutedCAll};
+  // (holes: the 16-lane list may hold more records than there are routed reaches.  Nothing is in flight here; without room the reaches go on
+  // in the classes they are in)
+  {
+    DBuf<MzrKwtRec> a[3], b[3];
+    bool grow[3];
+    for (int c = 0; c < 3; ++c) {
+      grow[c] = L[c].size() > devStage[c]->n || L[c].size() > devAll[c]->n;
+      if (!grow[c]) continue;
+      try { a[c].alloc(L[c].size() + L[c].size() / 4); b[c].alloc(L[c].size() + L[c].size() / 4); } catch (const std::string &) { (void)hipGetLastError(); return; }
+    }
+    for (int c = 0; c < 3; ++c) if (grow[c]) { devStage[c]->swap(a[c]); devAll[c]->swap(b[c]); }
+  }
   for (int c = 0; c < 3; ++c) {
     if (L[c].empty()) continue;
     (void)hipMemcpy(devStage[c]->p, L[c].data(), L[c].size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
@@ -1826,10 +1839,13 @@ static void kwt_regroup(mzr_handle h) {
     (void)hipMemcpy(devAll[c]->p, S.data(), S.size() * sizeof(MzrKwtRec), hipMemcpyHostToDevice);
   }
   h->kwtAllValid = true;
+  h->kwtRoutedOff = offA; h->kwtBOff = offB; h->kwtCOff = offC;
   if (getenv("MZR_KWT_CLASS_LOG")) {      // debugging aid: how the routed reaches spread over the work-array need and the lane classes
     int hist[64] = {0};
     for (const auto &rc : v) hist[std::min(63, std::max(0, need(rc)))]++;
-    fprintf(stderr, "[mzr] kwt classes: A %zu B %zu C %zu reaches (cuts %d / %d); need histogram:", L[0].size(), L[1].size(), L[2].size(), classBMax, classCMax);
+    size_t holes = 0, alone = 0;
+    for (size_t i = 0; i < L[0].size(); ++i) { holes += L[0][i].sigma >= MZR_KWT_HOLE; if (soloMin > 0 && L[0][i].sigma < MZR_KWT_HOLE && need(L[0][i]) >= soloMin) ++alone; }
+    fprintf(stderr, "[mzr] kwt classes: A %zu (+ %zu holes, %zu reaches of >= %d entries in passes of %d) B %zu C %zu reaches (cuts %d / %d); need histogram:", L[0].size() - holes, holes, alone, soloMin, soloPer, L[1].size(), L[2].size(), classBMax, classCMax);
     for (int i = 0; i < 64; ++i) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
     fprintf(stderr, "\n");
   }

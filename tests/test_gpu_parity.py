@@ -965,13 +965,15 @@ def test_restart_continues_bit_exact(tmp_path, hip_lib):
     f.close()
 
 
-@pytest.mark.parametrize("class_b_max,class_c_max,kc_wide", [("0", "0", "0"), ("64", "0", "0"), ("64", "64", "0"), ("0", "64", "0"),
-                                                             ("64", "64", "1"), ("24", "13", "1"), ("0", "13", "1")])
-def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, kc_wide, hip_lib, monkeypatch):
+@pytest.mark.parametrize("class_b_max,class_c_max,kc_wide,solo", [("0", "0", "0", ""), ("64", "0", "0", ""), ("64", "64", "0", ""), ("0", "64", "0", ""),
+                                                                  ("64", "64", "1", ""), ("24", "13", "1", ""), ("0", "13", "1", ""),
+                                                                  ("0", "0", "0", "6;1"), ("0", "0", "1", "9;2"), ("12", "6", "1", "14;3")])
+def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, kc_wide, solo, hip_lib, monkeypatch):
     """Routed reaches are served by 16, 8 or 4 lanes depending on a host-side guess of their particle
     count; a wrong guess is caught in the wavefront (wide fall-back).  Forcing every reach into any one
     class must not change a bit.  kc_wide: the sweep flavour whose 4-lane groups hold 15 entries instead of 11
-    (MZR_KWT_KC_WIDE_RUN; large domains pick it by themselves)."""
+    (MZR_KWT_KC_WIDE_RUN; large domains pick it by themselves).  solo = "n;k": 16-lane reaches that needed n entries or more share
+    their pass with k - 1 others at most, the other lane groups of the pass stand empty (MZR_KWT_SOLO_MIN / MZR_KWT_SOLO_PER)."""
     net = m.make_network(4000, seed=51)
     ro = m.make_runoff(net.H, 120, seed=52, storm_prob=0.03, storm_amp=3e-6)
     ff = np.array([0.5, 0.3, 0.2])
@@ -980,6 +982,9 @@ def test_kwt_lane_classes_give_the_same_answer(class_b_max, class_c_max, kc_wide
     monkeypatch.setenv("MZR_KWT_CLASSB_MAX", class_b_max)
     monkeypatch.setenv("MZR_KWT_CLASSC_MAX", class_c_max)
     monkeypatch.setenv("MZR_KWT_KC_WIDE_RUN", kc_wide)
+    if solo:
+        monkeypatch.setenv("MZR_KWT_SOLO_MIN", solo.split(";")[0])
+        monkeypatch.setenv("MZR_KWT_SOLO_PER", solo.split(";")[1])
     dom = m.RoutingDomain(net, 3600.0, [m.KWT], frac_future=ff, max_window=30)
     Qd = dom.run(ro)
     assert np.array_equal(Qd, Qr)
