@@ -1779,11 +1779,25 @@ static void kwt_regroup(mzr_handle h) {
   std::vector<MzrKwtRec> L[3];    // A, B, C
   for (auto &l : L) l.reserve(v.size());
   std::vector<std::pair<int, int>> key;
-  // MZR_KWT_SOLO_MIN=n (0 = off): class-A reaches that needed n entries or more get MZR_KWT_SOLO_PER (1; 2) lane groups of a pass of four
-  int soloMin = 0, soloPer = 1, soloIn = 0;
+  // Round 6, the latency path: a reach's step t + 1 waits for its step t, so the reaches with the longest lists -- 25 removals a step, each
+  // a chain of ~150 dependent instructions -- are the window's longest chain, and a pass is as long as its longest lane group: the 16-lane
+  // reaches that needed 45 entries or more (40 of 100 000 on the benchmark network) have their pass to themselves.  100 k reaches: 399.4 ->
+  // 387.0 ms per window of 16 384 (4 such reaches: the same; 294: the same; 581: slower than without -- the passes are paid for in wavefront
+  // slots).  Where instructions bound the sweep and not its chain (the rule of the B / A cut above) the empty lane groups only cost: 375 k
+  // shard 637.3 ms without, 644.2 with.  At most swCap / 32 of them (the threshold moves up).  MZR_KWT_SOLO_MIN=n (0 = off) /
+  // MZR_KWT_SOLO_PER=k (k reaches in such a pass, 1) override.
+  int soloMin = byInstructions ? 0 : 45, soloPer = 1, soloIn = 0;
   bool soloOpen = false;
   if (const char *e = getenv("MZR_KWT_SOLO_MIN")) soloMin = atoi(e);
   if (const char *e = getenv("MZR_KWT_SOLO_PER")) soloPer = std::max(1, std::min(3, atoi(e)));
+  if (soloMin > 0 && !getenv("MZR_KWT_SOLO_MIN")) {
+    int hist[66] = {0};
+    for (const auto &rc : v) { const int nd = need(rc); if (nd > classBMax) hist[std::min(65, std::max(0, nd))]++; }
+    const int most = std::max(64, h->swCap / 32);
+    int cnt = 0, T = 66;
+    while (T > soloMin && cnt + hist[T - 1] <= most) { --T; cnt += hist[T]; }
+    soloMin = T > 65 ? 0 : T;
+  }
   std::vector<int> offA(h->nStages + 1), offB(h->nStages + 1), offC(h->nStages + 1);      // (committed once the lists are on the device)
   for (int sg = 0; sg < h->nStages; ++sg) {
     offA[sg] = (int)L[0].size(); offB[sg] = (int)L[1].size(); offC[sg] = (int)L[2].size();
