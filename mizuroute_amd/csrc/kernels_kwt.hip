@@ -1071,7 +1071,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
             constexpr int KT = G >= 16 ? 64 / G : MZR_KWT_KTB;      // entries before thinning: at most 60 (16 lanes), 8 * KTB - 1 (8 lanes)
             // Round 4: the errors and the alive list live in LDS -- Xw[i] = error of particle i, Yw[i] = its links (round 6: one
-            // word, i << 16 | previous alive << 8 | next alive, which is also the PAYLOAD of the arg-min: the winner's links come out
+            // word, i << 24 | the alive one before the previous << 18 | previous alive << 12 | next alive << 6 | the one behind it, which is also the PAYLOAD of the arg-min: the winner's links come out
             // of the reduction with its index and the broadcast read of L[ISEL] -- one LDS round trip of the four a removal had, on
             // the longest chain of the window -- is gone) -- instead of four registers per lane and a 64-bit mask per lane: a removal costs one broadcast read of
             // the removed particle's links, one read of the neighbour's links (even lanes the lower, odd lanes the upper
@@ -1090,7 +1090,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               if (i <= NPRT) {
                 double ei = DBL_MAX;
                 if (i >= 1 && i < NPRT) ei = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
-                E[i] = ei; LK[2 * i] = (i << 16) | (((i - 1) & 0xff) << 8) | (i + 1);
+                E[i] = ei; LK[2 * i] = (i << 24) | (max(i - 2, 0) << 18) | (max(i - 1, 0) << 12) | (min(i + 1, NPRT) << 6) | min(i + 2, NPRT);
               }
             };
 #pragma unroll
@@ -1108,7 +1108,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // point's far link points one past the list, inside the wavefront's LDS; what is computed from it is not used), and the
             // turn without a candidate leaves through the loop's own condition (MPRT < 0) instead of a break of its own.
             const int sideEnd = side ? NPRT : 0;      // the end point on this lane's side: never re-evaluated
-            const bool isRem = gl == 2;
+            // where a lane finds its indices in the winner's word  i << 24 | aa << 18 | a << 12 | b << 6 | bb  (six bits each: a list that thins
+            // here holds at most 64 particles), by its role gl & 3
+            const int role = gl & 3;
+            const int shx = role == 0 ? 12 : role == 1 ? 6 : role == 2 ? 18 : 0;       // the particle whose word the lane patches: a, b, aa, bb
+            const int she = role == 0 ? 12 : role == 1 ? 6 : 24;                        // ... whose error it writes: a, b, ISEL
+            const int slo = side ? 12 : 18, shi = side ? 0 : 6;                         // the neighbours of the re-evaluation: (aa, b) | (a, bb)
+            const int shs = role == 2 ? 12 : role == 3 ? 0 : 6;                         // (pay << 6) >> shs puts the fields the lane moves in place
+            const int wmask = role == 0 ? 0x00000fff : role == 1 ? 0x00fff000 : role == 2 ? 0x0000003f : 0x00fc0000;
             do {
               double emin = DBL_MAX;
               int pay = 0;
@@ -1145,17 +1152,23 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               }
               pay = grp_argmin_pos<G>(emin, pay);          // first minimum of ABSERR (removed entries hold +Inf); the index leads the word
               const bool none = (unsigned)(pay - 1) >= 0x7ffffffeu;      // 0 (or 0x7fffffff): no finite interpolation error left (NaN/Inf input)
-              const int ISEL = pay >> 16, lsx = (pay >> 8) & 0xff, lsy = pay & 0xff;      // INDEX1(ISEL - 1), INDEX1(ISEL + 1)
-              const int c = side ? lsy : lsx;
-              const int lcw = LK[2 * c];
-              const int lcx = (lcw >> 8) & 0xff, lcy = lcw & 0xff;
-              const int a = side ? lsx : lcx, b = side ? lcy : lsy;
+              // The winner's word names its two neighbours a < ISEL < b AND theirs (aa = the one before a, bb = the one behind b): every index
+              // the turn needs, so what it reads -- the six values of the two re-evaluations, the four words it patches -- is ONE LDS round
+              // trip behind the reduction (reading the neighbour's word first to learn its far link was a second, dependent one).
+              //   lane 0: a between aa and b, word of a: (next, next-but-one) <- (b, bb)       lane 2: word of aa: next-but-one <- b, E[ISEL] <- Inf
+              //   lane 1: b between a and bb, word of b: (previous, the one before) <- (a, aa)   lane 3: word of bb: the one before <- a
+              // The fields a lane moves sit at the same bits in the winner's word (lanes 0-1) or six bits off (lanes 2-3): one shift pair
+              // and one v_bfi per lane.  A neighbour that is an end point gets its DBL_MAX back; end points' words are never a winner's.
+              const unsigned up = (unsigned)pay;
+              const int xw = (int)((up >> shx) & 63u), xe = (int)((up >> she) & 63u);
+              const int a = (int)((up >> slo) & 63u), b = (int)((up >> shi) & 63u);
+              const int c = xw;                                  // (lanes 0-1: the neighbour this lane re-evaluates)
+              const int wold = LK[2 * xw];
               const double en = fabs(interp3(Tw[c], Qw[a], Qw[b], Tw[a], Tw[b]) - Qw[c]);
-              const int x = isRem ? ISEL : c;
-              const int wx = isRem ? pay : ((c << 16) | (a << 8) | b);
-              const double vx = isRem ? (double)INFINITY : c != sideEnd ? en : DBL_MAX;      // removed: never the minimum again
+              const int wx = (wold & ~wmask) | ((int)(((unsigned)pay << 6) >> shs) & wmask);
+              const double vx = gl >= 2 ? (double)INFINITY : c != sideEnd ? en : DBL_MAX;      // removed: never the minimum again
               grp_sync();
-              if (gl < 3 && !none) { LK[2 * x] = wx; E[x] = vx; }
+              if (gl < 4 && !none) { LK[2 * xw] = wx; E[xe] = vx; }
               grp_sync();
               MPRT = none ? -1 : MPRT - 1;
             } while (MPRT >= MZR_MAXQPAR_DEV);
