@@ -920,6 +920,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             if (ns > 0 && k < nrA) { Xw[k] = aq[j]; Yw[k] = at[j]; }
             if (ns > 1 && k < nrB) { Xw[nrA + k] = bq[j]; Yw[nrA + k] = bt[j]; }
           }
+          if (ns == 1 && gl == 0) Yw[nrA] = DBL_MAX;      // (the second series does not exist: a time nothing is later than, where the rank search looks)
         }
         grp_sync();
         TSTAMP(10);
@@ -979,26 +980,28 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               // rank among the other tributary's particles = how many of them are earlier (an equal time anywhere sends the
               // group to the literal cursor walk, so "earlier" and "earlier or equal" need not be told apart).  Short lists:
               // one LDS round trip for four of them; long lists: bisection (each series is checked for order by its own lanes)
+              // (no range tests on the probes: the entry behind the other series' routed particles is its end-of-step particle at T1 > CT
+              // -- a probe clamped to it counts nothing -- and a series that does not exist is one sentinel, staged above)
               int cnt = 0;
+              const int lim = other ? nO + 1 : 0;
               if ((nA > nB ? nA : nB) <= 4) {
                 double tv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tv[u] = Ot[min(1 + u, nO > 0 ? nO : 1)];
+                for (int u = 0; u < 4; ++u) tv[u] = Ot[min(1 + u, lim)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                  const double tu = (1 + u <= nO) ? tv[u] : DBL_MAX;
-                  cnt += tu < CT ? 1 : 0;
-                  slow = slow || tu == CT;
+                  cnt += tv[u] < CT ? 1 : 0;
+                  slow = slow || tv[u] == CT;
                 }
               } else {
                 // cnt = how many of Ot[1..nO] (ascending) are earlier than CT: five probes at 16, 8, 4, 2, 1 (nO <= 19 < 32)
 #pragma unroll
                 for (int st = 16; st >= 1; st >>= 1) {
                   const int pr = cnt + st;
-                  const double tm = Ot[pr <= nO ? pr : 0];
-                  cnt = (pr <= nO && tm < CT) ? pr : cnt;
+                  const double tm = Ot[min(pr, lim)];
+                  cnt = tm < CT ? pr : cnt;
                 }
-                if (cnt < nO && Ot[cnt + 1] == CT) slow = true;
+                if (Ot[min(cnt + 1, lim)] == CT) slow = true;
               }
               pos = (i - 1) + cnt;
               TSTAMP(11);
