@@ -913,6 +913,12 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         const bool binary = !GEN && !upLake && NUPS != 1;   // GEN: launch over the confluences of more than two reaches
 #pragma unroll
         for (int j = 0; j < KS; ++j) { const int k = gl + j * G; if (k < n_own) { Qw[k] = q[j]; Tw[k] = ti[j]; } }
+        // minval(Q) < 0 (kwt_rch :163-174) is taken from the registers the list is made of -- the reach's own particles here, every merged
+        // flow where it is computed -- instead of a pass over the list in LDS (one dependent round trip per G entries, in every pass)
+        bool neg = false, negLds = GEN;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { const int k = gl + j * G; neg = neg || (k < n_own && q[j] < 0.0); }
+        const bool negOwn = neg;
         if (binary) {
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
@@ -929,10 +935,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         int ND;
         double *QD = Qw + NJ + 1, *TD = Tw + NJ + 1;
         if (upLake) {      // lake outflow enters the river as one particle, getusq_rch :554-559
-          if (gl == 0) { QD[0] = ldx<PERS>(Qrow + u0) / RW; TD[0] = T1; }
+          const double ql = ldx<PERS>(Qrow + u0) / RW;
+          if (gl == 0) { QD[0] = ql; TD[0] = T1; }
+          neg = neg || ql < 0.0;
           ND = 1;
         } else if (NUPS == 1) {   // one upstream basin that is a headwater, :743-759
-          if (gl == 0) { QD[0] = bs.b0q1 / RW; TD[0] = T1; }
+          const double qh = bs.b0q1 / RW;
+          if (gl == 0) { QD[0] = qh; TD[0] = T1; }
+          neg = neg || qh < 0.0;
           ND = 1;
         } else if (binary) {
           // Output = 2-way merge of the routed particles in time order, each with the other series
@@ -963,6 +973,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               Q_AGG = Q_AGG + (qb + SLOPE * (CT - tb)) * scB;
             }
             if (gl == 0) { QD[nA + nB] = Q_AGG; TD[nA + nB] = CT; }
+            neg = neg || Q_AGG < 0.0;
           }
           for (int m = gl; m < nA + nB; m += G) {
             double CT, Q_AGG = 0.0;
@@ -1019,6 +1030,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               else { Q_AGG = Q_AGG + SOTH; Q_AGG = Q_AGG + SOWN; }
             }
             QD[pos] = Q_AGG; TD[pos] = CT;
+            neg = neg || Q_AGG < 0.0;
             TSTAMP(12);
           }
           if (grp_any<G>(slow)) {
@@ -1027,6 +1039,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             int nd = 0;
             if (gl == 0) nd = kwt_merge_binary_serial(nup, ns, nrA, nrB, SAq, SAt, SBq, SBt, scA, scB, bs, T0, T1, QD, TD);
             ND = grp_first<G>(nd);
+            negLds = true; neg = negOwn;      // (the list was made by one lane: looked at in LDS; what the lanes had worked out does not count)
           }
         } else {
           int nd = -60;
@@ -1047,8 +1060,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 #endif
 
         {   // kwt_rch :163-174 (minval(Q) < 0: one vote of the group)
-          bool neg = false;
-          for (int k = gl; k < size; k += G) neg = neg || Qw[k] < 0.0;
+          if (negLds) { for (int k = gl + NJ + 1; k < size; k += G) neg = neg || Qw[k] < 0.0; }
           if (grp_any<G>(neg)) { mzr_raise(d, 20, r, t, 12); break; }
         }
         TSTAMP(2);
