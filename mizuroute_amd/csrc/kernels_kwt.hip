@@ -1005,14 +1005,21 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
                   slow = slow || tv[u] == CT;
                 }
               } else {
-                // cnt = how many of Ot[1..nO] (ascending) are earlier than CT: five probes at 16, 8, 4, 2, 1 (nO <= 19 < 32)
+                // cnt = how many of Ot[1..nO] (ascending, nO <= 19) are earlier than CT, in two LDS round trips: the pivots 4, 8, 12, 16
+                // together (k of them earlier: the answer lies in 4 k .. 4 k + 3), then the three entries behind pivot k together.  (Five
+                // dependent probes of a bisection and a sixth for the equal time: 0.8 us of a pass's 15-25.)  An equal time is the first
+                // entry that is not earlier, 4 k + 1 .. 4 k + 4: one of the seven values read.
+                double p1[4], p2[3];
 #pragma unroll
-                for (int st = 16; st >= 1; st >>= 1) {
-                  const int pr = cnt + st;
-                  const double tm = Ot[min(pr, lim)];
-                  cnt = tm < CT ? pr : cnt;
-                }
-                if (Ot[min(cnt + 1, lim)] == CT) slow = true;
+                for (int u = 0; u < 4; ++u) p1[u] = Ot[min(4 * (u + 1), lim)];
+                int k4 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { k4 += p1[u] < CT ? 4 : 0; slow = slow || p1[u] == CT; }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) p2[u] = Ot[min(k4 + 1 + u, lim)];
+                cnt = k4;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) { cnt += p2[u] < CT ? 1 : 0; slow = slow || p2[u] == CT; }
               }
               pos = (i - 1) + cnt;
               TSTAMP(11);
