@@ -294,6 +294,15 @@ template <int G> __device__ __forceinline__ int grp_first(int v) {
   return __shfl(v, mzr_lane() & ~(G - 1), 64);
 }
 
+// Values read from LDS for ALL slots of a lane before any of them is used.  Written as `if (in range && arr[i] < x)` per slot the
+// compiler puts every slot's read inside that slot's own divergent region, one LDS round trip (~130 cycles under the sweep's load) after
+// the other; read with a clamped index and held here, the slots' reads are in flight together and the tests follow.
+__device__ __forceinline__ void lds_held(double &v) { asm volatile("" : "+v"(v)); }
+template <int N> __device__ __forceinline__ void lds_held(double (&v)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));
+}
+
 // LDS traffic of one group is ordered by the hardware (one wavefront, in-order LDS queue); this
 // only keeps the compiler from moving accesses across a phase boundary.
 __device__ __forceinline__ void grp_sync() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
@@ -534,10 +543,19 @@ __device__ __forceinline__ int grp_interp_step(const double *X, const double *Q,
   if (!(T0 < x1)) AREAB = 0.0;
   if (!(T1 < xl)) AREAE = 0.0;
   // ---- interior trapezoids between points i-1 and i (1-based i = 3 .. NOLD-1, and NOLD when T1 sits on the last point)
+  {
+    double xh[KS], xl_[KS], qh[KS], ql[KS];
 #pragma unroll
-  for (int sl = 0; sl < KS; ++sl) {
-    const int i = gl + sl * G + 1;
-    if (i >= 3 && i <= NOLD) TERM[i - 1] = (X[i - 1] - X[i - 2]) * 0.5 * (Q[i - 2] + Q[i - 1]);
+    for (int sl = 0; sl < KS; ++sl) {
+      const int i = gl + sl * G + 1, ii = (i >= 3 && i <= NOLD) ? i : 2;
+      xh[sl] = X[ii - 1]; xl_[sl] = X[ii - 2]; qh[sl] = Q[ii - 1]; ql[sl] = Q[ii - 2];
+    }
+    lds_held(xh); lds_held(xl_); lds_held(qh); lds_held(ql);
+#pragma unroll
+    for (int sl = 0; sl < KS; ++sl) {
+      const int i = gl + sl * G + 1;
+      if (i >= 3 && i <= NOLD) TERM[i - 1] = (xh[sl] - xl_[sl]) * 0.5 * (ql[sl] + qh[sl]);
+    }
   }
   grp_sync();
   double AREAM = 0.0;
@@ -545,8 +563,12 @@ __device__ __forceinline__ int grp_interp_step(const double *X, const double *Q,
   const double *tp = TERM + 2;
 #pragma unroll 1
   for (int k0 = 0; __ballot(k0 < cnt) != 0ull; k0 += 6) {
+    double v[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { const double v = tp[k0 + k]; if (k0 + k < cnt) AREAM = AREAM + v; }
+    for (int k = 0; k < 6; ++k) v[k] = tp[k0 + k];
+    lds_held(v);      // (six terms in flight together; what lies behind the last one is inside the wavefront's LDS and not added)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k0 + k < cnt) AREAM = AREAM + v[k];
   }
   if (!(NOLD == 2 || T1 < x1)) *QNEW = (AREAB + AREAE + AREAM) / (T1 - T0);
   return 0;
@@ -985,38 +1007,41 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               const double *Ot = isA ? SBt : SAt, *Oq = isA ? SBq : SAq;
               const int nO = isA ? nB : nA;
               const bool other = isA ? ns > 1 : true;
+              // (everything of the loop body that does not depend on the particle's own time is read together with it: the particle before
+              // it, its flow, and the first four probes of the rank search)
+              const int lim = other ? nO + 1 : 0;
+              const int stride = (nA > nB ? nA : nB) <= 4 ? 1 : 4;
+              double Sp = St[i - 1], SqI = Sq[i], p1[4];
               CT = St[i];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) p1[u] = Ot[min(stride * (u + 1), lim)];
+              lds_held(CT); lds_held(Sp); lds_held(SqI); lds_held(p1);
               if (!(CT < T1)) slow = true;                            // error 40 in the cursor walk
-              if (i > 1 && !(St[i - 1] < CT)) slow = true;            // duplicate or unordered
+              if (i > 1 && !(Sp < CT)) slow = true;                   // duplicate or unordered
               // rank among the other tributary's particles = how many of them are earlier (an equal time anywhere sends the
               // group to the literal cursor walk, so "earlier" and "earlier or equal" need not be told apart).  Short lists:
               // one LDS round trip for four of them; long lists: bisection (each series is checked for order by its own lanes)
               // (no range tests on the probes: the entry behind the other series' routed particles is its end-of-step particle at T1 > CT
               // -- a probe clamped to it counts nothing -- and a series that does not exist is one sentinel, staged above)
               int cnt = 0;
-              const int lim = other ? nO + 1 : 0;
-              if ((nA > nB ? nA : nB) <= 4) {
-                double tv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) tv[u] = Ot[min(1 + u, lim)];
+              if (stride == 1) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                  cnt += tv[u] < CT ? 1 : 0;
-                  slow = slow || tv[u] == CT;
+                  cnt += p1[u] < CT ? 1 : 0;
+                  slow = slow || p1[u] == CT;
                 }
               } else {
                 // cnt = how many of Ot[1..nO] (ascending, nO <= 19) are earlier than CT, in two LDS round trips: the pivots 4, 8, 12, 16
                 // together (k of them earlier: the answer lies in 4 k .. 4 k + 3), then the three entries behind pivot k together.  (Five
                 // dependent probes of a bisection and a sixth for the equal time: 0.8 us of a pass's 15-25.)  An equal time is the first
                 // entry that is not earlier, 4 k + 1 .. 4 k + 4: one of the seven values read.
-                double p1[4], p2[3];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) p1[u] = Ot[min(4 * (u + 1), lim)];
+                double p2[3];
                 int k4 = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { k4 += p1[u] < CT ? 4 : 0; slow = slow || p1[u] == CT; }
 #pragma unroll
                 for (int u = 0; u < 3; ++u) p2[u] = Ot[min(k4 + 1 + u, lim)];
+                lds_held(p2);
                 cnt = k4;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) { cnt += p2[u] < CT ? 1 : 0; slow = slow || p2[u] == CT; }
@@ -1025,7 +1050,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               TSTAMP(11);
               Q_AGG = Q_AGG + (bs.b0q0 + bs.b0sl * (CT - T0)) * bs.bsc;
               if (nup > 1) Q_AGG = Q_AGG + (bs.b1q0 + bs.b1sl * (CT - T0)) * bs.bsc;
-              double SOWN = Sq[i] * (isA ? scA : scB), SOTH = 0.0;
+              double SOWN = SqI * (isA ? scA : scB), SOTH = 0.0;
               if (other) {
                 const double tb = Ot[cnt], te = Ot[cnt + 1], qb = Oq[cnt], qe = Oq[cnt + 1];
                 if (te < CT || tb > CT) slow = true;
@@ -1490,8 +1515,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           grp_sync();
           // exit times must increase: te <= previous -> previous + 1 s (:1423-1426); sequential only when it happens
           bool viol = false;
+          {
+            double xa[KS], xb[KS];
 #pragma unroll
-          for (int sl = 0; sl < KS; ++sl) { const int k2 = gl + sl * G; if (k2 >= 2 && k2 <= NQ2 && Xw[k2] <= Xw[k2 - 1]) viol = true; }
+            for (int sl = 0; sl < KS; ++sl) { const int k2 = gl + sl * G, kk = (k2 >= 2 && k2 <= NQ2) ? k2 : 1; xa[sl] = Xw[kk]; xb[sl] = Xw[kk - 1]; }
+            lds_held(xa); lds_held(xb);
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) { const int k2 = gl + sl * G; if (k2 >= 2 && k2 <= NQ2 && xa[sl] <= xb[sl]) viol = true; }
+          }
           if (grp_any<G>(viol)) {
             KCOUNT(9, 1);
             if (gl == 0) for (int k2 = 2; k2 <= NQ2; ++k2) { const double xp = Xw[k2 - 1]; if (Xw[k2] <= xp) Xw[k2] = xp + 1.0; }
@@ -1502,8 +1533,14 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
 
         // ---- time-step average and housekeeping, kwt_rch :257-311
         int NR = 0;
+        {
+          double xc[KS];
 #pragma unroll
-        for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && Xw[i] < T_END); }   // count(FROUTE)-1
+          for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; xc[sl] = Xw[(i >= 1 && i <= NQ2) ? i : 0]; }
+          lds_held(xc);
+#pragma unroll
+          for (int sl = 0; sl < KS; ++sl) { const int i = gl + sl * G; NR += grp_count<G>(i >= 1 && i <= NQ2 && xc[sl] < T_END); }   // count(FROUTE)-1
+        }
         if (NR + 1 > NQ2) { mzr_raise(d, 61, r, t, 14); break; }      // no waiting particle left
         TSTAMP(16);
         const double qN = Qw[NR], qN1 = Qw[NR + 1], xN = Xw[NR], xN1 = Xw[NR + 1], tN = Tw[NR], tN1 = Tw[NR + 1];
