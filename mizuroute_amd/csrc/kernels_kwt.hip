@@ -1132,20 +1132,28 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             // group of the wavefront needs them)
             constexpr int KN = KT < 2 ? KT : 2;
             const bool wide = KT > KN && __ballot(NPRT >= KN * G) != 0ull;
-            auto err0 = [&](int j) {
-              const int i = gl + j * G;
-              if (i <= NPRT) {
-                double ei = DBL_MAX;
-                if (i >= 1 && i < NPRT) ei = fabs(interp3(Tw[i], Qw[i - 1], Qw[i + 1], Tw[i - 1], Tw[i + 1]) - Qw[i]);
-                E[i] = ei; LK[2 * i] = (i << 24) | (max(i - 2, 0) << 18) | (max(i - 1, 0) << 12) | (min(i + 1, NPRT) << 6) | min(i + 2, NPRT);
+            // (the six values of a slot's first error for two slots at a time, read before either is worked on)
+            auto err0 = [&](int j0) {
+              double v[2][6];
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int i = gl + (j0 + jj) * G, ic = (i >= 1 && i < NPRT) ? i : 1;
+                v[jj][0] = Tw[ic]; v[jj][1] = Qw[ic - 1]; v[jj][2] = Qw[ic + 1]; v[jj][3] = Tw[ic - 1]; v[jj][4] = Tw[ic + 1]; v[jj][5] = Qw[ic];
+              }
+              lds_held(v[0]); lds_held(v[1]);
+#pragma unroll
+              for (int jj = 0; jj < 2; ++jj) {
+                const int i = gl + (j0 + jj) * G;
+                if (i <= NPRT) {
+                  double ei = DBL_MAX;
+                  if (i >= 1 && i < NPRT) ei = fabs(interp3(v[jj][0], v[jj][1], v[jj][2], v[jj][3], v[jj][4]) - v[jj][5]);
+                  E[i] = ei; LK[2 * i] = (i << 24) | (max(i - 2, 0) << 18) | (max(i - 1, 0) << 12) | (min(i + 1, NPRT) << 6) | min(i + 2, NPRT);
+                }
               }
             };
-#pragma unroll
-            for (int j = 0; j < KN; ++j) err0(j);
-            if (wide) {
-#pragma unroll
-              for (int j = KN; j < KT; ++j) err0(j);
-            }
+            static_assert(KN == 2 && (KT == 2 || KT == 4), "slots of the thinning in pairs");
+            err0(0);
+            if (wide) err0(2);
             grp_sync();
             // A removal is ~190 instructions of one wavefront, one after the other (the SIMD has other wavefronts to issue from, this
             // chain does not): on the reaches that thin 25 particles a step -- the window's longest chain at 100 k reaches -- every
@@ -1221,11 +1229,15 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             } while (MPRT >= MZR_MAXQPAR_DEV);
             {   // who is left
               mask = 0ull;
+              double ev[KT];
 #pragma unroll
-              for (int j = 0; j < KN; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && E[i <= NPRT ? i : 0] != INFINITY) << (j * G); }
+              for (int j = 0; j < KT; ++j) { const int i = gl + j * G; ev[j] = (j < KN || wide) ? E[i <= NPRT ? i : 0] : 0.0; }
+              lds_held(ev);
+#pragma unroll
+              for (int j = 0; j < KN; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && ev[j] != INFINITY) << (j * G); }
               if (wide) {
 #pragma unroll
-                for (int j = KN; j < KT; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && E[i <= NPRT ? i : 0] != INFINITY) << (j * G); }
+                for (int j = KN; j < KT; ++j) { const int i = gl + j * G; mask |= grp_bits<G>(i <= NPRT && ev[j] != INFINITY) << (j * G); }
               }
               grp_sync();
             }
@@ -1269,7 +1281,8 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
             constexpr int KC_ = G >= 16 ? 64 / G : MZR_KWT_KTB;
             double cq[KC_], ct[KC_];
 #pragma unroll
-            for (int j = 0; j < KC_; ++j) { const int i = gl + j * G; cq[j] = ct[j] = 0.0; if (i <= NPRT && ((mask >> i) & 1ull)) { cq[j] = Qw[i]; ct[j] = Tw[i]; } }
+            for (int j = 0; j < KC_; ++j) { const int i = gl + j * G, ic = i <= NPRT ? i : 0; cq[j] = Qw[ic]; ct[j] = Tw[ic]; }      // (all slots' reads together; a slot that does not survive is not written back)
+            lds_held(cq); lds_held(ct);
             grp_sync();
 #pragma unroll
             for (int j = 0; j < KC_; ++j) {
@@ -1322,11 +1335,15 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           bool shock = false;
           double tes[KS];
           bool zero = false;
+          double qv[KS], tv_[KS];      // flow and entry time of the lane's own particles (read together, before the first power)
+#pragma unroll
+          for (int j = 0; j < KS; ++j) { const int i = gl + j * G, ic = (i >= 1 && i <= NI) ? i : 1; qv[j] = Qw[ic]; tv_[j] = Tw[ic]; }
+          lds_held(qv); lds_held(tv_);
 #pragma unroll
           for (int j = 0; j < KS; ++j) {
             const int i = gl + j * G;
             wcs[j] = 0.0; rws[j] = 0.0;
-            if (i >= 1 && i <= NI) { const double wc = cw * pow_0p4(Qw[i]); wcs[j] = wc; rws[j] = 1.0 / wc; Xw[i] = wc; Yw[i] = rws[j]; }
+            if (i >= 1 && i <= NI) { const double wc = cw * pow_0p4(qv[j]); wcs[j] = wc; rws[j] = 1.0 / wc; Xw[i] = wc; Yw[i] = rws[j]; }
           }
           grp_sync();
           TSTAMP(4);
@@ -1340,13 +1357,17 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           shock = false;
           if (NI > 1) {
             bool cross = false;
+            double wn[KS], rn[KS], tn[KS];
+#pragma unroll
+            for (int sl = 0; sl < KS; ++sl) { const int jw = gl + sl * G, jc = (jw >= 1 && jw < NI) ? jw + 1 : 1; wn[sl] = Xw[jc]; rn[sl] = Yw[jc]; tn[sl] = Tw[jc]; }
+            lds_held(wn); lds_held(rn); lds_held(tn);
 #pragma unroll
             for (int sl = 0; sl < KS; ++sl) {
               const int jw = gl + sl * G;
               if (jw >= 1 && jw < NI) {
-                const double wcj = wcs[sl], wci = Xw[jw + 1], tj = Tw[jw], ti = Tw[jw + 1];
+                const double wcj = wcs[sl], wci = wn[sl], tj = tv_[sl], ti = tn[sl];
                 if (!(wci == 0.0 || wcj == 0.0) && !(wcj > wci && ti > tj)) {
-                  const double WDIFF = rws[sl] - Yw[jw + 1];
+                  const double WDIFF = rws[sl] - rn[sl];
                   // (a later, faster wave always catches up somewhere; nearly always far beyond the end of the reach.  The quotient
                   // is only formed where the product cannot rule that out: (ti - tj) > XMX * WDIFF * (1 + 1e-9) with both
                   // positive means (ti - tj) / WDIFF > XMX whatever the two roundings do)
@@ -1369,7 +1390,7 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
               if (h >= 1 && h <= NI) {
                 if (wcs[sl] < DBL_MIN) zero = true;                                // zero flow :1365
                 else {
-                  double te = fmin(XMX / wcs[sl] + Tw[h], DBL_MAX);
+                  double te = fmin(XMX / wcs[sl] + tv_[sl], DBL_MAX);
                   if (h == 1 && te <= T_START) te = T_START + 1.0;
                   tes[sl] = te;
                 }
@@ -1580,12 +1601,16 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           const __amdgpu_buffer_rsrc_t obWs = mzr_rsrc(obW);
           if (gl == 0 && outbox) stx<PERS>(obNw + r, NR + 2);
           if (gl == 0 && es >= 0) d.exN[(size_t)tq * d.nExp + es] = NR + 2;
+          double oq[OS], ox[OS];      // (the routed particles of all slots read before the first store)
+#pragma unroll
+          for (int j = 0; j < OS; ++j) { const int k2 = gl + j * G, kc = k2 <= NR ? k2 : 0; oq[j] = Qw[kc]; ox[j] = Xw[kc]; }
+          lds_held(oq); lds_held(ox);
 #pragma unroll
           for (int j = 0; j < OS; ++j) {
             const int k2 = gl + j * G;
             if (k2 <= NR + 2) {
-              const double q = k2 <= NR ? Qw[k2] : k2 == NR + 1 ? Q_END : qN1;
-              const double x = k2 <= NR ? Xw[k2] : k2 == NR + 1 ? T_END : xN1;
+              const double q = k2 <= NR ? oq[j] : k2 == NR + 1 ? Q_END : qN1;
+              const double x = k2 <= NR ? ox[j] : k2 == NR + 1 ? T_END : xN1;
               if (outbox) stq<PERS>(obWs, obW, MZR_OBI(k2, r), q, x);
               if (es >= 0) {   // tributary outlet of a partition: the same record goes to the time-indexed export buffer
                 const size_t nE = d.nExp;
@@ -1596,12 +1621,16 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
         }
         TSTAMP(19);
         // at-rest state: KWAVE(NR+1:NQ2+1)
+        double rq[KS], rt[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { const int k2 = gl + j * G, kc = NR + (k2 <= NN2 ? k2 : 0); rq[j] = Qw[kc]; rt[j] = Tw[kc]; }
+        lds_held(rq); lds_held(rt);
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           const int k2 = gl + j * G;
           if (k2 <= NN2) {
             const bool first = k2 == 0;
-            stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : Qw[NR + k2], first ? TIMEI : Tw[NR + k2]);
+            stq<PERS>(kwRs, d.kwQT, MZR_KWI(k2, r), first ? Q_END : rq[j], first ? TIMEI : rt[j]);
             // expected exit times are recomputed every step: only element 0 is read back, the others are kept for restart files (last step of a window)
             if ((first && !(PERS && d.W > 1)) || tq == d.W - 1) stx<PERS>(d.kwTR + MZR_KWI(k2, r), first ? T_END : Xw[NR + k2]);
           }
