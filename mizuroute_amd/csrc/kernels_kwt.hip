@@ -1113,18 +1113,16 @@ __device__ __forceinline__ int kwt_reach(const MzrDev &d, int s, const MzrKwtRec
           unsigned long long mask = NPRT >= 63 ? ~0ull : ((2ull << NPRT) - 1ull);   // bits 0..NPRT
           int MPRT = NPRT;
           if (!big) {
-            // The interpolation errors stay in registers (lane gl holds particles gl, gl+G, ...): one removal = local
-            // minimum, group arg-min, the two neighbours re-evaluated (one on even, one on odd lanes, results swapped
-            // inside lane pairs), owners patch their registers.  No LDS traffic but the six values of the re-evaluation.
+            // Errors and the alive list live in LDS: Xw[i] = interpolation error of particle i (removed: +Inf), Yw[i] = its WORD,
+            //   i << 24 | aa << 18 | a << 12 | b << 6 | bb     a / b = the alive particles before / behind i, aa / bb = the ones before a / behind b
+            // (six bits each: a list that thins here holds at most 64 particles).  The word is also the PAYLOAD of the arg-min -- its
+            // leading index makes the smallest word among equal errors MINLOC's first minimum -- so the winner's word names every
+            // particle the removal touches, and what a turn reads behind the reduction (the six values of the two re-evaluations, the
+            // four words it patches) is one LDS round trip.  History: round 3 kept errors and a 64-bit alive mask in registers (three
+            // compares and six selects per slot to patch them), round 4 moved them to LDS with prev / next links (a removal: read the
+            // winner's links, then the neighbour's, then the values: four dependent round trips), round 6 put the links into the
+            // payload and then the neighbours' neighbours too.  Same errors, same MINLOC order, same survivors throughout.
             constexpr int KT = G >= 16 ? 64 / G : MZR_KWT_KTB;      // entries before thinning: at most 60 (16 lanes), 8 * KTB - 1 (8 lanes)
-            // Round 4: the errors and the alive list live in LDS -- Xw[i] = error of particle i, Yw[i] = its links (round 6: one
-            // word, i << 24 | the alive one before the previous << 18 | previous alive << 12 | next alive << 6 | the one behind it, which is also the PAYLOAD of the arg-min: the winner's links come out
-            // of the reduction with its index and the broadcast read of L[ISEL] -- one LDS round trip of the four a removal had, on
-            // the longest chain of the window -- is gone) -- instead of four registers per lane and a 64-bit mask per lane: a removal costs one broadcast read of
-            // the removed particle's links, one read of the neighbour's links (even lanes the lower, odd lanes the upper
-            // neighbour), the six values of the re-evaluation, and three small writes; what it no longer costs is the patch of
-            // the register copies (three compares and six selects per slot) and the 64-bit mask arithmetic that found the
-            // neighbours (VALU issue is what bounds the sweep).  Same errors, same MINLOC order, same survivors.
             const bool side = gl & 1;
             double *E = Xw;
             int *LK = (int *)Yw;      // LK[2 i]: the word of particle i (8-byte slots: E[i] and LK[2 i] are one ds_read2_b64)
